@@ -1,0 +1,210 @@
+/*
+ * mmhand_hip.h — C-ABI of libmmhand_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (VITA-Group/mm-hand) has no FFI of its own: its hot path,
+ * MMHandModel.optimize_parameters() (models/MMHandModel.py:310-330), reaches
+ * the GPU only through torch.nn modules.  This header therefore declares the
+ * operator set those modules imply; every entry point
+ * names the reference call site it replaces.
+ *
+ * Conventions
+ *  - Activations are NHWC fp32 in HBM: element (b,h,w,c) of a tensor with
+ *    channel stride `cs` sits at ((b*H + h)*W + w)*cs + c.  Channel counts are
+ *    multiples of 4 (callers zero-pad 3/6/42-channel tensors to 4/8/44).
+ *  - Conv weights are [kh][kw][Cin][Cout] ("RSCK", Cout contiguous) for Conv2d
+ *    and [kh][kw][Cout_T][Cin_T] for ConvTranspose2d — the same physical
+ *    object as the Conv2d whose dgrad the transposed conv is.
+ *  - All device buffers are owned by the caller.  Nothing here allocates,
+ *    frees or synchronises; every call enqueues on the caller's hipStream_t.
+ *  - Return value: 0 on success, non-zero on error (mmh_last_error() gives the
+ *    thread-local message).  No exceptions cross this boundary.
+ */
+#ifndef MMHAND_HIP_H
+#define MMHAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mmh_stream_t; /* a hipStream_t */
+
+enum { MMH_PAD_ZERO = 0, MMH_PAD_REFLECT = 1 };
+enum { MMH_ACT_NONE = 0, MMH_ACT_RELU = 1, MMH_ACT_TANH = 2 };
+enum { MMH_F32 = 0, MMH_BF16 = 1 };
+
+/* Geometry of one Conv2d (forward orientation).  For ConvTranspose2d fill it
+ * in as the Conv2d whose input-gradient the transposed conv computes. */
+typedef struct mmh_conv_desc {
+    int32_t B, H, W;      /* input  (x)  batch and spatial size            */
+    int32_t Cin, Cout;    /* channels of w ([kh][kw][Cin][Cout]); %4 == 0   */
+    int32_t kh, kw;       /* 3x3 or 7x7 in the reference                    */
+    int32_t stride;       /* 1 or 2                                         */
+    int32_t pad;          /* symmetric padding                              */
+    int32_t pad_mode;     /* MMH_PAD_ZERO | MMH_PAD_REFLECT (stride 1 only) */
+    int32_t Ho, Wo;       /* output (y) spatial size                        */
+    int32_t x_cs, y_cs;   /* channel strides of x and y buffers (>= C)      */
+    int32_t dtype;        /* MMH_F32 (MMH_BF16 reserved)                    */
+} mmh_conv_desc;
+
+const char* mmh_last_error(void);
+int mmh_version(void);
+
+/* ---- convolutions: nn.Conv2d / nn.ReflectionPad2d / nn.ConvTranspose2d ----
+ * replaces models/Generator.py:40-113,158-259, models/Discriminator.py:14-99,
+ * losses/L1_plus_perceptualLoss.py:22-27 (cuDNN kernels behind torch.nn).   */
+
+/* y = act(conv(pad(x), w) + bias).  bias may be NULL. */
+int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
+                     const void* bias, void* y, int act, mmh_stream_t s);
+
+/* Gradient w.r.t. x.  MMH_PAD_ZERO: dx is [B,H,W,Cin] (channel stride
+ * dx_cs).  MMH_PAD_REFLECT: dx is the gradient on the padded domain,
+ * [B,H+2p,W+2p,Cin]; fold it with mmh_reflect_fold.                        */
+int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
+                     void* dx, int dx_cs, mmh_stream_t s);
+
+/* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
+ * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
+ * result deterministic.  accumulate!=0 adds into dw.                       */
+size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
+                     void* dw, void* ws, size_t ws_bytes, int accumulate,
+                     mmh_stream_t s);
+
+/* ConvTranspose2d(k3,s2,p1,op1) (models/Generator.py:240-253).  `d` is the
+ * stride-2 Conv2d of which this is the dgrad: d->{H,W,Cin} describe the
+ * transposed conv's OUTPUT, d->{Ho,Wo,Cout} its INPUT.                     */
+int mmh_convT2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
+                      const void* bias, void* y, int y_cs, mmh_stream_t s);
+int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
+                      void* dx, mmh_stream_t s);
+int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
+                      void* dw, void* ws, size_t ws_bytes, int accumulate,
+                      mmh_stream_t s);
+
+/* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
+ * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
+int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,
+                     int p, mmh_stream_t s);
+
+/* out[c] (+)= sum over rows of x[rows][C] (conv-bias gradient).           */
+size_t mmh_colsum_ws_bytes(int64_t rows, int C);
+int mmh_colsum(const void* x, int64_t rows, int C, int cs, void* out,
+               void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
+
+/* ---- BatchNorm2d / InstanceNorm2d + ReLU + Dropout ------------------------
+ * replaces norm_layer / nn.ReLU / nn.Dropout sites, models/Generator.py:66-77,
+ * models/Discriminator.py:29-34, models/network_utils.py:74-84.             */
+
+/* Per-(group,channel) mean and M2 = sum (x-mean)^2.  groups = B for instance
+ * norm (rows_per_group = H*W), 1 for batch norm (rows_per_group = B*H*W).   */
+size_t mmh_norm_stats_ws_bytes(int groups, int64_t rows_per_group, int C);
+int mmh_norm_stats(const void* x, int groups, int64_t rows_per_group, int C,
+                   int cs, void* mean, void* m2, void* ws, size_t ws_bytes,
+                   mmh_stream_t s);
+
+/* scale = gamma*rsqrt(m2/count+eps), shift = beta - mean*scale, invstd.
+ * gamma/beta may be NULL (affine=False).  If running_mean != NULL (batch
+ * norm, groups==1) they are updated with momentum and the unbiased variance
+ * m2/(count-1), as nn.BatchNorm2d does in training mode.                   */
+int mmh_norm_finalize(const void* mean, const void* m2, double count,
+                      const void* gamma, const void* beta, float eps,
+                      int groups, int C, void* scale, void* shift,
+                      void* invstd, void* running_mean, void* running_var,
+                      float momentum, mmh_stream_t s);
+
+/* out = dropout(relu(x*scale[g][c] + shift[g][c])) (+ residual).  scale and
+ * shift are [groups][C].  Dropout keeps an element when the counter-based
+ * hash of (seed, element index) < keep threshold and scales by 1/(1-p);
+ * if mask != NULL (uint8 per element, test hook) it is used instead.       */
+int mmh_scale_shift_act(const void* x, const void* scale, const void* shift,
+                        const void* residual, void* out, int groups,
+                        int64_t rows_per_group, int C, int relu, float drop_p,
+                        uint64_t seed, const void* mask, mmh_stream_t s);
+
+/* Backward of norm+relu+dropout.  dz = g * (relu||drop ? (out>0)/(1-p) : 1).
+ * reduce: s1[g][c] = sum dz, s2[g][c] = sum dz*xhat, xhat = (x-mean)*invstd.
+ * apply:  dx = gamma*invstd*(dz - s1/count - xhat*s2/count).               */
+size_t mmh_norm_bwd_ws_bytes(int groups, int64_t rows_per_group, int C);
+int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x,
+                        const void* mean, const void* invstd, int groups,
+                        int64_t rows_per_group, int C, int masked,
+                        float drop_p, void* s1, void* s2, void* ws,
+                        size_t ws_bytes, mmh_stream_t s);
+int mmh_norm_bwd_apply(const void* g, const void* out, const void* x,
+                       const void* mean, const void* invstd,
+                       const void* gamma, const void* s1, const void* s2,
+                       double count, int groups, int64_t rows_per_group,
+                       int C, int masked, float drop_p, void* dx,
+                       mmh_stream_t s);
+
+/* dx = g * act'(y): relu -> (y>0), tanh -> 1-y^2 (Generator.py:259 head).   */
+int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
+                mmh_stream_t s);
+
+/* ---- PATBlock gate + concat (models/Generator.py:115-130) -----------------
+ * out = x1 + s1*sigmoid(s2)*sigmoid(s3);  x2n = cat(s3,out); x3n = cat(s2,out)
+ * x1,s1,s2,s3,out: [rows][C];  x2n,x3n: [rows][2C] (NULL -> not produced).  */
+int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2,
+                          const void* s3, void* out, void* x2n, void* x3n,
+                          int64_t rows, int C, mmh_stream_t s);
+/* g_out/g_x2n/g_x3n may be NULL (treated as zero).                          */
+int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n,
+                          const void* g_x3n, const void* s1, const void* s2,
+                          const void* s3, void* g_x1, void* g_s1, void* g_s2,
+                          void* g_s3, int64_t rows, int C, mmh_stream_t s);
+
+/* ---- losses ----------------------------------------------------------------
+ * GANLoss = BCEWithLogits vs a constant target, mean (network_utils.py:129-163)
+ * L1 mean (L1_plus_perceptualLoss.py:37,66-67).  `out` is one device float:
+ * out = weight * mean(...) with the mean taken over `denom` elements.       */
+size_t mmh_reduce_ws_bytes(int64_t n);
+int mmh_bce_logits_fwd(const void* x, int64_t n, float target, float weight,
+                       double denom, void* out, void* ws, size_t ws_bytes,
+                       mmh_stream_t s);
+/* dx = gscalar[0] * weight/denom * (sigmoid(x) - target)                    */
+int mmh_bce_logits_bwd(const void* x, int64_t n, float target, float weight,
+                       double denom, const void* gscalar, void* dx,
+                       mmh_stream_t s);
+int mmh_l1_fwd(const void* a, const void* b, int64_t n, float weight,
+               double denom, void* out, void* ws, size_t ws_bytes,
+               mmh_stream_t s);
+/* da = gscalar[0] * weight/denom * sign(a-b)                                */
+int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight,
+               double denom, const void* gscalar, void* da, mmh_stream_t s);
+
+/* ---- Adam (torch.optim.Adam, MMHandModel.py:90-98) over a flat buffer ------
+ * step is the 1-based step count; no weight decay, no amsgrad.             */
+int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int step,
+                  float grad_scale, mmh_stream_t s);
+
+/* ---- layout: NCHW (any strides) <-> padded NHWC, with channel concat -------
+ * replaces torch.cat at MMHandModel.py:216-220,238,242,278-289.            */
+typedef struct mmh_plane_src {
+    void* ptr;                       /* NULL -> skipped                     */
+    int32_t C;                       /* channels taken from this source     */
+    int64_t sb, sc, sh, sw;          /* element strides                     */
+} mmh_plane_src;
+/* dir 0: gather srcs -> nhwc[B,H,W,Cd] (channels beyond sum(C) zeroed).
+ * dir 1: scatter nhwc -> srcs (backward of dir 0 / NHWC->NCHW export).     */
+int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B,
+                  int H, int W, int Cd, int dir, mmh_stream_t s);
+
+/* ---- pose maps (data/generic_dataset.py:191-217,239-242; util/util.py:94-114)
+ * uv: [n_maps][2] float64 (x,y).  out: [n_maps][H][W] fp32 =
+ * clamp/threshold(exp(-((gx-x)^2+(gy-y)^2)/(2 sigma^2))) computed in f64.  */
+int mmh_pose_heatmaps(const void* uv, int n_maps, int H, int W, double sigma,
+                      void* out, mmh_stream_t s);
+/* cords[n_maps][2] int32 = (y,x) of the first (row-major) arg-max above
+ * `threshold`, or (-1,-1).  maps: [n_maps][H][W] fp32.                      */
+int mmh_map_to_cord(const void* maps, int n_maps, int H, int W,
+                    float threshold, void* cords, mmh_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMHAND_HIP_H */

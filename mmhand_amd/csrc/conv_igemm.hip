@@ -1,0 +1,736 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X), fp32 on the f32 MFMA.
+//
+// One im2col-free gather serves all three passes of every Conv2d /
+// ConvTranspose2d on the MM-HAND hot path (reference: the cuDNN kernels behind
+// nn.Conv2d / nn.ReflectionPad2d / nn.ConvTranspose2d at
+// models/Generator.py:40-113,158-259, models/Discriminator.py:14-99,
+// losses/L1_plus_perceptualLoss.py:22-27):
+//
+//   fprop : y[pix][co]   = sum_{tap,ci} x[src(pix,tap)][ci]  * w[tap][ci][co]
+//   dgrad : dx[pix][ci]  = sum_{tap,co} dy[src'(pix,tap)][co] * w[tap][ci][co]
+//   wgrad : dw[tap,ci][co] = sum_pix    x[src(pix,tap)][ci]  * dy[pix][co]
+//
+// Activations are NHWC, so the contraction index (tap, channel) is contiguous
+// in groups of 4 channels and every global access is a 16-byte load.
+// ReflectionPad2d / zero padding / stride / transposed-conv parity classes are
+// all folded into src(): no padded tensor and no im2col buffer ever exists.
+//
+// Tiling (wave64, v_mfma_f32_32x32x2_f32): 256 threads = 4 waves per
+// workgroup, block tile 128 x BN x 32, each wave owns TM x TN tiles of 32x32
+// with 16 accumulator registers each.  Global loads for k-step i+1 are issued
+// into registers before the MFMAs of k-step i and written to LDS after them.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // rows (pixels, or (tap,ci) for wgrad) per workgroup
+constexpr int BK = 32;    // contraction depth per k-step
+constexpr int LDA = 36;   // LDS row pitch (floats) of a [row][k] tile: conflict-free ds_read_b128
+constexpr int LDW = 132;  // LDS row pitch of the wgrad [pixel][128] tile
+
+// How a (pixel, tap) pair maps to a source pixel.
+struct Gather {
+    const float* src;
+    int srcH, srcW;
+    unsigned src_cs;            // elements per source pixel
+    int PH, PW;                 // pixel domain per image (rows of the GEMM)
+    int TH, TW;                 // tap grid
+    int C4;                     // channel groups (of 4) per tap
+    int ap_h, at_h, a0_h;       // v_h = ph*ap_h + th*at_h + a0_h
+    int ap_w, at_w, a0_w;
+    int shift;                  // v >>= shift after the v >= 0 test (stride-2 dgrad)
+    int reflect;                // mirror v into [0, srcH)
+    int chunk_major;            // k order: 1 = (8-group chunk, tap), 0 = flat (tap, group)
+};
+
+struct ConvKP {
+    Gather g;
+    const float* w;
+    float* out;
+    const float* bias;
+    int M, N;                   // GEMM rows (batch*PH*PW) and columns
+    int nk;                     // k-steps
+    int Kflat;                  // TH*TW*C4*4 (flat order bound)
+    int wCin, wCout;            // weight tensor dims [taps][wCin][wCout]
+    int KW_true, kh0, kw0, tstep;  // true tap = (kh0+tstep*th)*KW_true + kw0+tstep*tw
+    int OH, OW, o_p, o0_h, o0_w;   // output pixel = (ph*o_p+o0_h, pw*o_p+o0_w) in OHxOW
+    unsigned out_cs;
+    int out_linear;             // output row offset is simply m*out_cs
+    int act;
+};
+
+struct KState { int th, tw, c4; };
+
+__device__ __forceinline__ void kstate_init(KState& s, const Gather& g, int grp) {
+    if (g.chunk_major) { s.th = 0; s.tw = 0; s.c4 = grp; }
+    else {
+        int tap = grp / g.C4;
+        s.c4 = grp - tap * g.C4;
+        s.th = tap / g.TW;
+        s.tw = tap - s.th * g.TW;
+    }
+}
+__device__ __forceinline__ void kstate_next(KState& s, const Gather& g) {
+    if (g.chunk_major) {
+        if (++s.tw == g.TW) { s.tw = 0; if (++s.th == g.TH) { s.th = 0; s.c4 += 8; } }
+    } else {
+        s.c4 += 8;
+        while (s.c4 >= g.C4) { s.c4 -= g.C4; if (++s.tw == g.TW) { s.tw = 0; ++s.th; } }
+    }
+}
+__device__ __forceinline__ bool kstate_valid(const KState& s, const Gather& g) {
+    return g.chunk_major ? (s.c4 < g.C4) : (s.th < g.TH);
+}
+
+// Fetch 4 channels of the source pixel for (pixel base bh,bw ; tap th,tw).
+__device__ __forceinline__ float4 gather4(const Gather& g, unsigned img_base, int bh, int bw,
+                                          const KState& s) {
+    int vh = bh + s.th * g.at_h;
+    int vw = bw + s.tw * g.at_w;
+    bool ok = true;
+    if (g.reflect) {
+        vh = vh < 0 ? -vh : vh;
+        vw = vw < 0 ? -vw : vw;
+        vh = vh >= g.srcH ? 2 * (g.srcH - 1) - vh : vh;
+        vw = vw >= g.srcW ? 2 * (g.srcW - 1) - vw : vw;
+    } else {
+        ok = (vh >= 0) && (vw >= 0);
+        vh >>= g.shift;
+        vw >>= g.shift;
+        ok = ok && (vh < g.srcH) && (vw < g.srcW);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        unsigned off = (img_base + (unsigned)(vh * g.srcW + vw)) * g.src_cs + (unsigned)s.c4 * 4u;
+        v = *reinterpret_cast<const float4*>(g.src + off);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == MMH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MMH_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// fprop / dgrad kernel.  B_NMAJOR=false: weights tile is [k][n] in LDS (fprop,
+// rows of w are contiguous in n).  B_NMAJOR=true: tile is [n][k] (dgrad: for a
+// fixed ci the co run is contiguous in w).
+// ---------------------------------------------------------------------------
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR>
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NB = BN / 32;  // float4 B loads per thread per k-step
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[B_NMAJOR ? BN * LDA : BK * BN];
+
+    const Gather& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    // --- per-thread A rows: 4 rows, one k-group (tid&7) ---
+    const int grp = tid & 7;
+    unsigned a_img[4];
+    int a_bh[4], a_bw[4];
+    bool a_ok[4];
+    const int PHW = g.PH * g.PW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + (tid >> 3) + 32 * i;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int b = mm / PHW;
+        int r = mm - b * PHW;
+        int ph = r / g.PW;
+        int pw = r - ph * g.PW;
+        a_img[i] = (unsigned)b * (unsigned)(g.srcH * g.srcW);
+        a_bh[i] = ph * g.ap_h + g.a0_h;
+        a_bw[i] = pw * g.ap_w + g.a0_w;
+    }
+
+    KState ks_t;   // this thread's k-group
+    KState ks_u;   // group 0 (block-uniform): row base of the weight tile
+    kstate_init(ks_t, g, grp);
+    kstate_init(ks_u, g, 0);
+
+    float4 ra[4];
+    float4 rb[NB];
+
+    auto load_tiles = [&](int ks) {
+        const bool kv = kstate_valid(ks_t, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (kv && a_ok[i]) ? gather4(g, a_img[i], a_bh[i], a_bw[i], ks_t)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!B_NMAJOR) {
+            // weight rows [rowbase, rowbase+32) x columns [n0, n0+BN)
+            int rowbase, rowlim;
+            if (g.chunk_major) {
+                rowbase = (ks_u.th * g.TW + ks_u.tw) * p.wCin + ks_u.c4 * 4;
+                rowlim = rowbase + BK;
+            } else {
+                rowbase = ks * BK;
+                rowlim = p.Kflat;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int idx = tid + 256 * i;
+                int krow = idx / (BN / 4);
+                int n4 = idx - krow * (BN / 4);
+                int row = rowbase + krow;
+                int n = n0 + 4 * n4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rowlim && n < p.N)
+                    v = *reinterpret_cast<const float4*>(p.w + (size_t)row * p.wCout + n);
+                rb[i] = v;
+            }
+        } else {
+            // B[k=(tap,co)][n=ci] = w[(tap_true*wCin + ci)*wCout + co]; same k-group as A
+            int tap_true = (p.kh0 + p.tstep * ks_t.th) * p.KW_true + p.kw0 + p.tstep * ks_t.tw;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int nrow = (tid >> 3) + 32 * i;
+                int n = n0 + nrow;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kv && n < p.N)
+                    v = *reinterpret_cast<const float4*>(
+                        p.w + ((size_t)tap_true * p.wCin + n) * p.wCout + ks_t.c4 * 4);
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * LDA + grp * 4]) = ra[i];
+        if (!B_NMAJOR) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                int idx = tid + 256 * i;
+                *reinterpret_cast<float4*>(&Bs[idx * 4]) = rb[i];  // [krow][BN] is linear in idx
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * LDA + grp * 4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    for (int ks = 0; ks < p.nk; ++ks) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (ks + 1 < p.nk) {
+            kstate_next(ks_t, g);
+            kstate_next(ks_u, g);
+            load_tiles(ks + 1);
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            float4 av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[i] = *reinterpret_cast<const float4*>(
+                    &As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
+            float bsc[TN][4];
+            if (B_NMAJOR) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float4 t = *reinterpret_cast<const float4*>(
+                        &Bs[(wn * WTN + j * 32 + l31) * LDA + kg * 8 + h * 4]);
+                    bsc[j][0] = t.x; bsc[j][1] = t.y; bsc[j][2] = t.z; bsc[j][3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float a = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // --- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            unsigned off;
+            if (p.out_linear) off = (unsigned)m * p.out_cs;
+            else {
+                int b = m / PHW;
+                int rr = m - b * PHW;
+                int ph = rr / g.PW;
+                int pw = rr - ph * g.PW;
+                off = ((unsigned)(b * p.OH + ph * p.o_p + p.o0_h) * (unsigned)p.OW +
+                       (unsigned)(pw * p.o_p + p.o0_w)) * p.out_cs;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[n];
+                    p.out[off + n] = apply_act(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// wgrad kernel: slab[z][(tap,ci)][co] = sum over this split's pixels.
+// Rows of the GEMM are the flat (tap, ci) index, the contraction runs over
+// pixels; the x tile is gathered exactly as in fprop and read transposed.
+// ---------------------------------------------------------------------------
+struct WgradKP {
+    Gather g;               // gathers x (fprop geometry); PH,PW = dy's domain
+    const float* dy;
+    unsigned dy_cs;
+    float* slab;            // [splits][Kflat][N]
+    int Mrows;              // Kflat = TH*TW*C4*4
+    int N;                  // Cout
+    int P;                  // total pixels = batch*PH*PW
+    int pix_per_split;      // multiple of 32
+};
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[BK * LDW];   // [pixel][128 rows]
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];    // [pixel][BN]
+
+    const Gather& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.P, pbeg + p.pix_per_split);
+    const int PHW = g.PH * g.PW;
+
+    // this thread's fixed (tap, channel group): flat group index
+    KState kt;
+    const int fg = (m0 >> 2) + (tid & 31);
+    const bool g_ok = fg * 4 < p.Mrows;
+    {
+        int tap = fg / g.C4;
+        kt.c4 = fg - tap * g.C4;
+        kt.th = tap / g.TW;
+        kt.tw = tap - kt.th * g.TW;
+    }
+
+    float4 ra[4];
+    float4 rb[NB];
+    auto load_tiles = [&](int pbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int pix = pbase + (tid >> 5) + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_ok && pix < pend) {
+                int b = pix / PHW;
+                int r = pix - b * PHW;
+                int ph = r / g.PW;
+                int pw = r - ph * g.PW;
+                v = gather4(g, (unsigned)b * (unsigned)(g.srcH * g.srcW), ph * g.ap_h + g.a0_h,
+                            pw * g.ap_w + g.a0_w, kt);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int idx = tid + 256 * i;
+            int prow = idx / (BN / 4);
+            int n4 = idx - prow * (BN / 4);
+            int pix = pbase + prow;
+            int n = n0 + 4 * n4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < pend && n < p.N)
+                v = *reinterpret_cast<const float4*>(p.dy + (size_t)pix * p.dy_cs + n);
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&As[((tid >> 5) + 8 * i) * LDW + (tid & 31) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(tid + 256 * i) * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (pbeg < pend) {
+        load_tiles(pbeg);
+        for (int pb = pbeg; pb < pend; pb += BK) {
+            __syncthreads();
+            store_tiles();
+            __syncthreads();
+            if (pb + BK < pend) load_tiles(pb + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + h) * LDW + wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + h) * BN + wn * WTN + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    float* slab = p.slab + (size_t)blockIdx.z * (size_t)p.Mrows * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= p.Mrows) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[i] (+)= sum_z slab[z][i], fixed order -> deterministic.
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                   int64_t n4, int splits, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 s = reinterpret_cast<const float4*>(slab)[i];
+        for (int z = 1; z < splits; ++z) {
+            float4 t = reinterpret_cast<const float4*>(slab)[(int64_t)z * n4 + i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float4* o = reinterpret_cast<float4*>(dw) + i;
+        if (accumulate) { float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        *o = s;
+    }
+}
+
+// Transpose of ReflectionPad2d: every real pixel sums the padded positions that mirror onto it.
+__global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int B,
+                                    int H, int W, int C4, int p) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int c = (int)(i % C4);
+        int64_t t = i / C4;
+        int w = (int)(t % W); t /= W;
+        int hh = (int)(t % H);
+        int b = (int)(t / H);
+        // padded coordinates that reflect to hh: hh itself, -hh (1<=hh<=p), 2(H-1)-hh (H-1-p<=hh<=H-2)
+        int hs[3], ws[3], nh = 0, nw = 0;
+        hs[nh++] = hh;
+        if (hh >= 1 && hh <= p) hs[nh++] = -hh;
+        if (hh >= H - 1 - p && hh <= H - 2) hs[nh++] = 2 * (H - 1) - hh;
+        ws[nw++] = w;
+        if (w >= 1 && w <= p) ws[nw++] = -w;
+        if (w >= W - 1 - p && w <= W - 2) ws[nw++] = 2 * (W - 1) - w;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < nh; ++a)
+            for (int e = 0; e < nw; ++e) {
+                const float4 v = reinterpret_cast<const float4*>(
+                    dxp)[(((int64_t)b * Hp + hs[a] + p) * Wp + ws[e] + p) * C4 + c];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        reinterpret_cast<float4*>(dx)[i] = s;
+    }
+}
+
+// --------------------------------------------------------------------------- host side
+int validate(const mmh_conv_desc* d) {
+    MMH_REQUIRE(d != nullptr, "conv desc is NULL");
+    MMH_REQUIRE(d->dtype == MMH_F32, "only MMH_F32 is implemented (dtype=%d)", d->dtype);
+    MMH_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "Cin/Cout must be multiples of 4 (%d,%d)",
+                d->Cin, d->Cout);
+    MMH_REQUIRE(d->x_cs % 4 == 0 && d->y_cs % 4 == 0 && d->x_cs >= d->Cin && d->y_cs >= d->Cout,
+                "bad channel strides x_cs=%d y_cs=%d", d->x_cs, d->y_cs);
+    MMH_REQUIRE(d->stride == 1 || d->stride == 2, "stride must be 1 or 2 (%d)", d->stride);
+    MMH_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->pad >= 0, "bad kernel/pad");
+    MMH_REQUIRE(d->pad_mode == MMH_PAD_ZERO || (d->stride == 1 && d->pad < d->H && d->pad < d->W),
+                "reflect padding needs stride 1 and pad < H,W");
+    MMH_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->kh) / d->stride + 1 &&
+                    d->Wo == (d->W + 2 * d->pad - d->kw) / d->stride + 1,
+                "Ho/Wo inconsistent with H,W,k,s,p");
+    MMH_REQUIRE((int64_t)d->B * d->H * d->W * d->x_cs < (1ll << 32) &&
+                    (int64_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) *
+                            (int64_t)(d->x_cs > d->y_cs ? d->x_cs : d->y_cs) < (1ll << 32),
+                "tensor too large for 32-bit element offsets");
+    return 0;
+}
+
+void set_korder(Gather& g, int& nk, int& Kflat) {
+    Kflat = g.TH * g.TW * g.C4 * 4;
+    if (g.C4 % 8 == 0) { g.chunk_major = 1; nk = (g.C4 / 8) * g.TH * g.TW; }
+    else { g.chunk_major = 0; nk = (Kflat + BK - 1) / BK; }
+}
+
+template <bool NMAJOR>
+int launch_conv(const ConvKP& p, hipStream_t st) {
+    dim3 block(256);
+    if (p.N > 64) {
+        dim3 grid((p.N + 127) / 128, (p.M + BM - 1) / BM);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2, NMAJOR>), grid, block, 0, st, p);
+    } else if (p.N > 32) {
+        dim3 grid(1, (p.M + BM - 1) / BM);
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2, NMAJOR>), grid, block, 0, st, p);
+    } else {
+        dim3 grid(1, (p.M + BM - 1) / BM);
+        hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1, NMAJOR>), grid, block, 0, st, p);
+    }
+    return mmh::check_launch("conv_igemm_kernel");
+}
+
+// forward-orientation gather of x (used by fprop and wgrad)
+Gather fwd_gather(const mmh_conv_desc* d, const void* x) {
+    Gather g{};
+    g.src = static_cast<const float*>(x);
+    g.srcH = d->H; g.srcW = d->W; g.src_cs = (unsigned)d->x_cs;
+    g.PH = d->Ho; g.PW = d->Wo;
+    g.TH = d->kh; g.TW = d->kw;
+    g.C4 = d->Cin / 4;
+    g.ap_h = d->stride; g.at_h = 1; g.a0_h = -d->pad;
+    g.ap_w = d->stride; g.at_w = 1; g.a0_w = -d->pad;
+    g.shift = 0;
+    g.reflect = d->pad_mode == MMH_PAD_REFLECT;
+    return g;
+}
+
+int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y,
+             int act, hipStream_t st) {
+    ConvKP p{};
+    p.g = fwd_gather(d, x);
+    set_korder(p.g, p.nk, p.Kflat);
+    p.w = static_cast<const float*>(w);
+    p.out = static_cast<float*>(y);
+    p.bias = static_cast<const float*>(bias);
+    p.M = d->B * d->Ho * d->Wo;
+    p.N = d->Cout;
+    p.wCin = d->Cin; p.wCout = d->Cout;
+    p.KW_true = d->kw; p.kh0 = 0; p.kw0 = 0; p.tstep = 1;
+    p.out_linear = 1; p.out_cs = (unsigned)d->y_cs;
+    p.OH = d->Ho; p.OW = d->Wo; p.o_p = 1;
+    p.act = act;
+    return launch_conv<false>(p, st);
+}
+
+// Gradient w.r.t. the conv input.  out: [B, OH, OW, Cin] with channel stride out_cs, where
+// (OH,OW) is the padded domain for reflect mode and (H,W) otherwise.
+int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx,
+             int dx_cs, hipStream_t st) {
+    const int s = d->stride;
+    const int off = d->pad_mode == MMH_PAD_REFLECT ? d->pad : 0;  // padded-domain origin shift
+    const int OH = d->H + 2 * off, OW = d->W + 2 * off;
+    MMH_REQUIRE(s == 1 || (OH % 2 == 0 && OW % 2 == 0), "stride-2 dgrad needs even H,W");
+    // one launch per output parity class (1 class for stride 1, 4 for stride 2)
+    for (int ch = 0; ch < s; ++ch)
+        for (int cw = 0; cw < s; ++cw) {
+            // real coordinate hi = ph*s + ch - off; taps with (hi + pad - kh) % s == 0
+            const int kh0 = ((ch - off + d->pad) % s + s) % s;
+            const int kw0 = ((cw - off + d->pad) % s + s) % s;
+            const int TH = kh0 < d->kh ? (d->kh - kh0 + s - 1) / s : 0;
+            const int TW = kw0 < d->kw ? (d->kw - kw0 + s - 1) / s : 0;
+            ConvKP p{};
+            Gather& g = p.g;
+            g.src = static_cast<const float*>(dy);
+            g.srcH = d->Ho; g.srcW = d->Wo; g.src_cs = (unsigned)d->y_cs;
+            g.PH = OH / s; g.PW = OW / s;
+            g.TH = TH; g.TW = TW;
+            g.C4 = d->Cout / 4;
+            // v = hi + pad - kh = ph*s + (ch - off + pad - kh0) - s*th
+            g.ap_h = s; g.at_h = -s; g.a0_h = ch - off + d->pad - kh0;
+            g.ap_w = s; g.at_w = -s; g.a0_w = cw - off + d->pad - kw0;
+            g.shift = s == 2 ? 1 : 0;
+            g.reflect = 0;
+            set_korder(g, p.nk, p.Kflat);
+            p.w = static_cast<const float*>(w);
+            p.out = static_cast<float*>(dx);
+            p.bias = static_cast<const float*>(bias);
+            p.M = d->B * g.PH * g.PW;
+            p.N = d->Cin;
+            p.wCin = d->Cin; p.wCout = d->Cout;
+            p.KW_true = d->kw; p.kh0 = kh0; p.kw0 = kw0; p.tstep = s;
+            p.OH = OH; p.OW = OW; p.o_p = s; p.o0_h = ch; p.o0_w = cw;
+            p.out_cs = (unsigned)dx_cs;
+            p.out_linear = s == 1;
+            p.act = MMH_ACT_NONE;
+            if (TH == 0 || TW == 0) p.nk = 0;  // no tap reaches this class: writes zeros
+            int rc = launch_conv<true>(p, st);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+int wgrad_splits(int Mrows, int N, int P) {
+    const int tiles = ((Mrows + BM - 1) / BM) * ((N + 127) / 128);
+    int splits = (1024 + tiles - 1) / tiles;          // aim for >= ~1024 workgroups
+    const int max_by_pixels = (P + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per split
+    if (splits > max_by_pixels) splits = max_by_pixels;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+size_t wgrad_ws(const mmh_conv_desc* d) {
+    const int Mrows = d->kh * d->kw * d->Cin;
+    const int P = d->B * d->Ho * d->Wo;
+    return (size_t)wgrad_splits(Mrows, d->Cout, P) * Mrows * d->Cout * sizeof(float);
+}
+
+int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
+             size_t ws_bytes, int accumulate, hipStream_t st) {
+    WgradKP p{};
+    p.g = fwd_gather(d, x);
+    p.g.chunk_major = 0;
+    p.dy = static_cast<const float*>(dy);
+    p.dy_cs = (unsigned)d->y_cs;
+    p.Mrows = d->kh * d->kw * d->Cin;
+    p.N = d->Cout;
+    p.P = d->B * d->Ho * d->Wo;
+    const int splits = wgrad_splits(p.Mrows, p.N, p.P);
+    MMH_REQUIRE(ws_bytes >= (size_t)splits * p.Mrows * p.N * sizeof(float),
+                "wgrad workspace too small: %zu < %zu", ws_bytes,
+                (size_t)splits * p.Mrows * p.N * sizeof(float));
+    p.slab = static_cast<float*>(ws);
+    p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), BK) * BK);
+    dim3 block(256);
+    if (p.N > 64) {
+        dim3 grid((p.N + 127) / 128, (p.Mrows + BM - 1) / BM, splits);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2>), grid, block, 0, st, p);
+    } else if (p.N > 32) {
+        dim3 grid(1, (p.Mrows + BM - 1) / BM, splits);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2>), grid, block, 0, st, p);
+    } else {
+        dim3 grid(1, (p.Mrows + BM - 1) / BM, splits);
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1>), grid, block, 0, st, p);
+    }
+    int rc = mmh::check_launch("conv_wgrad_kernel");
+    if (rc) return rc;
+    const int64_t n4 = (int64_t)p.Mrows * p.N / 4;
+    int blocks = (int)std::min<int64_t>(mmh::cdiv(n4, 256), 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab,
+                       static_cast<float*>(dw), n4, splits, accumulate);
+    return mmh::check_launch("slab_reduce_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias,
+                     void* y, int act, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(x && w && y, "mmh_conv2d_fprop: NULL buffer");
+    return do_fprop(d, x, w, bias, y, act, mmh::as_stream(s));
+}
+
+int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, int dx_cs,
+                     mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(dy && w && dx, "mmh_conv2d_dgrad: NULL buffer");
+    MMH_REQUIRE(dx_cs % 4 == 0 && dx_cs >= d->Cin, "mmh_conv2d_dgrad: bad dx_cs=%d", dx_cs);
+    return do_dgrad(d, dy, w, nullptr, dx, dx_cs, mmh::as_stream(s));
+}
+
+size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d) { return d ? wgrad_ws(d) : 0; }
+
+int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
+                     size_t ws_bytes, int accumulate, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(x && dy && dw && ws, "mmh_conv2d_wgrad: NULL buffer");
+    return do_wgrad(d, x, dy, dw, ws, ws_bytes, accumulate, mmh::as_stream(s));
+}
+
+// ConvTranspose2d == dgrad of the stride-2 conv `d`; its input plays dy, its output plays dx.
+int mmh_convT2d_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias,
+                      void* y, int y_cs, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(d->pad_mode == MMH_PAD_ZERO, "mmh_convT2d: zero padding only");
+    MMH_REQUIRE(x && w && y, "mmh_convT2d_fprop: NULL buffer");
+    return do_dgrad(d, x, w, bias, y, y_cs, mmh::as_stream(s));
+}
+
+int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void* dx,
+                      mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(d->pad_mode == MMH_PAD_ZERO, "mmh_convT2d: zero padding only");
+    MMH_REQUIRE(dy && w && dx, "mmh_convT2d_dgrad: NULL buffer");
+    return do_fprop(d, dy, w, nullptr, dx, MMH_ACT_NONE, mmh::as_stream(s));
+}
+
+int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
+                      size_t ws_bytes, int accumulate, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(x && dy && dw && ws, "mmh_convT2d_wgrad: NULL buffer");
+    // dw[tap][Cout_T][Cin_T]: the transposed conv's output-gradient is gathered like the
+    // stride-2 conv's input, its input is the per-pixel operand.
+    return do_wgrad(d, dy, x, dw, ws, ws_bytes, accumulate, mmh::as_stream(s));
+}
+
+int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C, int p,
+                     mmh_stream_t s) {
+    MMH_REQUIRE(dxp && dx, "mmh_reflect_fold: NULL buffer");
+    MMH_REQUIRE(C % 4 == 0 && p >= 0 && p < H && p < W,
+                "mmh_reflect_fold: bad shape C=%d p=%d H=%d W=%d", C, p, H, W);
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    int blocks = (int)std::min<int64_t>(mmh::cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(blocks), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(dxp), static_cast<float*>(dx), B, H, W, C / 4, p);
+    return mmh::check_launch("reflect_fold_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,835 @@
+// HBM-bound kernels of the MM-HAND step for gfx950: Batch/InstanceNorm statistics and
+// apply (+ReLU+Dropout+residual), their backward, the PATBlock gate, the GAN/L1 loss
+// reductions, fused Adam, NCHW<->NHWC packing with channel concat, bias gradients and the
+// pose-map kernels.  Everything is NHWC fp32, 16 bytes per lane, grid-stride; reductions
+// are two-stage with a fixed summation order (no float atomics) so results are
+// reproducible run to run.
+#include <algorithm>
+#include <cmath>
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4) {
+    return reinterpret_cast<const float4*>(p)[i4];
+}
+__device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) {
+    reinterpret_cast<float4*>(p)[i4] = v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+inline int grid_for(int64_t work_items, int cap = 4096) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(mmh::cdiv(work_items, TPB), cap));
+}
+
+// Column-reduction launch geometry shared by stats / bwd-reduce / colsum.
+struct ColGeom {
+    int lpp;      // lanes (float4 groups) per row = C/4
+    int rpi;      // rows handled per block iteration = TPB / lpp
+    int chunks;   // blocks per group
+    int64_t rows_per_chunk;
+};
+inline ColGeom col_geom(int groups, int64_t rows, int C) {
+    ColGeom g;
+    g.lpp = C / 4;
+    g.rpi = TPB / g.lpp;
+    int64_t want = std::max<int64_t>(1, 2048 / std::max(groups, 1));
+    int64_t maxc = std::max<int64_t>(1, rows / ((int64_t)g.rpi * 8));
+    g.chunks = (int)std::min<int64_t>(std::min(want, maxc), 1024);
+    g.rows_per_chunk = mmh::cdiv(rows, g.chunks);
+    return g;
+}
+
+// ------------------------------------------------------------------ norm statistics
+// partial layout: ws[((grp*chunks + chunk)*3 + {0:n,1:mean,2:M2})*C + c]
+__global__ void norm_stats_partial(const float* __restrict__ x, int64_t rows, int C, int cs,
+                                   ColGeom cg, float* __restrict__ ws) {
+    __shared__ float sh[3][TPB * 4];
+    const int tid = threadIdx.x;
+    const int q = tid % cg.lpp, rsub = tid / cg.lpp;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * cg.rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + cg.rows_per_chunk);
+    float4 K = make_float4(0, 0, 0, 0), s = K, ss = K;
+    float n = 0.f;
+    if (rsub < cg.rpi) {
+        const float* base = x + (int64_t)grp * rows * cs + q * 4;
+        for (int64_t r = r0 + rsub; r < r1; r += cg.rpi) {
+            float4 v = *reinterpret_cast<const float4*>(base + r * cs);
+            if (n == 0.f) K = v;
+            float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
+            s.x += dx; s.y += dy; s.z += dz; s.w += dw;
+            ss.x += dx * dx; ss.y += dy * dy; ss.z += dz * dz; ss.w += dw * dw;
+            n += 1.f;
+        }
+    }
+    // per-thread (n, mean, M2) for 4 channels
+    float inv = n > 0.f ? 1.f / n : 0.f;
+    float mean[4] = {K.x + s.x * inv, K.y + s.y * inv, K.z + s.z * inv, K.w + s.w * inv};
+    float m2[4] = {ss.x - s.x * s.x * inv, ss.y - s.y * s.y * inv, ss.z - s.z * s.z * inv,
+                   ss.w - s.w * s.w * inv};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[0][tid * 4 + e] = n;
+        sh[1][tid * 4 + e] = mean[e];
+        sh[2][tid * 4 + e] = m2[e] > 0.f ? m2[e] : 0.f;
+    }
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float na = sh[0][tid * 4 + e], ma = sh[1][tid * 4 + e], qa = sh[2][tid * 4 + e];
+            for (int j = 1; j < cg.rpi; ++j) {
+                const int t = (j * cg.lpp + q) * 4 + e;
+                float nb = sh[0][t], mb = sh[1][t], qb = sh[2][t];
+                if (nb > 0.f) {
+                    float nt = na + nb, d = mb - ma;
+                    ma += d * (nb / nt);
+                    qa += qb + d * d * (na * nb / nt);
+                    na = nt;
+                }
+            }
+            const int64_t o = ((int64_t)(grp * cg.chunks + chunk) * 3) * C + q * 4 + e;
+            ws[o] = na; ws[o + C] = ma; ws[o + 2 * C] = qa;
+        }
+    }
+}
+
+__global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C, int chunks,
+                                 float* __restrict__ mean, float* __restrict__ m2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    int grp = i / C, c = i - grp * C;
+    double na = 0, ma = 0, qa = 0;
+    for (int k = 0; k < chunks; ++k) {
+        const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
+        double nb = ws[o], mb = ws[o + C], qb = ws[o + 2 * C];
+        if (nb > 0) {
+            double nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+    }
+    mean[i] = (float)ma;
+    m2[i] = (float)qa;
+}
+
+__global__ void norm_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ m2,
+                                     double count, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float eps, int groups, int C,
+                                     float* __restrict__ scale, float* __restrict__ shift,
+                                     float* __restrict__ invstd, float* __restrict__ rmean,
+                                     float* __restrict__ rvar, float momentum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    int c = i % C;
+    float var = (float)((double)m2[i] / count);
+    float is = 1.f / sqrtf(var + eps);
+    float gm = gamma ? gamma[c] : 1.f;
+    float bt = beta ? beta[c] : 0.f;
+    float sc = gm * is;
+    scale[i] = sc;
+    shift[i] = bt - mean[i] * sc;
+    invstd[i] = is;
+    if (rmean && i < C) {
+        float unb = count > 1.0 ? (float)((double)m2[i] / (count - 1.0)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[i];
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+// ------------------------------------------------------------------ dropout hash
+__device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ void scale_shift_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift,
+                                       const float* __restrict__ residual, float* __restrict__ out,
+                                       int64_t n4, int64_t rows_per_group, int C4, int relu,
+                                       float drop_p, uint64_t seed,
+                                       const uint8_t* __restrict__ mask) {
+    const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        int64_t row = i / C4;
+        int c4 = (int)(i - row * C4);
+        int64_t grp = row / rows_per_group;
+        float4 v = ld4(x, i);
+        float4 sc = ld4(scale, grp * C4 + c4), sf = ld4(shift, grp * C4 + c4);
+        float r[4] = {v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w};
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
+        }
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool keep = mask ? (mask[i * 4 + e] != 0) : (mix_u32(seed, (uint64_t)(i * 4 + e)) >= thr);
+                r[e] = keep ? r[e] * dsc : 0.f;
+            }
+        }
+        if (residual) {
+            float4 q = ld4(residual, i);
+            r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
+        }
+        st4(out, i, make_float4(r[0], r[1], r[2], r[3]));
+    }
+}
+
+// ------------------------------------------------------------------ column reductions
+// MODE 0: colsum(x)            -> 1 output  (conv-bias gradient)
+// MODE 1: norm backward sums   -> 2 outputs (s1 = sum dz, s2 = sum dz*xhat)
+// partial layout: ws[((grp*chunks + chunk)*NOUT + o)*C + c]
+template <int MODE>
+__global__ void col_reduce_partial(const float* __restrict__ a, const float* __restrict__ outv,
+                                   const float* __restrict__ x, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, int64_t rows, int C, int cs,
+                                   int masked, float dsc, ColGeom cg, float* __restrict__ ws) {
+    constexpr int NOUT = MODE == 0 ? 1 : 2;
+    __shared__ float sh[NOUT][TPB * 4];
+    const int tid = threadIdx.x;
+    const int q = tid % cg.lpp, rsub = tid / cg.lpp;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * cg.rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + cg.rows_per_chunk);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (rsub < cg.rpi) {
+        const int64_t gbase = (int64_t)grp * rows;
+        float4 mu = make_float4(0, 0, 0, 0), is = mu;
+        if (MODE == 1) {
+            mu = ld4(mean, (int64_t)grp * cg.lpp + q);
+            is = ld4(invstd, (int64_t)grp * cg.lpp + q);
+        }
+        for (int64_t r = r0 + rsub; r < r1; r += cg.rpi) {
+            const int64_t off = (gbase + r) * cs + q * 4;
+            float4 g = *reinterpret_cast<const float4*>(a + off);
+            float gv[4] = {g.x, g.y, g.z, g.w};
+            if (MODE == 1) {
+                if (masked) {
+                    float4 o = *reinterpret_cast<const float4*>(outv + off);
+                    gv[0] = o.x > 0.f ? gv[0] * dsc : 0.f;
+                    gv[1] = o.y > 0.f ? gv[1] * dsc : 0.f;
+                    gv[2] = o.z > 0.f ? gv[2] * dsc : 0.f;
+                    gv[3] = o.w > 0.f ? gv[3] * dsc : 0.f;
+                }
+                float4 xv = *reinterpret_cast<const float4*>(x + off);
+                float xh[4] = {(xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z,
+                               (xv.w - mu.w) * is.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2[e] += gv[e] * xh[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[e] += gv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[0][tid * 4 + e] = s1[e];
+        if (NOUT == 2) sh[NOUT - 1][tid * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    if (rsub == 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = sh[o][tid * 4 + e];
+                for (int j = 1; j < cg.rpi; ++j) acc += sh[o][(j * cg.lpp + q) * 4 + e];
+                ws[((int64_t)(grp * cg.chunks + chunk) * NOUT + o) * C + q * 4 + e] = acc;
+            }
+    }
+}
+
+// out[o][grp][c] (+)= sum over chunks (double accumulation, fixed order)
+__global__ void col_reduce_final(const float* __restrict__ ws, int groups, int C, int chunks,
+                                 int nout, float* __restrict__ o0, float* __restrict__ o1,
+                                 int accumulate) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    int grp = i / C, c = i - grp * C;
+    for (int o = 0; o < nout; ++o) {
+        double acc = 0;
+        for (int k = 0; k < chunks; ++k) acc += ws[((int64_t)(grp * chunks + k) * nout + o) * C + c];
+        float* dst = o == 0 ? o0 : o1;
+        dst[i] = accumulate ? dst[i] + (float)acc : (float)acc;
+    }
+}
+
+__global__ void norm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ outv,
+                                      const float* __restrict__ x, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ s1,
+                                      const float* __restrict__ s2, float inv_count, int64_t n4,
+                                      int64_t rows_per_group, int C4, int masked, float dsc,
+                                      float* __restrict__ dx) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        int64_t row = i / C4;
+        int c4 = (int)(i - row * C4);
+        int64_t gi = (row / rows_per_group) * C4 + c4;
+        float4 gv4 = ld4(g, i), xv = ld4(x, i), mu = ld4(mean, gi), is = ld4(invstd, gi);
+        float4 a1 = ld4(s1, gi), a2 = ld4(s2, gi);
+        float4 gm = gamma ? ld4(gamma, c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+        if (masked) {
+            float4 o = ld4(outv, i);
+            gv[0] = o.x > 0.f ? gv[0] * dsc : 0.f;
+            gv[1] = o.y > 0.f ? gv[1] * dsc : 0.f;
+            gv[2] = o.z > 0.f ? gv[2] * dsc : 0.f;
+            gv[3] = o.w > 0.f ? gv[3] * dsc : 0.f;
+        }
+        float4 r;
+        r.x = gm.x * is.x * (gv[0] - a1.x * inv_count - (xv.x - mu.x) * is.x * a2.x * inv_count);
+        r.y = gm.y * is.y * (gv[1] - a1.y * inv_count - (xv.y - mu.y) * is.y * a2.y * inv_count);
+        r.z = gm.z * is.z * (gv[2] - a1.z * inv_count - (xv.z - mu.z) * is.z * a2.z * inv_count);
+        r.w = gm.w * is.w * (gv[3] - a1.w * inv_count - (xv.w - mu.w) * is.w * a2.w * inv_count);
+        st4(dx, i, r);
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                               float* __restrict__ dx, int64_t n4, int act) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 gv = ld4(g, i), yv = ld4(y, i), r;
+        if (act == MMH_ACT_RELU) {
+            r.x = yv.x > 0.f ? gv.x : 0.f; r.y = yv.y > 0.f ? gv.y : 0.f;
+            r.z = yv.z > 0.f ? gv.z : 0.f; r.w = yv.w > 0.f ? gv.w : 0.f;
+        } else {
+            r.x = gv.x * (1.f - yv.x * yv.x); r.y = gv.y * (1.f - yv.y * yv.y);
+            r.z = gv.z * (1.f - yv.z * yv.z); r.w = gv.w * (1.f - yv.w * yv.w);
+        }
+        st4(dx, i, r);
+    }
+}
+
+// ------------------------------------------------------------------ PATBlock gate
+__global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ s1,
+                                const float* __restrict__ s2, const float* __restrict__ s3,
+                                float* __restrict__ out, float* __restrict__ x2n,
+                                float* __restrict__ x3n, int64_t n4, int C4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 a = ld4(x1, i), b = ld4(s1, i), c = ld4(s2, i), d = ld4(s3, i), o;
+        o.x = a.x + b.x * sigmoidf_(c.x) * sigmoidf_(d.x);
+        o.y = a.y + b.y * sigmoidf_(c.y) * sigmoidf_(d.y);
+        o.z = a.z + b.z * sigmoidf_(c.z) * sigmoidf_(d.z);
+        o.w = a.w + b.w * sigmoidf_(c.w) * sigmoidf_(d.w);
+        st4(out, i, o);
+        if (x2n) {
+            int64_t row = i / C4;
+            int c4 = (int)(i - row * C4);
+            st4(x2n, row * 2 * C4 + c4, d);        // cat(s3, out)
+            st4(x2n, row * 2 * C4 + C4 + c4, o);
+            st4(x3n, row * 2 * C4 + c4, c);        // cat(s2, out)
+            st4(x3n, row * 2 * C4 + C4 + c4, o);
+        }
+    }
+}
+
+__global__ void gate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ g_x2n,
+                                const float* __restrict__ g_x3n, const float* __restrict__ s1,
+                                const float* __restrict__ s2, const float* __restrict__ s3,
+                                float* __restrict__ g_x1, float* __restrict__ g_s1,
+                                float* __restrict__ g_s2, float* __restrict__ g_s3, int64_t n4,
+                                int C4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 z4 = make_float4(0, 0, 0, 0);
+    for (; i < n4; i += stride) {
+        int64_t row = i / C4;
+        int c4 = (int)(i - row * C4);
+        float4 G = g_out ? ld4(g_out, i) : z4;
+        float4 e2 = z4, e3 = z4;  // direct grads on s2 (via x3n) and s3 (via x2n)
+        if (g_x2n) {
+            float4 t = ld4(g_x2n, row * 2 * C4 + C4 + c4);
+            G.x += t.x; G.y += t.y; G.z += t.z; G.w += t.w;
+            e3 = ld4(g_x2n, row * 2 * C4 + c4);
+        }
+        if (g_x3n) {
+            float4 t = ld4(g_x3n, row * 2 * C4 + C4 + c4);
+            G.x += t.x; G.y += t.y; G.z += t.z; G.w += t.w;
+            e2 = ld4(g_x3n, row * 2 * C4 + c4);
+        }
+        float4 b = ld4(s1, i), c = ld4(s2, i), d = ld4(s3, i);
+        float Gv[4] = {G.x, G.y, G.z, G.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        float cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float e2v[4] = {e2.x, e2.y, e2.z, e2.w}, e3v[4] = {e3.x, e3.y, e3.z, e3.w};
+        float r1[4], r2[4], r3[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a2 = sigmoidf_(cv[e]), a3 = sigmoidf_(dv[e]);
+            r1[e] = Gv[e] * a2 * a3;
+            r2[e] = Gv[e] * bv[e] * a3 * a2 * (1.f - a2) + e2v[e];
+            r3[e] = Gv[e] * bv[e] * a2 * a3 * (1.f - a3) + e3v[e];
+        }
+        st4(g_x1, i, G);
+        st4(g_s1, i, make_float4(r1[0], r1[1], r1[2], r1[3]));
+        st4(g_s2, i, make_float4(r2[0], r2[1], r2[2], r2[3]));
+        st4(g_s3, i, make_float4(r3[0], r3[1], r3[2], r3[3]));
+    }
+}
+
+// ------------------------------------------------------------------ scalar losses
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;  // valid in thread 0
+}
+
+// MODE 0: BCE-with-logits vs constant target; MODE 1: |a-b|
+template <int MODE>
+__global__ void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                    int64_t n, float target, float* __restrict__ partial) {
+    __shared__ float sh[TPB / 64];
+    float acc = 0.f;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n / 4;
+    for (; i < n4; i += stride) {
+        float4 v = ld4(a, i);
+        float xs[4] = {v.x, v.y, v.z, v.w};
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = xs[e];
+                acc += fmaxf(x, 0.f) - x * target + log1pf(__expf(-fabsf(x)));
+            }
+        } else {
+            float4 w = ld4(b, i);
+            acc += fabsf(v.x - w.x) + fabsf(v.y - w.y) + fabsf(v.z - w.z) + fabsf(v.w - w.w);
+        }
+    }
+    float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ partial, int nparts, double scale,
+                                  float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0;
+        for (int i = 0; i < nparts; ++i) acc += partial[i];
+        out[0] = (float)(acc * scale);
+    }
+}
+
+__global__ void bce_bwd_kernel(const float* __restrict__ x, int64_t n4, float target, float k,
+                               const float* __restrict__ gs, float* __restrict__ dx) {
+    const float kk = k * gs[0];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 v = ld4(x, i), r;
+        r.x = kk * (sigmoidf_(v.x) - target); r.y = kk * (sigmoidf_(v.y) - target);
+        r.z = kk * (sigmoidf_(v.z) - target); r.w = kk * (sigmoidf_(v.w) - target);
+        st4(dx, i, r);
+    }
+}
+
+__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n4,
+                              float k, const float* __restrict__ gs, float* __restrict__ da) {
+    const float kk = k * gs[0];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 v = ld4(a, i), w = ld4(b, i), r;
+        r.x = kk * sgn(v.x - w.x); r.y = kk * sgn(v.y - w.y);
+        r.z = kk * sgn(v.z - w.z); r.w = kk * sgn(v.w - w.w);
+        st4(da, i, r);
+    }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
+                            float b2, float eps, float step_size, float inv_sqrt_bc2,
+                            float gscale) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gr = g[i] * gscale;
+        float mm = b1 * m[i] + (1.f - b1) * gr;
+        float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mm / denom);
+    }
+}
+
+// ------------------------------------------------------------------ layout
+struct PackArgs {
+    mmh_plane_src s[4];
+    int nsrc;
+};
+__global__ void pack_nhwc_kernel(PackArgs a, float* __restrict__ nhwc, int B, int H, int W, int Cd,
+                                 int dir) {
+    const int64_t total = (int64_t)B * H * W;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int w = (int)(i % W);
+        int64_t t = i / W;
+        int hh = (int)(t % H);
+        int b = (int)(t / H);
+        float* px = nhwc + i * Cd;
+        int c0 = 0;
+        for (int k = 0; k < a.nsrc; ++k) {
+            const mmh_plane_src& s = a.s[k];
+            float* sp = static_cast<float*>(s.ptr);
+            if (sp) {
+                const int64_t base = b * s.sb + hh * s.sh + w * s.sw;
+                if (dir == 0) for (int c = 0; c < s.C; ++c) px[c0 + c] = sp[base + c * s.sc];
+                else          for (int c = 0; c < s.C; ++c) sp[base + c * s.sc] = px[c0 + c];
+            } else if (dir == 0) {
+                for (int c = 0; c < s.C; ++c) px[c0 + c] = 0.f;
+            }
+            c0 += s.C;
+        }
+        if (dir == 0) for (int c = c0; c < Cd; ++c) px[c] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ pose maps
+__global__ void pose_heatmap_kernel(const double* __restrict__ uv, int n_maps, int H, int W,
+                                    double sigma, float* __restrict__ out) {
+    const int64_t total = (int64_t)n_maps * H * W;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int x = (int)(i % W);
+        int64_t t = i / W;
+        int y = (int)(t % H);
+        int k = (int)(t / H);
+        double dx = (double)x - uv[2 * k], dy = (double)y - uv[2 * k + 1];
+        double d2 = dx * dx + dy * dy;
+        double v = exp(-d2 / 2.0 / sigma / sigma);
+        if (v > 1.0) v = 1.0;
+        if (v < 0.0099) v = 0.0;
+        out[i] = (float)v;
+    }
+}
+
+__global__ void map_to_cord_kernel(const float* __restrict__ maps, int H, int W, float thr,
+                                   int* __restrict__ cords) {
+    __shared__ float smax[TPB];
+    __shared__ int sidx[TPB];
+    const int k = blockIdx.x;
+    const float* m = maps + (int64_t)k * H * W;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+        float v = m[i];
+        if (v > best) { best = v; bi = i; }
+    }
+    smax[threadIdx.x] = best;
+    sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            float v = smax[threadIdx.x + o];
+            int j = sidx[threadIdx.x + o];
+            if (v > smax[threadIdx.x] || (v == smax[threadIdx.x] && j < sidx[threadIdx.x])) {
+                smax[threadIdx.x] = v;
+                sidx[threadIdx.x] = j;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (smax[0] > thr && sidx[0] != 0x7fffffff) {
+            cords[2 * k] = sidx[0] / W;      // y (row)
+            cords[2 * k + 1] = sidx[0] % W;  // x (col)
+        } else {
+            cords[2 * k] = -1;
+            cords[2 * k + 1] = -1;
+        }
+    }
+}
+
+int check_cols(const char* who, int C) {
+    MMH_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in (0,1024], got %d",
+                who, C);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mmh_norm_stats_ws_bytes(int groups, int64_t rows, int C) {
+    if (groups <= 0 || rows <= 0 || C <= 0 || C % 4) return 0;
+    ColGeom g = col_geom(groups, rows, C);
+    return (size_t)groups * g.chunks * 3 * C * sizeof(float);
+}
+
+int mmh_norm_stats(const void* x, int groups, int64_t rows, int C, int cs, void* mean, void* m2,
+                   void* ws, size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_norm_stats", C)) return rc;
+    MMH_REQUIRE(x && mean && m2 && ws && groups > 0 && rows > 0 && cs >= C && cs % 4 == 0,
+                "mmh_norm_stats: bad arguments");
+    MMH_REQUIRE(ws_bytes >= mmh_norm_stats_ws_bytes(groups, rows, C), "mmh_norm_stats: workspace too small");
+    ColGeom g = col_geom(groups, rows, C);
+    hipStream_t st = mmh::as_stream(s);
+    hipLaunchKernelGGL(norm_stats_partial, dim3(g.chunks, groups), dim3(TPB), 0, st,
+                       static_cast<const float*>(x), rows, C, cs, g, static_cast<float*>(ws));
+    hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + TPB - 1) / TPB), dim3(TPB), 0, st,
+                       static_cast<const float*>(ws), groups, C, g.chunks, static_cast<float*>(mean),
+                       static_cast<float*>(m2));
+    return mmh::check_launch("norm_stats");
+}
+
+int mmh_norm_finalize(const void* mean, const void* m2, double count, const void* gamma,
+                      const void* beta, float eps, int groups, int C, void* scale, void* shift,
+                      void* invstd, void* running_mean, void* running_var, float momentum,
+                      mmh_stream_t s) {
+    MMH_REQUIRE(mean && m2 && scale && shift && invstd && groups > 0 && C > 0 && count > 0,
+                "mmh_norm_finalize: bad arguments");
+    MMH_REQUIRE(!running_mean || (groups == 1 && running_var), "mmh_norm_finalize: running stats need groups==1");
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((groups * C + TPB - 1) / TPB), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const float*>(mean),
+                       static_cast<const float*>(m2), count, static_cast<const float*>(gamma),
+                       static_cast<const float*>(beta), eps, groups, C, static_cast<float*>(scale),
+                       static_cast<float*>(shift), static_cast<float*>(invstd),
+                       static_cast<float*>(running_mean), static_cast<float*>(running_var), momentum);
+    return mmh::check_launch("norm_finalize");
+}
+
+int mmh_scale_shift_act(const void* x, const void* scale, const void* shift, const void* residual,
+                        void* out, int groups, int64_t rows, int C, int relu, float drop_p,
+                        uint64_t seed, const void* mask, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_scale_shift_act", C)) return rc;
+    MMH_REQUIRE(x && scale && shift && out && groups > 0 && rows > 0, "mmh_scale_shift_act: bad arguments");
+    MMH_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu),
+                "mmh_scale_shift_act: dropout needs 0<=p<1 and a preceding ReLU");
+    const int64_t n4 = (int64_t)groups * rows * (C / 4);
+    hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x), static_cast<const float*>(scale),
+                       static_cast<const float*>(shift), static_cast<const float*>(residual),
+                       static_cast<float*>(out), n4, rows, C / 4, relu, drop_p, seed,
+                       static_cast<const uint8_t*>(mask));
+    return mmh::check_launch("scale_shift_act");
+}
+
+size_t mmh_norm_bwd_ws_bytes(int groups, int64_t rows, int C) {
+    if (groups <= 0 || rows <= 0 || C <= 0 || C % 4) return 0;
+    ColGeom g = col_geom(groups, rows, C);
+    return (size_t)groups * g.chunks * 2 * C * sizeof(float);
+}
+
+int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x, const void* mean,
+                        const void* invstd, int groups, int64_t rows, int C, int masked,
+                        float drop_p, void* s1, void* s2, void* ws, size_t ws_bytes,
+                        mmh_stream_t s) {
+    if (int rc = check_cols("mmh_norm_bwd_reduce", C)) return rc;
+    MMH_REQUIRE(g && x && mean && invstd && s1 && s2 && ws && (!masked || out),
+                "mmh_norm_bwd_reduce: NULL buffer");
+    MMH_REQUIRE(ws_bytes >= mmh_norm_bwd_ws_bytes(groups, rows, C), "mmh_norm_bwd_reduce: workspace too small");
+    ColGeom cg = col_geom(groups, rows, C);
+    hipStream_t st = mmh::as_stream(s);
+    const float dsc = 1.f / (1.f - drop_p);
+    hipLaunchKernelGGL((col_reduce_partial<1>), dim3(cg.chunks, groups), dim3(TPB), 0, st,
+                       static_cast<const float*>(g), static_cast<const float*>(out),
+                       static_cast<const float*>(x), static_cast<const float*>(mean),
+                       static_cast<const float*>(invstd), rows, C, C, masked, dsc, cg,
+                       static_cast<float*>(ws));
+    hipLaunchKernelGGL(col_reduce_final, dim3((groups * C + TPB - 1) / TPB), dim3(TPB), 0, st,
+                       static_cast<const float*>(ws), groups, C, cg.chunks, 2,
+                       static_cast<float*>(s1), static_cast<float*>(s2), 0);
+    return mmh::check_launch("norm_bwd_reduce");
+}
+
+int mmh_norm_bwd_apply(const void* g, const void* out, const void* x, const void* mean,
+                       const void* invstd, const void* gamma, const void* s1, const void* s2,
+                       double count, int groups, int64_t rows, int C, int masked, float drop_p,
+                       void* dx, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_norm_bwd_apply", C)) return rc;
+    MMH_REQUIRE(g && x && mean && invstd && s1 && s2 && dx && (!masked || out) && count > 0,
+                "mmh_norm_bwd_apply: bad arguments");
+    const int64_t n4 = (int64_t)groups * rows * (C / 4);
+    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(g), static_cast<const float*>(out),
+                       static_cast<const float*>(x), static_cast<const float*>(mean),
+                       static_cast<const float*>(invstd), static_cast<const float*>(gamma),
+                       static_cast<const float*>(s1), static_cast<const float*>(s2),
+                       (float)(1.0 / count), n4, rows, C / 4, masked, 1.f / (1.f - drop_p),
+                       static_cast<float*>(dx));
+    return mmh::check_launch("norm_bwd_apply");
+}
+
+size_t mmh_colsum_ws_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    ColGeom g = col_geom(1, rows, C);
+    return (size_t)g.chunks * C * sizeof(float);
+}
+
+int mmh_colsum(const void* x, int64_t rows, int C, int cs, void* out, void* ws, size_t ws_bytes,
+               int accumulate, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_colsum", C)) return rc;
+    MMH_REQUIRE(x && out && ws && rows > 0 && cs >= C && cs % 4 == 0, "mmh_colsum: bad arguments");
+    MMH_REQUIRE(ws_bytes >= mmh_colsum_ws_bytes(rows, C), "mmh_colsum: workspace too small");
+    ColGeom cg = col_geom(1, rows, C);
+    hipStream_t st = mmh::as_stream(s);
+    hipLaunchKernelGGL((col_reduce_partial<0>), dim3(cg.chunks, 1), dim3(TPB), 0, st,
+                       static_cast<const float*>(x), nullptr, nullptr, nullptr, nullptr, rows, C, cs,
+                       0, 1.f, cg, static_cast<float*>(ws));
+    hipLaunchKernelGGL(col_reduce_final, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, st,
+                       static_cast<const float*>(ws), 1, C, cg.chunks, 1, static_cast<float*>(out),
+                       nullptr, accumulate);
+    return mmh::check_launch("colsum");
+}
+
+int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act, mmh_stream_t s) {
+    MMH_REQUIRE(g && y && dx && n > 0 && n % 4 == 0, "mmh_act_bwd: bad arguments");
+    MMH_REQUIRE(act == MMH_ACT_RELU || act == MMH_ACT_TANH, "mmh_act_bwd: act must be relu or tanh");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(g), static_cast<const float*>(y),
+                       static_cast<float*>(dx), n / 4, act);
+    return mmh::check_launch("act_bwd");
+}
+
+int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2, const void* s3, void* out,
+                          void* x2n, void* x3n, int64_t rows, int C, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_patblock_gate_fwd", C)) return rc;
+    MMH_REQUIRE(x1 && s1 && s2 && s3 && out && rows > 0 && ((x2n == nullptr) == (x3n == nullptr)),
+                "mmh_patblock_gate_fwd: bad arguments");
+    const int64_t n4 = rows * (C / 4);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x1), static_cast<const float*>(s1),
+                       static_cast<const float*>(s2), static_cast<const float*>(s3),
+                       static_cast<float*>(out), static_cast<float*>(x2n), static_cast<float*>(x3n),
+                       n4, C / 4);
+    return mmh::check_launch("gate_fwd");
+}
+
+int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n, const void* g_x3n, const void* s1,
+                          const void* s2, const void* s3, void* g_x1, void* g_s1, void* g_s2,
+                          void* g_s3, int64_t rows, int C, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_patblock_gate_bwd", C)) return rc;
+    MMH_REQUIRE(s1 && s2 && s3 && g_x1 && g_s1 && g_s2 && g_s3 && rows > 0,
+                "mmh_patblock_gate_bwd: bad arguments");
+    const int64_t n4 = rows * (C / 4);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(g_out), static_cast<const float*>(g_x2n),
+                       static_cast<const float*>(g_x3n), static_cast<const float*>(s1),
+                       static_cast<const float*>(s2), static_cast<const float*>(s3),
+                       static_cast<float*>(g_x1), static_cast<float*>(g_s1),
+                       static_cast<float*>(g_s2), static_cast<float*>(g_s3), n4, C / 4);
+    return mmh::check_launch("gate_bwd");
+}
+
+size_t mmh_reduce_ws_bytes(int64_t n) { return (size_t)grid_for(n / 4, 1024) * sizeof(float); }
+
+static int loss_fwd(int mode, const void* a, const void* b, int64_t n, float target, float weight,
+                    double denom, void* out, void* ws, size_t ws_bytes, mmh_stream_t s) {
+    MMH_REQUIRE(a && out && ws && n > 0 && n % 4 == 0 && denom > 0, "loss_fwd: bad arguments");
+    const int blocks = grid_for(n / 4, 1024);
+    MMH_REQUIRE(ws_bytes >= blocks * sizeof(float), "loss_fwd: workspace too small");
+    hipStream_t st = mmh::as_stream(s);
+    if (mode == 0)
+        hipLaunchKernelGGL((loss_partial_kernel<0>), dim3(blocks), dim3(TPB), 0, st,
+                           static_cast<const float*>(a), nullptr, n, target, static_cast<float*>(ws));
+    else
+        hipLaunchKernelGGL((loss_partial_kernel<1>), dim3(blocks), dim3(TPB), 0, st,
+                           static_cast<const float*>(a), static_cast<const float*>(b), n, 0.f,
+                           static_cast<float*>(ws));
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, static_cast<const float*>(ws),
+                       blocks, (double)weight / denom, static_cast<float*>(out));
+    return mmh::check_launch("loss_fwd");
+}
+
+int mmh_bce_logits_fwd(const void* x, int64_t n, float target, float weight, double denom, void* out,
+                       void* ws, size_t ws_bytes, mmh_stream_t s) {
+    return loss_fwd(0, x, nullptr, n, target, weight, denom, out, ws, ws_bytes, s);
+}
+
+int mmh_bce_logits_bwd(const void* x, int64_t n, float target, float weight, double denom,
+                       const void* gscalar, void* dx, mmh_stream_t s) {
+    MMH_REQUIRE(x && gscalar && dx && n > 0 && n % 4 == 0 && denom > 0, "mmh_bce_logits_bwd: bad arguments");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x), n / 4, target, (float)((double)weight / denom),
+                       static_cast<const float*>(gscalar), static_cast<float*>(dx));
+    return mmh::check_launch("bce_bwd");
+}
+
+int mmh_l1_fwd(const void* a, const void* b, int64_t n, float weight, double denom, void* out,
+               void* ws, size_t ws_bytes, mmh_stream_t s) {
+    MMH_REQUIRE(b != nullptr, "mmh_l1_fwd: NULL buffer");
+    return loss_fwd(1, a, b, n, 0.f, weight, denom, out, ws, ws_bytes, s);
+}
+
+int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight, double denom,
+               const void* gscalar, void* da, mmh_stream_t s) {
+    MMH_REQUIRE(a && b && gscalar && da && n > 0 && n % 4 == 0 && denom > 0, "mmh_l1_bwd: bad arguments");
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(a), static_cast<const float*>(b), n / 4,
+                       (float)((double)weight / denom), static_cast<const float*>(gscalar),
+                       static_cast<float*>(da));
+    return mmh::check_launch("l1_bwd");
+}
+
+int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, mmh_stream_t s) {
+    MMH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "mmh_adam_step: bad arguments");
+    const double bc1 = 1.0 - std::pow((double)beta1, step);
+    const double bc2 = 1.0 - std::pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<float*>(p), static_cast<const float*>(g), static_cast<float*>(m),
+                       static_cast<float*>(v), n, beta1, beta2, eps, (float)((double)lr / bc1),
+                       (float)(1.0 / std::sqrt(bc2)), grad_scale);
+    return mmh::check_launch("adam");
+}
+
+int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B, int H, int W, int Cd,
+                  int dir, mmh_stream_t s) {
+    MMH_REQUIRE(srcs && nhwc && nsrc >= 1 && nsrc <= 4 && B > 0 && H > 0 && W > 0 && Cd > 0,
+                "mmh_pack_nhwc: bad arguments");
+    PackArgs a{};
+    a.nsrc = nsrc;
+    int tot = 0;
+    for (int i = 0; i < nsrc; ++i) { a.s[i] = srcs[i]; tot += srcs[i].C; }
+    MMH_REQUIRE(tot <= Cd, "mmh_pack_nhwc: %d source channels > Cd=%d", tot, Cd);
+    hipLaunchKernelGGL(pack_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(TPB), 0,
+                       mmh::as_stream(s), a, static_cast<float*>(nhwc), B, H, W, Cd, dir);
+    return mmh::check_launch("pack_nhwc");
+}
+
+int mmh_pose_heatmaps(const void* uv, int n_maps, int H, int W, double sigma, void* out,
+                      mmh_stream_t s) {
+    MMH_REQUIRE(uv && out && n_maps > 0 && H > 0 && W > 0 && sigma > 0, "mmh_pose_heatmaps: bad arguments");
+    hipLaunchKernelGGL(pose_heatmap_kernel, dim3(grid_for((int64_t)n_maps * H * W)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const double*>(uv), n_maps, H, W, sigma,
+                       static_cast<float*>(out));
+    return mmh::check_launch("pose_heatmaps");
+}
+
+int mmh_map_to_cord(const void* maps, int n_maps, int H, int W, float threshold, void* cords,
+                    mmh_stream_t s) {
+    MMH_REQUIRE(maps && cords && n_maps > 0 && H > 0 && W > 0, "mmh_map_to_cord: bad arguments");
+    hipLaunchKernelGGL(map_to_cord_kernel, dim3(n_maps), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(maps), H, W, threshold, static_cast<int*>(cords));
+    return mmh::check_launch("map_to_cord");
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""ctypes binding of libmmhand_hip.so (the C-ABI declared in include/mmhand_hip.h).
+
+The product path has no fallback: if the shared library is missing or a call
+returns non-zero, a RuntimeError is raised.  Nothing under ``oracle/`` is ever
+imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmhand_hip.so")
+
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+F32, BF16 = 0, 1
+
+
+class ConvDesc(C.Structure):
+    """mirror of mmh_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "pad", "pad_mode",
+        "Ho", "Wo", "x_cs", "y_cs", "dtype")]
+
+
+class PlaneSrc(C.Structure):
+    """mirror of mmh_plane_src"""
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32),
+                ("sb", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+_vp, _i, _i64, _f, _d, _u64, _sz = (C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double,
+                                    C.c_uint64, C.c_size_t)
+_DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/mmhand_hip.h
+SIGNATURES = {
+    "mmh_last_error": (C.c_char_p, []),
+    "mmh_version": (_i, []),
+    "mmh_conv2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mmh_conv2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _i, _vp]),
+    "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),
+    "mmh_conv2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_convT2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mmh_convT2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp]),
+    "mmh_convT2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmh_colsum_ws_bytes": (_sz, [_i64, _i]),
+    "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "mmh_norm_stats_ws_bytes": (_sz, [_i, _i64, _i]),
+    "mmh_norm_stats": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_norm_finalize": (_i, [_vp, _vp, _d, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "mmh_scale_shift_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp]),
+    "mmh_norm_bwd_ws_bytes": (_sz, [_i, _i64, _i]),
+    "mmh_norm_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _vp]),
+    "mmh_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "mmh_reduce_ws_bytes": (_sz, [_i64]),
+    "mmh_bce_logits_fwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _sz, _vp]),
+    "mmh_bce_logits_bwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _vp]),
+    "mmh_l1_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
+    "mmh_l1_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
+    "mmh_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
+    "mmh_pack_nhwc": (_i, [C.POINTER(PlaneSrc), _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmh_pose_heatmaps": (_i, [_vp, _i, _i, _i, _d, _vp, _vp]),
+    "mmh_map_to_cord": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mmhand_amd/csrc`.  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mmh_last_error()
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point and raise on error."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,538 @@
+"""PyTorch-ROCm shims over the C-ABI of libmmhand_hip.so.
+
+Two layers:
+  * ``raw_*`` functions: allocate outputs with the torch caching allocator and
+    enqueue the HIP kernels on torch's current stream (tensors are passed as raw
+    ``data_ptr()``; the library never allocates or synchronises);
+  * ``torch.autograd.Function`` shims whose backward calls the matching
+    dgrad/wgrad/backward kernels, so ``loss.backward()`` of the reference step
+    (models/MMHandModel.py:294-308) runs entirely on the hand-written kernels.
+
+All activations are physical NHWC fp32 tensors of shape [B, H, W, C] with C a
+multiple of 4 (3/6/42-channel tensors are zero-padded to 4/8/44).  Conv weights
+are physical [kh, kw, Cin, Cout]; the nn.Parameter objects the modules expose
+are permuted *views* of them with the reference's logical OIHW / IOHW shape.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous fp32 CUDA tensor, got "
+                           f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------- conv
+def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None):
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    return L.ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad,
+                      L.PAD_REFLECT if reflect else L.PAD_ZERO, Ho, Wo,
+                      x_cs or Cin, y_cs or Cout, L.F32)
+
+
+def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE):
+    _chk(x, "x"); _chk(w, "w")
+    B, H, W_, Cin = x.shape
+    k, _, wc, Cout = w.shape
+    assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    y = _empty((B, d.Ho, d.Wo, Cout), x)
+    L.call("mmh_conv2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
+    return y
+
+
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect):
+    _chk(dy, "dy"); _chk(w, "w")
+    B, H, W_, Cin = x_shape
+    k, _, _, Cout = w.shape
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if reflect and pad > 0:
+        dxp = _empty((B, H + 2 * pad, W_ + 2 * pad, Cin), dy)
+        L.call("mmh_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dxp), Cin, _stream())
+        dx = _empty((B, H, W_, Cin), dy)
+        L.call("mmh_reflect_fold", _ptr(dxp), _ptr(dx), B, H, W_, Cin, pad, _stream())
+        return dx
+    dx = _empty((B, H, W_, Cin), dy)
+    L.call("mmh_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), Cin, _stream())
+    return dx
+
+
+def raw_conv_wgrad(x, dy, k, stride, pad, reflect):
+    _chk(x, "x"); _chk(dy, "dy")
+    B, H, W_, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
+    nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
+    ws = _ws(nbytes, x)
+    dw = _empty((k, k, Cin, Cout), x)
+    L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
+           ws.numel() * 4, 0, _stream())
+    return dw
+
+
+def _convT_desc(x, w):
+    """ConvTranspose2d(k3,s2,p1,op1) seen as the dgrad of a stride-2 conv."""
+    B, h, w_, CinT = x.shape
+    k, _, CoutT, wc = w.shape   # physical [kh, kw, Cout_T, Cin_T]
+    assert wc == CinT and k == 3
+    return conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
+
+
+def raw_convT_fprop(x, w, bias):
+    _chk(x, "x"); _chk(w, "w")
+    d = _convT_desc(x, w)
+    y = _empty((d.B, d.H, d.W, d.Cin), x)
+    L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, _stream())
+    return y
+
+
+def raw_convT_dgrad(dy, w, x_shape):
+    _chk(dy, "dy")
+    B, h, w_, CinT = x_shape
+    d = conv_desc(B, 2 * h, 2 * w_, w.shape[2], CinT, 3, 2, 1, False)
+    dx = _empty((B, h, w_, CinT), dy)
+    L.call("mmh_convT2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _stream())
+    return dx
+
+
+def raw_convT_wgrad(x, dy):
+    _chk(x, "x"); _chk(dy, "dy")
+    B, h, w_, CinT = x.shape
+    CoutT = dy.shape[3]
+    d = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
+    nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
+    ws = _ws(nbytes, x)
+    dw = _empty((3, 3, CoutT, CinT), x)
+    L.call("mmh_convT2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
+           ws.numel() * 4, 0, _stream())
+    return dw
+
+
+def raw_colsum(x2d_rows, Ccols, x):
+    ws = _ws(L.load().mmh_colsum_ws_bytes(x2d_rows, Ccols), x)
+    out = _empty((Ccols,), x)
+    L.call("mmh_colsum", _ptr(x), x2d_rows, Ccols, Ccols, _ptr(out), _ptr(ws), ws.numel() * 4, 0,
+           _stream())
+    return out
+
+
+def raw_act_bwd(g, y, act):
+    g = g.contiguous()
+    dx = torch.empty_like(g)
+    L.call("mmh_act_bwd", _ptr(g), _ptr(y), _ptr(dx), g.numel(), act, _stream())
+    return dx
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, reflect, act):
+        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act)
+        ctx.cfg = (stride, pad, reflect, act, bias is not None)
+        ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        stride, pad, reflect, act, has_bias = ctx.cfg
+        g = g.contiguous()
+        if act != L.ACT_NONE:
+            g = raw_act_bwd(g, y, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = raw_conv_dgrad(g, w, x.shape, stride, pad, reflect)
+        if ctx.needs_input_grad[1]:
+            dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
+        return dx, dw, db, None, None, None, None
+
+
+class ConvT2dFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(k3,s2,p1,op1): fprop = stride-2 dgrad kernel, dgrad = stride-2 fprop."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y = raw_convT_fprop(x, w, bias)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = raw_convT_dgrad(g, w, x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = raw_convT_wgrad(x, g)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
+        return dx, dw, db
+
+
+# --------------------------------------------------------------------------- norm
+EPS = 1e-5
+_seed_counter = [0x5EED0001]
+
+
+def next_dropout_seed():
+    """Fresh 64-bit seed per dropout site per call (on-device counter-hash RNG)."""
+    _seed_counter[0] = (_seed_counter[0] * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+    return _seed_counter[0]
+
+
+def set_dropout_seed(seed):
+    _seed_counter[0] = int(seed) % (1 << 64)
+
+
+def raw_norm_stats(x, groups):
+    """mean, M2 per (group, channel); groups = B (instance) or 1 (batch)."""
+    B, H, W_, Cc = x.shape
+    rows = (B // groups) * H * W_
+    ws = _ws(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc), x)
+    mean = _empty((groups, Cc), x)
+    m2 = _empty((groups, Cc), x)
+    L.call("mmh_norm_stats", _ptr(x), groups, rows, Cc, Cc, _ptr(mean), _ptr(m2), _ptr(ws),
+           ws.numel() * 4, _stream())
+    return mean, m2, rows
+
+
+def raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var, momentum=0.1):
+    groups, Cc = mean.shape
+    scale = torch.empty_like(mean); shift = torch.empty_like(mean); invstd = torch.empty_like(mean)
+    L.call("mmh_norm_finalize", _ptr(mean), _ptr(m2), float(count), _ptr(gamma), _ptr(beta), EPS,
+           groups, Cc, _ptr(scale), _ptr(shift), _ptr(invstd), _ptr(running_mean),
+           _ptr(running_var), momentum, _stream())
+    return scale, shift, invstd
+
+
+def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask):
+    B, H, W_, Cc = x.shape
+    groups = scale.shape[0]
+    rows = (B // groups) * H * W_
+    out = torch.empty_like(x)
+    L.call("mmh_scale_shift_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _stream())
+    return out
+
+
+def _sync_stats(mean, m2, rows, group):
+    """SyncBN: merge per-rank (mean, M2) with Chan's formula (replaces apex SyncBatchNorm,
+    models/MMHandModel.py:109-116).  One all_gather of [2C] floats per norm site."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    packed = torch.cat([mean, m2], 0)          # [2, C]
+    gathered = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(gathered, packed, group=group)
+    means = torch.stack([t[0] for t in gathered])      # [world, C]
+    m2s = torch.stack([t[1] for t in gathered])
+    gmean = means.mean(0, keepdim=True)
+    gm2 = m2s.sum(0, keepdim=True) + rows * ((means - gmean) ** 2).sum(0, keepdim=True)
+    return gmean.contiguous(), gm2.contiguous(), rows * world
+
+
+class NormActFn(torch.autograd.Function):
+    """[Batch|Instance]Norm2d (training statistics) -> ReLU -> Dropout (+ residual add).
+
+    mode: 'batch' | 'instance'.  ``mask`` (uint8, test hook) replaces the on-device RNG.
+    """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
+                seed, mask, sync_group):
+        _chk(x, "x")
+        B = x.shape[0]
+        groups = B if mode == "instance" else 1
+        mean, m2, rows = raw_norm_stats(x, groups)
+        count = rows
+        if mode == "batch" and sync_group is not None:
+            mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
+        scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
+                                                 running_var)
+        out = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask)
+        ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
+                   residual is not None)
+        ctx.save_for_backward(x, out, mean, invstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, mean, invstd, gamma = ctx.saved_tensors
+        groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
+        if has_res and relu:
+            raise RuntimeError("NormActFn: residual together with ReLU is not on the reference path")
+        g = g.contiguous()
+        Cc = x.shape[3]
+        masked = int(relu or drop_p > 0)
+        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
+        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+        L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
+               rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
+        dgamma = dbeta = None
+        if gamma is not None:
+            dgamma = s2.sum(0) if groups > 1 else s2.reshape(-1).clone()
+            dbeta = s1.sum(0) if groups > 1 else s1.reshape(-1).clone()
+        if sync_group is not None:
+            import torch.distributed as dist
+            packed = torch.cat([s1, s2], 0)
+            dist.all_reduce(packed, group=sync_group)
+            s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
+        dx = torch.empty_like(x)
+        L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
+               _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
+               _ptr(dx), _stream())
+        dres = g if has_res else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+class AffineActFn(torch.autograd.Function):
+    """out = relu?(x*scale[c] + shift[c]) with fixed per-channel scale/shift: eval-mode
+    BatchNorm (aug.py:38-39) and the ImageNet pre-normalisation of the perceptual loss
+    (losses/L1_plus_perceptualLoss.py:40-58)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, relu):
+        out = raw_scale_shift_act(x, scale.reshape(1, -1), shift.reshape(1, -1), None, relu, 0.0,
+                                  0, None)
+        ctx.relu = relu
+        ctx.save_for_backward(scale, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, out = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            g = raw_act_bwd(g, out, L.ACT_RELU)
+        zero = torch.zeros_like(scale).reshape(1, -1)
+        dx = raw_scale_shift_act(g, scale.reshape(1, -1), zero, None, False, 0.0, 0, None)
+        return dx, None, None, None
+
+
+# --------------------------------------------------------------------------- gate
+class GateFn(torch.autograd.Function):
+    """PATBlock tail (models/Generator.py:115-130): out = x1 + s1*sig(s2)*sig(s3),
+    x2n = cat(s3, out), x3n = cat(s2, out) — the concat is written by the same kernel."""
+
+    @staticmethod
+    def forward(ctx, x1, s1, s2, s3, want_cat):
+        for t in (x1, s1, s2, s3):
+            _chk(t)
+        B, H, W_, Cc = x1.shape
+        out = torch.empty_like(x1)
+        x2n = x3n = None
+        if want_cat:
+            x2n = _empty((B, H, W_, 2 * Cc), x1)
+            x3n = _empty((B, H, W_, 2 * Cc), x1)
+        L.call("mmh_patblock_gate_fwd", _ptr(x1), _ptr(s1), _ptr(s2), _ptr(s3), _ptr(out),
+               _ptr(x2n), _ptr(x3n), B * H * W_, Cc, _stream())
+        ctx.save_for_backward(s1, s2, s3)
+        ctx.want_cat = want_cat
+        if want_cat:
+            return out, x2n, x3n
+        return out, None, None
+
+    @staticmethod
+    def backward(ctx, g_out, g_x2n, g_x3n):
+        s1, s2, s3 = ctx.saved_tensors
+        B, H, W_, Cc = s1.shape
+        g_out = None if g_out is None else g_out.contiguous()
+        g_x2n = None if g_x2n is None else g_x2n.contiguous()
+        g_x3n = None if g_x3n is None else g_x3n.contiguous()
+        gx1 = torch.empty_like(s1); gs1 = torch.empty_like(s1)
+        gs2 = torch.empty_like(s1); gs3 = torch.empty_like(s1)
+        L.call("mmh_patblock_gate_bwd", _ptr(g_out), _ptr(g_x2n), _ptr(g_x3n), _ptr(s1), _ptr(s2),
+               _ptr(s3), _ptr(gx1), _ptr(gs1), _ptr(gs2), _ptr(gs3), B * H * W_, Cc, _stream())
+        return gx1, gs1, gs2, gs3, None
+
+
+# --------------------------------------------------------------------------- losses
+class BCEWithLogitsConstFn(torch.autograd.Function):
+    """weight * mean(BCEWithLogits(x, target)) for a constant target (GANLoss,
+    models/network_utils.py:129-163)."""
+
+    @staticmethod
+    def forward(ctx, x, target, weight):
+        _chk(x, "x")
+        n = x.numel()
+        ws = _ws(L.load().mmh_reduce_ws_bytes(n), x)
+        out = _empty((), x)
+        L.call("mmh_bce_logits_fwd", _ptr(x), n, float(target), float(weight), float(n), _ptr(out),
+               _ptr(ws), ws.numel() * 4, _stream())
+        ctx.cfg = (float(target), float(weight))
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        target, weight = ctx.cfg
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        L.call("mmh_bce_logits_bwd", _ptr(x), x.numel(), target, weight, float(x.numel()), _ptr(g),
+               _ptr(dx), _stream())
+        return dx, None, None
+
+
+class L1MeanFn(torch.autograd.Function):
+    """weight * sum|a-b| / denom (F.l1_loss, losses/L1_plus_perceptualLoss.py:37,66-67).
+    ``denom`` is the logical element count (zero pad lanes contribute nothing)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, denom):
+        _chk(a, "a"); _chk(b, "b")
+        n = a.numel()
+        ws = _ws(L.load().mmh_reduce_ws_bytes(n), a)
+        out = _empty((), a)
+        L.call("mmh_l1_fwd", _ptr(a), _ptr(b), n, float(weight), float(denom), _ptr(out), _ptr(ws),
+               ws.numel() * 4, _stream())
+        ctx.cfg = (float(weight), float(denom))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        weight, denom = ctx.cfg
+        g = g.contiguous().float()
+        da = torch.empty_like(a)
+        L.call("mmh_l1_bwd", _ptr(a), _ptr(b), a.numel(), weight, denom, _ptr(g), _ptr(da),
+               _stream())
+        return da, None, None, None
+
+
+# --------------------------------------------------------------------------- layout
+def _plane(t, nchw):
+    """PlaneSrc for a logical-NCHW tensor (any strides) or a physical NHWC tensor."""
+    if nchw:
+        sb, sc, sh, sw = t.stride()
+        Cc = t.shape[1]
+    else:
+        sb, sh, sw, sc = t.stride()
+        Cc = t.shape[3]
+    return L.PlaneSrc(t.data_ptr(), Cc, sb, sc, sh, sw)
+
+
+def raw_pack(srcs, B, H, W_, Cd, device):
+    """srcs: list of (tensor, is_nchw, n_channels).  Returns NHWC [B,H,W,Cd] (zero padded)."""
+    arr = (L.PlaneSrc * len(srcs))()
+    for i, (t, nchw, nch) in enumerate(srcs):
+        assert t.dtype == torch.float32 and t.is_cuda
+        p = _plane(t, nchw)
+        p.C = nch
+        arr[i] = p
+    out = torch.empty((B, H, W_, Cd), dtype=torch.float32, device=device)
+    L.call("mmh_pack_nhwc", arr, len(srcs), _ptr(out), B, H, W_, Cd, 0, _stream())
+    return out
+
+
+def raw_unpack(nhwc, dsts):
+    """dsts: list of (tensor or None, is_nchw, n_channels): scatter channels of nhwc into them."""
+    B, H, W_, Cd = nhwc.shape
+    arr = (L.PlaneSrc * len(dsts))()
+    for i, (t, nchw, nch) in enumerate(dsts):
+        if t is None:
+            arr[i] = L.PlaneSrc(None, nch, 0, 0, 0, 0)
+        else:
+            p = _plane(t, nchw)
+            p.C = nch
+            arr[i] = p
+    L.call("mmh_pack_nhwc", arr, len(dsts), _ptr(nhwc), B, H, W_, Cd, 1, _stream())
+
+
+class PackFn(torch.autograd.Function):
+    """cat(channels) + zero pad to a multiple of 4 + (NCHW|NHWC) -> NHWC, one kernel; replaces
+    torch.cat at models/MMHandModel.py:216-220,238,242,278-289.  Sources are given as
+    (tensor, is_nchw) pairs flattened: PackFn.apply(Cd, t0, nchw0, c0, t1, nchw1, c1, ...)."""
+
+    @staticmethod
+    def forward(ctx, Cd, *args):
+        srcs = [(args[i], args[i + 1], args[i + 2]) for i in range(0, len(args), 3)]
+        t0, nchw0, _ = srcs[0]
+        if nchw0:
+            B, _, H, W_ = t0.shape
+        else:
+            B, H, W_, _ = t0.shape
+        ctx.meta = [(tuple(t.shape), nchw, nch) for t, nchw, nch in srcs]
+        return raw_pack(srcs, B, H, W_, Cd, t0.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        grads = [None]
+        dsts = []
+        for i, (shape, nchw, nch) in enumerate(ctx.meta):
+            if ctx.needs_input_grad[1 + 3 * i]:
+                t = torch.zeros(shape, dtype=torch.float32, device=g.device)
+                dsts.append((t, nchw, nch))
+                grads += [t, None, None]
+            else:
+                dsts.append((None, nchw, nch))
+                grads += [None, None, None]
+        raw_unpack(g, dsts)
+        return tuple(grads)
+
+
+def nhwc_to_nchw_view(t, Cc=None):
+    """Zero-copy logical-NCHW view of a physical NHWC tensor (first Cc channels)."""
+    v = t.permute(0, 3, 1, 2)
+    return v if Cc is None or Cc == t.shape[3] else v[:, :Cc]
+
+
+# --------------------------------------------------------------------------- optimiser
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """torch.optim.Adam.step (models/MMHandModel.py:90-98) on flat buffers, one launch."""
+    for t in (p, g, m, v):
+        _chk(t)
+    L.call("mmh_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
+           float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+# --------------------------------------------------------------------------- pose maps
+def pose_heatmaps(uv, H, W_, sigma=6.0):
+    """uv: float64 CUDA tensor [n_maps, 2] (x, y) -> fp32 [n_maps, H, W] (generic_dataset.py:191-242)."""
+    assert uv.dtype == torch.float64 and uv.is_cuda and uv.is_contiguous()
+    n = uv.shape[0]
+    out = torch.empty((n, H, W_), dtype=torch.float32, device=uv.device)
+    L.call("mmh_pose_heatmaps", _ptr(uv), n, H, W_, float(sigma), _ptr(out), _stream())
+    return out
+
+
+def map_to_cord(maps, threshold=0.1):
+    """maps: fp32 CUDA [n_maps, H, W] -> int32 [n_maps, 2] (y, x) or -1 (util/util.py:94-114)."""
+    _chk(maps, "maps")
+    n, H, W_ = maps.shape
+    out = torch.empty((n, 2), dtype=torch.int32, device=maps.device)
+    L.call("mmh_map_to_cord", _ptr(maps), n, H, W_, float(threshold), _ptr(out), _stream())
+    return out
