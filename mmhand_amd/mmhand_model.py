@@ -1,0 +1,447 @@
+"""MMHandModel — the training-step object of MM-HAND on MI355X.
+
+Drop-in for models/MMHandModel.py + models/base_model.py: same constructor argument (``opt``
+namespace, field list in SURVEY.md §5.6), same methods called by train.py:15-65
+(set_input / optimize_parameters / get_current_errors / get_current_visuals / save /
+update_learning_rate / pprint / name) and the same checkpoint files
+(<label>_net_<netG|netD_PB|netD_PP>.pth holding reference-format state_dicts).
+
+What differs is underneath: no apex, no cuDNN.  Every conv / norm / gate / loss / Adam launch is
+a hand-written gfx950 kernel reached through libmmhand_hip.so; data parallelism is one process
+per GPU with one RCCL all-reduce per network per backward on a side stream; the generator's
+all-reduce + Adam overlap the two discriminator steps (which only need the *old* fake image,
+models/MMHandModel.py:279-289).
+"""
+import os
+import random
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from . import ops
+from .networks import Discriminator, Generator, VGGHead
+from .ops import pad4
+
+
+# ----------------------------------------------------------------------------- helpers
+def get_norm_layer(norm_type="instance"):
+    """models/network_utils.py:74-84 — returns the tag the networks understand."""
+    if norm_type in ("batch", "instance"):
+        return norm_type
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+def get_scheduler(optimizer, opt):
+    """models/network_utils.py:87-109."""
+    from torch.optim import lr_scheduler
+    if opt.lr_policy == "lambda":
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + 1 + opt.epoch_count - opt.niter) / float(opt.niter_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.lr_policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    if opt.lr_policy == "plateau":
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.2, threshold=0.01,
+                                              patience=5)
+    raise NotImplementedError("learning rate policy [%s] is not implemented" % opt.lr_policy)
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (lr, betas, eps=1e-8, no weight decay) over a network's flat
+    parameter buffer: one fused kernel launch per step (mmh_adam_step)."""
+
+    def __init__(self, net, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        if net.flat_param is None:
+            net.flatten_parameters()
+        self.net = net
+        super().__init__([net.flat_param], dict(lr=lr, betas=betas, eps=eps))
+        self.exp_avg = torch.zeros_like(net.flat_param)
+        self.exp_avg_sq = torch.zeros_like(net.flat_param)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.net.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
+                      g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
+                      self.grad_scale)
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class ImagePool:
+    """util/image_pool.py:14-34 on device tensors; host RNG is Python's ``random`` as there."""
+
+    def __init__(self, pool_size):
+        self.pool_size = pool_size
+        self.images = []
+
+    def query(self, images):
+        if self.pool_size == 0:
+            return images
+        out = []
+        for i in range(images.shape[0]):
+            img = images[i:i + 1]
+            if len(self.images) < self.pool_size:
+                self.images.append(img.clone())
+                out.append(img)
+            elif random.uniform(0, 1) > 0.5:
+                j = random.randint(0, self.pool_size - 1)
+                out.append(self.images[j])
+                self.images[j] = img.clone()
+            else:
+                out.append(img)
+        return torch.cat(out, 0)
+
+
+class GANLoss:
+    """models/network_utils.py:129-163: BCEWithLogits against a constant label, mean."""
+
+    def __call__(self, logits_nhwc, target_is_real):
+        return ops.BCEWithLogitsConstFn.apply(logits_nhwc, 1.0 if target_is_real else 0.0, 1.0)
+
+
+class L1PlusPerceptualLoss:
+    """losses/L1_plus_perceptualLoss.py:32-75 on NHWC tensors (3 channels padded to 4)."""
+    MEAN = (0.485, 0.456, 0.406)
+    STD = (0.229, 0.224, 0.225)
+
+    def __init__(self, lambda_L1, lambda_perceptual, vgg, percep_is_l1=1):
+        if percep_is_l1 != 1:
+            raise NotImplementedError("percep_is_l1=0 (MSE) is not on the shipped path")
+        self.lambda_L1, self.lambda_perceptual, self.vgg = lambda_L1, lambda_perceptual, vgg
+        dev = next(vgg.parameters()).device
+        sc = [0.5 / s for s in self.STD] + [0.0]
+        sh = [(0.5 - m) / s for m, s in zip(self.MEAN, self.STD)] + [0.0]
+        self.scale = torch.tensor(sc, dtype=torch.float32, device=dev)
+        self.shift = torch.tensor(sh, dtype=torch.float32, device=dev)
+
+    def features(self, x):
+        return self.vgg.forward_nhwc(ops.AffineActFn.apply(x, self.scale, self.shift, False))
+
+    def __call__(self, fake, real):
+        B, H, W, _ = fake.shape
+        loss_l1 = ops.L1MeanFn.apply(fake, real, self.lambda_L1, float(B * 3 * H * W))
+        f = self.features(fake)
+        with torch.no_grad():
+            r = self.features(real)
+        loss_p = ops.L1MeanFn.apply(f, r, self.lambda_perceptual, float(f.numel()))
+        return loss_l1 + loss_p, loss_l1, loss_p
+
+
+class _frozen:
+    """Run a network with requires_grad off on its parameters (the G step back-propagates
+    *through* both discriminators but their weight gradients are never used:
+    models/MMHandModel.py:238-243 followed by zero_grad at :320,326)."""
+
+    def __init__(self, *nets):
+        self.ps = [p for n in nets for p in n.parameters()]
+
+    def __enter__(self):
+        self.old = [p.requires_grad for p in self.ps]
+        for p in self.ps:
+            p.requires_grad_(False)
+
+    def __exit__(self, *a):
+        for p, o in zip(self.ps, self.old):
+            p.requires_grad_(o)
+
+
+# ----------------------------------------------------------------------------- the model
+class MMHandModel(torch.nn.Module):
+    def name(self):
+        return "MMHandModel"
+
+    def __init__(self, opt):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError("MMHandModel needs an MI355X: the HIP path has no CPU fallback")
+        L.load()
+        self.opt = opt
+        self.gpu_ids = [opt.local_rank]
+        self.isTrain = opt.isTrain
+        self.device = torch.device("cuda", opt.local_rank)
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.master = opt.local_rank == 0 and (not dist.is_initialized() or dist.get_rank() == 0)
+        self.overflow = False
+        self.world = dist.get_world_size() if (getattr(opt, "distributed", False)
+                                               and dist.is_initialized()) else 1
+        seed = getattr(opt, "seed", 49)
+        norm = get_norm_layer(opt.norm)
+        input_nc = [opt.H_input_nc, opt.P_input_nc * 2, opt.D_input_nc * 2]
+        self.netG = Generator(input_nc, opt.output_nc, opt.ngf, norm, not opt.no_dropout,
+                              n_blocks=getattr(opt, "G_n_blocks", 9),
+                              n_downsampling=opt.G_n_downsampling)
+        self.netG.to(self.device).init_weights(opt.init_type, seed)
+        nets = [self.netG]
+        if self.isTrain:
+            self.netD_PB = Discriminator(opt.H_input_nc + opt.P_input_nc, opt.ndf, norm,
+                                         not opt.no_dropout_D, opt.n_layers_D,
+                                         n_downsampling=opt.D_n_downsampling)
+            self.netD_PP = Discriminator(opt.H_input_nc + opt.H_input_nc, opt.ndf, norm,
+                                         not opt.no_dropout_D, opt.n_layers_D,
+                                         n_downsampling=opt.D_n_downsampling)
+            self.netD_PB.to(self.device).init_weights(opt.init_type, seed + 1)
+            self.netD_PP.to(self.device).init_weights(opt.init_type, seed + 2)
+            nets += [self.netD_PB, self.netD_PP]
+        if not self.isTrain or opt.continue_train:
+            self.load_network()
+        for n in nets:
+            n.flatten_parameters()
+
+        if self.isTrain:
+            self.old_lr = opt.lr
+            self.fake_PP_pool = ImagePool(opt.pool_size)
+            self.fake_PB_pool = ImagePool(opt.pool_size)
+            self.criterionGAN = GANLoss()
+            if opt.L1_type == "l1_plus_perL1":
+                self.vgg = VGGHead().to(self.device)
+                vgg_path = getattr(opt, "vgg_weights", None)
+                if vgg_path:
+                    self.vgg.load_state_dict(torch.load(vgg_path, map_location="cpu"))
+                else:
+                    self.vgg.init_random()     # torchvision weights are not shipped offline
+                self.criterionL1 = L1PlusPerceptualLoss(opt.lambda_A, opt.lambda_B, self.vgg,
+                                                        opt.percep_is_l1)
+            elif opt.L1_type == "origin":
+                self.vgg = None
+                self.criterionL1 = None
+            else:
+                raise Exception("Unsurportted type of L1!")
+            betas = (opt.beta1, 0.999)
+            self.optimizer_G = FlatAdam(self.netG, opt.lr, betas)
+            self.optimizer_D_PB = FlatAdam(self.netD_PB, opt.lr, betas)
+            self.optimizer_D_PP = FlatAdam(self.netD_PP, opt.lr, betas)
+            self.optimizers = [self.optimizer_G, self.optimizer_D_PB, self.optimizer_D_PP]
+            self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
+            if self.world > 1:
+                self._init_data_parallel()
+        self.comm_stream = torch.cuda.Stream(self.device) if self.world > 1 else None
+        self._pending = None
+
+    # ------------------------------------------------------------------ data parallel
+    def _init_data_parallel(self):
+        """apex DDP(delay_allreduce=True)+convert_syncbn_model (models/MMHandModel.py:99-116):
+        broadcast rank-0 parameters once; gradients are averaged per backward; batch-norm
+        statistics are taken over the global batch."""
+        for net in (self.netG, self.netD_PB, self.netD_PP):
+            dist.broadcast(net.flat_param, 0)
+            for b in net.buffers():
+                dist.broadcast(b, 0)
+            if net.norm == "batch":
+                net.sync_group = dist.group.WORLD
+        for o in self.optimizers:
+            o.grad_scale = 1.0 / self.world
+
+    def _allreduce_async(self, net):
+        """One RCCL all-reduce(SUM) of the flat gradient buffer on the side stream; the 1/world
+        factor is folded into the Adam kernel."""
+        if self.world == 1:
+            return None
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            return dist.all_reduce(net.flat_grad, async_op=True)
+
+    @staticmethod
+    def _wait(work):
+        if work is not None:
+            work.wait()
+
+    # ------------------------------------------------------------------ input
+    def set_input(self, input):
+        dev = self.device
+        t = {k: input[k].to(dev, non_blocking=True).float() for k in ("H1", "P1", "D1", "H2", "P2", "D2")}
+        self.input_H1, self.input_P1, self.input_D1 = t["H1"], t["P1"], t["D1"]
+        self.input_H2, self.input_P2, self.input_D2 = t["H2"], t["P2"], t["D2"]
+        o = self.opt
+        B, _, H, W = t["H1"].shape
+        hc, pc, dc = o.H_input_nc, o.P_input_nc, o.D_input_nc
+        # NHWC packs: concat + zero-pad to multiples of 4 in one kernel each
+        self.x_H1 = ops.raw_pack([(t["H1"], True, hc)], B, H, W, pad4(hc), dev)
+        self.x_P = ops.raw_pack([(t["P1"], True, pc), (t["P2"], True, pc)], B, H, W, pad4(2 * pc), dev)
+        self.x_D = ops.raw_pack([(t["D1"], True, dc), (t["D2"], True, dc)], B, H, W, pad4(2 * dc), dev)
+        self.x_H2 = ops.raw_pack([(t["H2"], True, hc)], B, H, W, pad4(hc), dev)
+        if "H1_path" in input:
+            self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
+
+    def forward(self):
+        self.fake_nhwc = self.netG.forward_nhwc(self.x_H1, self.x_P, self.x_D)
+        self.fake_p2 = ops.nhwc_to_nchw_view(self.fake_nhwc, self.opt.output_nc)
+
+    def test(self):
+        with torch.no_grad():
+            self.forward()
+
+    def get_image_paths(self):
+        return self.image_paths
+
+    def _cat_PB(self, img_nhwc, img_is_fake):
+        """cat(image, P2) -> NHWC [B,H,W,24]."""
+        o = self.opt
+        B, H, W, _ = img_nhwc.shape
+        return ops.PackFn.apply(pad4(o.H_input_nc + o.P_input_nc), img_nhwc, False, o.H_input_nc,
+                                self.input_P2, True, o.P_input_nc)
+
+    def _cat_PP(self, img_nhwc):
+        """cat(image, H1) -> NHWC [B,H,W,8] (6 real channels)."""
+        o = self.opt
+        return ops.PackFn.apply(pad4(2 * o.H_input_nc), img_nhwc, False, o.H_input_nc,
+                                self.input_H1, True, o.H_input_nc)
+
+    # ------------------------------------------------------------------ G
+    def backward_G(self):
+        o = self.opt
+        with _frozen(self.netD_PB, self.netD_PP):
+            pred_fake_PB = self.netD_PB.forward_nhwc(self._cat_PB(self.fake_nhwc, True))
+            self.loss_G_GAN_PB = self.criterionGAN(pred_fake_PB, True)
+            pred_fake_PP = self.netD_PP.forward_nhwc(self._cat_PP(self.fake_nhwc))
+            self.loss_G_GAN_PP = self.criterionGAN(pred_fake_PP, True)
+            if self.criterionL1 is not None:
+                losses = self.criterionL1(self.fake_nhwc, self.x_H2)
+            else:
+                B, H, W, _ = self.fake_nhwc.shape
+                l1 = ops.L1MeanFn.apply(self.fake_nhwc, self.x_H2, 1.0, float(B * 3 * H * W))
+                losses = (l1, l1.detach(), torch.zeros_like(l1))
+            self.loss_G_L1 = losses[0]
+            self.loss_originL1 = losses[1].detach()
+            self.loss_perceptual = losses[2].detach()
+            pair_L1loss = self.loss_G_L1
+            pair_GANloss = (self.loss_G_GAN_PB * o.lambda_GAN + self.loss_G_GAN_PP * o.lambda_GAN) / 2
+            pair_loss = pair_L1loss + pair_GANloss
+            pair_loss.backward()
+        self.pair_L1loss = pair_L1loss.detach()
+        self.pair_GANloss = pair_GANloss.detach()
+
+    # ------------------------------------------------------------------ D
+    def backward_D_basic(self, netD, real, fake):
+        o = self.opt
+        pred_real = netD.forward_nhwc(real)
+        loss_D_real = self.criterionGAN(pred_real, True) * o.lambda_GAN
+        pred_fake = netD.forward_nhwc(fake.detach())
+        loss_D_fake = self.criterionGAN(pred_fake, False) * o.lambda_GAN
+        loss_D = (loss_D_real + loss_D_fake) * 0.5
+        loss_D.backward()
+        return loss_D
+
+    def backward_D_PB(self):
+        o = self.opt
+        B, _, H, W = self.input_H2.shape
+        real_PB = ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_P2, True, o.P_input_nc)],
+                               B, H, W, pad4(o.H_input_nc + o.P_input_nc), self.device)
+        with torch.no_grad():
+            fake_now = self._cat_PB(self.fake_nhwc.detach(), True)
+        fake_PB = self.fake_PB_pool.query(fake_now)
+        self.loss_D_PB = self.backward_D_basic(self.netD_PB, real_PB, fake_PB).detach()
+
+    def backward_D_PP(self):
+        o = self.opt
+        B, _, H, W = self.input_H2.shape
+        real_PP = ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_H1, True, o.H_input_nc)],
+                               B, H, W, pad4(2 * o.H_input_nc), self.device)
+        with torch.no_grad():
+            fake_now = self._cat_PP(self.fake_nhwc.detach())
+        fake_PP = self.fake_PP_pool.query(fake_now)
+        self.loss_D_PP = self.backward_D_basic(self.netD_PP, real_PP, fake_PP).detach()
+
+    # ------------------------------------------------------------------ the step
+    def optimize_parameters(self):
+        """models/MMHandModel.py:310-330.  Order of effects is the reference's; the generator's
+        gradient all-reduce and Adam are deferred behind the discriminator steps, which do not
+        read generator parameters."""
+        self.forward()
+        self.optimizer_G.zero_grad()
+        self.backward_G()
+        work_G = self._allreduce_async(self.netG)
+        if work_G is None:
+            self.optimizer_G.step()
+
+        for _ in range(self.opt.DG_ratio):
+            self.optimizer_D_PP.zero_grad()
+            self.backward_D_PP()
+            self._wait(self._allreduce_async(self.netD_PP))
+            self.optimizer_D_PP.step()
+
+        for _ in range(self.opt.DG_ratio):
+            self.optimizer_D_PB.zero_grad()
+            self.backward_D_PB()
+            self._wait(self._allreduce_async(self.netD_PB))
+            self.optimizer_D_PB.step()
+
+        if work_G is not None:
+            self._wait(work_G)
+            self.optimizer_G.step()
+        self.overflow = False
+
+    # ------------------------------------------------------------------ reporting / io
+    def get_current_errors(self):
+        return OrderedDict([("pair_L1loss", self.pair_L1loss), ("D_PP", self.loss_D_PP),
+                            ("D_PB", self.loss_D_PB), ("pair_GANloss", self.pair_GANloss),
+                            ("origin_L1", self.loss_originL1), ("perceptual", self.loss_perceptual)])
+
+    def get_current_visuals(self):
+        """H1 | P1 | D1 | H2 | P2 | D2 | fake strip as uint8 HxWx3 arrays
+        (models/MMHandModel.py:343-369; pose panels are the max over the 21 maps)."""
+        import numpy as np
+
+        def im(t):
+            a = t[0].detach().float().cpu().numpy()
+            if a.shape[0] == 1:
+                a = np.tile(a, (3, 1, 1))
+            return ((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0).clip(0, 255).astype(np.uint8)
+
+        def pose(t):
+            a = t[0].detach().float().max(0)[0].cpu().numpy()
+            return (np.stack([a] * 3, -1) * 255).clip(0, 255).astype(np.uint8)
+
+        panels = [im(self.input_H1), pose(self.input_P1), im(self.input_D1), im(self.input_H2),
+                  pose(self.input_P2), im(self.input_D2), im(self.fake_p2)]
+        return OrderedDict([("vis", np.concatenate(panels, 1))])
+
+    def save_network(self, network, network_label, epoch_label, gpu_ids=None):
+        if self.master:
+            os.makedirs(self.save_dir, exist_ok=True)
+            path = os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch_label, network_label))
+            torch.save(OrderedDict((k, v.cpu()) for k, v in network.state_dict().items()), path)
+
+    def save(self, label):
+        self.save_network(self.netG, "netG", label, self.gpu_ids)
+        self.save_network(self.netD_PB, "netD_PB", label, self.gpu_ids)
+        self.save_network(self.netD_PP, "netD_PP", label, self.gpu_ids)
+
+    def load_network(self):
+        """models/base_model.py:60-80: load every <which_epoch>_net_<name>.pth in the run dir."""
+        opt = self.opt
+        d = os.path.join(opt.checkpoints_dir, opt.name)
+        for fn in sorted(os.listdir(d)):
+            if opt.which_epoch not in fn or not fn.endswith(".pth") or "amp" in fn:
+                continue
+            name = fn[:-4].replace(f"{opt.which_epoch}_net_", "")
+            sub = getattr(self, name, None)
+            if sub is None:
+                continue
+            sub.load_state_dict(torch.load(os.path.join(d, fn), map_location="cpu"))
+            self.pprint(f"loading weights for {name}")
+
+    def update_learning_rate(self):
+        for scheduler in self.schedulers:
+            scheduler.step()
+        lr = self.optimizers[0].param_groups[0]["lr"]
+        self.pprint("learning rate = %.7f" % lr)
+
+    def pprint(self, msg):
+        if self.master:
+            print(msg)

@@ -1,0 +1,311 @@
+"""Generate the golden fixtures from the REAL reference (run in the build container only:
+needs /root/reference; nothing of the reference is copied, only its outputs are stored).
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz|json.  For each fixture the reference's own leaf modules
+(models/Generator.py, models/Discriminator.py, models/network_utils.py GANLoss,
+losses/L1_plus_perceptualLoss.py forward, util/image_pool.py, data/generic_dataset.py
+gaussian_kernel/gen_heatmap, util/util.py map_to_cord) are imported unmodified and driven with
+the deterministic weights of recipe.py.  Import-only stubs stand in for absent third-party
+modules (cv2, easydict, skimage, torchvision, apex) exactly as SURVEY.md §8(c) describes; they
+provide no arithmetic.  MMHandModel itself cannot be imported (apex + CUDA asserts), so the
+step fixture drives the reference leaf modules with the ~40 lines of orchestration of
+models/MMHandModel.py:215-330 restated here.
+"""
+import json
+import os
+import random
+import sys
+import types
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+# ---- import-only stubs for absent third-party packages
+for name in ("cv2", "easydict", "skimage", "skimage.draw", "torchvision", "torchvision.models",
+             "apex", "apex.amp", "apex.parallel"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["cv2"].cv2 = sys.modules["cv2"]
+sys.modules["easydict"].EasyDict = dict
+for n in ("circle", "line_aa", "polygon"):
+    setattr(sys.modules["skimage.draw"], n, None)
+sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+
+from models.Generator import Generator as RefG            # noqa: E402
+from models.Discriminator import Discriminator as RefD    # noqa: E402
+from models.network_utils import GANLoss as RefGANLoss, get_norm_layer as ref_norm  # noqa: E402
+from losses.L1_plus_perceptualLoss import L1_plus_perceptualLoss as RefL1P          # noqa: E402
+from util.image_pool import ImagePool as RefPool          # noqa: E402
+
+from tests.golden import recipe as RC                     # noqa: E402
+from oracle import mmhand_ref as O                        # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def shapes(sd):
+    return OrderedDict((k, list(v.shape)) for k, v in sd.items())
+
+
+def np_sd(sd, prefix):
+    return {prefix + k: v.detach().numpy() for k, v in sd.items()}
+
+
+def ref_criterion(vgg_sd, lam_a=10.0, lam_b=10.0):
+    """L1_plus_perceptualLoss without torchvision / DataParallel."""
+    crit = object.__new__(RefL1P)
+    nn.Module.__init__(crit)
+    crit.lambda_L1, crit.lambda_perceptual, crit.percep_is_l1, crit.gpu_ids = lam_a, lam_b, 1, ["cpu"]
+    vgg = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1),
+                        nn.ReLU())
+    vgg.load_state_dict(vgg_sd)
+    crit.vgg_submodel = vgg
+    return crit
+
+
+def inject_masks(net, masks):
+    """Replace each nn.Dropout forward by x*mask*2 with the recipe's mask for that site."""
+    for name, m in net.named_modules():
+        if isinstance(m, nn.Dropout):
+            site = name.rsplit(".", 1)[0]
+            m.forward = (lambda s: (lambda x: x * masks_for(masks, s, x) * 2.0))(site)
+
+
+def masks_for(masks, site, x):
+    if site not in masks:
+        masks[site] = RC.keep_mask(site, tuple(x.shape))
+    return masks[site].to(x.dtype)
+
+
+def make_keys():
+    out = {}
+    for norm in ("batch", "instance"):
+        nl = ref_norm(norm)
+        g = RefG([3, 42, 6], 3, 64, nl, True, 9)
+        dpb = RefD(24, 64, nl, True, 3)
+        dpp = RefD(6, 64, nl, True, 3)
+        out[norm] = {"G": shapes(g.state_dict()), "D_PB": shapes(dpb.state_dict()),
+                     "D_PP": shapes(dpp.state_dict()),
+                     "G_params": sum(p.numel() for p in g.parameters()),
+                     "D_PB_params": sum(p.numel() for p in dpb.parameters()),
+                     "D_PP_params": sum(p.numel() for p in dpp.parameters())}
+        gn = RefG([3, 42, 6], 3, 64, nl, False, 9)
+        out[norm]["G_nodrop"] = shapes(gn.state_dict())
+    json.dump(out, open(os.path.join(HERE, "keys.json"), "w"))
+    print("keys.json", {k: (len(v["G"]), v["G_params"]) for k, v in out.items()})
+
+
+def small_inputs(tag):
+    S = RC.SMALL
+    B, H, W = S["B"], S["H"], S["W"]
+    batch = O.synthetic_batch(B, H, W, seed=49)
+    return batch
+
+
+def make_generator():
+    S = RC.SMALL
+    batch = small_inputs("gen")
+    g_in = [batch["H1"], torch.cat((batch["P1"], batch["P2"]), 1), torch.cat((batch["D1"], batch["D2"]), 1)]
+    for norm in ("batch", "instance"):
+        for drop in (False, True):
+            net = RefG([3, 42, 6], 3, S["ngf"], ref_norm(norm), drop, S["n_blocks"])
+            sd = RC.recipe_state_dict(shapes(net.state_dict()))
+            net.load_state_dict(sd)
+            net.train()
+            masks = {}
+            if drop:
+                inject_masks(net, masks)
+            out = net(g_in)
+            probe = RC.randn("gen.probe", tuple(out.shape))
+            (out * probe).sum().backward()
+            grads = {"grad." + k: p.grad.numpy() for k, p in net.named_parameters()}
+            bufs = {"after." + k: v.numpy() for k, v in net.state_dict().items() if "running" in k}
+            # oracle must agree with the reference
+            onet = O._Net(sd, norm, drop)
+            oout = O.generator_forward(onet, g_in, S["n_blocks"], masks=masks if drop else None)
+            err = (oout - out).abs().max().item()
+            assert err < 1e-5, ("oracle generator mismatch", norm, drop, err)
+            (oout * probe).sum().backward()
+            for k, p in net.named_parameters():
+                ge = (onet.sd[k].grad - p.grad).abs().max().item()
+                assert ge < 1e-4 * max(1.0, p.grad.abs().max().item()), ("oracle grad mismatch", k, ge)
+            fn = os.path.join(HERE, f"gen_{norm}_{'drop' if drop else 'nodrop'}.npz")
+            np.savez_compressed(fn, out=out.detach().numpy(), probe=probe.numpy(),
+                                **{"mask." + k: v.numpy() for k, v in masks.items()}, **grads, **bufs)
+            print(os.path.basename(fn), "out", tuple(out.shape), "oracle max err", err)
+
+
+def make_discriminator():
+    S = RC.SMALL
+    for norm in ("batch", "instance"):
+        for cin in (24, 6):
+            net = RefD(cin, S["ndf"], ref_norm(norm), True, S["n_layers_D"])
+            sd = RC.recipe_state_dict(shapes(net.state_dict()))
+            net.load_state_dict(sd)
+            net.train()
+            masks = {}
+            inject_masks(net, masks)
+            x = RC.rand(f"disc.x{cin}", (S["B"], cin, S["H"], S["W"])).requires_grad_(True)
+            out = net(x)
+            probe = RC.randn("disc.probe", tuple(out.shape))
+            (out * probe).sum().backward()
+            onet = O._Net(sd, norm, True)
+            xo = x.detach().clone().requires_grad_(True)
+            oout = O.discriminator_forward(onet, xo, S["n_layers_D"], masks=masks)
+            err = (oout - out).abs().max().item()
+            assert err < 1e-5, ("oracle discriminator mismatch", norm, cin, err)
+            (oout * probe).sum().backward()
+            assert (xo.grad - x.grad).abs().max().item() < 1e-4
+            grads = {"grad." + k: p.grad.numpy() for k, p in net.named_parameters()}
+            fn = os.path.join(HERE, f"disc_{norm}_{cin}.npz")
+            np.savez_compressed(fn, x=x.detach().numpy(), out=out.detach().numpy(), probe=probe.numpy(),
+                                dx=x.grad.numpy(), **{"mask." + k: v.numpy() for k, v in masks.items()},
+                                **grads)
+            print(os.path.basename(fn), "out", tuple(out.shape), "oracle max err", err)
+
+
+def make_losses():
+    S = RC.SMALL
+    crit_gan = RefGANLoss(use_lsgan=False, gpu="cpu")
+    logits = RC.randn("loss.logits", (2, 32, 8, 8)) * 2
+    vgg_sd = RC.vgg_recipe()
+    crit = ref_criterion(vgg_sd)
+    fake = torch.tanh(RC.randn("loss.fake", (2, 3, 32, 32))).requires_grad_(True)
+    real = RC.rand("loss.real", (2, 3, 32, 32))
+    tot, l1, lp = crit(fake, real)
+    tot.backward()
+    ot, ol1, olp = O.l1_plus_perceptual(vgg_sd, fake.detach(), real, 10.0, 10.0)
+    assert abs(float(ot) - float(tot)) < 1e-5 and abs(float(olp) - float(lp)) < 1e-5
+    assert abs(float(O.gan_loss(logits, True)) - float(crit_gan(logits, True))) < 1e-6
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), logits=logits.numpy(),
+                        gan_real=float(crit_gan(logits, True)), gan_fake=float(crit_gan(logits, False)),
+                        fake=fake.detach().numpy(), real=real.numpy(), total=float(tot), l1=float(l1),
+                        perceptual=float(lp), dfake=fake.grad.numpy())
+    print("losses.npz", float(tot), float(l1), float(lp))
+
+
+def make_adam():
+    p = RC.randn("adam.p", (1000,)).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=2e-4, betas=(0.5, 0.999))
+    grads, ps = [], []
+    for i in range(3):
+        g = RC.randn(f"adam.g{i}", (1000,)) * (10.0 ** (i - 1))
+        p.grad = g.clone()
+        opt.step()
+        grads.append(g.numpy())
+        ps.append(p.detach().numpy().copy())
+    np.savez_compressed(os.path.join(HERE, "adam.npz"), p0=RC.randn("adam.p", (1000,)).numpy(),
+                        grads=np.stack(grads), ps=np.stack(ps))
+    print("adam.npz")
+
+
+def make_pose():
+    from data.generic_dataset import Genericdataset
+    from util.util import map_to_cord as ref_map_to_cord
+    H = W = 64
+    rs = np.random.RandomState(49)
+    uvs = rs.uniform(4, 60, size=(3, 21, 2))
+    uvs[0, 0] = (10.0, 20.0)          # exact integer centre -> value 1.0 at the peak
+    uvs[0, 1] = (-30.0, -30.0)        # off-image joint -> all-zero map -> MISSING (-1)
+    uvs[0, 2] = (63.0, 0.0)           # corner
+    maps, cords = [], []
+
+    class _D:                           # gen_heatmap only needs self.gaussian_kernel
+        gaussian_kernel = staticmethod(Genericdataset.gaussian_kernel)
+    for uv in uvs:
+        m = np.stack([Genericdataset.gen_heatmap(_D, x, y, (H, W), 6).astype(np.float32) for x, y in uv])
+        om = O.pose_heatmaps(uv, H, W)
+        assert np.array_equal(m, om), "oracle pose map mismatch"
+        c = ref_map_to_cord(np.transpose(m, (1, 2, 0)))
+        assert np.array_equal(c, O.map_to_cord(np.transpose(m, (1, 2, 0)))), "oracle map_to_cord mismatch"
+        maps.append(m)
+        cords.append(c)
+    np.savez_compressed(os.path.join(HERE, "pose.npz"), uv=uvs, maps=np.stack(maps),
+                        cords=np.stack(cords).astype(np.int64))
+    print("pose.npz", np.stack(maps).shape, "nonzero frac", float((np.stack(maps) > 0).mean()))
+
+
+def make_step():
+    """3 iterations of optimize_parameters on the reference leaf modules (batch & instance norm,
+    dropout off: --no_dropout --no_dropout_D, the parity configuration of SURVEY.md §7)."""
+    S = RC.SMALL
+    lam_a, lam_b, lam_g, lr, beta1, pool = 10.0, 10.0, 5.0, 2e-4, 0.5, 2
+    for norm in ("batch", "instance"):
+        nl = ref_norm(norm)
+        G = RefG([3, 42, 6], 3, S["ngf"], nl, False, S["n_blocks"])
+        DPB = RefD(24, S["ndf"], nl, False, S["n_layers_D"])
+        DPP = RefD(6, S["ndf"], nl, False, S["n_layers_D"])
+        sds = []
+        for tag, net in (("G", G), ("DPB", DPB), ("DPP", DPP)):
+            sd = RC.recipe_state_dict(OrderedDict((tag + "/" + k, s) for k, s in shapes(net.state_dict()).items()))
+            sd = OrderedDict((k.split("/", 1)[1], v) for k, v in sd.items())
+            net.load_state_dict(sd)
+            net.train()
+            sds.append(sd)
+        vgg_sd = RC.vgg_recipe()
+        crit = ref_criterion(vgg_sd, lam_a, lam_b)
+        gan = RefGANLoss(use_lsgan=False, gpu="cpu")
+        oG = torch.optim.Adam(G.parameters(), lr=lr, betas=(beta1, 0.999))
+        oPB = torch.optim.Adam(DPB.parameters(), lr=lr, betas=(beta1, 0.999))
+        oPP = torch.optim.Adam(DPP.parameters(), lr=lr, betas=(beta1, 0.999))
+        random.seed(49)
+        pool_pp, pool_pb = RefPool(pool), RefPool(pool)
+        oracle = O.StepOracle(sds[0], sds[1], sds[2], vgg_sd, norm, False, False, S["n_blocks"],
+                              S["n_layers_D"], lr, beta1, lam_a, lam_b, lam_g, pool,
+                              rng=random.Random(49))
+        trace = []
+        for it in range(3):
+            b = O.synthetic_batch(S["B"], S["H"], S["W"], seed=100 + it)
+            fake = G([b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)])
+            oG.zero_grad()
+            l_pb = gan(DPB(torch.cat((fake, b["P2"]), 1)), True)
+            l_pp = gan(DPP(torch.cat((fake, b["H1"]), 1)), True)
+            tot, l1, lp = crit(fake, b["H2"])
+            pair_gan = (l_pb * lam_g + l_pp * lam_g) / 2
+            (tot + pair_gan).backward()
+            oG.step()
+
+            def dstep(D, opt, pl, real, fk):
+                opt.zero_grad()
+                fq = pl.query(fk.data)
+                loss = (gan(D(real), True) * lam_g + gan(D(fq.detach()), False) * lam_g) * 0.5
+                loss.backward()
+                opt.step()
+                return float(loss)
+            d_pp = dstep(DPP, oPP, pool_pp, torch.cat((b["H2"], b["H1"]), 1), torch.cat((fake, b["H1"]), 1))
+            d_pb = dstep(DPB, oPB, pool_pb, torch.cat((b["H2"], b["P2"]), 1), torch.cat((fake, b["P2"]), 1))
+            row = [float(tot), d_pp, d_pb, float(pair_gan), float(l1), float(lp)]
+            orow = list(oracle.step(b).values())
+            assert np.allclose(row, orow, rtol=2e-4, atol=1e-6), ("oracle step mismatch", it, row, orow)
+            trace.append(row)
+        final = {}
+        for tag, net in (("G", G), ("DPB", DPB), ("DPP", DPP)):
+            for k, v in net.state_dict().items():
+                final[f"{tag}/{k}"] = v.numpy()
+        # oracle end state must match too
+        for tag, onet, net in (("G", oracle.G, G), ("DPB", oracle.DPB, DPB), ("DPP", oracle.DPP, DPP)):
+            for k, v in net.state_dict().items():
+                if v.is_floating_point() and not RC.is_null_grad_bias(tag, k, norm):
+                    d = (onet.sd[k].detach() - v).abs().max().item()
+                    assert d < 5e-4, ("oracle end-state mismatch", tag, k, d)
+        np.savez_compressed(os.path.join(HERE, f"step_{norm}.npz"), losses=np.array(trace),
+                            fake_last=fake.detach().numpy(), **final)
+        print(f"step_{norm}.npz", np.array(trace))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "adam", "pose", "step"]
+    for w in which:
+        globals()["make_" + w]()

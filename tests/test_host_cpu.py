@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: the C-ABI library exports, the options surface, the
+checkpoint (state_dict) contract of the drop-in networks."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from mmhand_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mmhand_amd", "csrc")])
+    return lib
+
+
+def test_abi_exports_every_declared_symbol(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "mmhand_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mmh_[a-z0-9_]+)\s*\(", hdr, flags=re.I))
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert len(declared) >= 30
+    assert declared == set(built_lib.SIGNATURES), declared ^ set(built_lib.SIGNATURES)
+    cdll = ctypes.CDLL(built_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(cdll, name), name
+    assert built_lib.load().mmh_version() >= 100
+
+
+def test_abi_rejects_bad_arguments_without_gpu(built_lib):
+    """Argument validation happens before any launch, so it is testable on the CPU."""
+    l = built_lib.load()
+    d = built_lib.ConvDesc(1, 8, 8, 3, 8, 3, 3, 1, 1, 0, 8, 8, 3, 8, 0)   # Cin=3 not %4
+    assert l.mmh_conv2d_fprop(ctypes.byref(d), None, None, None, None, 0, None) != 0
+    assert b"multiples of 4" in l.mmh_last_error()
+    assert l.mmh_adam_step(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None) != 0
+
+
+def test_product_path_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mmhand_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_options_surface():
+    from mmhand_amd.options import TrainOptions, TestOptions
+    args = ("--dataroot ./datasets/stb_dataset/train --name x --lambda_GAN 5 --lambda_A 10 "
+            "--lambda_B 10 --no_lsgan --n_layers 3 --batchSize 3 --no_flip --nThreads 4 "
+            "--checkpoints_dir /tmp/mmh_ckpt --opt_level O1 --augmentation_ratio 1 "
+            "--augmentation_method GEN --dataset stb --save_latest_freq 400 --niter 100 "
+            "--niter_decay 0").split()     # scripts/mm-train-ratio.sh:19-40 without --distributed
+    opt = TrainOptions().parse(args, save=False)
+    assert opt.isTrain and opt.n_layers_D == 3 and opt.batchSize == 3 and opt.norm == "batch"
+    assert opt.lr == 2e-4 and opt.beta1 == 0.5 and opt.pool_size == 50 and opt.DG_ratio == 1
+    assert opt.H_input_nc == 3 and opt.P_input_nc == 21 and opt.D_input_nc == 3 and opt.seed == 49
+    assert opt.gpu_ids == [0] and not opt.no_dropout and not opt.no_dropout_D
+    t = TestOptions().parse(["--name", "x", "--checkpoints_dir", "/tmp/mmh_ckpt"], save=False)
+    assert not t.isTrain and t.how_many == 200
+
+
+def test_lambda_lr_rule():
+    from mmhand_amd.options import default_train_opt
+    from mmhand_amd.mmhand_model import get_scheduler
+    opt = default_train_opt(niter=2, niter_decay=2, epoch_count=1)
+    p = torch.zeros(1, requires_grad=True)
+    o = torch.optim.SGD([p], lr=1.0)
+    s = get_scheduler(o, opt)
+    lrs = []
+    for _ in range(4):
+        lrs.append(o.param_groups[0]["lr"])
+        o.step(); s.step()
+    assert np.allclose(lrs, [1.0, 1.0 - 1 / 3, 1.0 - 2 / 3, 0.0])
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_state_dict_contract_matches_reference(norm):
+    """Key names and logical shapes of the true-size networks == the reference's (keys.json
+    was dumped from the reference classes)."""
+    from mmhand_amd.networks import Generator, Discriminator
+    keys = json.load(open(os.path.join(G, "keys.json")))[norm]
+    g = Generator([3, 42, 6], 3, 64, norm, True, 9)
+    sd = g.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == keys["G"]
+    g2 = Generator([3, 42, 6], 3, 64, norm, False, 9)
+    assert {k: list(v.shape) for k, v in g2.state_dict().items()} == keys["G_nodrop"]
+    for cin, tag in ((24, "D_PB"), (6, "D_PP")):
+        d = Discriminator(cin, 64, norm, True, 3)
+        assert {k: list(v.shape) for k, v in d.state_dict().items()} == keys[tag]
+    # logical parameter count equals the reference's
+    n = sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k)
+    assert n == keys["G_params"]
+
+
+def test_state_dict_roundtrip_and_layout():
+    from mmhand_amd.networks import Generator
+    from tests.golden import recipe as RC
+    g = Generator([3, 42, 6], 3, 8, "batch", True, 2)
+    shapes = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    sd = RC.recipe_state_dict(shapes)
+    g.load_state_dict(sd)
+    back = g.state_dict()
+    for k in sd:
+        assert torch.equal(back[k], sd[k]), k
+    # physical layout: [kh,kw,Cin_pad,Cout]; pad lanes are zero
+    cp = g.model["stream1_down"][1]
+    assert tuple(cp.weight.shape) == (7, 7, 4, 8)
+    assert torch.equal(cp.weight[:, :, :3, :].permute(3, 2, 0, 1), sd["model.stream1_down.1.weight"])
+    assert float(cp.weight[:, :, 3, :].abs().sum()) == 0.0
+    up = g.model["stream1_up"][0]                      # ConvTranspose2d(32 -> 16): logical [32,16,3,3]
+    assert tuple(up.logical_weight().shape) == (32, 16, 3, 3) and tuple(up.weight.shape) == (3, 3, 16, 32)
+    with pytest.raises(RuntimeError):
+        bad = dict(sd); bad["model.stream1_down.1.weight"] = torch.zeros(8, 4, 7, 7)
+        g.load_state_dict(bad)
+
+
+def test_flat_parameter_views():
+    from mmhand_amd.networks import Discriminator
+    d = Discriminator(6, 8, "batch", False, 1).init_weights("normal", seed=1)
+    before = {k: v.clone() for k, v in d.state_dict().items()}
+    flat, gflat = d.flatten_parameters()
+    assert flat.numel() == sum(p.numel() for p in d.parameters())
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    flat.mul_(2.0)                                     # parameters are views of the flat buffer
+    assert torch.allclose(d.state_dict()["model.1.weight"], before["model.1.weight"] * 2)
+    p = next(d.parameters())
+    assert p.grad.data_ptr() == gflat.data_ptr()

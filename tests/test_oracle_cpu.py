@@ -1,0 +1,126 @@
+"""The CPU oracle against the golden vectors produced by the real reference modules
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import os
+import random
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmhand_ref as O
+from tests.golden import recipe as RC
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+S = RC.SMALL
+
+
+def _load(name):
+    return dict(np.load(os.path.join(G, name), allow_pickle=False))
+
+
+def _key_shapes(fix, prefix="grad."):
+    return OrderedDict((k[len(prefix):], v.shape) for k, v in fix.items() if k.startswith(prefix))
+
+
+def _full_shapes(norm, ref_keys, c):
+    """state_dict shapes (params + BN buffers) for a small net from the param grads of a fixture."""
+    out = OrderedDict()
+    for k, s in ref_keys.items():
+        out[k] = s
+        if norm == "batch" and len(s) == 1 and k.endswith(".weight"):
+            base = k[:-len("weight")]
+            out[base + "running_mean"] = s
+            out[base + "running_var"] = s
+            out[base + "num_batches_tracked"] = ()
+    return out
+
+
+def _g_inputs():
+    b = O.synthetic_batch(S["B"], S["H"], S["W"], seed=49)
+    return [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+@pytest.mark.parametrize("drop", [False, True])
+def test_generator_matches_reference_fixture(norm, drop):
+    fix = _load(f"gen_{norm}_{'drop' if drop else 'nodrop'}.npz")
+    sd = RC.recipe_state_dict(_full_shapes(norm, _key_shapes(fix), None))
+    net = O._Net(sd, norm, drop)
+    masks = {k[5:]: torch.from_numpy(v) for k, v in fix.items() if k.startswith("mask.")}
+    out = O.generator_forward(net, _g_inputs(), S["n_blocks"], masks=masks if drop else None)
+    assert np.allclose(out.detach().numpy(), fix["out"], atol=1e-5)
+    (out * torch.from_numpy(fix["probe"])).sum().backward()
+    for k, t in net.named_parameters():
+        ref = fix["grad." + k]
+        assert np.allclose(t.grad.numpy(), ref, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(ref).max())), k
+    for k, v in fix.items():
+        if k.startswith("after."):
+            assert np.allclose(net.sd[k[6:]].numpy(), v, atol=1e-5), k
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+@pytest.mark.parametrize("cin", [24, 6])
+def test_discriminator_matches_reference_fixture(norm, cin):
+    fix = _load(f"disc_{norm}_{cin}.npz")
+    sd = RC.recipe_state_dict(_full_shapes(norm, _key_shapes(fix), None))
+    net = O._Net(sd, norm, True)
+    masks = {k[5:]: torch.from_numpy(v) for k, v in fix.items() if k.startswith("mask.")}
+    x = torch.from_numpy(fix["x"]).requires_grad_(True)
+    out = O.discriminator_forward(net, x, S["n_layers_D"], masks=masks)
+    assert np.allclose(out.detach().numpy(), fix["out"], atol=1e-5)
+    (out * torch.from_numpy(fix["probe"])).sum().backward()
+    assert np.allclose(x.grad.numpy(), fix["dx"], atol=1e-4)
+
+
+def test_losses_match_reference_fixture():
+    fix = _load("losses.npz")
+    logits = torch.from_numpy(fix["logits"])
+    assert abs(float(O.gan_loss(logits, True)) - float(fix["gan_real"])) < 1e-6
+    assert abs(float(O.gan_loss(logits, False)) - float(fix["gan_fake"])) < 1e-6
+    fake = torch.from_numpy(fix["fake"]).requires_grad_(True)
+    tot, l1, lp = O.l1_plus_perceptual(RC.vgg_recipe(), fake, torch.from_numpy(fix["real"]), 10.0, 10.0)
+    assert abs(float(tot) - float(fix["total"])) < 1e-5
+    assert abs(float(l1) - float(fix["l1"])) < 1e-6
+    assert abs(float(lp) - float(fix["perceptual"])) < 1e-5
+    tot.backward()
+    assert np.allclose(fake.grad.numpy(), fix["dfake"], atol=1e-7)
+
+
+def test_pose_maps_bit_exact():
+    fix = _load("pose.npz")
+    for uv, maps, cords in zip(fix["uv"], fix["maps"], fix["cords"]):
+        m = O.pose_heatmaps(uv, 64, 64)
+        assert np.array_equal(m, maps)                      # values and support mask, bit-exact
+        assert np.array_equal(O.map_to_cord(np.transpose(m, (1, 2, 0))), cords)
+    assert (fix["cords"][0][1] == -1).all()                 # off-image joint -> MISSING_VALUE
+    assert fix["maps"][0][0].max() == 1.0
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_step_trace_matches_reference_fixture(norm):
+    fix = _load(f"step_{norm}.npz")
+    sds = {}
+    for tag in ("G", "DPB", "DPP"):
+        shapes = OrderedDict((k, v.shape) for k, v in fix.items() if k.startswith(tag + "/"))
+        sd = RC.recipe_state_dict(shapes)
+        sds[tag] = OrderedDict((k.split("/", 1)[1], v) for k, v in sd.items())
+    orc = O.StepOracle(sds["G"], sds["DPB"], sds["DPP"], RC.vgg_recipe(), norm, False, False,
+                       S["n_blocks"], S["n_layers_D"], pool_size=2, rng=random.Random(49))
+    for it in range(3):
+        row = list(orc.step(O.synthetic_batch(S["B"], S["H"], S["W"], seed=100 + it)).values())
+        assert np.allclose(row, fix["losses"][it], rtol=2e-4, atol=1e-6), (it, row)
+    for tag, net in (("G", orc.G), ("DPB", orc.DPB), ("DPP", orc.DPP)):
+        for k, t in net.sd.items():
+            if t.is_floating_point() and not RC.is_null_grad_bias(tag, k, norm):
+                assert np.allclose(t.detach().numpy(), fix[f"{tag}/{k}"], atol=5e-4), (tag, k)
+
+
+def test_image_pool_semantics():
+    pool = O.ImagePoolRef(2, random.Random(3))
+    a = torch.arange(4.0).view(4, 1, 1, 1)
+    out1 = pool.query(a[:2])
+    assert torch.equal(out1, a[:2])                 # filling phase returns the inputs
+    out2 = pool.query(a[2:])
+    assert out2.shape == (2, 1, 1, 1)
+    assert set(out2.flatten().tolist()) <= {0.0, 1.0, 2.0, 3.0}
