@@ -1,0 +1,166 @@
+"""Module- and step-level GPU parity: the drop-in Generator / Discriminator / MMHandModel on the
+HIP kernels against (a) golden vectors produced by the reference's own modules and (b) the CPU
+oracle, on identical weights and inputs.  Bar: 1e-3 relative L1 (BASELINE.json north_star)."""
+import os
+import random
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmhand_ref as O
+from oracle import ops_ref as R
+from tests.golden import recipe as RC
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+S = RC.SMALL
+TOL = 1e-3
+
+
+def _load(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+def logical_grads(net):
+    """reference-format {key: grad} from the physical-layout parameter gradients."""
+    from mmhand_amd.networks import ConvParam, NormParam
+    out = {}
+    for name, m in net.named_modules():
+        if isinstance(m, ConvParam):
+            g = m.weight.grad.permute(3, 2, 0, 1)
+            out[name + ".weight"] = (g[: m.cin, : m.cout] if m.transposed else g[: m.cout, : m.cin]).cpu()
+            if m.bias is not None:
+                out[name + ".bias"] = m.bias.grad[: m.cout].cpu()
+        elif isinstance(m, NormParam):
+            out[name + ".weight"] = m.weight.grad.cpu()
+            out[name + ".bias"] = m.bias.grad.cpu()
+    return out
+
+
+def _masks_to_dev(fix, dev):
+    return {k[5:]: torch.from_numpy(v).permute(0, 2, 3, 1).contiguous().to(dev)
+            for k, v in fix.items() if k.startswith("mask.")}
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+@pytest.mark.parametrize("drop", [False, True])
+def test_generator_vs_reference_fixture(norm, drop, dev):
+    from mmhand_amd.networks import Generator
+    fix = _load(f"gen_{norm}_{'drop' if drop else 'nodrop'}.npz")
+    net = Generator([3, 42, 6], 3, S["ngf"], norm, drop, S["n_blocks"])
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    net.flatten_parameters()
+    if drop:
+        net._mask_src = _masks_to_dev(fix, dev)
+    b = O.synthetic_batch(S["B"], S["H"], S["W"], seed=49)
+    g_in = [b["H1"].to(dev), torch.cat((b["P1"], b["P2"]), 1).to(dev), torch.cat((b["D1"], b["D2"]), 1).to(dev)]
+    out = net(g_in)
+    assert tuple(out.shape) == (S["B"], 3, S["H"], S["W"])
+    assert R.rel_l1(out, torch.from_numpy(fix["out"])) < TOL
+    (out * torch.from_numpy(fix["probe"]).to(dev)).sum().backward()
+    grads = logical_grads(net)
+    worst = 0.0
+    for k, g in grads.items():
+        if RC.is_null_grad_bias("G", k, norm):
+            continue
+        worst = max(worst, R.rel_l1(g, torch.from_numpy(fix["grad." + k])))
+    assert worst < TOL, worst
+    for k, v in fix.items():
+        if k.startswith("after."):
+            assert np.allclose(net.state_dict()[k[6:]].cpu().numpy(), v, rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+@pytest.mark.parametrize("cin", [24, 6])
+def test_discriminator_vs_reference_fixture(norm, cin, dev):
+    from mmhand_amd.networks import Discriminator
+    fix = _load(f"disc_{norm}_{cin}.npz")
+    net = Discriminator(cin, S["ndf"], norm, True, S["n_layers_D"])
+    net.load_state_dict(RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    net.to(dev).train()
+    net._mask_src = _masks_to_dev(fix, dev)
+    x = torch.from_numpy(fix["x"]).to(dev).requires_grad_(True)
+    out = net(x)
+    assert R.rel_l1(out, torch.from_numpy(fix["out"])) < TOL
+    (out * torch.from_numpy(fix["probe"]).to(dev)).sum().backward()
+    assert R.rel_l1(x.grad, torch.from_numpy(fix["dx"])) < TOL
+    for k, g in logical_grads(net).items():
+        if not RC.is_null_grad_bias("DPB", k, norm):
+            assert R.rel_l1(g, torch.from_numpy(fix["grad." + k])) < TOL, k
+
+
+def test_generator_eval_mode_matches_oracle(dev):
+    """aug.py path: eval-mode BatchNorm (running stats) and no dropout."""
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, S["ngf"], "batch", True, S["n_blocks"])
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = RC.recipe_state_dict(shapes)
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=torch.Generator().manual_seed(1))
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(2))
+    net.load_state_dict(sd)
+    net.to(dev).eval()
+    b = O.synthetic_batch(1, S["H"], S["W"], seed=5)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    with torch.no_grad():
+        out = net([t.to(dev) for t in g_in])
+    onet = O._Net(sd, "batch", True); onet.training = False
+    ref = O.generator_forward(onet, g_in, S["n_blocks"])
+    assert R.rel_l1(out, ref) < TOL
+
+
+def _small_opt(norm, dev_index=0, **kw):
+    from mmhand_amd.options import default_train_opt
+    args = dict(batchSize=S["B"], ngf=S["ngf"], ndf=S["ndf"], n_layers_D=S["n_layers_D"],
+                G_n_blocks=S["n_blocks"], norm=norm, no_dropout=True, no_dropout_D=True,
+                pool_size=2, name="pytest", checkpoints_dir="/tmp/mmh_pytest_ckpt",
+                local_rank=dev_index)
+    args.update(kw)
+    return default_train_opt(**args)
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_optimize_parameters_vs_reference_trace(norm, dev):
+    """3 iterations of MMHandModel.optimize_parameters(): the six loss scalars per iteration and
+    the post-step weights / BN running stats against the trace produced by the reference modules."""
+    from mmhand_amd.mmhand_model import MMHandModel
+    fix = _load(f"step_{norm}.npz")
+    model = MMHandModel(_small_opt(norm))
+    for tag, net in (("G", model.netG), ("DPB", model.netD_PB), ("DPP", model.netD_PP)):
+        shapes = OrderedDict((f"{tag}/{k}", tuple(v.shape)) for k, v in net.state_dict().items())
+        sd = RC.recipe_state_dict(shapes)
+        net.load_state_dict(OrderedDict((k.split("/", 1)[1], v) for k, v in sd.items()))
+    model.vgg.load_state_dict(RC.vgg_recipe())
+    random.seed(49)
+    for it in range(3):
+        model.set_input(O.synthetic_batch(S["B"], S["H"], S["W"], seed=100 + it))
+        model.optimize_parameters()
+        row = [float(v) for v in model.get_current_errors().values()]
+        assert np.allclose(row, fix["losses"][it], rtol=1e-3), (it, row, fix["losses"][it])
+    assert R.rel_l1(model.fake_p2, torch.from_numpy(fix["fake_last"])) < TOL
+    for tag, net in (("G", model.netG), ("DPB", model.netD_PB), ("DPP", model.netD_PP)):
+        for k, v in net.state_dict().items():
+            if v.is_floating_point() and not RC.is_null_grad_bias(tag, k, norm):
+                ref = fix[f"{tag}/{k}"]
+                assert np.allclose(v.cpu().numpy(), ref, atol=6e-4 + 1e-3 * np.abs(ref).max()), (tag, k)
+
+
+def test_checkpoint_roundtrip(dev, tmp_path):
+    from mmhand_amd.mmhand_model import MMHandModel
+    opt = _small_opt("batch", checkpoints_dir=str(tmp_path))
+    m = MMHandModel(opt)
+    m.save("latest")
+    files = sorted(os.listdir(os.path.join(str(tmp_path), opt.name)))
+    assert files == ["latest_net_netD_PB.pth", "latest_net_netD_PP.pth", "latest_net_netG.pth"]
+    sd = torch.load(os.path.join(str(tmp_path), opt.name, "latest_net_netG.pth"))
+    assert sd["model.stream1_down.1.weight"].shape == (S["ngf"], 3, 7, 7)
+    opt2 = _small_opt("batch", checkpoints_dir=str(tmp_path), continue_train=True)
+    m2 = MMHandModel(opt2)
+    for k, v in m.netG.state_dict().items():
+        assert torch.equal(v.cpu(), m2.netG.state_dict()[k].cpu()), k

@@ -1,0 +1,192 @@
+"""GPU parity of the HBM-bound kernels (norm+relu+dropout fwd/bwd, gate, losses, Adam, pack,
+reflect fold, pose maps) against the CPU oracle, through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mmhand_ref as O
+from oracle import ops_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _mk(shape, seed, dev, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale + shift).to(dev)
+
+
+@pytest.mark.parametrize("mode", ["batch", "instance"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 16, 16, 64), (2, 64, 64, 256), (2, 5, 7, 512),
+                                   (2, 6, 6, 24)])
+@pytest.mark.parametrize("relu,drop", [(False, False), (True, False), (True, True)])
+def test_norm_act_fwd_bwd(mode, shape, relu, drop, dev):
+    from mmhand_amd import ops
+    B, H, W, C = shape
+    x = _mk(shape, 1, dev, 2.0, 3.0).requires_grad_(True)      # non-zero mean: exercises the shifted sums
+    gamma = _mk((C,), 2, dev, 0.1, 1.0).requires_grad_(True) if mode == "batch" else None
+    beta = _mk((C,), 3, dev, 0.1).requires_grad_(True) if mode == "batch" else None
+    rm = torch.zeros(C, device=dev) if mode == "batch" else None
+    rv = torch.ones(C, device=dev) if mode == "batch" else None
+    mask = (torch.rand(shape, generator=torch.Generator().manual_seed(5)) >= 0.5).to(torch.uint8).to(dev) if drop else None
+    out = ops.NormActFn.apply(x, gamma, beta, None, rm, rv, mode, relu, 0.5 if drop else 0.0, 0, mask, None)
+    dy = _mk(shape, 4, dev)
+    out.backward(dy)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    gc = gamma.detach().cpu().double().requires_grad_(True) if gamma is not None else None
+    bc = beta.detach().cpu().double().requires_grad_(True) if beta is not None else None
+    ref = R.norm_act(xc, gc, bc, mode, relu, None if mask is None else mask.cpu(), 0.5)
+    ref.backward(dy.cpu().double())
+    assert R.rel_l1(out, ref) < TOL
+    assert R.rel_l1(x.grad, xc.grad) < 5e-5
+    if mode == "batch":
+        # with ReLU a handful of elements sit within fp32 rounding of 0 and flip their mask
+        # relative to the fp64 oracle; each flip moves a channel sum by O(|dy|)
+        gtol = 5e-4 if relu else 5e-5
+        assert R.rel_l1(gamma.grad, gc.grad) < gtol
+        assert R.rel_l1(beta.grad, bc.grad) < gtol
+        xn = R.to_nchw(x.detach().cpu())
+        assert torch.allclose(rm.cpu(), 0.1 * xn.mean((0, 2, 3)), atol=1e-5)
+        assert torch.allclose(rv.cpu(), 0.9 + 0.1 * xn.transpose(0, 1).reshape(C, -1).var(1, unbiased=True), rtol=1e-4)
+
+
+def test_norm_residual(dev):
+    from mmhand_amd import ops
+    shape = (2, 8, 8, 32)
+    x = _mk(shape, 1, dev).requires_grad_(True)
+    res = _mk(shape, 2, dev).requires_grad_(True)
+    out = ops.NormActFn.apply(x, None, None, res, None, None, "instance", False, 0.0, 0, None, None)
+    dy = _mk(shape, 3, dev)
+    out.backward(dy)
+    ref = R.norm_act(x.detach().cpu(), None, None, "instance", False, residual=res.detach().cpu())
+    assert R.rel_l1(out, ref) < TOL
+    assert R.rel_l1(res.grad, dy) == 0.0
+
+
+def test_dropout_rng_statistics(dev):
+    """On-device counter-hash dropout: keep rate ~ 0.5, kept values scaled by 2, masks differ per seed."""
+    from mmhand_amd import ops
+    x = torch.ones((4, 32, 32, 64), device=dev)
+    one = torch.ones((1, 64), device=dev); zero = torch.zeros((1, 64), device=dev)
+    a = ops.raw_scale_shift_act(x, one, zero, None, True, 0.5, 123, None)
+    b = ops.raw_scale_shift_act(x, one, zero, None, True, 0.5, 124, None)
+    a2 = ops.raw_scale_shift_act(x, one, zero, None, True, 0.5, 123, None)
+    assert torch.equal(a, a2)
+    keep = (a > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    assert set(a.unique().tolist()) == {0.0, 2.0}
+    assert ((a > 0) != (b > 0)).float().mean().item() > 0.4
+
+
+def test_affine_act(dev):
+    from mmhand_amd import ops
+    x = _mk((2, 8, 8, 4), 1, dev).requires_grad_(True)
+    sc = torch.tensor([2.0, 3.0, -1.0, 0.0], device=dev); sh = torch.tensor([0.1, -0.2, 0.3, 0.0], device=dev)
+    y = ops.AffineActFn.apply(x, sc, sh, True)
+    dy = _mk((2, 8, 8, 4), 2, dev)
+    y.backward(dy)
+    xr = x.detach().cpu().requires_grad_(True)
+    yr = torch.relu(xr * sc.cpu() + sh.cpu())
+    yr.backward(dy.cpu())
+    assert R.rel_l1(y, yr) < TOL and R.rel_l1(x.grad, xr.grad) < TOL
+
+
+@pytest.mark.parametrize("want_cat", [True, False])
+def test_gate_fwd_bwd(want_cat, dev):
+    from mmhand_amd import ops
+    shape = (2, 8, 8, 32)
+    ts = [_mk(shape, i, dev).requires_grad_(True) for i in range(4)]
+    out, x2n, x3n = ops.GateFn.apply(*ts, want_cat)
+    cs = [t.detach().cpu().double().requires_grad_(True) for t in ts]
+    ro, r2, r3 = R.gate(*cs)
+    assert R.rel_l1(out, ro) < TOL
+    g0 = _mk(shape, 10, dev)
+    if want_cat:
+        assert R.rel_l1(x2n, r2) < TOL and R.rel_l1(x3n, r3) < TOL
+        g2 = _mk((2, 8, 8, 64), 11, dev); g3 = _mk((2, 8, 8, 64), 12, dev)
+        torch.autograd.backward([out, x2n, x3n], [g0, g2, g3])
+        torch.autograd.backward([ro, r2, r3], [g0.cpu().double(), g2.cpu().double(), g3.cpu().double()])
+    else:
+        out.backward(g0)
+        ro.backward(g0.cpu().double())
+    for t, c in zip(ts, cs):
+        assert R.rel_l1(t.grad, c.grad) < TOL
+
+
+def test_losses_vs_reference_fixture(dev):
+    """GANLoss and L1 against values produced by the reference's own GANLoss / F.l1_loss."""
+    from mmhand_amd import ops
+    fix = dict(np.load(os.path.join(G, "losses.npz")))
+    logits = torch.from_numpy(fix["logits"]).permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    real = ops.BCEWithLogitsConstFn.apply(logits, 1.0, 1.0)
+    fake = ops.BCEWithLogitsConstFn.apply(logits, 0.0, 1.0)
+    assert abs(real.item() - float(fix["gan_real"])) < 1e-5
+    assert abs(fake.item() - float(fix["gan_fake"])) < 1e-5
+    (real * 3.0).backward()
+    lc = torch.from_numpy(fix["logits"]).requires_grad_(True)
+    (O.gan_loss(lc, True) * 3.0).backward()
+    assert R.rel_l1(logits.grad.permute(0, 3, 1, 2), lc.grad) < TOL
+    a = _mk((2, 16, 16, 4), 1, dev).requires_grad_(True); b = _mk((2, 16, 16, 4), 2, dev)
+    l = ops.L1MeanFn.apply(a, b, 10.0, float(a.numel()))
+    l.backward()
+    ar = a.detach().cpu().requires_grad_(True)
+    lr = 10.0 * F.l1_loss(ar, b.cpu()); lr.backward()
+    assert abs(l.item() - lr.item()) < 1e-4 and R.rel_l1(a.grad, ar.grad) < TOL
+
+
+def test_adam_matches_torch_fixture(dev):
+    from mmhand_amd import ops
+    fix = dict(np.load(os.path.join(G, "adam.npz")))
+    p = torch.from_numpy(fix["p0"]).to(dev)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for i in range(3):
+        g = torch.from_numpy(fix["grads"][i]).to(dev)
+        ops.adam_step(p, g, m, v, 2e-4, 0.5, 0.999, 1e-8, i + 1)
+        assert np.allclose(p.cpu().numpy(), fix["ps"][i], rtol=1e-5, atol=1e-7), i
+
+
+def test_pack_unpack_concat(dev):
+    from mmhand_amd import ops
+    a = _mk((2, 3, 8, 10), 1, dev); b = _mk((2, 21, 8, 10), 2, dev)
+    nh = _mk((2, 8, 10, 4), 3, dev)
+    out = ops.raw_pack([(a, True, 3), (b, True, 21)], 2, 8, 10, 24, dev)
+    ref = torch.cat([a, b], 1).permute(0, 2, 3, 1)
+    assert torch.equal(out, ref.contiguous())
+    out2 = ops.raw_pack([(nh, False, 3), (a.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), True, 3)],
+                        2, 8, 10, 8, dev)      # NHWC source + non-contiguous NCHW source, zero padded
+    assert torch.equal(out2[..., :3], nh[..., :3]) and torch.equal(out2[..., 3:6], a.permute(0, 2, 3, 1))
+    assert float(out2[..., 6:].abs().sum()) == 0.0
+    x = nh.clone().requires_grad_(True)
+    y = ops.PackFn.apply(8, x, False, 3, a, True, 3)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad[..., :3], torch.ones_like(x.grad[..., :3])) and float(x.grad[..., 3].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("p,H,W", [(1, 8, 8), (3, 16, 12), (3, 5, 5), (1, 3, 4)])
+def test_reflect_fold_is_pad_transpose(p, H, W, dev):
+    from mmhand_amd import ops, lib as L
+    import ctypes as C
+    B, Cc = 2, 8
+    gp = _mk((B, H + 2 * p, W + 2 * p, Cc), 1, dev)
+    dx = torch.empty((B, H, W, Cc), device=dev)
+    L.call("mmh_reflect_fold", ops._ptr(gp), ops._ptr(dx), B, H, W, Cc, p, ops._stream())
+    x = torch.zeros((B, Cc, H, W), dtype=torch.float64, requires_grad=True)
+    F.pad(x, (p,) * 4, mode="reflect").backward(gp.cpu().double().permute(0, 3, 1, 2))
+    assert R.rel_l1(dx.permute(0, 3, 1, 2), x.grad) < 1e-6
+
+
+def test_pose_maps_bit_exact_vs_reference_fixture(dev):
+    """a15: support mask and arg-max indices bit-exact, values within 1 ulp (fp32)."""
+    from mmhand_amd import ops
+    fix = dict(np.load(os.path.join(G, "pose.npz")))
+    for uv, maps, cords in zip(fix["uv"], fix["maps"], fix["cords"]):
+        out = ops.pose_heatmaps(torch.from_numpy(uv).to(dev), 64, 64).cpu().numpy()
+        assert np.array_equal(out > 0, maps > 0)
+        ulp = np.abs(out.view(np.int32).astype(np.int64) - maps.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+        c = ops.map_to_cord(torch.from_numpy(maps).to(dev)).cpu().numpy()
+        assert np.array_equal(c, cords)
