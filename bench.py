@@ -1,0 +1,176 @@
+"""Headline benchmark: 256x256 hand images/s for one full G+D step (optimize_parameters).
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): RHD-shaped synthetic batch, 256x256, per-GPU batch 32, fp32,
+Generator (9 PATBlocks, ngf 64) + D_PB + D_PP + L1/perceptual/GAN losses + 3 Adams, dropout on,
+--norm instance (north_star; --norm batch is the reference's script default).  One process per
+GPU; with N>1 the global batch is sharded (weak scaling) and G/D gradients are all-reduced over
+RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE_STEP = 2444.4       # algorithmic conv FLOPs of one G+D step
+PEAK_F32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def synthetic_batch_gpu(B, H, W, seed, dev):
+    """SURVEY.md §8(d) synthetic inputs generated on the device (pose maps by the HIP kernel)."""
+    from mmhand_amd import ops
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = {}
+    for s in ("1", "2"):
+        out["H" + s] = torch.rand((B, 3, H, W), generator=g, device=dev) * 2 - 1
+        uv = (torch.rand((B * 21, 2), generator=g, device=dev, dtype=torch.float64) * (H - 40) + 20)
+        out["P" + s] = ops.pose_heatmaps(uv.contiguous(), H, W).view(B, 21, H, W)
+        d = torch.rand((B, 1, H, W), generator=g, device=dev) * 2 - 1
+        out["D" + s] = d.expand(B, 3, H, W).contiguous()
+    return out
+
+
+class KernelTimer:
+    """HIP-event brackets around every launch of one kernel shape during the timed region."""
+
+    def __init__(self, match):
+        self.match, self.pairs, self.enabled = match, [], False
+
+    def want(self, d):
+        return self.enabled and all(getattr(d, k) == v for k, v in self.match.items())
+
+    def bracket(self):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self.pairs.append((e0, e1))
+        return e0, e1
+
+    def mean_ms(self):
+        ts = [a.elapsed_time(b) for a, b in self.pairs]
+        return sum(ts) / len(ts), len(ts)
+
+
+def cpu_baseline(H, W, norm, budget_s=25.0):
+    """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
+    host's cores on a bounded sample of the same workload: B=1 steps at full resolution."""
+    import random
+    from collections import OrderedDict
+    from mmhand_amd.networks import Discriminator, Generator, VGGHead
+    from oracle import mmhand_ref as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = Generator([3, 42, 6], 3, 64, norm, True, 9).init_weights("normal", 49)
+    dpb = Discriminator(24, 64, norm, True, 3).init_weights("normal", 50)
+    dpp = Discriminator(6, 64, norm, True, 3).init_weights("normal", 51)
+    vgg = VGGHead().init_random()
+    orc = O.StepOracle(g.state_dict(), dpb.state_dict(), dpp.state_dict(), vgg.state_dict(), norm,
+                       True, True, 9, 3, rng=random.Random(0))
+    batch = O.synthetic_batch(1, H, W, seed=49)
+    t0 = time.time(); orc.step(batch); warm = time.time() - t0
+    n, t1 = 0, time.time()
+    while n < 1 or (time.time() - t1 + warm < budget_s and n < 4):
+        orc.step(batch); n += 1
+    dt = (time.time() - t1) / n
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} timed G+D steps at B=1, {H}x{W}, fp32, --norm {norm}, "
+            f"dropout on, after 1 warm-up step ({warm:.1f}s); oracle/mmhand_ref.py StepOracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or a.gpus > 1:
+        assert world == a.gpus, f"launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    from mmhand_amd.options import default_train_opt
+    opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="bench", local_rank=local,
+                            checkpoints_dir="/tmp/mmh_bench", distributed=world > 1)
+    model = MMHandModel(opt)
+    H = W = a.size
+    batch = synthetic_batch_gpu(a.batch, H, W, 49 + rank, dev)
+    model.set_input(batch)
+
+    # dominant kernel: the 3x3 reflect-pad 512->512 conv fprop at 64x64 (PATBlock streams 2/3)
+    hs = H // 4
+    timer = KernelTimer(dict(Cin=512, Cout=512, kh=3, stride=1, H=hs, W=hs))
+    ops.fprop_timer = timer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model.optimize_parameters()
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.optimize_parameters()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = {k: float(v) for k, v in model.get_current_errors().items()}
+
+    if rank == 0:
+        imgs_per_s = world * a.batch * a.steps / dt
+        k_ms, k_n = timer.mean_ms()
+        k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
+        achieved = k_flop / (k_ms * 1e-3) / 1e12
+        line = {
+            "metric": "256x256 hand images/sec (G+D step)", "value": round(imgs_per_s, 3),
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RHD-shaped {H}x{W}, per-GPU batch {a.batch}, fp32, G(9 PATBlocks,"
+                       f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}"},
+            "step_mfma_frac": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world
+                                    / 1e3 / PEAK_F32_MFMA_TF, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
+                         "traffic": None,
+                         "kernel": "conv_igemm_kernel<128,2,2,false> fprop 3x3 512->512 @64x64 "
+                                   f"(B={a.batch}): {k_flop / 1e9:.1f} GFLOP/launch, {k_ms:.3f} ms avg "
+                                   f"over {k_n} launches in the timed region"},
+            "losses": {k: round(v, 5) for k, v in losses.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,9 @@ def _ws(nbytes, like):
 
 
 # --------------------------------------------------------------------------- conv
+fprop_timer = None   # optional bench hook: object with want(desc) / bracket() -> (event, event)
+
+
 def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None):
     Ho = (H + 2 * pad - k) // stride + 1
     Wo = (W + 2 * pad - k) // stride + 1
@@ -63,6 +66,12 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE):
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
+    if fprop_timer is not None and fprop_timer.want(d):
+        e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
+        e0.record()
+        L.call("mmh_conv2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
+        e1.record()
+        return y
     L.call("mmh_conv2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
     return y
 
