@@ -51,6 +51,10 @@ typedef struct mmh_conv_desc {
 
 const char* mmh_last_error(void);
 int mmh_version(void);
+/* Tuning knobs for A/B measurements inside one process (results never change):
+ * "conv_dbuf" 0|1 (LDS double buffering of the 128-wide conv tile), "wgrad_slots" n
+ * (resident-workgroup count the split-K factor is rounded to).               */
+int mmh_set_option(const char* key, int value);
 
 /* ---- convolutions: nn.Conv2d / nn.ReflectionPad2d / nn.ConvTranspose2d ----
  * replaces models/Generator.py:40-113,158-259, models/Discriminator.py:14-99,

@@ -36,6 +36,7 @@ _DP = C.POINTER(ConvDesc)
 SIGNATURES = {
     "mmh_last_error": (C.c_char_p, []),
     "mmh_version": (_i, []),
+    "mmh_set_option": (_i, [C.c_char_p, _i]),
     "mmh_conv2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),

@@ -1,0 +1,15 @@
+"""Launch the three passes of the dominant conv (3x3 reflect 512->512 @64x64, B=32) a few times;
+run under `rocprofv3 --pmc ...` to collect counters per dispatch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmhand_amd import ops
+dev = torch.device("cuda:0")
+B, H, W, Cin, Cout = 32, 64, 64, 512, 512
+x = torch.randn(B, H, W, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
+y = ops.raw_conv_fprop(x, w, None, 1, 1, True, 0); dy = torch.randn_like(y)
+for _ in range(3):
+    ops.raw_conv_fprop(x, w, None, 1, 1, True, 0)
+    ops.raw_conv_dgrad(dy, w, x.shape, 1, 1, True)
+    ops.raw_conv_wgrad(x, dy, 3, 1, 1, True)
+torch.cuda.synchronize()
