@@ -99,22 +99,40 @@ __global__ void norm_stats_partial(const float* __restrict__ x, int64_t rows, in
 
 __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C, int chunks,
                                  float* __restrict__ mean, float* __restrict__ m2) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    int grp = i / C, c = i - grp * C;
+    // 32 channels x 8 chunk-lanes per block: each lane merges its chunks (Chan), then the 8
+    // lanes are merged in a fixed order.
+    __shared__ double sh[3][8][32];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
+    const bool ok = i < groups * C;
+    const int grp = ok ? i / C : 0, c = ok ? i - grp * C : 0;
     double na = 0, ma = 0, qa = 0;
-    for (int k = 0; k < chunks; ++k) {
-        const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
-        double nb = ws[o], mb = ws[o + C], qb = ws[o + 2 * C];
-        if (nb > 0) {
-            double nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
+    if (ok)
+        for (int k = kl; k < chunks; k += 8) {
+            const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
+            double nb = ws[o], mb = ws[o + C], qb = ws[o + 2 * C];
+            if (nb > 0) {
+                double nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
         }
+    sh[0][kl][cl] = na; sh[1][kl][cl] = ma; sh[2][kl][cl] = qa;
+    __syncthreads();
+    if (kl == 0 && ok) {
+        for (int j = 1; j < 8; ++j) {
+            double nb = sh[0][j][cl], mb = sh[1][j][cl], qb = sh[2][j][cl];
+            if (nb > 0) {
+                double nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+        mean[i] = (float)ma;
+        m2[i] = (float)qa;
     }
-    mean[i] = (float)ma;
-    m2[i] = (float)qa;
 }
 
 __global__ void norm_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ m2,
@@ -250,18 +268,31 @@ __global__ void col_reduce_partial(const float* __restrict__ a, const float* __r
     }
 }
 
-// out[o][grp][c] (+)= sum over chunks (double accumulation, fixed order)
+// out[o][grp][c] (+)= sum over chunks.  32 channels x 8 chunk-lanes per block; each lane adds
+// its chunks in double, the 8 lanes are combined in a fixed order -> deterministic.
 __global__ void col_reduce_final(const float* __restrict__ ws, int groups, int C, int chunks,
                                  int nout, float* __restrict__ o0, float* __restrict__ o1,
                                  int accumulate) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= groups * C) return;
-    int grp = i / C, c = i - grp * C;
+    __shared__ double sh[8][32];
+    const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
+    const bool ok = i < groups * C;
+    const int grp = ok ? i / C : 0, c = ok ? i - grp * C : 0;
     for (int o = 0; o < nout; ++o) {
         double acc = 0;
-        for (int k = 0; k < chunks; ++k) acc += ws[((int64_t)(grp * chunks + k) * nout + o) * C + c];
-        float* dst = o == 0 ? o0 : o1;
-        dst[i] = accumulate ? dst[i] + (float)acc : (float)acc;
+        if (ok)
+            for (int k = kl; k < chunks; k += 8)
+                acc += ws[((int64_t)(grp * chunks + k) * nout + o) * C + c];
+        sh[kl][cl] = acc;
+        __syncthreads();
+        if (kl == 0 && ok) {
+            double t = sh[0][cl];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) t += sh[j][cl];
+            float* dst = o == 0 ? o0 : o1;
+            dst[i] = accumulate ? dst[i] + (float)t : (float)t;
+        }
+        __syncthreads();
     }
 }
 
@@ -594,7 +625,7 @@ int mmh_norm_stats(const void* x, int groups, int64_t rows, int C, int cs, void*
     hipStream_t st = mmh::as_stream(s);
     hipLaunchKernelGGL(norm_stats_partial, dim3(g.chunks, groups), dim3(TPB), 0, st,
                        static_cast<const float*>(x), rows, C, cs, g, static_cast<float*>(ws));
-    hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + TPB - 1) / TPB), dim3(TPB), 0, st,
+    hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, st,
                        static_cast<const float*>(ws), groups, C, g.chunks, static_cast<float*>(mean),
                        static_cast<float*>(m2));
     return mmh::check_launch("norm_stats");
@@ -654,7 +685,7 @@ int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x, const voi
                        static_cast<const float*>(x), static_cast<const float*>(mean),
                        static_cast<const float*>(invstd), rows, C, C, masked, dsc, cg,
                        static_cast<float*>(ws));
-    hipLaunchKernelGGL(col_reduce_final, dim3((groups * C + TPB - 1) / TPB), dim3(TPB), 0, st,
+    hipLaunchKernelGGL(col_reduce_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, st,
                        static_cast<const float*>(ws), groups, C, cg.chunks, 2,
                        static_cast<float*>(s1), static_cast<float*>(s2), 0);
     return mmh::check_launch("norm_bwd_reduce");
@@ -694,7 +725,7 @@ int mmh_colsum(const void* x, int64_t rows, int C, int cs, void* out, void* ws, 
     hipLaunchKernelGGL((col_reduce_partial<0>), dim3(cg.chunks, 1), dim3(TPB), 0, st,
                        static_cast<const float*>(x), nullptr, nullptr, nullptr, nullptr, rows, C, cs,
                        0, 1.f, cg, static_cast<float*>(ws));
-    hipLaunchKernelGGL(col_reduce_final, dim3((C + TPB - 1) / TPB), dim3(TPB), 0, st,
+    hipLaunchKernelGGL(col_reduce_final, dim3((C + 31) / 32), dim3(TPB), 0, st,
                        static_cast<const float*>(ws), 1, C, cg.chunks, 1, static_cast<float*>(out),
                        nullptr, accumulate);
     return mmh::check_launch("colsum");
