@@ -84,6 +84,37 @@ def cpu_baseline(H, W, norm, budget_s=25.0):
             f"dropout on, after 1 warm-up step ({warm:.1f}s); oracle/mmhand_ref.py StepOracle"}
 
 
+def infer_main(a):
+    """configs[3]: STB-shaped 256x256, batch 64, inference-only Generator throughput."""
+    from mmhand_amd.inference import InferenceGenerator
+    from mmhand_amd.networks import Generator
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    B = a.batch if a.batch != 32 else 64
+    net = Generator([3, 42, 6], 3, 64, "batch", True, 9).init_weights("normal", 49).to(dev).eval()
+    gen = InferenceGenerator(net, use_graph=True)
+    b = synthetic_batch_gpu(B, a.size, a.size, 49, dev)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    for _ in range(max(a.warmup, 1)):
+        gen(g_in)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gen(g_in)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ips = B * a.steps / dt
+    print(json.dumps({
+        "metric": "256x256 hand images/sec (Generator inference)", "value": round(ips, 2),
+        "unit": "images/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"STB-shaped {a.size}x{a.size}, batch {B}, fp32, Generator forward only "
+                   "(eval BatchNorm folded into convs, hipGraph replay)"},
+        "step_mfma_frac": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 / PEAK_F32_MFMA_TF, 4)}),
+        flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +124,11 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer = BASELINE.json configs[3]: Generator forward only, BN folded, hipGraph")
     a = ap.parse_args()
+    if a.mode == "infer":
+        return infer_main(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -82,7 +82,8 @@ int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
  * stride-2 Conv2d of which this is the dgrad: d->{H,W,Cin} describe the
  * transposed conv's OUTPUT, d->{Ho,Wo,Cout} its INPUT.                     */
 int mmh_convT2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
-                      const void* bias, void* y, int y_cs, mmh_stream_t s);
+                      const void* bias, void* y, int y_cs, int act,
+                      mmh_stream_t s);
 int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
                       void* dx, mmh_stream_t s);
 int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,

@@ -1,0 +1,44 @@
+"""Generation driver — counterpart of the reference's aug.py:14-71.
+
+    python -m mmhand_amd.aug <checkpoint_name> <dst_dir> [n_batches] [batch] [device]
+
+Loads checkpoints/<name>/latest_net_netG.pth (reference format), builds
+Generator([3,42,6],3,64,BatchNorm,use_dropout=True,n_blocks=9).eval(), folds BN into the convs,
+captures the forward in a hipGraph and writes the generated images ((x*0.5+0.5)*255, RGB->BGR
+byte order as cv2.imwrite would store them) as binary PPM-free raw .npy files (cv2 is absent)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .data import SyntheticHandLoader
+from .inference import InferenceGenerator
+from .networks import Generator
+from .options import default_train_opt
+
+
+def main(argv):
+    ckp, dst = argv[0], argv[1]
+    n_batches = int(argv[2]) if len(argv) > 2 else 4
+    batch = int(argv[3]) if len(argv) > 3 else 1
+    device = int(argv[4]) if len(argv) > 4 else 0
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    weights = torch.load(os.path.join("checkpoints", ckp, "latest_net_netG.pth"), map_location="cpu")
+    model = Generator(input_nc=[3, 42, 6], output_nc=3, ngf=64, norm_layer="batch", use_dropout=True,
+                      n_blocks=9)
+    model.load_state_dict(weights)
+    gen = InferenceGenerator(model.to(dev).eval(), use_graph=True)
+    opt = default_train_opt(batchSize=batch, local_rank=device, isTrain=False)
+    loader = SyntheticHandLoader(opt, n_batches * batch)
+    os.makedirs(dst, exist_ok=True)
+    for i, sample in enumerate(loader):
+        fake = gen([sample["H1"], torch.cat((sample["P1"], sample["P2"]), 1),
+                    torch.cat((sample["D1"], sample["D2"]), 1)])
+        img = ((fake.permute(0, 2, 3, 1) * 0.5 + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
+        np.save(os.path.join(dst, "fake_%05d.npy" % i), img.flip(-1).cpu().numpy())   # BGR
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

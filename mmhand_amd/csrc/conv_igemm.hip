@@ -648,7 +648,7 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
 // Gradient w.r.t. the conv input.  out: [B, OH, OW, Cin] with channel stride out_cs, where
 // (OH,OW) is the padded domain for reflect mode and (H,W) otherwise.
 int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx,
-             int dx_cs, hipStream_t st) {
+             int dx_cs, int act, hipStream_t st) {
     const int s = d->stride;
     const int off = d->pad_mode == MMH_PAD_REFLECT ? d->pad : 0;  // padded-domain origin shift
     const int OH = d->H + 2 * off, OW = d->W + 2 * off;
@@ -686,7 +686,7 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
             p.OH = OH; p.OW = OW; p.o_p = s; p.o0_h = ch; p.o0_w = cw;
             p.out_cs = (unsigned)dx_cs;
             p.out_linear = s == 1;
-            p.act = MMH_ACT_NONE;
+            p.act = act;
             if (TH == 0 || TW == 0) p.nk = 0;  // no tap reaches this class: writes zeros
             int rc = launch_conv<true>(p, st);
             if (rc) return rc;
@@ -789,7 +789,7 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(dy && w && dx, "mmh_conv2d_dgrad: NULL buffer");
     MMH_REQUIRE(dx_cs % 4 == 0 && dx_cs >= d->Cin, "mmh_conv2d_dgrad: bad dx_cs=%d", dx_cs);
-    return do_dgrad(d, dy, w, nullptr, dx, dx_cs, mmh::as_stream(s));
+    return do_dgrad(d, dy, w, nullptr, dx, dx_cs, MMH_ACT_NONE, mmh::as_stream(s));
 }
 
 size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d) { return d ? wgrad_ws(d) : 0; }
@@ -803,11 +803,11 @@ int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void
 
 // ConvTranspose2d == dgrad of the stride-2 conv `d`; its input plays dy, its output plays dx.
 int mmh_convT2d_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias,
-                      void* y, int y_cs, mmh_stream_t s) {
+                      void* y, int y_cs, int act, mmh_stream_t s) {
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(d->pad_mode == MMH_PAD_ZERO, "mmh_convT2d: zero padding only");
     MMH_REQUIRE(x && w && y, "mmh_convT2d_fprop: NULL buffer");
-    return do_dgrad(d, x, w, bias, y, y_cs, mmh::as_stream(s));
+    return do_dgrad(d, x, w, bias, y, y_cs, act, mmh::as_stream(s));
 }
 
 int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void* dx,

@@ -1,0 +1,131 @@
+"""Inference-only Generator (the reference's aug.py:26-58 path; BASELINE.json configs[3]).
+
+eval-mode BatchNorm uses running statistics, so it is folded into the producing conv once
+(w' = w*gamma/sqrt(var+eps), b' = beta - mean*that) and ReLU/Tanh run in the conv epilogue: the
+whole forward becomes 66 conv launches + 9 gate launches + 3 pack launches with no normalisation
+pass at all.  The static launch sequence is captured in a hipGraph (torch.cuda.CUDAGraph) and
+replayed per batch.  InstanceNorm generators cannot be folded (per-sample statistics); they run
+the regular eval forward under the same graph capture.
+"""
+import torch
+
+from . import lib as L
+from . import ops
+from .networks import Generator
+from .ops import pad4
+
+
+def _fold(conv, norm, transposed=False):
+    """(w', b') of conv followed by eval-mode BatchNorm `norm` (None -> conv as is)."""
+    w = conv.weight.detach()
+    b = conv.bias.detach() if conv.bias is not None else None
+    if norm is None:
+        return w.contiguous(), b
+    scale = norm.weight.detach() / torch.sqrt(norm.running_var + ops.EPS)
+    shift = norm.bias.detach() - norm.running_mean * scale
+    co = scale.numel()
+    if transposed:                       # physical [kh,kw,CoutT,CinT]
+        w2 = w.clone()
+        w2[:, :, :co, :] *= scale.view(1, 1, -1, 1)
+    else:                                # physical [kh,kw,Cin,Cout]
+        w2 = w.clone()
+        w2[..., :co] *= scale.view(1, 1, 1, -1)
+    b2 = torch.zeros(pad4(co), dtype=torch.float32, device=w.device)
+    b2[:co] = shift if b is None else shift + b[:co] * scale
+    return w2.contiguous(), b2
+
+
+class InferenceGenerator:
+    """Callable drop-in for ``Generator.eval()``: ``gen([H1, cat(P1,P2), cat(D1,D2)]) -> NCHW``."""
+
+    def __init__(self, net: Generator, use_graph=True):
+        assert isinstance(net, Generator)
+        self.net = net.eval()
+        self.folded = net.norm == "batch"
+        self.use_graph = use_graph
+        self._graph = None
+        self._key = None
+        if self.folded:
+            self._build_folded()
+
+    # ------------------------------------------------------------------ folded weights
+    def _build_folded(self):
+        n, m = self.net, self.net.model
+        i2 = 6 if n.use_dropout else 5
+        f = {}
+        for s in (1, 2, 3):
+            d = m[f"stream{s}_down"]
+            f[("down", s, 0)] = _fold(d[1], d[2])
+            for i in range(n.n_down):
+                f[("down", s, 1 + i)] = _fold(d[4 + 3 * i], d[5 + 3 * i])
+        for b in range(n.n_blocks):
+            blk = m["att"][b]
+            for s in (1, 2, 3):
+                cb = blk[f"conv_block_stream{s}"]
+                f[("att", b, s, 0)] = _fold(cb[1], cb[2])
+                f[("att", b, s, 1)] = _fold(cb[i2], cb[i2 + 1] if s == 1 else None)
+        up = m["stream1_up"]
+        for i in range(n.n_down):
+            f[("up", i)] = _fold(up[3 * i], up[3 * i + 1], transposed=True)
+        f[("head",)] = _fold(up[3 * n.n_down + 1], None)
+        self.f = f
+
+    def _forward_folded(self, x1, x2, x3):
+        n, f = self.net, self.f
+        xs = []
+        for s, x in zip((1, 2, 3), (x1, x2, x3)):
+            w, b = f[("down", s, 0)]
+            x = ops.raw_conv_fprop(x, w, b, 1, 3, True, L.ACT_RELU)
+            for i in range(n.n_down):
+                w, b = f[("down", s, 1 + i)]
+                x = ops.raw_conv_fprop(x, w, b, 2, 1, False, L.ACT_RELU)
+            xs.append(x)
+        x1, x2, x3 = xs
+        for blk in range(n.n_blocks):
+            ss = []
+            for s, x in zip((1, 2, 3), (x1, x2, x3)):
+                w, b = f[("att", blk, s, 0)]
+                y = ops.raw_conv_fprop(x, w, b, 1, 1, True, L.ACT_RELU)
+                w, b = f[("att", blk, s, 1)]
+                ss.append(ops.raw_conv_fprop(y, w, b, 1, 1, True, L.ACT_NONE))
+            x1, x2, x3 = ops.GateFn.apply(x1, ss[0], ss[1], ss[2], blk + 1 < n.n_blocks)
+        y = x1
+        for i in range(n.n_down):
+            w, b = f[("up", i)]
+            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU)
+        w, b = f[("head",)]
+        return ops.raw_conv_fprop(y, w, b, 1, 3, True, L.ACT_TANH)
+
+    # ------------------------------------------------------------------ call
+    def _eager(self, inputs):
+        n = self.net
+        xs = [ops.raw_pack([(x, True, nc)], x.shape[0], x.shape[2], x.shape[3], pad4(nc), x.device)
+              for x, nc in zip(inputs, n.input_nc)]
+        y = self._forward_folded(*xs) if self.folded else n.forward_nhwc(*xs)
+        return ops.nhwc_to_nchw_view(y, n.output_nc)
+
+    @torch.no_grad()
+    def __call__(self, inputs):
+        inputs = [x.float() for x in inputs]
+        if not self.use_graph:
+            return self._eager(inputs)
+        key = tuple(tuple(x.shape) for x in inputs) + (inputs[0].device,)
+        if self._graph is None or key != self._key:
+            self._capture(inputs, key)
+        for s, x in zip(self._static_in, inputs):
+            s.copy_(x, non_blocking=True)
+        self._graph.replay()
+        return self._static_out
+
+    def _capture(self, inputs, key):
+        self._static_in = [x.clone() for x in inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm-up: one-time attribute calls, allocs
+            for _ in range(2):
+                self._eager(self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_out = self._eager(self._static_in)
+        self._graph, self._key = g, key

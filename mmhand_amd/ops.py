@@ -114,11 +114,12 @@ def _convT_desc(x, w):
     return conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
 
 
-def raw_convT_fprop(x, w, bias):
+def raw_convT_fprop(x, w, bias, act=L.ACT_NONE):
     _chk(x, "x"); _chk(w, "w")
     d = _convT_desc(x, w)
     y = _empty((d.B, d.H, d.W, d.Cin), x)
-    L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, _stream())
+    L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, act,
+           _stream())
     return y
 
 

@@ -1,0 +1,74 @@
+"""Data-parallel MMHandModel on real kernels: 2 processes sharing cuda:0 over the gloo backend
+(RCCL refuses two ranks on one device; the N-GPU RCCL run is the driver's).  Checks that a
+2-rank step equals the 1-rank step on the concatenated batch: exactly the apex-DDP semantics the
+reference relies on (gradient = mean over ranks; SyncBN statistics over the global batch)."""
+import os
+import random
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _opt(norm, B, distributed, rank=0):
+    from mmhand_amd.options import default_train_opt
+    return default_train_opt(batchSize=B, ngf=8, ndf=8, n_layers_D=2, G_n_blocks=2, norm=norm,
+                             no_dropout=True, no_dropout_D=True, pool_size=0, name="dp",
+                             checkpoints_dir="/tmp/mmh_dp_gpu", local_rank=0, distributed=distributed)
+
+
+def _run(norm, batch, distributed):
+    from mmhand_amd.mmhand_model import MMHandModel
+    random.seed(0)
+    model = MMHandModel(_opt(norm, batch["H1"].shape[0], distributed))
+    out = []
+    for _ in range(2):
+        model.set_input(batch)
+        model.optimize_parameters()
+        out.append([float(v) for v in model.get_current_errors().values()])
+    torch.cuda.synchronize()
+    sd = OrderedDict((k, v.detach().cpu()) for k, v in model.netG.state_dict().items())
+    return out, sd
+
+
+def _worker(rank, world, port, norm, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    from oracle import mmhand_ref as O
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = O.synthetic_batch(4, 32, 32, seed=7)
+    shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    losses, sd = _run(norm, shard, True)
+    torch.save({"losses": losses, "sd": sd}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("norm,port", [("instance", 29621), ("batch", 29622)])
+def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_path):
+    from oracle import mmhand_ref as O
+    from tests.golden.recipe import is_null_grad_bias
+    mp.spawn(_worker, args=(2, port, norm, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
+    full = O.synthetic_batch(4, 32, 32, seed=7)
+    ref_losses, ref_sd = _run(norm, full, False)
+    # replicas stay identical
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    # mean of the rank losses == loss on the global batch (losses are means over the batch)
+    mean_losses = (np.array(r0["losses"]) + np.array(r1["losses"])) / 2
+    if norm == "instance":
+        assert np.allclose(mean_losses, np.array(ref_losses), rtol=2e-4), (mean_losses, ref_losses)
+    # parameters after two steps == single-process training on the concatenated batch
+    for k, v in ref_sd.items():
+        if v.is_floating_point() and not is_null_grad_bias("G", k, norm):
+            assert torch.allclose(r0["sd"][k], v, atol=2e-4 + 1e-3 * v.abs().max().item()), k

@@ -164,3 +164,41 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     m2 = MMHandModel(opt2)
     for k, v in m.netG.state_dict().items():
         assert torch.equal(v.cpu(), m2.netG.state_dict()[k].cpu()), k
+
+
+@pytest.mark.parametrize("norm", ["batch", "instance"])
+def test_inference_generator_folded_and_graphed(norm, dev):
+    """aug.py path (config 4): BN folded into the convs + hipGraph replay == eval-mode oracle."""
+    from mmhand_amd.inference import InferenceGenerator
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, S["ngf"], norm, True, S["n_blocks"])
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=torch.Generator().manual_seed(1))
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(2))
+    net.load_state_dict(sd)
+    net.to(dev)
+    gen = InferenceGenerator(net, use_graph=True)
+    onet = O._Net(sd, norm, True); onet.training = False
+    for seed in (5, 6):                                   # second call replays the captured graph
+        b = O.synthetic_batch(2, S["H"], S["W"], seed=seed)
+        g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+        out = gen([t.to(dev) for t in g_in])
+        torch.cuda.synchronize()
+        ref = O.generator_forward(onet, g_in, S["n_blocks"])
+        assert R.rel_l1(out, ref) < TOL, (norm, seed, R.rel_l1(out, ref))
+
+
+def test_train_driver_smoke(dev, tmp_path):
+    """mmhand_amd.train (train.py counterpart): 1 epoch of 2 synthetic batches, loss log + checkpoints."""
+    from mmhand_amd import train
+    train.main(["--name", "drv", "--checkpoints_dir", str(tmp_path), "--batchSize", "2", "--ngf", "8",
+                "--ndf", "8", "--n_layers_D", "1", "--G_n_blocks", "1", "--fineSize", "64",
+                "--norm", "instance", "--niter", "1", "--niter_decay", "0", "--print_freq", "2",
+                "--synthetic_samples", "4", "--pool_size", "2"])
+    d = os.path.join(str(tmp_path), "drv")
+    log = open(os.path.join(d, "loss_log.txt")).read().strip().splitlines()
+    assert len(log) == 2 and log[0].startswith("(epoch: 1, iters: 2, time:") and "pair_L1loss:" in log[0]
+    assert {"latest_net_netG.pth", "1_net_netG.pth", "latest_net_netD_PB.pth", "opt.txt"} <= set(os.listdir(d))
