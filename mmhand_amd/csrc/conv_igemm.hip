@@ -45,7 +45,8 @@ struct Gather {
     int ap_w, at_w, a0_w;
     int shift;                  // v >>= shift after the v >= 0 test (stride-2 dgrad)
     int reflect;                // mirror v into [0, srcH)
-    int chunk_major;            // k order: 1 = (8-group chunk, tap), 0 = flat (tap, group)
+    int chunk_major;            // k order: 1 = (super-chunk, tap, chunk), 0 = flat (tap, group)
+    int cw;                     // chunks (of 8 groups = 32 channels) per tap visit, chunk_major only
 };
 
 struct ConvKP {
@@ -63,11 +64,14 @@ struct ConvKP {
     unsigned out_cs;
     int out_linear;             // output row offset is simply m*out_cs
     int act;
+    int dbg;                    // timing-only ablation bits (mmh_set_option "conv_dbg"): results wrong
+    int xcd_remap;              // remap (blockIdx.y, blockIdx.x) so column tiles of a row tile share an XCD
 };
 
-struct KState { int th, tw, c4; };
+struct KState { int th, tw, c4, j; };   // j: chunk index inside the current tap visit
 
 __device__ __forceinline__ void kstate_init(KState& s, const Gather& g, int grp) {
+    s.j = 0;
     if (g.chunk_major) { s.th = 0; s.tw = 0; s.c4 = grp; }
     else {
         int tap = grp / g.C4;
@@ -78,7 +82,13 @@ __device__ __forceinline__ void kstate_init(KState& s, const Gather& g, int grp)
 }
 __device__ __forceinline__ void kstate_next(KState& s, const Gather& g) {
     if (g.chunk_major) {
-        if (++s.tw == g.TW) { s.tw = 0; if (++s.th == g.TH) { s.th = 0; s.c4 += 8; } }
+        // order (super-chunk of cw chunks, tap, chunk): a tap's row offsets serve cw k-steps
+        s.c4 += 8;
+        if (++s.j == g.cw) {
+            s.j = 0;
+            s.c4 -= 8 * g.cw;
+            if (++s.tw == g.TW) { s.tw = 0; if (++s.th == g.TH) { s.th = 0; s.c4 += 8 * g.cw; } }
+        }
     } else {
         s.c4 += 8;
         while (s.c4 >= g.C4) { s.c4 -= g.C4; if (++s.tw == g.TW) { s.tw = 0; ++s.th; } }
@@ -99,6 +109,26 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned b
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+
+// Byte offset of the source pixel (channel 0) for (pixel base bh,bw ; tap th,tw), or OOB.
+__device__ __forceinline__ unsigned gather_base(const Gather& g, unsigned img_base, int bh, int bw,
+                                                const KState& s, bool ok) {
+    int vh = bh + s.th * g.at_h;
+    int vw = bw + s.tw * g.at_w;
+    if (g.reflect) {
+        vh = vh < 0 ? -vh : vh;
+        vw = vw < 0 ? -vw : vw;
+        vh = vh >= g.srcH ? 2 * (g.srcH - 1) - vh : vh;
+        vw = vw >= g.srcW ? 2 * (g.srcW - 1) - vw : vw;
+    } else {
+        ok = ok && (vh >= 0) && (vw >= 0);
+        vh >>= g.shift;
+        vw >>= g.shift;
+        ok = ok && (vh < g.srcH) && (vw < g.srcW);
+    }
+    const unsigned off = (img_base + (unsigned)(vh * g.srcW + vw)) * g.src_cs * 4u;
+    return ok ? off : OOB;
 }
 
 // Byte offset of the 4 channels of the source pixel for (pixel base bh,bw ; tap th,tw), or OOB.
@@ -153,8 +183,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs, so ids L, L+8,
+    // L+16, ... share an L2.  Give those to the column tiles of ONE row tile: the gathered A rows
+    // are then fetched into one L2 instead of into gridDim.x of them.  (Speed only.)
+    int mt = blockIdx.y, nt = blockIdx.x;
+    if (p.xcd_remap) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = 8 * gridDim.x;
+        const int grp8 = L / per, r = L - grp8 * per;
+        mt = grp8 * 8 + (r & 7);
+        nt = r >> 3;
+    }
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.w, p.w_bytes);
 
@@ -201,15 +242,21 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
 
     KState ks_t;   // this thread's k-group
     kstate_init(ks_t, g, grp);
+    unsigned a_off[4] = {OOB, OOB, OOB, OOB};   // row byte offsets of the current tap
 
     float4 ra[4];
     float4 rb[NB];
 
     auto load_tiles = [&](int ks) {
         const bool kv = kstate_valid(ks_t, g);
+        if (ks_t.j == 0) {   // new tap (or flat order): recompute the 4 row offsets
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], ks_t, a_ok[i]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            ra[i] = bload4(rsA, gather_off(g, a_img[i], a_bh[i], a_bw[i], ks_t, kv && a_ok[i]));
+            ra[i] = bload4(rsA, (kv && a_off[i] != OOB) ? a_off[i] + (unsigned)ks_t.c4 * 16u : OOB);
         if (!B_NMAJOR) {
             // weight rows [rowbase, rowbase+32) x columns [n0, n0+BN)
             int rowbase, rowlim;
@@ -274,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
         const float* Bs = Bs_base + (DBUF ? (ks & 1) : 0) * BSZ;
         if (ks + 1 < p.nk) {
             kstate_next(ks_t, g);
-            load_tiles(ks + 1);          // global -> registers, in flight during the MFMAs
+            if (!(p.dbg & 1)) load_tiles(ks + 1);   // global -> registers, in flight during the MFMAs
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -309,9 +356,11 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
                 }
             }
         }
-        if (!DBUF) __syncthreads();      // everyone is done reading the single buffer
-        if (ks + 1 < p.nk) store_tiles(DBUF ? ((ks + 1) & 1) : 0);
-        __syncthreads();
+        if (!(p.dbg & 2)) {
+            if (!DBUF) __syncthreads();      // everyone is done reading the single buffer
+            if (ks + 1 < p.nk) store_tiles(DBUF ? ((ks + 1) & 1) : 0);
+            __syncthreads();
+        }
     }
 
     // --- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---
@@ -573,10 +622,17 @@ int validate(const mmh_conv_desc* d) {
     return 0;
 }
 
+int g_conv_cw = 0;   // tuning knob: chunks per tap visit (0 = auto)
+
 void set_korder(Gather& g, int& nk, int& Kflat) {
     Kflat = g.TH * g.TW * g.C4 * 4;
-    if (g.C4 % 8 == 0) { g.chunk_major = 1; nk = (g.C4 / 8) * g.TH * g.TW; }
-    else { g.chunk_major = 0; nk = (Kflat + BK - 1) / BK; }
+    if (g.C4 % 8 == 0) {
+        g.chunk_major = 1;
+        nk = (g.C4 / 8) * g.TH * g.TW;
+        const int chunks = g.C4 / 8;
+        g.cw = (g_conv_cw > 0 && chunks % g_conv_cw == 0) ? g_conv_cw
+               : (chunks % 8 == 0 ? 8 : (chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1)));
+    } else { g.chunk_major = 0; g.cw = 1; nk = (Kflat + BK - 1) / BK; }
 }
 
 // Dynamic LDS above 64 KiB must be opted into once per kernel.
@@ -589,6 +645,8 @@ int allow_lds(K kernel, size_t bytes) {
 }
 
 int g_conv_dbuf = 0;   // tuning knob (mmh_set_option "conv_dbuf")
+int g_conv_dbg = 0;    // ablation bits, timing only
+int g_conv_xcd = 1;    // XCD-aware tile mapping on/off
 
 template <int BN, int WM, int WN, bool NMAJOR, bool DBUF>
 int launch_conv_t(const ConvKP& p, hipStream_t st) {
@@ -603,6 +661,12 @@ int launch_conv_t(const ConvKP& p, hipStream_t st) {
 
 template <bool NMAJOR>
 int launch_conv(const ConvKP& p, hipStream_t st) {
+    const_cast<ConvKP&>(p).dbg = g_conv_dbg;
+    {   // the remap needs gridDim.y to be a multiple of 8 (else the last group would run past M)
+        const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
+        const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy % 8 == 0) ? 1 : 0;
+    }
     if (p.N > 64)
         return g_conv_dbuf ? launch_conv_t<128, 2, 2, NMAJOR, true>(p, st)
                            : launch_conv_t<128, 2, 2, NMAJOR, false>(p, st);
@@ -772,6 +836,9 @@ extern "C" {
 int mmh_set_option(const char* key, int value) {
     MMH_REQUIRE(key != nullptr, "mmh_set_option: NULL key");
     if (!strcmp(key, "conv_dbuf")) { g_conv_dbuf = value; return 0; }
+    if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
+    if (!strcmp(key, "conv_cw")) { g_conv_cw = value; return 0; }
+    if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
     return mmh::fail("mmh_set_option: unknown key '%s'", key);
