@@ -59,14 +59,17 @@ class KernelTimer:
         return sum(ts) / len(ts), len(ts)
 
 
-def cpu_baseline(H, W, norm, budget_s=25.0):
-    """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
-    host's cores on a bounded sample of the same workload: B=1 steps at full resolution."""
+CPU_THREADS = 16   # measured on the GPU box (256 logical CPUs): oneDNN conv fwd+bwd is fastest at
+                   # 16 threads (14 ms) and 14x slower at 128 (tools/cpu_probe.py)
+
+
+def cpu_baseline_child(H, W, norm, budget_s):
+    """Runs in a child process that never touches the GPU.  Prints one JSON object."""
     import random
-    from collections import OrderedDict
     from mmhand_amd.networks import Discriminator, Generator, VGGHead
     from oracle import mmhand_ref as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    nthreads = max(1, min(CPU_THREADS, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(nthreads)
     g = Generator([3, 42, 6], 3, 64, norm, True, 9).init_weights("normal", 49)
     dpb = Discriminator(24, 64, norm, True, 3).init_weights("normal", 50)
     dpp = Discriminator(6, 64, norm, True, 3).init_weights("normal", 51)
@@ -76,12 +79,32 @@ def cpu_baseline(H, W, norm, budget_s=25.0):
     batch = O.synthetic_batch(1, H, W, seed=49)
     t0 = time.time(); orc.step(batch); warm = time.time() - t0
     n, t1 = 0, time.time()
-    while n < 1 or (time.time() - t1 + warm < budget_s and n < 4):
+    while n < 1 or (time.time() - t1 + warm < budget_s and n < 8):
         orc.step(batch); n += 1
     dt = (time.time() - t1) / n
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n} timed G+D steps at B=1, {H}x{W}, fp32, --norm {norm}, "
-            f"dropout on, after 1 warm-up step ({warm:.1f}s); oracle/mmhand_ref.py StepOracle"}
+    print(json.dumps({"value": round(1.0 / dt, 4), "unit": "images/s", "cores": nthreads,
+                      "kind": "port", "sample": f"{n} timed G+D steps at B=1, {H}x{W}, fp32, --norm "
+                      f"{norm}, dropout on, after 1 warm-up step ({warm:.1f}s), {nthreads} threads of "
+                      f"{os.cpu_count()} logical CPUs; oracle/mmhand_ref.py StepOracle"}), flush=True)
+
+
+def cpu_baseline(H, W, norm, budget_s=25.0, hard_timeout_s=240):
+    """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
+    host's cores on a bounded sample of the same workload, in a child process with a hard timeout."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--size", str(H),
+           "--norm", norm, "--cpu-budget", str(budget_s)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "images/s", "cores": CPU_THREADS, "kind": "port",
+                "sample": "child failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "images/s", "cores": CPU_THREADS, "kind": "port",
+                "sample": f"child exceeded the {hard_timeout_s}s hard timeout"}
 
 
 def infer_main(a):
@@ -124,9 +147,13 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help=argparse.SUPPRESS)
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE.json configs[3]: Generator forward only, BN folded, hipGraph")
     a = ap.parse_args()
+    if a.cpu_baseline_child:
+        return cpu_baseline_child(a.size, a.size, a.norm, a.cpu_budget)
     if a.mode == "infer":
         return infer_main(a)
 
@@ -180,6 +207,10 @@ def main():
     if rank == 0:
         imgs_per_s = world * a.batch * a.steps / dt
         k_ms, k_n = timer.mean_ms()
+        traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and a.batch == 32 and a.size == 256:
+            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
         k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         line = {
@@ -194,7 +225,7 @@ def main():
                                     / 1e3 / PEAK_F32_MFMA_TF, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
-                         "traffic": None,
+                         "traffic": traffic,
                          "kernel": "conv_igemm_kernel<128,2,2,false> fprop 3x3 512->512 @64x64 "
                                    f"(B={a.batch}): {k_flop / 1e9:.1f} GFLOP/launch, {k_ms:.3f} ms avg "
                                    f"over {k_n} launches in the timed region"},

@@ -184,15 +184,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs, so ids L, L+8,
-    // L+16, ... share an L2.  Give those to the column tiles of ONE row tile: the gathered A rows
-    // are then fetched into one L2 instead of into gridDim.x of them.  (Speed only.)
+    // L+16, ... share an L2.  XCD x walks its own contiguous band of row tiles, visiting all the
+    // column tiles of a row tile back to back: the gathered A rows (and the halo rows shared with
+    // the next row tile) are fetched into ONE L2 instead of several.  Speed/traffic only.
     int mt = blockIdx.y, nt = blockIdx.x;
     if (p.xcd_remap) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x;
-        const int per = 8 * gridDim.x;
-        const int grp8 = L / per, r = L - grp8 * per;
-        mt = grp8 * 8 + (r & 7);
-        nt = r >> 3;
+        const int gx = gridDim.x, band = gridDim.y / 8;     // row tiles per XCD (whole bands)
+        const int L = blockIdx.y * gx + blockIdx.x;
+        if (L < band * 8 * gx) {                             // the ragged rest keeps its ids
+            const int x = L & 7, i = L >> 3;
+            nt = i % gx;
+            mt = x * band + i / gx;
+        }
     }
     const int m0 = mt * BM;
     const int n0 = nt * BN;
@@ -631,7 +634,7 @@ void set_korder(Gather& g, int& nk, int& Kflat) {
         nk = (g.C4 / 8) * g.TH * g.TW;
         const int chunks = g.C4 / 8;
         g.cw = (g_conv_cw > 0 && chunks % g_conv_cw == 0) ? g_conv_cw
-               : (chunks % 8 == 0 ? 8 : (chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1)));
+               : (chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1));   // 4: +4 % time, traffic ~cw=1
     } else { g.chunk_major = 0; g.cw = 1; nk = (Kflat + BK - 1) / BK; }
 }
 
@@ -662,10 +665,10 @@ int launch_conv_t(const ConvKP& p, hipStream_t st) {
 template <bool NMAJOR>
 int launch_conv(const ConvKP& p, hipStream_t st) {
     const_cast<ConvKP&>(p).dbg = g_conv_dbg;
-    {   // the remap needs gridDim.y to be a multiple of 8 (else the last group would run past M)
+    {
         const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
         const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;
-        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy % 8 == 0) ? 1 : 0;
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
     }
     if (p.N > 64)
         return g_conv_dbuf ? launch_conv_t<128, 2, 2, NMAJOR, true>(p, st)

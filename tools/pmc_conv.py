@@ -3,7 +3,11 @@ run under `rocprofv3 --pmc ...` to collect counters per dispatch."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from mmhand_amd import ops
+from mmhand_amd import ops, lib
+for kv in os.environ.get('MMH_OPTS', '').split(','):
+    if kv:
+        k, v = kv.split('=')
+        lib.check(lib.load().mmh_set_option(k.encode(), int(v)), 'opt')
 dev = torch.device("cuda:0")
 B, H, W, Cin, Cout = 32, 64, 64, 512, 512
 x = torch.randn(B, H, W, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
