@@ -209,6 +209,22 @@ int mmh_pose_heatmaps(const void* uv, int n_maps, int H, int W, double sigma,
 int mmh_map_to_cord(const void* maps, int n_maps, int H, int W,
                     float threshold, void* cords, mmh_stream_t s);
 
+/* ---- on-device input pipeline (data/generic_dataset.py:133-180) ---------------
+ * One kernel turns what the loader workers produce per sample on the CPU —
+ * normalize(BGR->RGB image), 21 pose maps per hand, depth = 256*G+R -> /700 ->
+ * (.-0.5)/0.5 replicated x3 — into the stems' NHWC buffers directly:
+ *   img1,img2 : uint8 [B,H,W,3] BGR (as cv2.imread returns them)
+ *   dep1,dep2 : uint8 [B,H,W,3] BGR depth PNGs
+ *   uv1,uv2   : float64 [B,21,2] joint (x,y)
+ *   x_h1,x_h2 : fp32 [B,H,W,4]  RGB in [-1,1], lane 3 = 0
+ *   x_p       : fp32 [B,H,W,44] P1 in 0..20, P2 in 21..41, lanes 42,43 = 0
+ *   x_d       : fp32 [B,H,W,8]  D1 x3, D2 x3, lanes 6,7 = 0
+ * All arithmetic is float64 then cast, exactly as numpy does it in the reference. */
+int mmh_decode_inputs(const void* img1, const void* img2, const void* dep1,
+                      const void* dep2, const void* uv1, const void* uv2,
+                      int B, int H, int W, double sigma, void* x_h1, void* x_h2,
+                      void* x_p, void* x_d, mmh_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

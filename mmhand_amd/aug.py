@@ -5,7 +5,9 @@
 Loads checkpoints/<name>/latest_net_netG.pth (reference format), builds
 Generator([3,42,6],3,64,BatchNorm,use_dropout=True,n_blocks=9).eval(), folds BN into the convs,
 captures the forward in a hipGraph and writes the generated images ((x*0.5+0.5)*255, RGB->BGR
-byte order as cv2.imwrite would store them) as binary PPM-free raw .npy files (cv2 is absent)."""
+then cv2.imwrite) as PNG files via PIL (cv2 is absent here; cv2.imwrite of a BGR float array
+rounds to nearest uint8 and stores RGB-ordered PNG pixels, which is what PIL is given) or, without
+PIL, as .npy arrays."""
 import os
 import sys
 
@@ -36,8 +38,14 @@ def main(argv):
     for i, sample in enumerate(loader):
         fake = gen([sample["H1"], torch.cat((sample["P1"], sample["P2"]), 1),
                     torch.cat((sample["D1"], sample["D2"]), 1)])
-        img = ((fake.permute(0, 2, 3, 1) * 0.5 + 0.5) * 255.0).clamp(0, 255).to(torch.uint8)
-        np.save(os.path.join(dst, "fake_%05d.npy" % i), img.flip(-1).cpu().numpy())   # BGR
+        img = ((fake.permute(0, 2, 3, 1) * 0.5 + 0.5) * 255.0).round().clamp(0, 255).to(torch.uint8)
+        arr = img.cpu().numpy()                                     # RGB, what the PNG stores
+        try:
+            from PIL import Image
+            for j in range(arr.shape[0]):
+                Image.fromarray(arr[j]).save(os.path.join(dst, "fake_%05d_%d.png" % (i, j)))
+        except ImportError:
+            np.save(os.path.join(dst, "fake_%05d.npy" % i), arr)
 
 
 if __name__ == "__main__":

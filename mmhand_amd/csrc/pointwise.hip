@@ -599,6 +599,57 @@ __global__ void map_to_cord_kernel(const float* __restrict__ maps, int H, int W,
     }
 }
 
+// ------------------------------------------------------------------ input pipeline
+__device__ __forceinline__ float norm_u8(uint8_t v) { return (float)(((double)v / 255.0 - 0.5) / 0.5); }
+__device__ __forceinline__ float depth_u8(uint8_t g, uint8_t r) {
+    double d = 256.0 * (double)g + (double)r;
+    return (float)(((d / 700.0) - 0.5) / 0.5);
+}
+__device__ __forceinline__ float heat(double x, double y, double ux, double uy, double sigma) {
+    double dx = x - ux, dy = y - uy;
+    double v = exp(-(dx * dx + dy * dy) / 2.0 / sigma / sigma);
+    if (v > 1.0) v = 1.0;
+    if (v < 0.0099) v = 0.0;
+    return (float)v;
+}
+
+__global__ void decode_inputs_kernel(const uint8_t* __restrict__ img1, const uint8_t* __restrict__ img2,
+                                     const uint8_t* __restrict__ dep1, const uint8_t* __restrict__ dep2,
+                                     const double* __restrict__ uv1, const double* __restrict__ uv2,
+                                     int B, int H, int W, double sigma, float* __restrict__ xh1,
+                                     float* __restrict__ xh2, float* __restrict__ xp,
+                                     float* __restrict__ xd) {
+    const int64_t total = (int64_t)B * H * W;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int x = (int)(i % W);
+        const int64_t t = i / W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        // images: BGR uint8 -> RGB normalised
+        const uint8_t* p1 = img1 + i * 3;
+        st4(xh1, i, make_float4(norm_u8(p1[2]), norm_u8(p1[1]), norm_u8(p1[0]), 0.f));
+        const uint8_t* p2 = img2 + i * 3;
+        st4(xh2, i, make_float4(norm_u8(p2[2]), norm_u8(p2[1]), norm_u8(p2[0]), 0.f));
+        // depth: 256*G + R (BGR order: index 1 = G, 2 = R)
+        const float d1 = depth_u8(dep1[i * 3 + 1], dep1[i * 3 + 2]);
+        const float d2 = depth_u8(dep2[i * 3 + 1], dep2[i * 3 + 2]);
+        st4(xd, i * 2, make_float4(d1, d1, d1, d2));
+        st4(xd, i * 2 + 1, make_float4(d2, d2, 0.f, 0.f));
+        // pose maps
+        float* pp = xp + i * 44;
+        const double* u1 = uv1 + (int64_t)b * 42;
+        const double* u2 = uv2 + (int64_t)b * 42;
+        for (int k = 0; k < 21; ++k) {
+            pp[k] = heat((double)x, (double)y, u1[2 * k], u1[2 * k + 1], sigma);
+            pp[21 + k] = heat((double)x, (double)y, u2[2 * k], u2[2 * k + 1], sigma);
+        }
+        pp[42] = 0.f;
+        pp[43] = 0.f;
+    }
+}
+
 int check_cols(const char* who, int C) {
     MMH_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in (0,1024], got %d",
                 who, C);
@@ -853,6 +904,21 @@ int mmh_pose_heatmaps(const void* uv, int n_maps, int H, int W, double sigma, vo
                        mmh::as_stream(s), static_cast<const double*>(uv), n_maps, H, W, sigma,
                        static_cast<float*>(out));
     return mmh::check_launch("pose_heatmaps");
+}
+
+int mmh_decode_inputs(const void* img1, const void* img2, const void* dep1, const void* dep2,
+                      const void* uv1, const void* uv2, int B, int H, int W, double sigma,
+                      void* x_h1, void* x_h2, void* x_p, void* x_d, mmh_stream_t s) {
+    MMH_REQUIRE(img1 && img2 && dep1 && dep2 && uv1 && uv2 && x_h1 && x_h2 && x_p && x_d,
+                "mmh_decode_inputs: NULL buffer");
+    MMH_REQUIRE(B > 0 && H > 0 && W > 0 && sigma > 0, "mmh_decode_inputs: bad shape");
+    hipLaunchKernelGGL(decode_inputs_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const uint8_t*>(img1),
+                       static_cast<const uint8_t*>(img2), static_cast<const uint8_t*>(dep1),
+                       static_cast<const uint8_t*>(dep2), static_cast<const double*>(uv1),
+                       static_cast<const double*>(uv2), B, H, W, sigma, static_cast<float*>(x_h1),
+                       static_cast<float*>(x_h2), static_cast<float*>(x_p), static_cast<float*>(x_d));
+    return mmh::check_launch("decode_inputs");
 }
 
 int mmh_map_to_cord(const void* maps, int n_maps, int H, int W, float threshold, void* cords,

@@ -278,6 +278,22 @@ class MMHandModel(torch.nn.Module):
         if "H1_path" in input:
             self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
 
+    def set_input_raw(self, img1, img2, dep1, dep2, uv1, uv2, paths=None):
+        """Input straight from decoded files: uint8 BGR images / depth PNGs [B,H,W,3] and float64
+        joints [B,21,2] on the device.  One kernel (mmh_decode_inputs) does what the reference's
+        loader workers do per sample on the CPU (data/generic_dataset.py:133-180) and writes the
+        stems' NHWC buffers directly; the NCHW tensors the rest of the API exposes are views."""
+        self.x_H1, self.x_H2, self.x_P, self.x_D = ops.decode_inputs(img1, img2, dep1, dep2, uv1, uv2)
+        v = ops.nhwc_to_nchw_view
+        o = self.opt
+        self.input_H1, self.input_H2 = v(self.x_H1, o.H_input_nc), v(self.x_H2, o.H_input_nc)
+        self.input_P1 = v(self.x_P)[:, : o.P_input_nc]
+        self.input_P2 = v(self.x_P)[:, o.P_input_nc: 2 * o.P_input_nc]
+        self.input_D1 = v(self.x_D)[:, : o.D_input_nc]
+        self.input_D2 = v(self.x_D)[:, o.D_input_nc: 2 * o.D_input_nc]
+        if paths is not None:
+            self.image_paths = paths[0][0] + "___" + paths[1][0]
+
     def forward(self):
         self.fake_nhwc = self.netG.forward_nhwc(self.x_H1, self.x_P, self.x_D)
         self.fake_p2 = ops.nhwc_to_nchw_view(self.fake_nhwc, self.opt.output_nc)

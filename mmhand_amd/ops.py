@@ -546,3 +546,21 @@ def map_to_cord(maps, threshold=0.1):
     out = torch.empty((n, 2), dtype=torch.int32, device=maps.device)
     L.call("mmh_map_to_cord", _ptr(maps), n, H, W_, float(threshold), _ptr(out), _stream())
     return out
+
+
+def decode_inputs(img1, img2, dep1, dep2, uv1, uv2, sigma=6.0):
+    """On-device input pipeline (data/generic_dataset.py:133-180): uint8 BGR images + depth PNGs
+    [B,H,W,3] and float64 joints [B,21,2] -> the stems' NHWC buffers (x_H1, x_H2, x_P, x_D)."""
+    B, H, W_, _ = img1.shape
+    for t in (img1, img2, dep1, dep2):
+        assert t.dtype == torch.uint8 and t.is_cuda and t.is_contiguous() and tuple(t.shape) == (B, H, W_, 3)
+    for t in (uv1, uv2):
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous() and tuple(t.shape) == (B, 21, 2)
+    dev = img1.device
+    xh1 = torch.empty((B, H, W_, 4), dtype=torch.float32, device=dev)
+    xh2 = torch.empty((B, H, W_, 4), dtype=torch.float32, device=dev)
+    xp = torch.empty((B, H, W_, 44), dtype=torch.float32, device=dev)
+    xd = torch.empty((B, H, W_, 8), dtype=torch.float32, device=dev)
+    L.call("mmh_decode_inputs", _ptr(img1), _ptr(img2), _ptr(dep1), _ptr(dep2), _ptr(uv1), _ptr(uv2),
+           B, H, W_, float(sigma), _ptr(xh1), _ptr(xh2), _ptr(xp), _ptr(xd), _stream())
+    return xh1, xh2, xp, xd

@@ -190,3 +190,32 @@ def test_pose_maps_bit_exact_vs_reference_fixture(dev):
         assert ulp.max() <= 1
         c = ops.map_to_cord(torch.from_numpy(maps).to(dev)).cpu().numpy()
         assert np.array_equal(c, cords)
+
+
+def test_decode_inputs_bit_exact(dev):
+    """image normalise, depth decode, pose maps and the channel concat written
+    straight into the stems' NHWC buffers; image/depth values bit-exact vs the float64 numpy maths
+    of the reference loader, pose maps as in a15."""
+    from mmhand_amd import ops
+    rs = np.random.RandomState(3)
+    B, H, W = 2, 32, 48
+    imgs = [rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8) for _ in range(2)]
+    deps = [rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8) for _ in range(2)]
+    for d in deps:
+        d[..., 1] = rs.randint(0, 3, size=(B, H, W))          # realistic range: depth < 700
+    uvs = [rs.uniform(4, 28, size=(B, 21, 2)) for _ in range(2)]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    xh1, xh2, xp, xd = ops.decode_inputs(t(imgs[0]), t(imgs[1]), t(deps[0]), t(deps[1]), t(uvs[0]), t(uvs[1]))
+    for b in range(B):
+        h1, d1 = O.decode_sample(imgs[0][b], deps[0][b])
+        h2, d2 = O.decode_sample(imgs[1][b], deps[1][b])
+        assert torch.equal(xh1[b, ..., :3].cpu(), h1.permute(1, 2, 0)) and float(xh1[b, ..., 3].abs().sum()) == 0
+        assert torch.equal(xh2[b, ..., :3].cpu(), h2.permute(1, 2, 0))
+        assert torch.equal(xd[b, ..., 0:3].cpu(), d1.permute(1, 2, 0))
+        assert torch.equal(xd[b, ..., 3:6].cpu(), d2.permute(1, 2, 0)) and float(xd[b, ..., 6:].abs().sum()) == 0
+        p1 = O.pose_heatmaps(uvs[0][b], H, W); p2 = O.pose_heatmaps(uvs[1][b], H, W)
+        got = xp[b].cpu().numpy()
+        ref = np.concatenate([p1, p2], 0).transpose(1, 2, 0)
+        assert np.array_equal(got[..., :42] > 0, ref > 0)
+        assert np.abs(got[..., :42].view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max() <= 1
+        assert float(np.abs(got[..., 42:]).sum()) == 0
