@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
     constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr bool IL = B_NMAJOR;   // dgrad: loads interleaved with the MFMA groups (+1-2 % measured)
     constexpr int ASZ = BM * LDA;
     constexpr int BSZ = B_NMAJOR ? BN * LDA : BK * BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -250,41 +251,56 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     float4 ra[4];
     float4 rb[NB];
 
-    auto load_tiles = [&](int ks) {
+    // The loader is cut into 4 parts so that it can either run as one burst before the MFMAs
+    // (load_tiles) or be interleaved with the 4 MFMA groups of the k-step (p.interleave).
+    auto load_part = [&](int ks, int part) {
         const bool kv = kstate_valid(ks_t, g);
-        if (ks_t.j == 0) {   // new tap (or flat order): recompute the 4 row offsets
+        if (part == 0) {
+            if (ks_t.j == 0) {   // new tap (or flat order): recompute the 4 row offsets
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], ks_t, a_ok[i]);
+            }
+        } else if (part == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], ks_t, a_ok[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ra[i] = bload4(rsA, (kv && a_off[i] != OOB) ? a_off[i] + (unsigned)ks_t.c4 * 16u : OOB);
-        if (!B_NMAJOR) {
-            // weight rows [rowbase, rowbase+32) x columns [n0, n0+BN)
-            int rowbase, rowlim;
-            if (g.chunk_major) {   // all threads share (th,tw) and the 8-group chunk
-                rowbase = (ks_t.th * g.TW + ks_t.tw) * p.wCin + (ks_t.c4 - grp) * 4;
-                rowlim = rowbase + BK;
-            } else {
-                rowbase = ks * BK;
-                rowlim = p.Kflat;
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int row = rowbase + b_krow[i];
-                const unsigned off = (unsigned)row * (unsigned)p.wCout * 4u + b_col[i];
-                rb[i] = bload4(rsW, (row < rowlim && b_col[i] != OOB) ? off : OOB);
-            }
+                ra[i] = bload4(rsA, (kv && a_off[i] != OOB) ? a_off[i] + (unsigned)ks_t.c4 * 16u : OOB);
         } else {
-            // B[k=(tap,co)][n=ci] = w[(tap_true*wCin + ci)*wCout + co]; same k-group as A
-            const int tap_true = (p.kh0 + p.tstep * ks_t.th) * p.KW_true + p.kw0 + p.tstep * ks_t.tw;
-            const unsigned tap_off = ((unsigned)tap_true * (unsigned)p.wCin * (unsigned)p.wCout +
-                                      (unsigned)ks_t.c4 * 4u) * 4u;
+            constexpr int H0 = (NB + 1) / 2;
+            const int i0 = part == 2 ? 0 : H0, i1 = part == 2 ? H0 : NB;
+            if (!B_NMAJOR) {
+                // weight rows [rowbase, rowbase+32) x columns [n0, n0+BN)
+                int rowbase, rowlim;
+                if (g.chunk_major) {   // all threads share (th,tw) and the 8-group chunk
+                    rowbase = (ks_t.th * g.TW + ks_t.tw) * p.wCin + (ks_t.c4 - grp) * 4;
+                    rowlim = rowbase + BK;
+                } else {
+                    rowbase = ks * BK;
+                    rowlim = p.Kflat;
+                }
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                rb[i] = bload4(rsW, (kv && b_row[i] != OOB) ? tap_off + b_row[i] : OOB);
+                for (int i = 0; i < NB; ++i) {
+                    if (i < i0 || i >= i1) continue;
+                    const int row = rowbase + b_krow[i];
+                    const unsigned off = (unsigned)row * (unsigned)p.wCout * 4u + b_col[i];
+                    rb[i] = bload4(rsW, (row < rowlim && b_col[i] != OOB) ? off : OOB);
+                }
+            } else {
+                // B[k=(tap,co)][n=ci] = w[(tap_true*wCin + ci)*wCout + co]; same k-group as A
+                const int tap_true = (p.kh0 + p.tstep * ks_t.th) * p.KW_true + p.kw0 + p.tstep * ks_t.tw;
+                const unsigned tap_off = ((unsigned)tap_true * (unsigned)p.wCin * (unsigned)p.wCout +
+                                          (unsigned)ks_t.c4 * 4u) * 4u;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    if (i < i0 || i >= i1) continue;
+                    rb[i] = bload4(rsW, (kv && b_row[i] != OOB) ? tap_off + b_row[i] : OOB);
+                }
+            }
         }
+    };
+    auto load_tiles = [&](int ks) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) load_part(ks, part);
     };
 
     auto store_tiles = [&](int buf) {
@@ -322,12 +338,14 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     for (int ks = 0; ks < p.nk; ++ks) {
         const float* As = As_base + (DBUF ? (ks & 1) : 0) * ASZ;
         const float* Bs = Bs_base + (DBUF ? (ks & 1) : 0) * BSZ;
-        if (ks + 1 < p.nk) {
+        const bool more = ks + 1 < p.nk;
+        if (more) {
             kstate_next(ks_t, g);
-            if (!(p.dbg & 1)) load_tiles(ks + 1);   // global -> registers, in flight during the MFMAs
+            if (!(p.dbg & 1) && !IL) load_tiles(ks + 1);   // global -> registers, one burst
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
+            if (IL && more) load_part(ks + 1, kg);         // ... or spread over the MFMA groups
             float4 av[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -411,6 +429,7 @@ struct WgradKP {
     int N;                  // Cout
     int P;                  // total pixels = batch*PH*PW
     int pix_per_split;      // multiple of 32
+    int dbg;                // timing-only ablation bits (results wrong)
 };
 
 template <int BN, int WAVES_M, int WAVES_N, bool DBUF>
@@ -449,8 +468,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
         kt.tw = tap - kt.th * g.TW;
     }
     // this thread's 4 pixels of the current k-step, advanced by 32 pixels per step without
-    // divisions: (image, row, col) counters
+    // divisions: (image, row, col) counters.  The row part of the source offset (image base +
+    // reflected/checked source row) only changes when the pixel row does, so it is cached.
     int px_b[4], px_h[4], px_w[4];
+    unsigned hpart[4];     // (image*srcH + source row) * srcW, or OOB when the row is out of range
+    auto row_part = [&](int b, int ph) -> unsigned {
+        int vh = ph * g.ap_h + g.a0_h + kt.th * g.at_h;
+        bool ok = true;
+        if (g.reflect) {
+            vh = vh < 0 ? -vh : vh;
+            vh = vh >= g.srcH ? 2 * (g.srcH - 1) - vh : vh;
+        } else {
+            ok = vh >= 0 && vh < g.srcH;
+        }
+        return ok ? ((unsigned)b * (unsigned)g.srcH + (unsigned)vh) * (unsigned)g.srcW : OOB;
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pix = pbeg + (tid >> 5) + 8 * i;
@@ -458,6 +490,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
         const int r = pix - px_b[i] * PHW;
         px_h[i] = r / g.PW;
         px_w[i] = r - px_h[i] * g.PW;
+        hpart[i] = row_part(px_b[i], px_h[i]);
     }
     // dy tile columns
     unsigned d_col[NB];
@@ -476,14 +509,24 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pix = pbase + (tid >> 5) + 8 * i;
-            ra[i] = bload4(rsA, gather_off(g, (unsigned)px_b[i] * (unsigned)(g.srcH * g.srcW),
-                                           px_h[i] * g.ap_h + g.a0_h, px_w[i] * g.ap_w + g.a0_w,
-                                           kt, g_ok && pix < pend));
+            int vw = px_w[i] * g.ap_w + g.a0_w + kt.tw * g.at_w;
+            bool ok = g_ok && pix < pend && hpart[i] != OOB;
+            if (g.reflect) {
+                vw = vw < 0 ? -vw : vw;
+                vw = vw >= g.srcW ? 2 * (g.srcW - 1) - vw : vw;
+            } else {
+                ok = ok && vw >= 0 && vw < g.srcW;
+            }
+            const unsigned off = ((hpart[i] + (unsigned)vw) * g.src_cs + (unsigned)kt.c4 * 4u) * 4u;
+            ra[i] = bload4(rsA, ok ? off : OOB);
             // advance 32 pixels
             px_w[i] += BK;
-            while (px_w[i] >= g.PW) {
-                px_w[i] -= g.PW;
-                if (++px_h[i] == g.PH) { px_h[i] = 0; ++px_b[i]; }
+            if (px_w[i] >= g.PW) {
+                do {
+                    px_w[i] -= g.PW;
+                    if (++px_h[i] == g.PH) { px_h[i] = 0; ++px_b[i]; }
+                } while (px_w[i] >= g.PW);
+                hpart[i] = row_part(px_b[i], px_h[i]);
             }
         }
 #pragma unroll
@@ -519,7 +562,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
         for (int pb = pbeg; pb < pend; pb += BK) {
             const float* As = As_base + cur * ASZ;
             const float* Bs = Bs_base + cur * BSZ;
-            if (pb + BK < pend) load_tiles(pb + BK);
+            if (pb + BK < pend && !(p.dbg & 1)) load_tiles(pb + BK);
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
                 float a[TM], b[TN];
@@ -533,9 +576,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            if (DBUF) cur ^= 1; else __syncthreads();
-            if (pb + BK < pend) store_tiles(cur);
-            __syncthreads();
+            if (!(p.dbg & 2)) {
+                if (DBUF) cur ^= 1; else __syncthreads();
+                if (pb + BK < pend) store_tiles(cur);
+                __syncthreads();
+            }
         }
     }
 
@@ -819,6 +864,7 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
                 (size_t)splits * p.Mrows * p.N * sizeof(float));
     p.slab = static_cast<float*>(ws);
     p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), BK) * BK);
+    p.dbg = g_conv_dbg;
     int rc;
     if (p.N > 64) rc = g_wgrad_dbuf ? launch_wgrad_t<128, 2, 2, true>(p, splits, st)
                                     : launch_wgrad_t<128, 2, 2, false>(p, splits, st);
