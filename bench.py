@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE_STEP = 2444.4       # algorithmic conv FLOPs of one G+D step
 PEAK_F32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA_TF = 2500.0          # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def synthetic_batch_gpu(B, H, W, seed, dev):
@@ -147,6 +148,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE.json configs[1] (default); bf16 = bf16 MFMA compute, fp32 master "
+                         "weights/accumulate/HBM tensors (the --opt_level O1 path; configs[2]/[4] precision)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=25.0, help=argparse.SUPPRESS)
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
@@ -172,7 +176,9 @@ def main():
     from mmhand_amd.mmhand_model import MMHandModel
     from mmhand_amd.options import default_train_opt
     opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="bench", local_rank=local,
-                            checkpoints_dir="/tmp/mmh_bench", distributed=world > 1)
+                            checkpoints_dir="/tmp/mmh_bench", distributed=world > 1,
+                            opt_level="O1" if a.dtype == "bf16" else "O0")
+    peak = PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF
     model = MMHandModel(opt)
     H = W = a.size
     batch = synthetic_batch_gpu(a.batch, H, W, 49 + rank, dev)
@@ -209,7 +215,7 @@ def main():
         k_ms, k_n = timer.mean_ms()
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and a.batch == 32 and a.size == 256:
+        if os.path.exists(tj) and a.batch == 32 and a.size == 256 and a.dtype == "f32":
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
         k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
         achieved = k_flop / (k_ms * 1e-3) / 1e12
@@ -217,16 +223,18 @@ def main():
             "metric": "256x256 hand images/sec (G+D step)", "value": round(imgs_per_s, 3),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RHD-shaped {H}x{W}, per-GPU batch {a.batch}, fp32, G(9 PATBlocks,"
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"RHD-shaped {H}x{W}, per-GPU batch {a.batch}, "
+                       f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}, G(9 PATBlocks,"
                        f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}"},
             "step_mfma_frac": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world
-                                    / 1e3 / PEAK_F32_MFMA_TF, 4),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TF, 4),
+                                    / 1e3 / peak, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<128,2,2,false> fprop 3x3 512->512 @64x64 "
+                         "kernel": ("conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
+                                    "conv_igemm_kernel<128,2,2,false>") + " fprop 3x3 512->512 @64x64 "
                                    f"(B={a.batch}): {k_flop / 1e9:.1f} GFLOP/launch, {k_ms:.3f} ms avg "
                                    f"over {k_n} launches in the timed region"},
             "losses": {k: round(v, 5) for k, v in losses.items()},

@@ -46,7 +46,13 @@ typedef struct mmh_conv_desc {
     int32_t pad_mode;     /* MMH_PAD_ZERO | MMH_PAD_REFLECT (stride 1 only) */
     int32_t Ho, Wo;       /* output (y) spatial size                        */
     int32_t x_cs, y_cs;   /* channel strides of x and y buffers (>= C)      */
-    int32_t dtype;        /* MMH_F32 (MMH_BF16 reserved)                    */
+    int32_t dtype;        /* MMH_F32, or MMH_BF16 = bf16 MFMA compute:      */
+                          /* x, y, dy, dx stay fp32 in HBM (rounded to bf16 */
+                          /* while staged), fp32 accumulate; `w` must then  */
+                          /* be a tensor made by mmh_prep_weights_bf16      */
+                          /* (fprop / convT dgrad: w_t; dgrad / convT       */
+                          /* fprop: w_plain); channels % 64 == 0.  wgrad also  */
+                          /* rounds x and dy to bf16 (no channel rule).     */
 } mmh_conv_desc;
 
 const char* mmh_last_error(void);
@@ -89,6 +95,12 @@ int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
 int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
                       void* dw, void* ws, size_t ws_bytes, int accumulate,
                       mmh_stream_t s);
+
+/* fp32 weights [taps][Cin][Cout] -> bf16 copies for the MMH_BF16 conv path:
+ * w_plain [taps][Cin][Cout] (contraction = Cout, used by dgrad) and
+ * w_t [taps][Cout][Cin] (contraction = Cin, used by fprop).  Either may be NULL. */
+int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout,
+                          void* w_plain, void* w_t, mmh_stream_t s);
 
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */

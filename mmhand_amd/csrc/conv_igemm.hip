@@ -59,6 +59,7 @@ struct ConvKP {
     int nk;                     // k-steps
     int Kflat;                  // TH*TW*C4*4 (flat order bound)
     int wCin, wCout;            // weight tensor dims [taps][wCin][wCout]
+    int wRows, wKper;           // bf16 path: prepared weights are [taps][wRows][wKper] (k contiguous)
     int KW_true, kh0, kw0, tstep;  // true tap = (kh0+tstep*th)*KW_true + kw0+tstep*tw
     int OH, OW, o_p, o0_h, o0_w;   // output pixel = (ph*o_p+o0_h, pw*o_p+o0_w) in OHxOW
     unsigned out_cs;
@@ -415,6 +416,192 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
 }
 
 // ---------------------------------------------------------------------------
+// bf16-MFMA variant of the fprop / dgrad kernel (mmh_conv_desc.dtype = MMH_BF16).
+// Activations stay fp32 in HBM and are rounded to bf16 (RNE) while being staged into LDS;
+// weights come pre-rounded to bf16 and laid out with the contraction index contiguous
+// (mmh_prep_weights_bf16: [tap][Cout][Cin] for fprop, [tap][Cin][Cout] for dgrad), so both LDS
+// tiles are [row][k] and both MFMA operands are one ds_read_b128 per 32x32x16 step.
+// Accumulation and output are fp32.  k-step = 64 channels of one tap; needs channels % 64 == 0
+// (the 3x3 stacks; the small-Cin stems keep the fp32 kernel).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BK16 = 64;     // contraction depth per k-step (bf16 kernel)
+constexpr int LDH = 72;      // LDS row pitch in bf16 elements (144 B: conflict-free ds_read_b128)
+
+__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+    return r;
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NBL = BN / 32;            // 16-byte weight loads per thread per k-step
+    constexpr int ASZ = BM * LDH, BSZ = BN * LDH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* const As = reinterpret_cast<__bf16*>(smem);
+    __bf16* const Bs = As + ASZ;
+
+    const Gather& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int mt = blockIdx.y, nt = blockIdx.x;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, band = gridDim.y / 8;
+        const int L = blockIdx.y * gx + blockIdx.x;
+        if (L < band * 8 * gx) {
+            const int x = L & 7, i = L >> 3;
+            nt = i % gx;
+            mt = x * band + i / gx;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.w, p.w_bytes);
+
+    // A: 128 rows x 16 groups of 4 channels; thread = (group tid&15, rows (tid>>4)+16i, i<8)
+    const int grp = tid & 15;
+    unsigned a_img[8];
+    int a_bh[8], a_bw[8];
+    bool a_ok[8];
+    const int PHW = g.PH * g.PW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int m = m0 + (tid >> 4) + 16 * i;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int b = mm / PHW;
+        int r = mm - b * PHW;
+        int ph = r / g.PW;
+        int pw = r - ph * g.PW;
+        a_img[i] = (unsigned)b * (unsigned)(g.srcH * g.srcW);
+        a_bh[i] = ph * g.ap_h + g.a0_h;
+        a_bw[i] = pw * g.ap_w + g.a0_w;
+    }
+    // B: BN rows x 8 groups of 8 bf16 (16 B); thread = (group tid&7, rows (tid>>3)+32i)
+    const int bgrp = tid & 7;
+    unsigned b_row[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        b_row[i] = n < p.N ? (unsigned)n * (unsigned)p.wKper * 2u : OOB;   // bytes
+    }
+
+    // k order: (super-chunk of cw chunks, tap, chunk); chunk = 64 channels
+    int th = 0, tw = 0, cc = 0, j = 0;       // block-uniform
+    unsigned a_off[8];
+    float4 ra[8];
+    uint4 rb[NBL];
+
+    auto load_tiles = [&]() {
+        if (j == 0) {
+            KState s; s.th = th; s.tw = tw; s.c4 = 0; s.j = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], s, a_ok[i]);
+        }
+        const unsigned coff = (unsigned)(cc * 16 + grp) * 16u;      // bytes: 4 fp32 channels per group
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = bload4(rsA, a_off[i] != OOB ? a_off[i] + coff : OOB);
+        const int tap_true = (p.kh0 + p.tstep * th) * p.KW_true + p.kw0 + p.tstep * tw;
+        const unsigned tap_off = ((unsigned)tap_true * (unsigned)p.wRows * (unsigned)p.wKper +
+                                  (unsigned)(cc * 64 + bgrp * 8)) * 2u;
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_row[i] != OOB ? tap_off + b_row[i] : OOB, 0, 0);
+            rb[i] = __builtin_bit_cast(uint4, r);
+        }
+    };
+    auto advance = [&]() {
+        ++cc;
+        if (++j == g.cw) {
+            j = 0;
+            cc -= g.cw;
+            if (++tw == g.TW) { tw = 0; if (++th == g.TH) { th = 0; cc += g.cw; } }
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_bf16x4(ra[i]);
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+            *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + 32 * i) * LDH + bgrp * 8]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+
+    if (p.nk > 0) {
+        load_tiles();
+        store_tiles();
+    }
+    __syncthreads();
+    for (int ks = 0; ks < p.nk; ++ks) {
+        const bool more = ks + 1 < p.nk;
+        if (more) {
+            advance();
+            load_tiles();
+        }
+#pragma unroll
+        for (int s16 = 0; s16 < BK16 / 16; ++s16) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 32 + l31) * LDH + s16 * 16 + h * 8]);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                bfr[jn] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + jn * 32 + l31) * LDH + s16 * 16 + h * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tiles();
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            unsigned off;
+            if (p.out_linear) off = (unsigned)m * p.out_cs;
+            else {
+                int b = m / PHW;
+                int rr = m - b * PHW;
+                int ph = rr / g.PW;
+                int pw = rr - ph * g.PW;
+                off = ((unsigned)(b * p.OH + ph * p.o_p + p.o0_h) * (unsigned)p.OW +
+                       (unsigned)(pw * p.o_p + p.o0_w)) * p.out_cs;
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const int n = n0 + wn * WTN + jn * 32 + l31;
+                if (n < p.N) {
+                    float v = acc[i][jn][r];
+                    if (p.bias) v += p.bias[n];
+                    p.out[off + n] = apply_act(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // wgrad kernel: slab[z][(tap,ci)][co] = sum over this split's pixels.
 // Rows of the GEMM are the flat (tap, ci) index, the contraction runs over
 // pixels; the x tile is gathered exactly as in fprop and read transposed.
@@ -599,6 +786,164 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
         }
 }
 
+// ---------------------------------------------------------------------------
+// bf16-MFMA wgrad.  Same GEMM as conv_wgrad_kernel (rows = flat (tap,ci), cols = co,
+// contraction over pixels) but x and dy are rounded to bf16 while staged and both MFMA operands
+// are read TRANSPOSED from LDS with ds_read_b64_tr_b16: the tiles sit as [pixel][channel] (the
+// order they arrive in, channel contiguous) and the 32x32x16 operands need 8 consecutive pixels
+// per lane.  Row pitch 320 B puts the 4 rows of a transposed 4x16 block on disjoint banks.
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKP = 64;      // pixels per k-step
+constexpr int LDT = 160;     // LDS row pitch in bf16 elements (128 + 32 pad = 320 B)
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0, int lane) {
+    // operand fragment for lane: 8 consecutive rows (pixels) row0 + 8h + 0..7 of column
+    // col0 + (lane & 31), from a row-major [pixel][channel] bf16 tile.
+    const int h = lane >> 5, G1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p2 = lane & 3;
+    const __bf16* a = tile + (row0 + 8 * h + q) * LDT + col0 + 16 * G1 + 4 * p2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * LDT));
+    struct { s16x4 a, b; } both = {lo, hi};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NBD = BN / 16;            // dy float4 loads per thread per k-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* const As = reinterpret_cast<__bf16*>(smem);     // [BKP][LDT]
+    __bf16* const Bs = As + BKP * LDT;                      // [BKP][LDT]
+
+    const Gather& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int pend = min(p.P, pbeg + p.pix_per_split);
+    const int PHW = g.PH * g.PW;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dy, p.dy_bytes);
+
+    KState kt;
+    const int fg = (m0 >> 2) + (tid & 31);
+    const bool g_ok = fg * 4 < p.Mrows;
+    {
+        int tap = fg / g.C4;
+        kt.c4 = fg - tap * g.C4;
+        kt.th = tap / g.TW;
+        kt.tw = tap - kt.th * g.TW;
+        kt.j = 0;
+    }
+    // 8 pixels per thread per k-step: rows (tid>>5) + 8i
+    int px_b[8], px_h[8], px_w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pix = pbeg + (tid >> 5) + 8 * i;
+        px_b[i] = pix / PHW;
+        const int r = pix - px_b[i] * PHW;
+        px_h[i] = r / g.PW;
+        px_w[i] = r - px_h[i] * g.PW;
+    }
+    unsigned d_col[NBD];
+    int d_prow[NBD];
+#pragma unroll
+    for (int i = 0; i < NBD; ++i) {
+        const int idx = tid + 256 * i;
+        d_prow[i] = idx / (BN / 4);
+        const int n = n0 + 4 * (idx - d_prow[i] * (BN / 4));
+        d_col[i] = n < p.N ? (unsigned)n * 4u : OOB;
+    }
+
+    float4 ra[8];
+    float4 rb[NBD];
+    auto load_tiles = [&](int pbase) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pix = pbase + (tid >> 5) + 8 * i;
+            ra[i] = bload4(rsA, gather_off(g, (unsigned)px_b[i] * (unsigned)(g.srcH * g.srcW),
+                                           px_h[i] * g.ap_h + g.a0_h, px_w[i] * g.ap_w + g.a0_w, kt,
+                                           g_ok && pix < pend));
+            px_w[i] += BKP;
+            while (px_w[i] >= g.PW) {
+                px_w[i] -= g.PW;
+                if (++px_h[i] == g.PH) { px_h[i] = 0; ++px_b[i]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NBD; ++i) {
+            const int pix = pbase + d_prow[i];
+            const unsigned off = (unsigned)pix * p.dy_cs * 4u + d_col[i];
+            rb[i] = bload4(rsD, (pix < pend && d_col[i] != OOB) ? off : OOB);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_bf16x4(ra[i]);
+#pragma unroll
+        for (int i = 0; i < NBD; ++i) {
+            const int idx = tid + 256 * i;
+            const int prow = idx / (BN / 4), c4 = idx - prow * (BN / 4);
+            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_bf16x4(rb[i]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (pbeg < pend) {
+        load_tiles(pbeg);
+        store_tiles();
+        __syncthreads();
+        for (int pb = pbeg; pb < pend; pb += BKP) {
+            const bool more = pb + BKP < pend;
+            if (more) load_tiles(pb + BKP);
+#pragma unroll
+            for (int s16 = 0; s16 < BKP / 16; ++s16) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = tr_frag(As, s16 * 16, wm * WTM + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Bs, s16 * 16, wn * WTN + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
+    }
+
+    float* slab = p.slab + (size_t)blockIdx.z * (size_t)p.Mrows * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= p.Mrows) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
 // dw[i] (+)= sum_z slab[z][i], fixed order -> deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                    int64_t n4, int splits, int accumulate) {
@@ -651,7 +996,7 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __rest
 // --------------------------------------------------------------------------- host side
 int validate(const mmh_conv_desc* d) {
     MMH_REQUIRE(d != nullptr, "conv desc is NULL");
-    MMH_REQUIRE(d->dtype == MMH_F32, "only MMH_F32 is implemented (dtype=%d)", d->dtype);
+    MMH_REQUIRE(d->dtype == MMH_F32 || d->dtype == MMH_BF16, "bad dtype=%d", d->dtype);
     MMH_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "Cin/Cout must be multiples of 4 (%d,%d)",
                 d->Cin, d->Cout);
     MMH_REQUIRE(d->x_cs % 4 == 0 && d->y_cs % 4 == 0 && d->x_cs >= d->Cin && d->y_cs >= d->Cout,
@@ -707,6 +1052,37 @@ int launch_conv_t(const ConvKP& p, hipStream_t st) {
     return mmh::check_launch("conv_igemm_kernel");
 }
 
+template <int BN, int WM, int WN>
+int launch_conv_bf16_t(const ConvKP& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)(BM + BN) * LDH * 2;
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_igemm_bf16_kernel<BN, WM, WN>, lds);
+    if (ready != 0) return ready;
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BN, WM, WN>), grid, dim3(256), lds, st, p);
+    return mmh::check_launch("conv_igemm_bf16_kernel");
+}
+
+// bf16 MFMA path: needs the contraction channels per tap to be a multiple of 64
+bool bf16_ok(const ConvKP& p) { return p.g.C4 % 16 == 0 && p.N % 4 == 0; }
+
+int launch_conv_bf16(ConvKP& p, hipStream_t st) {
+    Gather& g = p.g;
+    const int chunks = g.C4 / 16;                   // 64-channel chunks per tap
+    g.chunk_major = 1;
+    g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
+    p.nk = chunks * g.TH * g.TW;
+    p.dbg = 0;
+    {
+        const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
+        const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;
+        p.xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+    }
+    if (p.N > 64) return launch_conv_bf16_t<128, 2, 2>(p, st);
+    if (p.N > 32) return launch_conv_bf16_t<64, 2, 2>(p, st);
+    return launch_conv_bf16_t<32, 4, 1>(p, st);
+}
+
 template <bool NMAJOR>
 int launch_conv(const ConvKP& p, hipStream_t st) {
     const_cast<ConvKP&>(p).dbg = g_conv_dbg;
@@ -754,6 +1130,13 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
     p.out_linear = 1; p.out_cs = (unsigned)d->y_cs;
     p.OH = d->Ho; p.OW = d->Wo; p.o_p = 1;
     p.act = act;
+    if (d->dtype == MMH_BF16) {
+        // w is the prepared bf16 tensor [taps][Cout][Cin]
+        p.wRows = d->Cout; p.wKper = d->Cin;
+        p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
+        MMH_REQUIRE(bf16_ok(p), "bf16 fprop needs Cin %% 64 == 0 (Cin=%d)", d->Cin);
+        return launch_conv_bf16(p, st);
+    }
     return launch_conv<false>(p, st);
 }
 
@@ -800,7 +1183,17 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
             p.out_linear = s == 1;
             p.act = act;
             if (TH == 0 || TW == 0) p.nk = 0;  // no tap reaches this class: writes zeros
-            int rc = launch_conv<true>(p, st);
+            int rc;
+            if (d->dtype == MMH_BF16) {
+                // w is the prepared bf16 tensor [taps][Cin][Cout]
+                p.wRows = d->Cin; p.wKper = d->Cout;
+                p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
+                MMH_REQUIRE(bf16_ok(p), "bf16 dgrad needs Cout %% 64 == 0 (Cout=%d)", d->Cout);
+                const bool empty = (TH == 0 || TW == 0);
+                rc = launch_conv_bf16(p, st);
+                (void)empty;
+            } else
+                rc = launch_conv<true>(p, st);
             if (rc) return rc;
         }
     return 0;
@@ -841,6 +1234,17 @@ int launch_wgrad_t(const WgradKP& p, int splits, hipStream_t st) {
     return mmh::check_launch("conv_wgrad_kernel");
 }
 
+template <int BN, int WM, int WN>
+int launch_wgrad_bf16_t(const WgradKP& p, int splits, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * BKP * LDT * 2;
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_wgrad_bf16_kernel<BN, WM, WN>, lds);
+    if (ready != 0) return ready;
+    dim3 grid((p.N + BN - 1) / BN, (p.Mrows + BM - 1) / BM, splits);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BN, WM, WN>), grid, dim3(256), lds, st, p);
+    return mmh::check_launch("conv_wgrad_bf16_kernel");
+}
+
 size_t wgrad_ws(const mmh_conv_desc* d) {
     const int Mrows = d->kh * d->kw * d->Cin;
     const int P = d->B * d->Ho * d->Wo;
@@ -863,10 +1267,15 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
                 "wgrad workspace too small: %zu < %zu", ws_bytes,
                 (size_t)splits * p.Mrows * p.N * sizeof(float));
     p.slab = static_cast<float*>(ws);
-    p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), BK) * BK);
+    const bool bf16 = d->dtype == MMH_BF16;
+    p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), bf16 ? BKP : BK) * (bf16 ? BKP : BK));
     p.dbg = g_conv_dbg;
     int rc;
-    if (p.N > 64) rc = g_wgrad_dbuf ? launch_wgrad_t<128, 2, 2, true>(p, splits, st)
+    if (bf16) {
+        if (p.N > 64) rc = launch_wgrad_bf16_t<128, 2, 2>(p, splits, st);
+        else if (p.N > 32) rc = launch_wgrad_bf16_t<64, 2, 2>(p, splits, st);
+        else rc = launch_wgrad_bf16_t<32, 4, 1>(p, splits, st);
+    } else if (p.N > 64) rc = g_wgrad_dbuf ? launch_wgrad_t<128, 2, 2, true>(p, splits, st)
                                     : launch_wgrad_t<128, 2, 2, false>(p, splits, st);
     else if (p.N > 32) rc = launch_wgrad_t<64, 2, 2, false>(p, splits, st);
     else rc = launch_wgrad_t<32, 4, 1, false>(p, splits, st);

@@ -650,6 +650,23 @@ __global__ void decode_inputs_kernel(const uint8_t* __restrict__ img1, const uin
     }
 }
 
+// ------------------------------------------------------------------ bf16 weight copies
+__global__ void prep_weights_bf16_kernel(const float* __restrict__ w, int taps, int R, int C,
+                                         __bf16* __restrict__ plain, __bf16* __restrict__ tr) {
+    const int64_t total = (int64_t)taps * R * C;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const int64_t t2 = i / C;
+        const int r = (int)(t2 % R);
+        const int t = (int)(t2 / R);
+        const __bf16 v = (__bf16)w[i];
+        if (plain) plain[i] = v;
+        if (tr) tr[((int64_t)t * C + c) * R + r] = v;
+    }
+}
+
 int check_cols(const char* who, int C) {
     MMH_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in (0,1024], got %d",
                 who, C);
@@ -919,6 +936,15 @@ int mmh_decode_inputs(const void* img1, const void* img2, const void* dep1, cons
                        static_cast<const double*>(uv2), B, H, W, sigma, static_cast<float*>(x_h1),
                        static_cast<float*>(x_h2), static_cast<float*>(x_p), static_cast<float*>(x_d));
     return mmh::check_launch("decode_inputs");
+}
+
+int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout, void* w_plain, void* w_t,
+                          mmh_stream_t s) {
+    MMH_REQUIRE(w && (w_plain || w_t) && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_bf16: bad arguments");
+    hipLaunchKernelGGL(prep_weights_bf16_kernel, dim3(grid_for((int64_t)taps * Cin * Cout)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout,
+                       static_cast<__bf16*>(w_plain), static_cast<__bf16*>(w_t));
+    return mmh::check_launch("prep_weights_bf16");
 }
 
 int mmh_map_to_cord(const void* maps, int n_maps, int H, int W, float threshold, void* cords,

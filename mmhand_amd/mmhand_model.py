@@ -72,6 +72,7 @@ class FlatAdam(torch.optim.Optimizer):
         ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
                       self.grad_scale)
+        ops.bump_weights_epoch()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
@@ -202,6 +203,11 @@ class MMHandModel(torch.nn.Module):
             self.load_network()
         for n in nets:
             n.flatten_parameters()
+        # --opt_level O1/O2 (apex AMP in the reference, scripts/mm-train-ratio.sh:7-11) -> bf16 MFMA
+        # compute with fp32 master weights / accumulation / statistics; O0 -> fp32.
+        self.bf16 = str(getattr(opt, "opt_level", "O0")).upper() in ("O1", "O2", "BF16")
+        for n in nets:
+            n.bf16 = self.bf16
 
         if self.isTrain:
             self.old_lr = opt.lr
@@ -210,6 +216,7 @@ class MMHandModel(torch.nn.Module):
             self.criterionGAN = GANLoss()
             if opt.L1_type == "l1_plus_perL1":
                 self.vgg = VGGHead().to(self.device)
+                self.vgg.bf16 = self.bf16
                 vgg_path = getattr(opt, "vgg_weights", None)
                 if vgg_path:
                     self.vgg.load_state_dict(torch.load(vgg_path, map_location="cpu"))

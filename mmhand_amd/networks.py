@@ -48,6 +48,7 @@ class ConvParam(nn.Module):
             if bias is not None and self.bias is not None:
                 self.bias.zero_()
                 self.bias[: self.cout].copy_(bias)
+        ops.bump_weights_epoch()
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         destination[prefix + "weight"] = self.logical_weight().contiguous().clone()
@@ -116,6 +117,7 @@ class _Net(nn.Module):
         self.use_bias = self.norm == "instance"
         self.use_dropout = use_dropout
         self.sync_group = None        # set by MMHandModel for SyncBN under data parallel
+        self.bf16 = False             # bf16 MFMA compute for the convs (apex O1/O2 analogue)
         self.flat_param = None
         self.flat_grad = None
         self._mask_src = None         # test hook: dict site -> uint8 NHWC keep mask
@@ -146,6 +148,7 @@ class _Net(nn.Module):
                 p.grad = gflat[off:off + k].view(p.shape)
                 off += k
         self.flat_param, self.flat_grad = flat, gflat
+        ops.bump_weights_epoch()
         return flat, gflat
 
     def _apply(self, fn, *a, **kw):
@@ -185,10 +188,10 @@ class _Net(nn.Module):
 
     # -- functional layers
     def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE):
-        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act)
+        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16)
 
     def convT(self, cp, x):
-        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias)
+        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16)
 
     def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None):
         drop_p = 0.5 if (drop and self.training) else 0.0
@@ -363,6 +366,7 @@ class VGGHead(nn.Module):
 
     def __init__(self):
         super().__init__()
+        self.bf16 = False
         self.net = Bag()
         self.net.put(0, ConvParam(3, 64, 3, True))
         self.net.put(2, ConvParam(64, 64, 3, True))
@@ -386,5 +390,5 @@ class VGGHead(nn.Module):
 
     def forward_nhwc(self, x):
         a, b = self.net[0], self.net[2]
-        y = ops.Conv2dFn.apply(x, a.weight, a.bias, 1, 1, False, L.ACT_RELU)
-        return ops.Conv2dFn.apply(y, b.weight, b.bias, 1, 1, False, L.ACT_RELU)
+        y = ops.Conv2dFn.apply(x, a.weight, a.bias, 1, 1, False, L.ACT_RELU, self.bf16)
+        return ops.Conv2dFn.apply(y, b.weight, b.bias, 1, 1, False, L.ACT_RELU, self.bf16)

@@ -50,6 +50,30 @@ def _ws(nbytes, like):
 # --------------------------------------------------------------------------- conv
 fprop_timer = None   # optional bench hook: object with want(desc) / bracket() -> (event, event)
 
+# bf16 MFMA path ("--opt_level O1/O2": the reference's apex AMP mixed precision becomes bf16
+# compute with fp32 master weights, fp32 accumulation and fp32 tensors in HBM).  The bf16 weight
+# copies are rebuilt lazily whenever the weights epoch moves (optimizer step, load_state_dict).
+_weights_epoch = [0]
+_bf16_cache = {}
+
+
+def bump_weights_epoch():
+    _weights_epoch[0] += 1
+
+
+def bf16_weights(w):
+    """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) bf16 copies of a physical fp32 weight."""
+    key = w.data_ptr()
+    ent = _bf16_cache.get(key)
+    if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
+        k, _, cin, cout = w.shape
+        wp = torch.empty((k, k, cin, cout), dtype=torch.bfloat16, device=w.device)
+        wt = torch.empty((k, k, cout, cin), dtype=torch.bfloat16, device=w.device)
+        L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), _ptr(wt), _stream())
+        ent = (_weights_epoch[0], tuple(w.shape), wp, wt)
+        _bf16_cache[key] = ent
+    return ent[2], ent[3]
+
 
 def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None):
     Ho = (H + 2 * pad - k) // stride + 1
@@ -59,13 +83,16 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
                       x_cs or Cin, y_cs or Cout, L.F32)
 
 
-def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE):
+def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape
     k, _, wc, Cout = w.shape
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
+    if bf16 and Cin % 64 == 0:
+        d.dtype = L.BF16
+        w = bf16_weights(w)[1]
     if fprop_timer is not None and fprop_timer.want(d):
         e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
         e0.record()
@@ -76,11 +103,14 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE):
     return y
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect):
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False):
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     k, _, _, Cout = w.shape
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if bf16 and Cout % 64 == 0:
+        d.dtype = L.BF16
+        w = bf16_weights(w)[0]
     if reflect and pad > 0:
         dxp = _empty((B, H + 2 * pad, W_ + 2 * pad, Cin), dy)
         L.call("mmh_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dxp), Cin, _stream())
@@ -92,11 +122,13 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect):
     return dx
 
 
-def raw_conv_wgrad(x, dy, k, stride, pad, reflect):
+def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if bf16:
+        d.dtype = L.BF16
     assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
@@ -114,29 +146,37 @@ def _convT_desc(x, w):
     return conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
 
 
-def raw_convT_fprop(x, w, bias, act=L.ACT_NONE):
+def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False):
     _chk(x, "x"); _chk(w, "w")
     d = _convT_desc(x, w)
     y = _empty((d.B, d.H, d.W, d.Cin), x)
+    if bf16 and d.Cout % 64 == 0:
+        d.dtype = L.BF16
+        w = bf16_weights(w)[0]
     L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, act,
            _stream())
     return y
 
 
-def raw_convT_dgrad(dy, w, x_shape):
+def raw_convT_dgrad(dy, w, x_shape, bf16=False):
     _chk(dy, "dy")
     B, h, w_, CinT = x_shape
     d = conv_desc(B, 2 * h, 2 * w_, w.shape[2], CinT, 3, 2, 1, False)
     dx = _empty((B, h, w_, CinT), dy)
+    if bf16 and d.Cin % 64 == 0:
+        d.dtype = L.BF16
+        w = bf16_weights(w)[1]
     L.call("mmh_convT2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _stream())
     return dx
 
 
-def raw_convT_wgrad(x, dy):
+def raw_convT_wgrad(x, dy, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, h, w_, CinT = x.shape
     CoutT = dy.shape[3]
     d = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
+    if bf16:
+        d.dtype = L.BF16
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
     dw = _empty((3, 3, CoutT, CinT), x)
@@ -164,36 +204,37 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act):
-        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act)
-        ctx.cfg = (stride, pad, reflect, act, bias is not None)
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False):
+        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act, bf16)
+        ctx.cfg = (stride, pad, reflect, act, bias is not None, bf16)
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        stride, pad, reflect, act, has_bias = ctx.cfg
+        stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         g = g.contiguous()
         if act != L.ACT_NONE:
             g = raw_act_bwd(g, y, act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = raw_conv_dgrad(g, w, x.shape, stride, pad, reflect)
+            dx = raw_conv_dgrad(g, w, x.shape, stride, pad, reflect, bf16)
         if ctx.needs_input_grad[1]:
-            dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect)
+            dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d(k3,s2,p1,op1): fprop = stride-2 dgrad kernel, dgrad = stride-2 fprop."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
-        y = raw_convT_fprop(x, w, bias)
+    def forward(ctx, x, w, bias, bf16=False):
+        y = raw_convT_fprop(x, w, bias, L.ACT_NONE, bf16)
         ctx.has_bias = bias is not None
+        ctx.bf16 = bf16
         ctx.save_for_backward(x, w)
         return y
 
@@ -203,12 +244,12 @@ class ConvT2dFn(torch.autograd.Function):
         g = g.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = raw_convT_dgrad(g, w, x.shape)
+            dx = raw_convT_dgrad(g, w, x.shape, ctx.bf16)
         if ctx.needs_input_grad[1]:
-            dw = raw_convT_wgrad(x, g)
+            dw = raw_convT_wgrad(x, g, ctx.bf16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 # --------------------------------------------------------------------------- norm

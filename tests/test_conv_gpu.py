@@ -98,3 +98,57 @@ def test_conv_autograd_shim(dev):
     assert R.rel_l1(x.grad, dxr) < TOL
     assert R.rel_l1(w.grad, dwr) < TOL
     assert R.rel_l1(b.grad, dbr) < TOL
+
+
+BF16_TOL = 1e-2   # bf16 operands (8 significand bits), fp32 accumulate: stated tolerance of the O1/O2 path
+
+BF16_CASES = [
+    (2, 16, 16, 8, 64, 7, 1, 3, True),       # small Cin: fprop falls back to fp32, wgrad is bf16
+    (2, 10, 12, 64, 4, 7, 1, 3, True),       # head: dgrad falls back to fp32
+    (2, 16, 16, 64, 64, 3, 1, 1, True),
+    (1, 12, 20, 256, 256, 3, 1, 1, True),
+    (2, 8, 8, 512, 256, 3, 1, 1, True),
+    (2, 16, 16, 64, 128, 3, 2, 1, False),
+    (1, 16, 16, 64, 64, 3, 1, 1, False),
+    (2, 8, 8, 128, 192, 3, 1, 1, True),      # N not a multiple of the 128 tile
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES)
+def test_conv2d_bf16_mfma_path(case, dev):
+    """MMH_BF16: bf16 MFMA fprop/dgrad vs the fp64 oracle on bf16-rounded operands (tight) and on
+    the original fp32 operands (the stated bf16 tolerance)."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, k, s, p, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((k, k, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    ops.bump_weights_epoch()
+    y = ops.raw_conv_fprop(x, w, bias, s, p, refl, 0, bf16=True)
+    dy = _mk(tuple(y.shape), 4, dev)
+    dx = ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl, bf16=True)
+    dw = ops.raw_conv_wgrad(x, dy, k, s, p, refl, bf16=True)
+    rb = lambda t: t.cpu().bfloat16().float()
+    yr, dxr, dwr, _ = R.conv2d_grads(rb(x), rb(w), bias.cpu(), rb(dy), s, p, refl)
+    yf, dxf, dwf, _ = R.conv2d_grads(x.cpu(), w.cpu(), bias.cpu(), dy.cpu(), s, p, refl)
+    # passes whose contraction channels are not a multiple of 64 keep the fp32 kernel
+    y_ref = yr if Cin % 64 == 0 else yf
+    dx_ref = dxr if Cout % 64 == 0 else dxf
+    assert R.rel_l1(y, y_ref) < 5e-5, ("fprop vs matching-precision oracle", R.rel_l1(y, y_ref))
+    assert R.rel_l1(dx, dx_ref) < 5e-5, ("dgrad vs matching-precision oracle", R.rel_l1(dx, dx_ref))
+    assert R.rel_l1(dw, dwr) < 5e-5, ("bf16 wgrad vs rounded-operand oracle", R.rel_l1(dw, dwr))
+    assert R.rel_l1(y, yf) < BF16_TOL and R.rel_l1(dx, dxf) < BF16_TOL and R.rel_l1(dw, dwf) < BF16_TOL
+
+
+def test_convT_bf16_mfma_path(dev):
+    from mmhand_amd import ops
+    x = _mk((2, 8, 8, 128), 1, dev)
+    w = _mk((3, 3, 64, 128), 2, dev) * 0.1
+    ops.bump_weights_epoch()
+    y = ops.raw_convT_fprop(x, w, None, 0, bf16=True)
+    dy = _mk(tuple(y.shape), 4, dev)
+    dx = ops.raw_convT_dgrad(dy, w, x.shape, bf16=True)
+    rb = lambda t: t.cpu().bfloat16().float()
+    dw = ops.raw_convT_wgrad(x, dy, bf16=True)
+    yr, dxr, dwr, _ = R.convT2d_grads(rb(x), rb(w), None, rb(dy))
+    assert R.rel_l1(y, yr) < 5e-5 and R.rel_l1(dx, dxr) < 5e-5 and R.rel_l1(dw, dwr) < 5e-5

@@ -202,3 +202,34 @@ def test_train_driver_smoke(dev, tmp_path):
     log = open(os.path.join(d, "loss_log.txt")).read().strip().splitlines()
     assert len(log) == 2 and log[0].startswith("(epoch: 1, iters: 2, time:") and "pair_L1loss:" in log[0]
     assert {"latest_net_netG.pth", "1_net_netG.pth", "latest_net_netD_PB.pth", "opt.txt"} <= set(os.listdir(d))
+
+
+def test_optimize_parameters_bf16_opt_level_O1(dev):
+    """--opt_level O1 (apex AMP in the reference) -> bf16 MFMA convs with fp32 master weights.  The
+    reference's fp16 path has no pinned numerics (apex absent), so the bar is the stated bf16
+    tolerance against the fp32 reference trace: loss scalars within 2 % over 3 iterations."""
+    from mmhand_amd.mmhand_model import MMHandModel
+    S64 = dict(S, ngf=16, ndf=16)          # channels 64 at the PATBlocks so the bf16 kernels engage
+    fix32 = None
+    rows = {}
+    for level in ("O0", "O1"):
+        from mmhand_amd.options import default_train_opt
+        opt = default_train_opt(batchSize=2, ngf=16, ndf=16, n_layers_D=2, G_n_blocks=2, norm="instance",
+                                no_dropout=True, no_dropout_D=True, pool_size=2, name="bf16",
+                                checkpoints_dir="/tmp/mmh_pytest_ckpt", local_rank=0, opt_level=level)
+        model = MMHandModel(opt)
+        assert model.bf16 == (level == "O1")
+        for tag, net in (("G", model.netG), ("DPB", model.netD_PB), ("DPP", model.netD_PP)):
+            shapes = OrderedDict((f"{tag}/{k}", tuple(v.shape)) for k, v in net.state_dict().items())
+            sd = RC.recipe_state_dict(shapes)
+            net.load_state_dict(OrderedDict((k.split("/", 1)[1], v) for k, v in sd.items()))
+        model.vgg.load_state_dict(RC.vgg_recipe())
+        random.seed(49)
+        out = []
+        for it in range(3):
+            model.set_input(O.synthetic_batch(2, 32, 32, seed=100 + it))
+            model.optimize_parameters()
+            out.append([float(v) for v in model.get_current_errors().values()])
+        rows[level] = np.array(out)
+    assert np.allclose(rows["O1"], rows["O0"], rtol=2e-2), (rows["O1"], rows["O0"])
+    assert not np.array_equal(rows["O1"], rows["O0"])       # the bf16 kernels really ran
