@@ -165,19 +165,32 @@ class _Net(nn.Module):
             super().zero_grad(set_to_none=set_to_none)
 
     def init_weights(self, init_type="normal", seed=None):
-        """weights_init_normal (models/network_utils.py:12-20): conv W ~ N(0,0.02), BN gamma ~
-        N(1,0.02), beta = 0; conv bias keeps nn.Conv2d's default U(+-1/sqrt(fan_in))."""
-        if init_type != "normal":
-            raise NotImplementedError(f"initialization method [{init_type}] is not implemented")
+        """init_weights (models/network_utils.py:12-71).  'normal': conv W ~ N(0,0.02); 'xavier':
+        xavier_normal(gain 0.02); 'kaiming': kaiming_normal(fan_in); 'orthogonal': gain 1.  In all
+        four BN gamma ~ N(1,0.02), beta = 0, and conv biases keep nn.Conv2d's default
+        U(+-1/sqrt(fan_in)).  Draws come from a seeded CPU generator (the reference never seeds)."""
+        if init_type not in ("normal", "xavier", "kaiming", "orthogonal"):
+            raise NotImplementedError("initialization method [%s] is not implemented" % init_type)
         g = torch.Generator().manual_seed(seed) if seed is not None else None
         for m in self.modules():
             if isinstance(m, ConvParam):
-                shape = tuple(m.logical_weight().shape)
-                w = torch.randn(shape, generator=g) * 0.02
-                fan_in = (m.cout if m.transposed else m.cin) * m.k * m.k
+                shape = tuple(m.logical_weight().shape)          # OIHW, or IOHW when transposed
+                rf = m.k * m.k
+                fan_in, fan_out = shape[1] * rf, shape[0] * rf   # torch's convention on dims 1 / 0
+                if init_type == "normal":
+                    w = torch.randn(shape, generator=g) * 0.02
+                elif init_type == "xavier":
+                    w = torch.randn(shape, generator=g) * (0.02 * math.sqrt(2.0 / (fan_in + fan_out)))
+                elif init_type == "kaiming":
+                    w = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+                else:
+                    flat = torch.randn((shape[0], fan_in), generator=g)
+                    q, r = torch.linalg.qr(flat.t() if shape[0] < fan_in else flat)
+                    q = q * torch.sign(torch.diagonal(r)).unsqueeze(0)
+                    w = (q.t() if shape[0] < fan_in else q).reshape(shape)
                 b = None
                 if m.bias is not None:
-                    bound = 1.0 / math.sqrt(fan_in)
+                    bound = 1.0 / math.sqrt((m.cout if m.transposed else m.cin) * rf)
                     b = (torch.rand(m.cout, generator=g) * 2 - 1) * bound
                 m.set_logical(w, b)
             elif isinstance(m, NormParam):

@@ -136,3 +136,24 @@ def test_flat_parameter_views():
     assert torch.allclose(d.state_dict()["model.1.weight"], before["model.1.weight"] * 2)
     p = next(d.parameters())
     assert p.grad.data_ptr() == gflat.data_ptr()
+
+
+@pytest.mark.parametrize("kind", ["normal", "xavier", "kaiming", "orthogonal"])
+def test_init_types(kind):
+    """models/network_utils.py:12-71: the four --init_type choices."""
+    from mmhand_amd.networks import Discriminator
+    d = Discriminator(6, 16, "batch", False, 1).init_weights(kind, seed=3)
+    sd = d.state_dict()
+    w = sd["model.4.weight"]                                   # Conv2d(16 -> 32, 3x3)
+    if kind == "normal":
+        assert abs(w.std().item() - 0.02) < 0.004
+    elif kind == "kaiming":
+        assert abs(w.std().item() - (2.0 / (16 * 9)) ** 0.5) < 0.02
+    elif kind == "xavier":
+        assert abs(w.std().item() - 0.02 * (2.0 / (16 * 9 + 32 * 9)) ** 0.5) < 1e-3
+    else:
+        m = w.reshape(32, -1)
+        assert torch.allclose(m @ m.t(), torch.eye(32), atol=1e-4)
+    assert torch.allclose(sd["model.5.bias"], torch.zeros(32)) and abs(sd["model.5.weight"].mean().item() - 1) < 0.02
+    with pytest.raises(NotImplementedError):
+        d.init_weights("bogus")

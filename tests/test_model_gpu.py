@@ -233,3 +233,17 @@ def test_optimize_parameters_bf16_opt_level_O1(dev):
         rows[level] = np.array(out)
     assert np.allclose(rows["O1"], rows["O0"], rtol=2e-2), (rows["O1"], rows["O0"])
     assert not np.array_equal(rows["O1"], rows["O0"])       # the bf16 kernels really ran
+
+
+def test_generator_512x512_config5_shape(dev):
+    """BASELINE.json configs[4]: 512x512 inputs (PATBlocks at 128x128) — same kernels, larger tiles."""
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, 8, "instance", False, 1)
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    b = O.synthetic_batch(1, 512, 512, seed=3)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    out = net([t.to(dev) for t in g_in])
+    ref = O.generator_forward(O._Net(sd, "instance", False), g_in, 1)
+    assert tuple(out.shape) == (1, 3, 512, 512) and R.rel_l1(out, ref) < TOL
