@@ -76,6 +76,15 @@ int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
 int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
                      void* dx, int dx_cs, mmh_stream_t s);
 
+/* Gradient w.r.t. x, already folded back onto [B,H,W,Cin] for either pad mode.  For the
+ * 3x3 / pad 1 reflect convs (the PATBlock / ResnetBlock stack) no padded buffer exists: a
+ * tile-aligned zero-pad dgrad on the real domain plus one multi-piece launch that adds the
+ * eight border terms of the pad ring.  Larger reflect pads go through `ws`
+ * (mmh_conv2d_dgrad_folded_ws_bytes) and mmh_reflect_fold.                       */
+size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* w,
+                            void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
  * result deterministic.  accumulate!=0 adds into dw.                       */

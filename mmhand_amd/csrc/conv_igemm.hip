@@ -67,6 +67,7 @@ struct ConvKP {
     int act;
     int dbg;                    // timing-only ablation bits (mmh_set_option "conv_dbg"): results wrong
     int xcd_remap;              // remap (blockIdx.y, blockIdx.x) so column tiles of a row tile share an XCD
+    int accum;                  // epilogue adds into out instead of overwriting it
 };
 
 struct KState { int th, tw, c4, j; };   // j: chunk index inside the current tap visit
@@ -166,7 +167,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // (3 workgroups/CU; measured 5-6 % faster on the 512-channel shapes).
 // ---------------------------------------------------------------------------
 template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF>
-__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, const int by,
+                                                const int gx, const int gy) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NB = BN / 32;  // float4 B loads per thread per k-step
@@ -189,10 +191,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     // L+16, ... share an L2.  XCD x walks its own contiguous band of row tiles, visiting all the
     // column tiles of a row tile back to back: the gathered A rows (and the halo rows shared with
     // the next row tile) are fetched into ONE L2 instead of several.  Speed/traffic only.
-    int mt = blockIdx.y, nt = blockIdx.x;
+    int mt = by, nt = bx;
     if (p.xcd_remap) {
-        const int gx = gridDim.x, band = gridDim.y / 8;     // row tiles per XCD (whole bands)
-        const int L = blockIdx.y * gx + blockIdx.x;
+        const int band = gy / 8;                             // row tiles per XCD (whole bands)
+        const int L = by * gx + bx;
         if (L < band * 8 * gx) {                             // the ragged rest keeps its ids
             const int x = L & 7, i = L >> 3;
             nt = i % gx;
@@ -408,11 +410,39 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
                 if (n < p.N) {
                     float v = acc[i][j][r];
                     if (p.bias) v += p.bias[n];
+                    if (p.accum) v += p.out[off + n];
                     p.out[off + n] = apply_act(v, p.act);
                 }
             }
         }
     }
+}
+
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF>
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
+    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, DBUF>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// Several small problems in one launch (blockIdx.z picks the piece): the border terms of the
+// reflect-pad dgrad.  Each piece has its own extent; surplus workgroups exit at once.
+constexpr int MAXP = 9;
+struct MultiKP {
+    ConvKP p[MAXP];
+    int start[MAXP + 1];    // first workgroup id of each piece (prefix sums); 1-D grid
+    int n;
+};
+__device__ __forceinline__ int multi_piece(const MultiKP& mp, int L) {
+    int k = 0;
+    while (k + 1 < mp.n && L >= mp.start[k + 1]) ++k;
+    return k;
+}
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR>
+__global__ void __launch_bounds__(256, 2) conv_igemm_multi_kernel(const MultiKP mp) {
+    const int k = multi_piece(mp, blockIdx.x);
+    const ConvKP& p = mp.p[k];
+    const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
+    const int local = blockIdx.x - mp.start[k];
+    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false>(p, local % gx, local / gx, gx, gy);
 }
 
 // ---------------------------------------------------------------------------
@@ -436,7 +466,8 @@ __device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
 }
 
 template <int BN, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p) {
+__device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int bx, const int by,
+                                                     const int gx, const int gy) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NBL = BN / 32;            // 16-byte weight loads per thread per k-step
@@ -450,10 +481,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p)
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    int mt = blockIdx.y, nt = blockIdx.x;
+    int mt = by, nt = bx;
     if (p.xcd_remap) {
-        const int gx = gridDim.x, band = gridDim.y / 8;
-        const int L = blockIdx.y * gx + blockIdx.x;
+        const int band = gy / 8;
+        const int L = by * gx + bx;
         if (L < band * 8 * gx) {
             const int x = L & 7, i = L >> 3;
             nt = i % gx;
@@ -594,10 +625,69 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p)
                 if (n < p.N) {
                     float v = acc[i][jn][r];
                     if (p.bias) v += p.bias[n];
+                    if (p.accum) v += p.out[off + n];
                     p.out[off + n] = apply_act(v, p.act);
                 }
             }
         }
+    }
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p) {
+    conv_igemm_bf16_body<BN, WAVES_M, WAVES_N>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_igemm_bf16_multi_kernel(const MultiKP mp) {
+    const int k = multi_piece(mp, blockIdx.x);
+    const ConvKP& p = mp.p[k];
+    const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
+    const int local = blockIdx.x - mp.start[k];
+    conv_igemm_bf16_body<BN, WAVES_M, WAVES_N>(p, local % gx, local / gx, gx, gy);
+}
+
+// dx += the border terms produced by the multi-piece dgrad launch.  One thread per (target
+// pixel, 4 channels); every target sums its terms in a fixed order (deterministic).
+// scratch: rows [B][2][W][C], cols [B][H][2][C], corners [B][4][C].
+__global__ void border_add_kernel(float* __restrict__ dx, const float* __restrict__ rows,
+                                  const float* __restrict__ cols, const float* __restrict__ corners,
+                                  int B, int H, int W, int C4) {
+    const int nr = (H - 2 == 1) ? 1 : 2, nc = (W - 2 == 1) ? 1 : 2;
+    const int per_img = nr * W + (H - nr) * nc;
+    const int64_t total = (int64_t)B * per_img * C4;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const int c = (int)(t % C4);
+        int64_t u = t / C4;
+        const int e = (int)(u % per_img);
+        const int b = (int)(u / per_img);
+        int i, j;
+        if (e < nr * W) { i = (e / W == 0) ? 1 : H - 2; j = e % W; }
+        else {
+            const int f = e - nr * W;
+            int ii = f / nc;                       // index among rows that are not 1 / H-2
+            i = ii >= 1 ? ii + 1 : ii;             // skip row 1
+            if (nr == 2 && i >= H - 2) i += 1;     // skip row H-2
+            j = (f % nc == 0) ? 1 : W - 2;
+        }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add = [&](const float* src, int64_t idx) {
+            const float4 v = reinterpret_cast<const float4*>(src)[idx];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        };
+        if (i == 1) add(rows, (((int64_t)b * 2 + 0) * W + j) * C4 + c);
+        if (i == H - 2) add(rows, (((int64_t)b * 2 + 1) * W + j) * C4 + c);
+        if (j == 1) add(cols, (((int64_t)b * H + i) * 2 + 0) * C4 + c);
+        if (j == W - 2) add(cols, (((int64_t)b * H + i) * 2 + 1) * C4 + c);
+        if (i == 1 && j == 1) add(corners, ((int64_t)b * 4 + 0) * C4 + c);
+        if (i == 1 && j == W - 2) add(corners, ((int64_t)b * 4 + 1) * C4 + c);
+        if (i == H - 2 && j == 1) add(corners, ((int64_t)b * 4 + 2) * C4 + c);
+        if (i == H - 2 && j == W - 2) add(corners, ((int64_t)b * 4 + 3) * C4 + c);
+        float4* o = reinterpret_cast<float4*>(dx) + (((int64_t)b * H + i) * W + j) * C4 + c;
+        float4 v = *o;
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        *o = v;
     }
 }
 
@@ -1199,6 +1289,126 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Reflect-pad(1) dgrad, folded, without the padded domain.  With R = ReflectionPad2d(1),
+// dx = R^T g where g is the full correlation of dy with the flipped taps on the padded domain.
+// g restricted to the real HxW domain is an ordinary zero-padded dgrad (the main launch, tile
+// aligned, full speed).  The pad ring folds onto rows/cols 1 and H-2/W-2 only, and each ring
+// element is reached by ONE row (or column) of taps:
+//   dx[1, j]   += sum_kw dy[0,   j+1-kw] w[0][kw]      dx[H-2, j] += sum_kw dy[H-1, j+1-kw] w[2][kw]
+//   dx[i, 1]   += sum_kh dy[i+1-kh, 0]   w[kh][0]      dx[i, W-2] += sum_kh dy[i+1-kh, W-1] w[kh][2]
+//   dx[1,1] += dy[0,0] w[0][0], ... (4 corners)
+// i.e. 8 small GEMMs (~2 % of the main one) that accumulate into dx; they run as ONE multi-piece
+// launch after the main kernel.  Versus the padded-domain + fold route this saves the 6.3 % ring
+// rows, the misaligned 66-pixel rows and the fold pass.
+// ---------------------------------------------------------------------------
+template <int BN, int WM, int WN>
+int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st) {
+    int total = 0;
+    for (int i = 0; i < mp.n; ++i) {
+        mp.start[i] = total;
+        total += ((mp.p[i].N + BN - 1) / BN) * ((mp.p[i].M + BM - 1) / BM);
+    }
+    mp.start[mp.n] = total;
+    if (bf16) {
+        constexpr size_t lds = (size_t)(BM + BN) * LDH * 2;
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(conv_igemm_bf16_multi_kernel<BN, WM, WN>, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL((conv_igemm_bf16_multi_kernel<BN, WM, WN>), dim3(total), dim3(256), lds, st, mp);
+    } else {
+        constexpr size_t lds = (BM * LDA + BN * LDA) * sizeof(float);
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(conv_igemm_multi_kernel<BN, WM, WN, true>, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL((conv_igemm_multi_kernel<BN, WM, WN, true>), dim3(total), dim3(256), lds, st, mp);
+    }
+    return mmh::check_launch("conv_igemm_multi_kernel");
+}
+
+size_t reflect1_ws_bytes(const mmh_conv_desc* d) {
+    return (size_t)d->B * (2 * d->W + 2 * d->H + 4) * d->Cin * sizeof(float);
+}
+
+int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
+                      hipStream_t st) {
+    const int H = d->H, W = d->W, C = d->Cin;
+    const bool bf16 = d->dtype == MMH_BF16;
+    float* rows = static_cast<float*>(ws);                       // [B][2][W][C]
+    float* cols = rows + (size_t)d->B * 2 * W * C;               // [B][H][2][C]
+    float* corners = cols + (size_t)d->B * H * 2 * C;            // [B][4][C]
+    auto piece = [&](float* out, int OH, int OW, int PH, int PW, int o0h, int o0w, int TH, int TW,
+                     int kh0, int kw0, int aph, int ath, int a0h, int apw, int atw, int a0w) {
+        ConvKP p{};
+        Gather& g = p.g;
+        g.src = static_cast<const float*>(dy);
+        g.src_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->y_cs * sizeof(float));
+        g.srcH = d->Ho; g.srcW = d->Wo; g.src_cs = (unsigned)d->y_cs;
+        g.PH = PH; g.PW = PW; g.TH = TH; g.TW = TW;
+        g.C4 = d->Cout / 4;
+        g.ap_h = aph; g.at_h = ath; g.a0_h = a0h;
+        g.ap_w = apw; g.at_w = atw; g.a0_w = a0w;
+        g.shift = 0; g.reflect = 0;
+        if (bf16) {
+            const int chunks = g.C4 / 16;
+            g.chunk_major = 1;
+            g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
+            p.nk = chunks * TH * TW;
+            p.wRows = d->Cin; p.wKper = d->Cout;
+            p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
+        } else {
+            set_korder(g, p.nk, p.Kflat);
+            p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * sizeof(float));
+        }
+        p.w = static_cast<const float*>(w);
+        p.out = out;
+        p.M = d->B * PH * PW;
+        p.N = C;
+        p.wCin = d->Cin; p.wCout = d->Cout;
+        p.KW_true = d->kw; p.kh0 = kh0; p.kw0 = kw0; p.tstep = 1;
+        p.OH = OH; p.OW = OW; p.o_p = 1; p.o0_h = o0h; p.o0_w = o0w;
+        p.out_cs = (unsigned)C;
+        p.out_linear = (PH == OH && PW == OW) ? 1 : 0;
+        p.act = MMH_ACT_NONE;
+        return p;
+    };
+    MultiKP mp{};
+    int n = 0;
+    // Border pieces first (few workgroups, long serial k loops): they overlap with the main tiles.
+    // ring rows -1 / H : taps kh = 0 / 2, source rows 0 / H-1  -> rows[b][0|1][j]
+    mp.p[n++] = piece(rows, 2, W, 1, W, 0, 0, 1, 3, 0, 0, 0, 0, 0, 1, -1, 1);
+    mp.p[n++] = piece(rows, 2, W, 1, W, 1, 0, 1, 3, 2, 0, 0, 0, H - 1, 1, -1, 1);
+    // ring cols -1 / W : taps kw = 0 / 2, source cols 0 / W-1  -> cols[b][i][0|1]
+    mp.p[n++] = piece(cols, H, 2, H, 1, 0, 0, 3, 1, 0, 0, 1, -1, 1, 0, 0, 0);
+    mp.p[n++] = piece(cols, H, 2, H, 1, 0, 1, 3, 1, 0, 2, 1, -1, 1, 0, 0, W - 1);
+    // ring corners -> corners[b][0..3]
+    mp.p[n++] = piece(corners, 1, 4, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0);
+    mp.p[n++] = piece(corners, 1, 4, 1, 1, 0, 1, 1, 1, 0, 2, 0, 0, 0, 0, 0, W - 1);
+    mp.p[n++] = piece(corners, 1, 4, 1, 1, 0, 2, 1, 1, 2, 0, 0, 0, H - 1, 0, 0, 0);
+    mp.p[n++] = piece(corners, 1, 4, 1, 1, 0, 3, 1, 1, 2, 2, 0, 0, H - 1, 0, 0, W - 1);
+    // main: g on the real domain: source = (i + 1 - kh, j + 1 - kw), zero outside
+    ConvKP main = piece(static_cast<float*>(dx), H, W, H, W, 0, 0, 3, 3, 0, 0, 1, -1, 1, 1, -1, 1);
+    {
+        const int BNsel = C > 64 ? 128 : (C > 32 ? 64 : 32);
+        const int gx = (C + BNsel - 1) / BNsel, gy = (main.M + BM - 1) / BM;
+        main.xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+    }
+    if (bf16) MMH_REQUIRE(bf16_ok(main), "bf16 dgrad needs Cout %% 64 == 0 (Cout=%d)", d->Cout);
+    mp.p[n++] = main;
+    mp.n = n;
+    int rc;
+    if (C > 64) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
+    else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);
+    else rc = launch_multi_t<32, 4, 1>(mp, bf16, st);
+    if (rc) return rc;
+    const int nr = (H - 2 == 1) ? 1 : 2, nc = (W - 2 == 1) ? 1 : 2;
+    const int64_t total = (int64_t)d->B * (nr * W + (H - nr) * nc) * (C / 4);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
+    hipLaunchKernelGGL(border_add_kernel, dim3(blocks), dim3(256), 0, st, static_cast<float*>(dx), rows, cols,
+                       corners, d->B, H, W, C / 4);
+    return mmh::check_launch("border_add_kernel");
+}
+
 // Split-K factor: fill whole rounds of the 512 resident workgroups (256 CUs x 2 per CU, LDS
 // bound) so the last round is not a mostly empty tail; keep >= 8 k-steps per split.
 int g_wgrad_slots = 768;   // tuning knob (mmh_set_option "wgrad_slots")
@@ -1315,6 +1525,28 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
     MMH_REQUIRE(dy && w && dx, "mmh_conv2d_dgrad: NULL buffer");
     MMH_REQUIRE(dx_cs % 4 == 0 && dx_cs >= d->Cin, "mmh_conv2d_dgrad: bad dx_cs=%d", dx_cs);
     return do_dgrad(d, dy, w, nullptr, dx, dx_cs, MMH_ACT_NONE, mmh::as_stream(s));
+}
+
+size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {
+    if (!d || d->pad_mode != MMH_PAD_REFLECT || d->pad == 0) return 0;
+    if (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 3 && d->W >= 3)
+        return reflect1_ws_bytes(d);
+    return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * d->Cin * sizeof(float);
+}
+
+int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
+                            size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(dy && w && dx, "mmh_conv2d_dgrad_folded: NULL buffer");
+    MMH_REQUIRE(d->x_cs == d->Cin, "mmh_conv2d_dgrad_folded: dx must be dense (x_cs == Cin)");
+    hipStream_t st = mmh::as_stream(s);
+    if (d->pad_mode != MMH_PAD_REFLECT || d->pad == 0) return do_dgrad(d, dy, w, nullptr, dx, d->Cin, MMH_ACT_NONE, st);
+    const size_t need = mmh_conv2d_dgrad_folded_ws_bytes(d);
+    MMH_REQUIRE(ws && ws_bytes >= need, "mmh_conv2d_dgrad_folded: workspace too small (%zu < %zu)", ws_bytes, need);
+    if (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 3 && d->W >= 3)
+        return do_dgrad_reflect1(d, dy, w, dx, ws, st);
+    if (int rc = do_dgrad(d, dy, w, nullptr, ws, d->Cin, MMH_ACT_NONE, st)) return rc;
+    return mmh_reflect_fold(ws, dx, d->B, d->H, d->W, d->Cin, d->pad, s);
 }
 
 size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d) { return d ? wgrad_ws(d) : 0; }

@@ -111,14 +111,11 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False):
     if bf16 and Cout % 64 == 0:
         d.dtype = L.BF16
         w = bf16_weights(w)[0]
-    if reflect and pad > 0:
-        dxp = _empty((B, H + 2 * pad, W_ + 2 * pad, Cin), dy)
-        L.call("mmh_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dxp), Cin, _stream())
-        dx = _empty((B, H, W_, Cin), dy)
-        L.call("mmh_reflect_fold", _ptr(dxp), _ptr(dx), B, H, W_, Cin, pad, _stream())
-        return dx
     dx = _empty((B, H, W_, Cin), dy)
-    L.call("mmh_conv2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), Cin, _stream())
+    nbytes = L.load().mmh_conv2d_dgrad_folded_ws_bytes(C.byref(d))
+    ws = _ws(nbytes, dy) if nbytes else None
+    L.call("mmh_conv2d_dgrad_folded", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws),
+           ws.numel() * 4 if ws is not None else 0, _stream())
     return dx
 
 

@@ -152,3 +152,17 @@ def test_convT_bf16_mfma_path(dev):
     dw = ops.raw_convT_wgrad(x, dy, bf16=True)
     yr, dxr, dwr, _ = R.convT2d_grads(rb(x), rb(w), None, rb(dy))
     assert R.rel_l1(y, yr) < 5e-5 and R.rel_l1(dx, dxr) < 5e-5 and R.rel_l1(dw, dwr) < 5e-5
+
+
+@pytest.mark.parametrize("hw", [(3, 3), (3, 8), (8, 3), (4, 4), (5, 9), (64, 64)])
+def test_reflect1_dgrad_border_terms(hw, dev):
+    """3x3 reflect dgrad without the padded domain: main zero-pad dgrad + row / column / corner
+    border launches, down to the degenerate H or W == 3 where the two mirrored rows coincide."""
+    from mmhand_amd import ops
+    H, W = hw
+    x_shape = (2, H, W, 16)
+    w = _mk((3, 3, 16, 32), 2, dev) * 0.2
+    dy = _mk((2, H, W, 32), 4, dev)
+    dx = ops.raw_conv_dgrad(dy, w, x_shape, 1, 1, True)
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(x_shape), w.cpu(), None, dy.cpu(), 1, 1, True)
+    assert R.rel_l1(dx, dxr) < TOL, R.rel_l1(dx, dxr)
