@@ -1,0 +1,99 @@
+"""Full-size (BASELINE.json configs[1]: B=32, 64x64x512 PATBlock tensors, 256x256 stems) checks of
+the HIP kernels through size-independent properties — the oracle cannot run these sizes in
+seconds, the algebra can:
+  * adjointness  <conv(x), dy> == <x, dgrad(dy)> == <w, wgrad(x, dy)>  (exact identities of the
+    bilinear map, evaluated in fp64 on the device),
+  * linearity    conv(a*x1 + b*x2) == a*conv(x1) + b*conv(x2),
+  * norm         per-(sample,channel) mean 0 / variance 1 after InstanceNorm, per-channel for batch,
+  * Adam         a zero gradient leaves parameters untouched; a constant gradient moves every
+                 parameter by exactly lr on the first step,
+  * dropout      keep rate 0.5 and scale 2 on 134M elements.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.rand(shape, generator=g, device=dev) * 2 - 1) * scale
+
+
+FULL = [
+    # B, H, W, Cin, Cout, k, stride, pad, reflect
+    (32, 64, 64, 512, 512, 3, 1, 1, True),      # the dominant PATBlock conv
+    (32, 64, 64, 512, 256, 3, 1, 1, True),
+    (32, 128, 128, 128, 256, 3, 2, 1, False),   # stride-2 down
+    (32, 256, 256, 44, 64, 7, 1, 3, True),      # pose stem
+    (32, 256, 256, 64, 4, 7, 1, 3, True),       # head
+]
+
+
+@pytest.mark.parametrize("case", FULL)
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv_adjoint_identities_full_size(case, bf16, dev):
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, k, s, p, refl = case
+    x = _rand((B, H, W, Cin), 1, dev)
+    w = _rand((k, k, Cin, Cout), 2, dev, 0.05)
+    ops.bump_weights_epoch()
+    y = ops.raw_conv_fprop(x, w, None, s, p, refl, 0, bf16=bf16)
+    dy = _rand(tuple(y.shape), 3, dev)
+    dx = ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl, bf16=bf16)
+    dw = ops.raw_conv_wgrad(x, dy, k, s, p, refl, bf16=bf16)
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    tol = 2e-3 if bf16 else 2e-5          # bf16 rounds the operands of each pass independently
+    scale = max(abs(a), (y.double().abs() * dy.double().abs()).sum().item() * 1e-3)
+    assert abs(a - b) / scale < tol and abs(a - c) / scale < tol, (a, b, c)
+
+
+def test_conv_linearity_full_size(dev):
+    from mmhand_amd import ops
+    B, H, W, C = 32, 64, 64, 256
+    x1, x2 = _rand((B, H, W, C), 1, dev), _rand((B, H, W, C), 2, dev)
+    w = _rand((3, 3, C, C), 3, dev, 0.05)
+    y12 = ops.raw_conv_fprop(0.5 * x1 - 2.0 * x2, w, None, 1, 1, True, 0)
+    y1 = ops.raw_conv_fprop(x1, w, None, 1, 1, True, 0)
+    y2 = ops.raw_conv_fprop(x2, w, None, 1, 1, True, 0)
+    ref = 0.5 * y1 - 2.0 * y2
+    assert ((y12 - ref).abs().sum() / ref.abs().sum()).item() < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["instance", "batch"])
+def test_norm_moments_full_size(mode, dev):
+    from mmhand_amd import ops
+    x = _rand((32, 64, 64, 512), 1, dev, 3.0) + 5.0
+    out = ops.NormActFn.apply(x, None, None, None, None, None, mode, False, 0.0, 0, None, None)
+    dims = (1, 2) if mode == "instance" else (0, 1, 2)
+    m = out.double().mean(dims)
+    v = out.double().var(dims, unbiased=False)
+    assert m.abs().max().item() < 1e-4 and (v - 1).abs().max().item() < 1e-3
+
+
+def test_dropout_rate_full_size(dev):
+    from mmhand_amd import ops
+    x = torch.ones((32, 64, 64, 512), device=dev)
+    one = torch.ones((1, 512), device=dev); zero = torch.zeros((1, 512), device=dev)
+    y = ops.raw_scale_shift_act(x, one, zero, None, True, 0.5, 0xC0FFEE, None)
+    keep = (y > 0).double().mean().item()
+    assert abs(keep - 0.5) < 2e-4 and y.max().item() == 2.0
+
+
+def test_adam_properties_full_size(dev):
+    from mmhand_amd import ops
+    n = 71_272_836                                  # Generator-sized flat buffer (multiple of 4)
+    p = _rand((n,), 1, dev)
+    p0 = p.clone()
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    ops.adam_step(p, torch.zeros_like(p), m, v, 2e-4, 0.5, 0.999, 1e-8, 1)
+    assert torch.equal(p, p0)
+    g = torch.full_like(p, 0.37)
+    ops.adam_step(p, g, m, v, 2e-4, 0.5, 0.999, 1e-8, 2)
+    # m = 0.5*0.37, v = 0.001*0.37^2; bias corrections 1-0.25, 1-0.999^2
+    step = 2e-4 / (1 - 0.5 ** 2) * (0.5 * 0.37) / ((0.001 * 0.37 ** 2 / (1 - 0.999 ** 2)) ** 0.5 + 1e-8)
+    assert ((p0 - p) - step).abs().max().item() < 1e-7
