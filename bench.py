@@ -168,7 +168,8 @@ def main():
         assert world == a.gpus, f"launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dp = os.environ.get("MMH_FORCE_DP") == "1" and "RANK" in os.environ
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
@@ -176,7 +177,7 @@ def main():
     from mmhand_amd.mmhand_model import MMHandModel
     from mmhand_amd.options import default_train_opt
     opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="bench", local_rank=local,
-                            checkpoints_dir="/tmp/mmh_bench", distributed=world > 1,
+                            checkpoints_dir="/tmp/mmh_bench", distributed=world > 1 or force_dp,
                             opt_level="O1" if a.dtype == "bf16" else "O0")
     peak = PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF
     model = MMHandModel(opt)
@@ -190,7 +191,7 @@ def main():
     ops.fprop_timer = timer
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +205,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -242,7 +243,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

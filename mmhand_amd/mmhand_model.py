@@ -235,9 +235,11 @@ class MMHandModel(torch.nn.Module):
             self.optimizer_D_PP = FlatAdam(self.netD_PP, opt.lr, betas)
             self.optimizers = [self.optimizer_G, self.optimizer_D_PB, self.optimizer_D_PP]
             self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
-            if self.world > 1:
+            # MMH_FORCE_DP=1: take the data-parallel code path even with one rank (RCCL smoke test)
+            self.dp = self.world > 1 or (os.environ.get("MMH_FORCE_DP") == "1" and dist.is_initialized())
+            if self.dp:
                 self._init_data_parallel()
-        self.comm_stream = torch.cuda.Stream(self.device) if self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream(self.device) if getattr(self, "dp", False) else None
         self._pending = None
 
     # ------------------------------------------------------------------ data parallel
@@ -257,7 +259,7 @@ class MMHandModel(torch.nn.Module):
     def _allreduce_async(self, net):
         """One RCCL all-reduce(SUM) of the flat gradient buffer on the side stream; the 1/world
         factor is folded into the Adam kernel."""
-        if self.world == 1:
+        if not self.dp:
             return None
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
