@@ -581,7 +581,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
         const bool more = ks + 1 < p.nk;
         if (more) {
             advance();
-            load_tiles();
+            if (!(p.dbg & 1)) load_tiles();
         }
 #pragma unroll
         for (int s16 = 0; s16 < BK16 / 16; ++s16) {
@@ -598,9 +598,11 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
                 for (int jn = 0; jn < TN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
         }
-        __syncthreads();
-        if (more) store_tiles();
-        __syncthreads();
+        if (!(p.dbg & 2)) {
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -1162,7 +1164,7 @@ int launch_conv_bf16(ConvKP& p, hipStream_t st) {
     g.chunk_major = 1;
     g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
     p.nk = chunks * g.TH * g.TW;
-    p.dbg = 0;
+    p.dbg = g_conv_dbg;
     {
         const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
         const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;

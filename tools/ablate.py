@@ -11,11 +11,12 @@ def timeit(fn, iters=3):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-fn = lambda: ops.raw_conv_fprop(x, w, None, 1, 1, True, 0)
+BF = len(sys.argv) > 1 and sys.argv[1] == 'bf16'
+fn = lambda: ops.raw_conv_fprop(x, w, None, 1, 1, True, 0, bf16=BF)
 fl = 2.0 * B * 4096 * Cin * Cout * 9
 res = {}
 for r in range(5):
-    for dbg in (0, 1, 2, 3, 4, 6):
+    for dbg in (0, 1, 2, 3):
         lib.check(L.mmh_set_option(b"conv_dbg", dbg), "set"); fn(); torch.cuda.synchronize()
         res.setdefault(dbg, []).append(timeit(fn))
 for dbg, v in res.items():
