@@ -116,7 +116,7 @@ def infer_main(a):
     dev = torch.device("cuda", 0)
     B = a.batch if a.batch != 32 else 64
     net = Generator([3, 42, 6], 3, 64, "batch", True, 9).init_weights("normal", 49).to(dev).eval()
-    gen = InferenceGenerator(net, use_graph=True)
+    gen = InferenceGenerator(net, use_graph=True, bf16=a.dtype == "bf16")
     b = synthetic_batch_gpu(B, a.size, a.size, 49, dev)
     g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
     for _ in range(max(a.warmup, 1)):
@@ -132,10 +132,12 @@ def infer_main(a):
         "metric": "256x256 hand images/sec (Generator inference)", "value": round(ips, 2),
         "unit": "images/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"STB-shaped {a.size}x{a.size}, batch {B}, fp32, Generator forward only "
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"STB-shaped {a.size}x{a.size}, batch {B}, "
+                   f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}, Generator forward only "
                    "(eval BatchNorm folded into convs, hipGraph replay)"},
-        "step_mfma_frac": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 / PEAK_F32_MFMA_TF, 4)}),
+        "step_mfma_frac": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 /
+                                (PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF), 4)}),
         flush=True)
 
 

@@ -38,9 +38,11 @@ def _fold(conv, norm, transposed=False):
 class InferenceGenerator:
     """Callable drop-in for ``Generator.eval()``: ``gen([H1, cat(P1,P2), cat(D1,D2)]) -> NCHW``."""
 
-    def __init__(self, net: Generator, use_graph=True):
+    def __init__(self, net: Generator, use_graph=True, bf16=False):
         assert isinstance(net, Generator)
         self.net = net.eval()
+        self.bf16 = bool(bf16)        # bf16 MFMA compute for the channel-%64 convs (fp32 I/O)
+        self.net.bf16 = self.bf16
         self.folded = net.norm == "batch"
         self.use_graph = use_graph
         self._graph = None
@@ -75,26 +77,26 @@ class InferenceGenerator:
         xs = []
         for s, x in zip((1, 2, 3), (x1, x2, x3)):
             w, b = f[("down", s, 0)]
-            x = ops.raw_conv_fprop(x, w, b, 1, 3, True, L.ACT_RELU)
+            x = ops.raw_conv_fprop(x, w, b, 1, 3, True, L.ACT_RELU, self.bf16)
             for i in range(n.n_down):
                 w, b = f[("down", s, 1 + i)]
-                x = ops.raw_conv_fprop(x, w, b, 2, 1, False, L.ACT_RELU)
+                x = ops.raw_conv_fprop(x, w, b, 2, 1, False, L.ACT_RELU, self.bf16)
             xs.append(x)
         x1, x2, x3 = xs
         for blk in range(n.n_blocks):
             ss = []
             for s, x in zip((1, 2, 3), (x1, x2, x3)):
                 w, b = f[("att", blk, s, 0)]
-                y = ops.raw_conv_fprop(x, w, b, 1, 1, True, L.ACT_RELU)
+                y = ops.raw_conv_fprop(x, w, b, 1, 1, True, L.ACT_RELU, self.bf16)
                 w, b = f[("att", blk, s, 1)]
-                ss.append(ops.raw_conv_fprop(y, w, b, 1, 1, True, L.ACT_NONE))
+                ss.append(ops.raw_conv_fprop(y, w, b, 1, 1, True, L.ACT_NONE, self.bf16))
             x1, x2, x3 = ops.GateFn.apply(x1, ss[0], ss[1], ss[2], blk + 1 < n.n_blocks)
         y = x1
         for i in range(n.n_down):
             w, b = f[("up", i)]
-            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU)
+            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU, self.bf16)
         w, b = f[("head",)]
-        return ops.raw_conv_fprop(y, w, b, 1, 3, True, L.ACT_TANH)
+        return ops.raw_conv_fprop(y, w, b, 1, 3, True, L.ACT_TANH, self.bf16)
 
     # ------------------------------------------------------------------ call
     def _eager(self, inputs):

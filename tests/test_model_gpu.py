@@ -247,3 +247,22 @@ def test_generator_512x512_config5_shape(dev):
     out = net([t.to(dev) for t in g_in])
     ref = O.generator_forward(O._Net(sd, "instance", False), g_in, 1)
     assert tuple(out.shape) == (1, 3, 512, 512) and R.rel_l1(out, ref) < TOL
+
+
+def test_inference_generator_bf16(dev):
+    """bf16 MFMA inference (folded BN, hipGraph) stays within the stated bf16 tolerance of the
+    eval-mode oracle."""
+    from mmhand_amd.inference import InferenceGenerator
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, 16, "batch", True, 2)          # 64 channels in the PATBlocks
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.to(dev)
+    gen = InferenceGenerator(net, use_graph=True, bf16=True)
+    b = O.synthetic_batch(2, S["H"], S["W"], seed=5)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    out = gen([t.to(dev) for t in g_in])
+    onet = O._Net(sd, "batch", True); onet.training = False
+    ref = O.generator_forward(onet, g_in, 2)
+    err = R.rel_l1(out, ref)
+    assert 1e-6 < err < 2e-2, err
