@@ -50,9 +50,10 @@ typedef struct mmh_conv_desc {
                           /* x, y, dy, dx stay fp32 in HBM (rounded to bf16 */
                           /* while staged), fp32 accumulate; `w` must then  */
                           /* be a tensor made by mmh_prep_weights_bf16      */
-                          /* (fprop / convT dgrad: w_t; dgrad / convT       */
-                          /* fprop: w_plain); channels % 64 == 0.  wgrad also  */
-                          /* rounds x and dy to bf16 (no channel rule).     */
+                          /* (fprop / convT dgrad: w_t, or w_flat when Cin    */
+                          /* % 64 != 0; dgrad / convT fprop: w_plain, Cout  */
+                          /* % 64 == 0).  wgrad also rounds x and dy to     */
+                          /* bf16 (no channel rule).                        */
 } mmh_conv_desc;
 
 const char* mmh_last_error(void);
@@ -110,6 +111,10 @@ int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
  * w_t [taps][Cout][Cin] (contraction = Cin, used by fprop).  Either may be NULL. */
 int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout,
                           void* w_plain, void* w_t, mmh_stream_t s);
+/* For fprop of convs whose Cin is not a multiple of 64 (the 7x7 stems): w_flat is
+ * [Cout][Kpad] bf16, Kpad = ceil(taps*Cin/64)*64, contraction index k = tap*Cin + ci. */
+int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout,
+                               void* w_flat, mmh_stream_t s);
 
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */

@@ -60,6 +60,7 @@ struct ConvKP {
     int Kflat;                  // TH*TW*C4*4 (flat order bound)
     int wCin, wCout;            // weight tensor dims [taps][wCin][wCout]
     int wRows, wKper;           // bf16 path: prepared weights are [taps][wRows][wKper] (k contiguous)
+    int flat16;                 // bf16 path, small Cin: flat k = (tap, channel), weights [N][wKper]
     int KW_true, kh0, kw0, tstep;  // true tap = (kh0+tstep*th)*KW_true + kw0+tstep*tw
     int OH, OW, o_p, o0_h, o0_w;   // output pixel = (ph*o_p+o0_h, pw*o_p+o0_w) in OHxOW
     unsigned out_cs;
@@ -528,8 +529,31 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
     unsigned a_off[8];
     float4 ra[8];
     uint4 rb[NBL];
+    // flat order (small Cin): this thread's 4-channel group walks (tap, c4) 16 groups per k-step
+    KState kf;
+    int kstep = 0;
+    if (p.flat16) {
+        kf.j = 0;
+        const int tap = grp / g.C4;
+        kf.c4 = grp - tap * g.C4;
+        kf.th = tap / g.TW;
+        kf.tw = tap - kf.th * g.TW;
+    }
 
     auto load_tiles = [&]() {
+        if (p.flat16) {
+            const bool kv = kf.th < g.TH;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                ra[i] = bload4(rsA, gather_off(g, a_img[i], a_bh[i], a_bw[i], kf, kv && a_ok[i]));
+            const unsigned koff = (unsigned)(kstep * 64 + bgrp * 8) * 2u;
+#pragma unroll
+            for (int i = 0; i < NBL; ++i) {
+                u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsW, b_row[i] != OOB ? koff + b_row[i] : OOB, 0, 0);
+                rb[i] = __builtin_bit_cast(uint4, r);
+            }
+            return;
+        }
         if (j == 0) {
             KState s; s.th = th; s.tw = tw; s.c4 = 0; s.j = 0;
 #pragma unroll
@@ -548,6 +572,12 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
         }
     };
     auto advance = [&]() {
+        if (p.flat16) {
+            ++kstep;
+            kf.c4 += 16;
+            while (kf.c4 >= g.C4) { kf.c4 -= g.C4; if (++kf.tw == g.TW) { kf.tw = 0; ++kf.th; } }
+            return;
+        }
         ++cc;
         if (++j == g.cw) {
             j = 0;
@@ -1161,10 +1191,16 @@ bool bf16_ok(const ConvKP& p) { return p.g.C4 % 16 == 0 && p.N % 4 == 0; }
 
 int launch_conv_bf16(ConvKP& p, hipStream_t st) {
     Gather& g = p.g;
-    const int chunks = g.C4 / 16;                   // 64-channel chunks per tap
-    g.chunk_major = 1;
-    g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
-    p.nk = chunks * g.TH * g.TW;
+    if (p.flat16) {
+        g.chunk_major = 0;
+        g.cw = 1;
+        p.nk = (g.TH * g.TW * g.C4 + 15) / 16;      // 64 flat k per step
+    } else {
+        const int chunks = g.C4 / 16;               // 64-channel chunks per tap
+        g.chunk_major = 1;
+        g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
+        p.nk = chunks * g.TH * g.TW;
+    }
     p.dbg = g_conv_dbg;
     {
         const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
@@ -1224,10 +1260,17 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
     p.OH = d->Ho; p.OW = d->Wo; p.o_p = 1;
     p.act = act;
     if (d->dtype == MMH_BF16) {
-        // w is the prepared bf16 tensor [taps][Cout][Cin]
-        p.wRows = d->Cout; p.wKper = d->Cin;
-        p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
-        MMH_REQUIRE(bf16_ok(p), "bf16 fprop needs Cin %% 64 == 0 (Cin=%d)", d->Cin);
+        if (d->Cin % 64 == 0) {
+            // w is the prepared bf16 tensor w_t [taps][Cout][Cin]
+            p.wRows = d->Cout; p.wKper = d->Cin;
+            p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
+        } else {
+            // small Cin: w is w_flat [Cout][Kpad], Kpad = ceil(taps*Cin/64)*64, flat k = (tap, ci)
+            const int Kpad = (d->kh * d->kw * d->Cin + 63) / 64 * 64;
+            p.flat16 = 1;
+            p.wRows = d->Cout; p.wKper = Kpad;
+            p.w_bytes = (unsigned)((size_t)d->Cout * Kpad * 2);
+        }
         return launch_conv_bf16(p, st);
     }
     return launch_conv<false>(p, st);

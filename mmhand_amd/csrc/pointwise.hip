@@ -667,6 +667,21 @@ __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, int taps, 
     }
 }
 
+// w [taps][R][C] fp32 -> flat [C][Kpad] bf16 with k = t*R + r (zero padded): fprop of small-Cin convs
+__global__ void prep_weights_bf16_flat_kernel(const float* __restrict__ w, int taps, int R, int C,
+                                              int Kpad, __bf16* __restrict__ out) {
+    const int64_t total = (int64_t)C * Kpad;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int k = (int)(i % Kpad);
+        const int n = (int)(i / Kpad);
+        float v = 0.f;
+        if (k < taps * R) v = w[(int64_t)k * C + n];      // [t][r][n] is flat in k = t*R + r
+        out[i] = (__bf16)v;
+    }
+}
+
 int check_cols(const char* who, int C) {
     MMH_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in (0,1024], got %d",
                 who, C);
@@ -945,6 +960,16 @@ int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout, void* w_pl
                        mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout,
                        static_cast<__bf16*>(w_plain), static_cast<__bf16*>(w_t));
     return mmh::check_launch("prep_weights_bf16");
+}
+
+int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout, void* w_flat,
+                               mmh_stream_t s) {
+    MMH_REQUIRE(w && w_flat && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_bf16_flat: bad arguments");
+    const int Kpad = (taps * Cin + 63) / 64 * 64;
+    hipLaunchKernelGGL(prep_weights_bf16_flat_kernel, dim3(grid_for((int64_t)Cout * Kpad)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout, Kpad,
+                       static_cast<__bf16*>(w_flat));
+    return mmh::check_launch("prep_weights_bf16_flat");
 }
 
 int mmh_map_to_cord(const void* maps, int n_maps, int H, int W, float threshold, void* cords,

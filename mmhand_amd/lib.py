@@ -48,6 +48,7 @@ SIGNATURES = {
     "mmh_convT2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmh_prep_weights_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mmh_prep_weights_bf16_flat": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmh_colsum_ws_bytes": (_sz, [_i64, _i]),
     "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "mmh_norm_stats_ws_bytes": (_sz, [_i, _i64, _i]),

@@ -62,14 +62,21 @@ def bump_weights_epoch():
 
 
 def bf16_weights(w):
-    """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) bf16 copies of a physical fp32 weight."""
+    """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) bf16 copies of a physical fp32 weight; for
+    Cin % 64 != 0 the second entry is w_flat [Cout, Kpad] (flat (tap, ci) contraction index)."""
     key = w.data_ptr()
     ent = _bf16_cache.get(key)
     if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
         k, _, cin, cout = w.shape
         wp = torch.empty((k, k, cin, cout), dtype=torch.bfloat16, device=w.device)
-        wt = torch.empty((k, k, cout, cin), dtype=torch.bfloat16, device=w.device)
-        L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), _ptr(wt), _stream())
+        if cin % 64 == 0:
+            wt = torch.empty((k, k, cout, cin), dtype=torch.bfloat16, device=w.device)
+            L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), _ptr(wt), _stream())
+        else:
+            kpad = (k * k * cin + 63) // 64 * 64
+            wt = torch.empty((cout, kpad), dtype=torch.bfloat16, device=w.device)
+            L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), None, _stream())
+            L.call("mmh_prep_weights_bf16_flat", _ptr(w), k * k, cin, cout, _ptr(wt), _stream())
         ent = (_weights_epoch[0], tuple(w.shape), wp, wt)
         _bf16_cache[key] = ent
     return ent[2], ent[3]
@@ -90,7 +97,7 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
-    if bf16 and Cin % 64 == 0:
+    if bf16:
         d.dtype = L.BF16
         w = bf16_weights(w)[1]
     if fprop_timer is not None and fprop_timer.want(d):
