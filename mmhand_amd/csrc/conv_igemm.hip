@@ -1212,9 +1212,16 @@ int launch_conv_bf16(ConvKP& p, hipStream_t st) {
     return launch_conv_bf16_t<32, 4, 1>(p, st);
 }
 
+int g_conv_bn256 = 1;   // 128x256 block tile (wave tile 64x128) when N % 256 == 0: +2.4 % on fprop
+
 template <bool NMAJOR>
 int launch_conv(const ConvKP& p, hipStream_t st) {
     const_cast<ConvKP&>(p).dbg = g_conv_dbg;
+    if (g_conv_bn256 && !NMAJOR && p.N % 256 == 0) {
+        const int gx = p.N / 256, gy = (p.M + BM - 1) / BM;
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+        return launch_conv_t<256, 2, 2, NMAJOR, false>(p, st);
+    }
     {
         const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
         const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;
@@ -1443,7 +1450,10 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     mp.p[n++] = main;
     mp.n = n;
     int rc;
-    if (C > 64) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
+    if (!bf16 && g_conv_bn256 == 2 && C % 256 == 0) {   // measured: no gain for the [n][k] weight tile
+        mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
+        rc = launch_multi_t<256, 2, 2>(mp, false, st);
+    } else if (C > 64) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
     else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);
     else rc = launch_multi_t<32, 4, 1>(mp, bf16, st);
     if (rc) return rc;
@@ -1552,6 +1562,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_dbuf")) { g_conv_dbuf = value; return 0; }
     if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
     if (!strcmp(key, "conv_cw")) { g_conv_cw = value; return 0; }
+    if (!strcmp(key, "conv_bn256")) { g_conv_bn256 = value; return 0; }
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
