@@ -1468,9 +1468,11 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
 // Split-K factor: fill whole rounds of the 512 resident workgroups (256 CUs x 2 per CU, LDS
 // bound) so the last round is not a mostly empty tail; keep >= 8 k-steps per split.
 int g_wgrad_slots = 768;   // tuning knob (mmh_set_option "wgrad_slots")
+int g_wgrad_bn256 = 1;     // 128x256 wgrad tile when Cout % 256 == 0
 
 int wgrad_splits(int Mrows, int N, int P) {
-    const int tiles = ((Mrows + BM - 1) / BM) * ((N + 127) / 128);
+    const int bn = (g_wgrad_bn256 && N % 256 == 0) ? 256 : 128;
+    const int tiles = ((Mrows + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int slots = g_wgrad_slots;
     int max_splits = P / (8 * BK);
     if (max_splits > 256) max_splits = 256;
@@ -1541,7 +1543,8 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
         if (p.N > 64) rc = launch_wgrad_bf16_t<128, 2, 2>(p, splits, st);
         else if (p.N > 32) rc = launch_wgrad_bf16_t<64, 2, 2>(p, splits, st);
         else rc = launch_wgrad_bf16_t<32, 4, 1>(p, splits, st);
-    } else if (p.N > 64) rc = g_wgrad_dbuf ? launch_wgrad_t<128, 2, 2, true>(p, splits, st)
+    } else if (g_wgrad_bn256 && p.N % 256 == 0) rc = launch_wgrad_t<256, 2, 2, false>(p, splits, st);
+    else if (p.N > 64) rc = g_wgrad_dbuf ? launch_wgrad_t<128, 2, 2, true>(p, splits, st)
                                     : launch_wgrad_t<128, 2, 2, false>(p, splits, st);
     else if (p.N > 32) rc = launch_wgrad_t<64, 2, 2, false>(p, splits, st);
     else rc = launch_wgrad_t<32, 4, 1, false>(p, splits, st);
@@ -1566,6 +1569,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
+    if (!strcmp(key, "wgrad_bn256")) { g_wgrad_bn256 = value; return 0; }
     return mmh::fail("mmh_set_option: unknown key '%s'", key);
 }
 
