@@ -172,6 +172,7 @@ class MMHandModel(torch.nn.Module):
         if not torch.cuda.is_available():
             raise RuntimeError("MMHandModel needs an MI355X: the HIP path has no CPU fallback")
         L.load()
+        torch.cuda.set_device(opt.local_rank)      # train.py:14; kernels go to this device's stream
         self.opt = opt
         self.gpu_ids = [opt.local_rank]
         self.isTrain = opt.isTrain

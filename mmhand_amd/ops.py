@@ -25,6 +25,8 @@ def _ptr(t):
 
 
 def _stream():
+    # current stream of the CURRENT device: MMHandModel / the drivers set the device to the rank's
+    # GPU before anything runs (one process per GPU), tensors are created on that same device
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

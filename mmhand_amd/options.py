@@ -7,7 +7,8 @@ Differences, all deliberate:
     base_options.py:191 by calling .split on a list);
   * --distributed reads RANK/LOCAL_RANK/WORLD_SIZE from the environment (torchrun) and
     initialises the 'nccl' backend, which is RCCL on ROCm;
-  * --opt_level is accepted for compatibility and ignored (no apex; fp32 compute);
+  * --opt_level O0 = fp32; O1/O2 (apex AMP in the reference) = bf16 MFMA compute with fp32 master
+    weights, accumulation and statistics (no apex, no loss scaling needed);
   * two additions: --G_n_blocks (the reference hard-codes 9) and --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline).
 """
@@ -53,7 +54,7 @@ _BASE = [
     ("--local_rank", dict(type=int, default=0, help="determine which is the master process")),
     ("--distributed", dict(action="store_true", help="one process per GPU, RCCL all-reduce")),
     ("--seed", dict(type=int, default=49, help="manual seed for weight init")),
-    ("--opt_level", dict(type=str, default="O0", help="accepted, ignored (no apex)")),
+    ("--opt_level", dict(type=str, default="O0", help="O0 fp32 | O1/O2 bf16 MFMA compute")),
     ("--G_n_blocks", dict(type=int, default=9, help="PATBlocks in the generator")),
     ("--vgg_weights", dict(type=str, default=None, help="vgg19.features[0:4] state_dict file")),
 ]
@@ -162,9 +163,16 @@ class TestOptions(BaseOptions):
 
 
 def default_train_opt(**overrides):
-    """Programmatic TrainOptions namespace (defaults of the tables above) for bench/tests."""
+    """Programmatic TrainOptions namespace (defaults of the tables above) for bench/tests.  Never
+    touches the current CUDA device or the process group: the caller owns both."""
     o = TrainOptions()
-    opt = o.parse([], init_dist=False, save=False)
+    o.initialize()
+    opt = o.parser.parse_args([])
+    opt.isTrain = True
+    lr = int(overrides.get("local_rank", 0))
+    opt.gpu_ids = [lr]
+    opt.gpu = lr
+    opt.world_size = 1
     for k, v in overrides.items():
         setattr(opt, k, v)
     return opt
