@@ -86,6 +86,17 @@ size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* w,
                             void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
 
+/* Winograd F(2x2,3x3) fprop for fp32 3x3 / stride 1 / pad 1 convs (even H, W; dense tensors):
+ * 2.25x fewer multiplications than the direct implicit GEMM.  U = mmh_wino_weights(w):
+ * [16][Cin][Cout] (flip_transpose=1 gives the dgrad filter [16][Cout][Cin]).  ws holds the
+ * transformed input and product planes (mmh_conv2d_fprop_wino_ws_bytes).            */
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U,
+                     mmh_stream_t s);
+size_t mmh_conv2d_fprop_wino_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U,
+                          const void* bias, void* y, int act, void* ws, size_t ws_bytes,
+                          mmh_stream_t s);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
  * result deterministic.  accumulate!=0 adds into dw.                       */

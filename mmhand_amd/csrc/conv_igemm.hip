@@ -446,6 +446,158 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_multi_kernel(const MultiKP 
     conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false>(p, local % gx, local / gx, gx, gy);
 }
 
+// Batched plain GEMMs (blockIdx.z = batch): the 16 Winograd-domain products.  Each batch is
+// the same problem on pointers advanced by fixed strides.
+struct BatchKP {
+    ConvKP p;
+    long long src_bs, w_bs, out_bs;     // element strides between batches
+};
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR>
+__global__ void __launch_bounds__(256, 2) conv_igemm_batched_kernel(const BatchKP bp) {
+    ConvKP p = bp.p;
+    const long long z = blockIdx.z;
+    p.g.src += z * bp.src_bs;
+    p.w += z * bp.w_bs;
+    p.out += z * bp.out_bs;
+    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// ---------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (fp32).  y = A^T[(G g G^T) . (B^T d B)]A:
+// 16 multiplications per 2x2 output tile instead of 36, i.e. 2.25x fewer MFMA flops than the
+// direct implicit GEMM.  Three kernels around the batched GEMM above:
+//   wino_weights  : U[xi][K][N]   = G g G^T                  (once per weight update)
+//   wino_input    : V[xi][tile][C] = B^T d B, d = 4x4 patch   (reflect / zero padding in the gather)
+//   (16 GEMMs)    : M[xi][tile][N] = V[xi] . U[xi]
+//   wino_output   : y tile = A^T M A (+bias, activation)
+// ---------------------------------------------------------------------------
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin,
+                                    int Cout, int flip_transpose) {
+    // w: [3][3][Cin][Cout].  U: [16][K][N] with (K,N) = (Cin,Cout), or (Cout,Cin) with the taps
+    // flipped when flip_transpose (the dgrad filter).
+    const int total = Cin * Cout;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i / Cout, co = i - ci * Cout;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ka = flip_transpose ? 2 - a : a, kb = flip_transpose ? 2 - b : b;
+            g[a][b] = w[((size_t)(ka * 3 + kb) * Cin + ci) * Cout + co];
+        }
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const size_t plane = (size_t)Cin * Cout;
+    const size_t o = flip_transpose ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        U[(size_t)(a * 4 + 0) * plane + o] = t[a][0];
+        U[(size_t)(a * 4 + 1) * plane + o] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(size_t)(a * 4 + 2) * plane + o] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(size_t)(a * 4 + 3) * plane + o] = t[a][2];
+    }
+}
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// V[xi][tile][C]: one thread per (tile, 4 channels).  Padding 1, reflect or zero.
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H,
+                                  int W, int C4, int reflect) {
+    const int TH = H / 2, TW = W / 2;
+    const long long tiles = (long long)B * TH * TW;
+    const long long total = tiles * C4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    const long long tile = i / C4;
+    const int tx = (int)(tile % TW);
+    const int ty = (int)((tile / TW) % TH);
+    const int b = (int)(tile / ((long long)TW * TH));
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int hh = 2 * ty - 1 + r;
+        bool okh = true;
+        if (reflect) { hh = hh < 0 ? -hh : hh; hh = hh >= H ? 2 * (H - 1) - hh : hh; }
+        else okh = hh >= 0 && hh < H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int ww = 2 * tx - 1 + q;
+            bool ok = okh;
+            if (reflect) { ww = ww < 0 ? -ww : ww; ww = ww >= W ? 2 * (W - 1) - ww : ww; }
+            else ok = ok && ww >= 0 && ww < W;
+            d[r][q] = ok ? reinterpret_cast<const float4*>(x)[(((long long)b * H + hh) * W + ww) * C4 + c]
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[0][q] = f4sub(d[0][q], d[2][q]);
+        t[1][q] = f4add(d[1][q], d[2][q]);
+        t[2][q] = f4sub(d[2][q], d[1][q]);
+        t[3][q] = f4sub(d[1][q], d[3][q]);
+    }
+    const long long plane = tiles * C4;
+    float4* out = reinterpret_cast<float4*>(V) + tile * C4 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[(long long)(r * 4 + 0) * plane] = f4sub(t[r][0], t[r][2]);
+        out[(long long)(r * 4 + 1) * plane] = f4add(t[r][1], t[r][2]);
+        out[(long long)(r * 4 + 2) * plane] = f4sub(t[r][2], t[r][1]);
+        out[(long long)(r * 4 + 3) * plane] = f4sub(t[r][1], t[r][3]);
+    }
+}
+
+// y[b, 2ty+i, 2tx+j, :] = (A^T M A)[i][j] (+ bias, act).  One thread per (tile, 4 channels).
+__global__ void wino_output_kernel(const float* __restrict__ M, float* __restrict__ y,
+                                   const float* __restrict__ bias, int B, int H, int W, int C4,
+                                   int act) {
+    const int TH = H / 2, TW = W / 2;
+    const long long tiles = (long long)B * TH * TW;
+    const long long total = tiles * C4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    const long long tile = i / C4;
+    const int tx = (int)(tile % TW);
+    const int ty = (int)((tile / TW) % TH);
+    const int b = (int)(tile / ((long long)TW * TH));
+    const long long plane = tiles * C4;
+    const float4* in = reinterpret_cast<const float4*>(M) + tile * C4 + c;
+    float4 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[r][q] = in[(long long)(r * 4 + q) * plane];
+    float4 s[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s[0][q] = f4add(f4add(m[0][q], m[1][q]), m[2][q]);
+        s[1][q] = f4sub(f4sub(m[1][q], m[2][q]), m[3][q]);
+    }
+    float4 bv = bias ? reinterpret_cast<const float4*>(bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float4 y0 = f4add(f4add(f4add(s[r][0], s[r][1]), s[r][2]), bv);
+        float4 y1 = f4add(f4sub(f4sub(s[r][1], s[r][2]), s[r][3]), bv);
+        y0 = make_float4(apply_act(y0.x, act), apply_act(y0.y, act), apply_act(y0.z, act), apply_act(y0.w, act));
+        y1 = make_float4(apply_act(y1.x, act), apply_act(y1.y, act), apply_act(y1.z, act), apply_act(y1.w, act));
+        float4* o = reinterpret_cast<float4*>(y) + (((long long)b * H + 2 * ty + r) * W + 2 * tx) * C4 + c;
+        o[0] = y0;
+        o[C4] = y1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // bf16-MFMA variant of the fprop / dgrad kernel (mmh_conv_desc.dtype = MMH_BF16).
 // Activations stay fp32 in HBM and are rounded to bf16 (RNE) while being staged into LDS;
@@ -1465,6 +1617,59 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     return mmh::check_launch("border_add_kernel");
 }
 
+// ------------------------------------------------------------------ Winograd host side
+template <int BN, int WM, int WN, bool NMAJOR>
+int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
+    constexpr size_t lds = (BM * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_igemm_batched_kernel<BN, WM, WN, NMAJOR>, lds);
+    if (ready != 0) return ready;
+    dim3 grid((bp.p.N + BN - 1) / BN, (bp.p.M + BM - 1) / BM, nbatch);
+    hipLaunchKernelGGL((conv_igemm_batched_kernel<BN, WM, WN, NMAJOR>), grid, dim3(256), lds, st, bp);
+    return mmh::check_launch("conv_igemm_batched_kernel");
+}
+
+// 16 x ( [tiles x K] . [K x N] ): V [16][tiles][K], U [16][K][N] -> M [16][tiles][N]
+int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st) {
+    MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
+    BatchKP bp{};
+    ConvKP& p = bp.p;
+    Gather& g = p.g;
+    g.src = V;
+    g.src_bytes = (unsigned)((size_t)tiles * K * sizeof(float));
+    g.srcH = 1; g.srcW = (int)tiles; g.src_cs = (unsigned)K;
+    g.PH = 1; g.PW = (int)tiles; g.TH = 1; g.TW = 1;
+    g.C4 = K / 4;
+    g.ap_h = 0; g.at_h = 0; g.a0_h = 0; g.ap_w = 1; g.at_w = 0; g.a0_w = 0;
+    g.shift = 0; g.reflect = 0;
+    set_korder(g, p.nk, p.Kflat);
+    p.w = U;
+    p.w_bytes = (unsigned)((size_t)K * N * sizeof(float));
+    p.out = Mo;
+    p.M = (int)tiles; p.N = N;
+    p.wCin = K; p.wCout = N;
+    p.KW_true = 1; p.kh0 = 0; p.kw0 = 0; p.tstep = 1;
+    p.OH = 1; p.OW = (int)tiles; p.o_p = 1;
+    p.out_cs = (unsigned)N; p.out_linear = 1;
+    p.act = MMH_ACT_NONE;
+    bp.src_bs = tiles * K; bp.w_bs = (long long)K * N; bp.out_bs = tiles * N;
+    {
+        const int bn = (N % 256 == 0) ? 256 : 128;
+        const int gx = (N + bn - 1) / bn, gy = (p.M + BM - 1) / BM;
+        p.xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+    }
+    if (N % 256 == 0) return launch_batched_t<256, 2, 2, false>(bp, 16, st);
+    if (N > 64) return launch_batched_t<128, 2, 2, false>(bp, 16, st);
+    if (N > 32) return launch_batched_t<64, 2, 2, false>(bp, 16, st);
+    return launch_batched_t<32, 4, 1, false>(bp, 16, st);
+}
+
+bool wino_ok(const mmh_conv_desc* d) {
+    return d->dtype == MMH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+           d->H % 2 == 0 && d->W % 2 == 0 && d->H >= 4 && d->W >= 4 && d->x_cs == d->Cin &&
+           d->y_cs == d->Cout && d->Cin % 32 == 0;
+}
+
 // Split-K factor: fill whole rounds of the 512 resident workgroups (256 CUs x 2 per CU, LDS
 // bound) so the last round is not a mostly empty tail; keep >= 8 k-steps per split.
 int g_wgrad_slots = 768;   // tuning knob (mmh_set_option "wgrad_slots")
@@ -1586,6 +1791,46 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
     MMH_REQUIRE(dy && w && dx, "mmh_conv2d_dgrad: NULL buffer");
     MMH_REQUIRE(dx_cs % 4 == 0 && dx_cs >= d->Cin, "mmh_conv2d_dgrad: bad dx_cs=%d", dx_cs);
     return do_dgrad(d, dy, w, nullptr, dx, dx_cs, MMH_ACT_NONE, mmh::as_stream(s));
+}
+
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U, mmh_stream_t s) {
+    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0, "mmh_wino_weights: bad arguments");
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+    return mmh::check_launch("wino_weights_kernel");
+}
+
+size_t mmh_conv2d_fprop_wino_ws_bytes(const mmh_conv_desc* d) {
+    if (!d || !wino_ok(d)) return 0;
+    const size_t tiles = (size_t)d->B * (d->H / 2) * (d->W / 2);
+    return 16 * tiles * (size_t)(d->Cin + d->Cout) * sizeof(float);
+}
+
+int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U, const void* bias, void* y,
+                          int act, void* ws, size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(wino_ok(d), "mmh_conv2d_fprop_wino: needs fp32 3x3 stride 1 pad 1, even H,W, Cin %% 32 == 0");
+    MMH_REQUIRE(x && U && y && ws && ws_bytes >= mmh_conv2d_fprop_wino_ws_bytes(d),
+                "mmh_conv2d_fprop_wino: NULL buffer or workspace too small");
+    hipStream_t st = mmh::as_stream(s);
+    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
+    float* V = static_cast<float*>(ws);
+    float* Mo = V + 16 * tiles * d->Cin;
+    {
+        const long long total = tiles * (d->Cin / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(x), V, d->B, d->H, d->W, d->Cin / 4,
+                           d->pad_mode == MMH_PAD_REFLECT ? 1 : 0);
+        if (int rc = mmh::check_launch("wino_input_kernel")) return rc;
+    }
+    if (int rc = wino_gemm(V, static_cast<const float*>(U), Mo, tiles, d->Cin, d->Cout, st)) return rc;
+    {
+        const long long total = tiles * (d->Cout / 4);
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Mo,
+                           static_cast<float*>(y), static_cast<const float*>(bias), d->B, d->H, d->W,
+                           d->Cout / 4, act);
+        return mmh::check_launch("wino_output_kernel");
+    }
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

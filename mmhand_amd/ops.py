@@ -92,6 +92,39 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
                       x_cs or Cin, y_cs or Cout, L.F32)
 
 
+_wino_cache = {}
+
+
+def wino_weights(w, flip_transpose=False):
+    """Winograd-domain filter U [16,K,N] of a physical 3x3 weight (cached per weights epoch)."""
+    key = (w.data_ptr(), bool(flip_transpose))
+    ent = _wino_cache.get(key)
+    if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
+        _, _, cin, cout = w.shape
+        U = torch.empty((16, cout, cin) if flip_transpose else (16, cin, cout), dtype=torch.float32,
+                        device=w.device)
+        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), _ptr(U), _stream())
+        ent = (_weights_epoch[0], tuple(w.shape), U)
+        _wino_cache[key] = ent
+    return ent[2]
+
+
+def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE):
+    """fp32 3x3 / stride 1 / pad 1 conv by Winograd F(2x2,3x3)."""
+    _chk(x, "x"); _chk(w, "w")
+    B, H, W_, Cin = x.shape
+    Cout = w.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    nbytes = L.load().mmh_conv2d_fprop_wino_ws_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("winograd path not applicable to this shape")
+    ws = _ws(nbytes, x)
+    y = _empty((B, H, W_, Cout), x)
+    L.call("mmh_conv2d_fprop_wino", C.byref(d), _ptr(x), _ptr(wino_weights(w)), _ptr(bias), _ptr(y), act,
+           _ptr(ws), ws.numel() * 4, _stream())
+    return y
+
+
 def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape

@@ -170,3 +170,19 @@ def test_reflect1_dgrad_border_terms(hw, dev):
     dx = ops.raw_conv_dgrad(dy, w, x_shape, 1, 1, True)
     _, dxr, _, _ = R.conv2d_grads(torch.zeros(x_shape), w.cpu(), None, dy.cpu(), 1, 1, True)
     assert R.rel_l1(dx, dxr) < TOL, R.rel_l1(dx, dxr)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, True), (1, 12, 20, 256, 256, True), (2, 8, 8, 64, 128, False),
+                                  (3, 4, 6, 32, 64, True), (1, 16, 16, 512, 256, True)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_winograd_fprop(case, act, dev):
+    """Winograd F(2x2,3x3) fprop == direct convolution (fp64 oracle) within fp32 rounding."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    ops.bump_weights_epoch()
+    y = ops.raw_conv_fprop_wino(x, w, bias, refl, act)
+    yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 1, refl, act)
+    assert R.rel_l1(y, yr) < 2e-5, R.rel_l1(y, yr)

@@ -1,0 +1,22 @@
+import sys, os, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmhand_amd import ops
+dev = torch.device("cuda:0"); B = 32
+def timeit(fn, iters=3):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256), (256, 64, 64)]:
+    x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
+    fl = 2.0 * B * H * H * Cin * Cout * 9
+    fd = lambda: ops.raw_conv_fprop(x, w, None, 1, 1, True, 0)
+    fw = lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0)
+    fd(); fw(); torch.cuda.synchronize()
+    rd, rw = [], []
+    for _ in range(5):
+        rd.append(timeit(fd)); rw.append(timeit(fw))
+    md, mw = statistics.median(rd), statistics.median(rw)
+    print(f"{Cin}->{Cout}@{H}: direct {md:.3f} ms ({fl/md/1e9:.1f} TF) | winograd {mw:.3f} ms ({fl/mw/1e9:.1f} TF-equivalent) | speedup {md/mw:.2f}x", flush=True)
