@@ -97,6 +97,13 @@ int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U,
                           const void* bias, void* y, int act, void* ws, size_t ws_bytes,
                           mmh_stream_t s);
 
+/* Winograd dgrad (folded): Ut = mmh_wino_weights(w, flip_transpose=1); `w` (fp32, plain)
+ * is still needed for the eight reflect-border terms.                                */
+size_t mmh_conv2d_dgrad_wino_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut,
+                          const void* w, void* dx, void* ws, size_t ws_bytes,
+                          mmh_stream_t s);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
  * result deterministic.  accumulate!=0 adds into dw.                       */

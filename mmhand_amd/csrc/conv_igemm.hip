@@ -1536,7 +1536,7 @@ size_t reflect1_ws_bytes(const mmh_conv_desc* d) {
 }
 
 int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
-                      hipStream_t st) {
+                      hipStream_t st, bool with_main = true) {
     const int H = d->H, W = d->W, C = d->Cin;
     const bool bf16 = d->dtype == MMH_BF16;
     float* rows = static_cast<float*>(ws);                       // [B][2][W][C]
@@ -1599,11 +1599,11 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
         main.xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
     }
     if (bf16) MMH_REQUIRE(bf16_ok(main), "bf16 dgrad needs Cout %% 64 == 0 (Cout=%d)", d->Cout);
-    mp.p[n++] = main;
+    if (with_main) mp.p[n++] = main;      // else: the main term was produced by the Winograd path
     mp.n = n;
     int rc;
     if (!bf16 && g_conv_bn256 == 2 && C % 256 == 0) {   // measured: no gain for the [n][k] weight tile
-        mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
+        if (with_main) mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
         rc = launch_multi_t<256, 2, 2>(mp, false, st);
     } else if (C > 64) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
     else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);
@@ -1831,6 +1831,47 @@ int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U, 
                            d->Cout / 4, act);
         return mmh::check_launch("wino_output_kernel");
     }
+}
+
+// Winograd dgrad: the zero-padded correlation of dy with the flipped filter (U' from
+// mmh_wino_weights(flip_transpose=1)) gives g on the real domain; reflect padding then adds the
+// eight border terms exactly as the direct path does.
+size_t mmh_conv2d_dgrad_wino_ws_bytes(const mmh_conv_desc* d) {
+    if (!d || !wino_ok(d)) return 0;
+    const size_t tiles = (size_t)d->B * (d->H / 2) * (d->W / 2);
+    size_t b = 16 * tiles * (size_t)(d->Cin + d->Cout) * sizeof(float);
+    if (d->pad_mode == MMH_PAD_REFLECT) b += reflect1_ws_bytes(d);
+    return b;
+}
+
+int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut, const void* w, void* dx,
+                          void* ws, size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(wino_ok(d), "mmh_conv2d_dgrad_wino: needs fp32 3x3 stride 1 pad 1, even H,W, dense tensors");
+    MMH_REQUIRE(dy && Ut && w && dx && ws && ws_bytes >= mmh_conv2d_dgrad_wino_ws_bytes(d),
+                "mmh_conv2d_dgrad_wino: NULL buffer or workspace too small");
+    MMH_REQUIRE(d->Cout % 32 == 0, "mmh_conv2d_dgrad_wino: Cout %% 32 != 0");
+    hipStream_t st = mmh::as_stream(s);
+    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
+    float* V = static_cast<float*>(ws);
+    float* Mo = V + 16 * tiles * d->Cout;
+    float* border = Mo + 16 * tiles * d->Cin;
+    {
+        const long long total = tiles * (d->Cout / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(dy), V, d->B, d->H, d->W, d->Cout / 4, 0);
+        if (int rc = mmh::check_launch("wino_input_kernel")) return rc;
+    }
+    if (int rc = wino_gemm(V, static_cast<const float*>(Ut), Mo, tiles, d->Cout, d->Cin, st)) return rc;
+    {
+        const long long total = tiles * (d->Cin / 4);
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Mo,
+                           static_cast<float*>(dx), static_cast<const float*>(nullptr), d->B, d->H, d->W,
+                           d->Cin / 4, MMH_ACT_NONE);
+        if (int rc = mmh::check_launch("wino_output_kernel")) return rc;
+    }
+    if (d->pad_mode == MMH_PAD_REFLECT) return do_dgrad_reflect1(d, dy, w, dx, border, st, false);
+    return 0;
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

@@ -125,6 +125,22 @@ def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE):
     return y
 
 
+def raw_conv_dgrad_wino(dy, w, x_shape, reflect):
+    """fp32 3x3 / stride 1 / pad 1 dgrad (folded) by Winograd F(2x2,3x3)."""
+    _chk(dy, "dy"); _chk(w, "w")
+    B, H, W_, Cin = x_shape
+    Cout = w.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    nbytes = L.load().mmh_conv2d_dgrad_wino_ws_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("winograd path not applicable to this shape")
+    ws = _ws(nbytes, dy)
+    dx = _empty((B, H, W_, Cin), dy)
+    L.call("mmh_conv2d_dgrad_wino", C.byref(d), _ptr(dy), _ptr(wino_weights(w, True)), _ptr(w), _ptr(dx),
+           _ptr(ws), ws.numel() * 4, _stream())
+    return dx
+
+
 def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape

@@ -186,3 +186,8 @@ def test_winograd_fprop(case, act, dev):
     y = ops.raw_conv_fprop_wino(x, w, bias, refl, act)
     yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 1, refl, act)
     assert R.rel_l1(y, yr) < 2e-5, R.rel_l1(y, yr)
+    if act == 0:
+        dy = _mk(tuple(y.shape), 4, dev)
+        dx = ops.raw_conv_dgrad_wino(dy, w, x.shape, refl)
+        _, dxr, _, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
+        assert R.rel_l1(dx, dxr) < 2e-5, ("winograd dgrad", R.rel_l1(dx, dxr))

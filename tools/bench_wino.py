@@ -14,7 +14,14 @@ for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256), (256, 64,
     fl = 2.0 * B * H * H * Cin * Cout * 9
     fd = lambda: ops.raw_conv_fprop(x, w, None, 1, 1, True, 0)
     fw = lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0)
-    fd(); fw(); torch.cuda.synchronize()
+    y = fd(); dy = torch.randn_like(y)
+    gd = lambda: ops.raw_conv_dgrad(dy, w, x.shape, 1, 1, True)
+    gw = lambda: ops.raw_conv_dgrad_wino(dy, w, x.shape, True)
+    fd(); fw(); gd(); gw(); torch.cuda.synchronize()
+    r1, r2 = [], []
+    for _ in range(5):
+        r1.append(timeit(gd)); r2.append(timeit(gw))
+    print(f"{Cin}->{Cout}@{H}: dgrad direct {statistics.median(r1):.3f} ms | winograd {statistics.median(r2):.3f} ms | speedup {statistics.median(r1)/statistics.median(r2):.2f}x", flush=True)
     rd, rw = [], []
     for _ in range(5):
         rd.append(timeit(fd)); rw.append(timeit(fw))
