@@ -104,6 +104,11 @@ int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut
                           const void* w, void* dx, void* ws, size_t ws_bytes,
                           mmh_stream_t s);
 
+/* Winograd wgrad: dw = G^T [ sum_tiles (B^T d B) . (A dY A^T) ] G.                     */
+size_t mmh_conv2d_wgrad_wino_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_wgrad_wino(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
+                          void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
+
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
  * result deterministic.  accumulate!=0 adds into dw.                       */

@@ -891,6 +891,8 @@ struct WgradKP {
     int P;                  // total pixels = batch*PH*PW
     int pix_per_split;      // multiple of 32
     int dbg;                // timing-only ablation bits (results wrong)
+    int nsplit;             // splits per batch: blockIdx.z = batch * nsplit + split
+    long long src_bs, dy_bs;   // element strides between batches (Winograd: 16 planes)
 };
 
 template <int BN, int WAVES_M, int WAVES_N, bool DBUF>
@@ -912,11 +914,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
-    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int batch = blockIdx.z / p.nsplit, split = blockIdx.z - batch * p.nsplit;
+    const int pbeg = split * p.pix_per_split;
     const int pend = min(p.P, pbeg + p.pix_per_split);
     const int PHW = g.PH * g.PW;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
-    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src + batch * p.src_bs, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dy + batch * p.dy_bs, p.dy_bytes);
 
     // this thread's fixed (tap, channel group): flat group index
     KState kt;
@@ -1099,11 +1102,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
-    const int pbeg = blockIdx.z * p.pix_per_split;
+    const int batch = blockIdx.z / p.nsplit, split = blockIdx.z - batch * p.nsplit;
+    const int pbeg = split * p.pix_per_split;
     const int pend = min(p.P, pbeg + p.pix_per_split);
     const int PHW = g.PH * g.PW;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
-    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src + batch * p.src_bs, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(p.dy + batch * p.dy_bs, p.dy_bytes);
 
     KState kt;
     const int fg = (m0 >> 2) + (tid & 31);
@@ -1220,13 +1224,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
 
 // dw[i] (+)= sum_z slab[z][i], fixed order -> deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                   int64_t n4, int splits, int accumulate) {
+                                   int64_t n4_total, int splits, int accumulate, int64_t n4) {
+    // n4 = float4 elements per batch; batch b's slabs are [b*splits .. b*splits+splits)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n4; i += stride) {
-        float4 s = reinterpret_cast<const float4*>(slab)[i];
+    for (; i < n4_total; i += stride) {
+        const int64_t b = i / n4, r = i - b * n4;
+        const float4* base = reinterpret_cast<const float4*>(slab) + b * splits * n4 + r;
+        float4 s = base[0];
         for (int z = 1; z < splits; ++z) {
-            float4 t = reinterpret_cast<const float4*>(slab)[(int64_t)z * n4 + i];
+            float4 t = base[(int64_t)z * n4];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         float4* o = reinterpret_cast<float4*>(dw) + i;
@@ -1617,6 +1624,72 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     return mmh::check_launch("border_add_kernel");
 }
 
+// Yhat[xi][tile][C] = A dY A^T for the 2x2 output-gradient tile (Winograd wgrad).
+__global__ void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Yh, int B, int H, int W,
+                               int C4) {
+    const int TH = H / 2, TW = W / 2;
+    const long long tiles = (long long)B * TH * TW;
+    const long long total = tiles * C4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    const long long tile = i / C4;
+    const int tx = (int)(tile % TW);
+    const int ty = (int)((tile / TW) % TH);
+    const int b = (int)(tile / ((long long)TW * TH));
+    const float4* in = reinterpret_cast<const float4*>(dy) + (((long long)b * H + 2 * ty) * W + 2 * tx) * C4 + c;
+    const float4 y00 = in[0], y01 = in[C4], y10 = in[(long long)W * C4], y11 = in[(long long)W * C4 + C4];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows of A dY: [y0, y0+y1, y0-y1, -y1]
+    float4 t[4][2] = {{y00, y01}, {f4add(y00, y10), f4add(y01, y11)}, {f4sub(y00, y10), f4sub(y01, y11)},
+                      {f4sub(z, y10), f4sub(z, y11)}};
+    const long long plane = tiles * C4;
+    float4* out = reinterpret_cast<float4*>(Yh) + tile * C4 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        out[(long long)(r * 4 + 0) * plane] = t[r][0];
+        out[(long long)(r * 4 + 1) * plane] = f4add(t[r][0], t[r][1]);
+        out[(long long)(r * 4 + 2) * plane] = f4sub(t[r][0], t[r][1]);
+        out[(long long)(r * 4 + 3) * plane] = f4sub(z, t[r][1]);
+    }
+}
+
+// dw[3][3][Cin][Cout] (+)= G^T dU G, dU: [16][Cin][Cout]
+__global__ void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int64_t plane4,
+                               int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane4) return;
+    const float4* in = reinterpret_cast<const float4*>(dU) + i;
+    float4 u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u[a][b] = in[(int64_t)(a * 4 + b) * plane4];
+    auto half = [](float4 v) { return make_float4(0.5f * v.x, 0.5f * v.y, 0.5f * v.z, 0.5f * v.w); };
+    float4 t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float4 hs = half(f4add(u[1][b], u[2][b])), hd = half(f4sub(u[1][b], u[2][b]));
+        t[0][b] = f4add(u[0][b], hs);
+        t[1][b] = hd;
+        t[2][b] = f4add(hs, u[3][b]);
+    }
+    float4* out = reinterpret_cast<float4*>(dw) + i;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float4 hs = half(f4add(t[a][1], t[a][2])), hd = half(f4sub(t[a][1], t[a][2]));
+        float4 g0 = f4add(t[a][0], hs), g1 = hd, g2 = f4add(hs, t[a][3]);
+        if (accumulate) {
+            g0 = f4add(g0, out[(int64_t)(a * 3 + 0) * plane4]);
+            g1 = f4add(g1, out[(int64_t)(a * 3 + 1) * plane4]);
+            g2 = f4add(g2, out[(int64_t)(a * 3 + 2) * plane4]);
+        }
+        out[(int64_t)(a * 3 + 0) * plane4] = g0;
+        out[(int64_t)(a * 3 + 1) * plane4] = g1;
+        out[(int64_t)(a * 3 + 2) * plane4] = g2;
+    }
+}
+
 // ------------------------------------------------------------------ Winograd host side
 template <int BN, int WM, int WN, bool NMAJOR>
 int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
@@ -1718,6 +1791,16 @@ int launch_wgrad_bf16_t(const WgradKP& p, int splits, hipStream_t st) {
     return mmh::check_launch("conv_wgrad_bf16_kernel");
 }
 
+template <int BN, int WM, int WN>
+int launch_wgrad_grid_t(const WgradKP& p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (BK * LDW + BK * BN) * sizeof(float);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_wgrad_kernel<BN, WM, WN, false>, lds);
+    if (ready != 0) return ready;
+    hipLaunchKernelGGL((conv_wgrad_kernel<BN, WM, WN, false>), grid, dim3(256), lds, st, p);
+    return mmh::check_launch("conv_wgrad_kernel");
+}
+
 size_t wgrad_ws(const mmh_conv_desc* d) {
     const int Mrows = d->kh * d->kw * d->Cin;
     const int P = d->B * d->Ho * d->Wo;
@@ -1743,6 +1826,7 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
     const bool bf16 = d->dtype == MMH_BF16;
     p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), bf16 ? BKP : BK) * (bf16 ? BKP : BK));
     p.dbg = g_conv_dbg;
+    p.nsplit = splits;
     int rc;
     if (bf16) {
         if (p.N > 64) rc = launch_wgrad_bf16_t<128, 2, 2>(p, splits, st);
@@ -1757,7 +1841,7 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
     const int64_t n4 = (int64_t)p.Mrows * p.N / 4;
     int blocks = (int)std::min<int64_t>(mmh::cdiv(n4, 256), 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab,
-                       static_cast<float*>(dw), n4, splits, accumulate);
+                       static_cast<float*>(dw), n4, splits, accumulate, n4);
     return mmh::check_launch("slab_reduce_kernel");
 }
 
@@ -1872,6 +1956,82 @@ int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut
     }
     if (d->pad_mode == MMH_PAD_REFLECT) return do_dgrad_reflect1(d, dy, w, dx, border, st, false);
     return 0;
+}
+
+// Winograd wgrad: dU[xi] = V[xi]^T . Yhat[xi] (16 batched split-K GEMMs over the tiles), then
+// dw = G^T dU G.
+static int wino_wgrad_splits(const mmh_conv_desc* d, long long tiles) {
+    const int bn = (g_wgrad_bn256 && d->Cout % 256 == 0) ? 256 : 128;
+    const int per = ((d->Cin + BM - 1) / BM) * ((d->Cout + bn - 1) / bn) * 16;
+    int s = std::max(1, g_wgrad_slots / per);
+    const long long maxs = std::max<long long>(1, tiles / (8 * BK));
+    return (int)std::min<long long>(s, maxs);
+}
+
+size_t mmh_conv2d_wgrad_wino_ws_bytes(const mmh_conv_desc* d) {
+    if (!d || !wino_ok(d)) return 0;
+    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
+    const int splits = wino_wgrad_splits(d, tiles);
+    return (size_t)(16 * tiles * (d->Cin + d->Cout) + (size_t)16 * (splits + 1) * d->Cin * d->Cout) * sizeof(float);
+}
+
+int mmh_conv2d_wgrad_wino(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
+                          size_t ws_bytes, int accumulate, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(wino_ok(d) && d->Cout % 32 == 0, "mmh_conv2d_wgrad_wino: needs fp32 3x3 stride 1 pad 1, even H,W");
+    MMH_REQUIRE(x && dy && dw && ws && ws_bytes >= mmh_conv2d_wgrad_wino_ws_bytes(d),
+                "mmh_conv2d_wgrad_wino: NULL buffer or workspace too small");
+    hipStream_t st = mmh::as_stream(s);
+    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
+    const int splits = wino_wgrad_splits(d, tiles);
+    float* V = static_cast<float*>(ws);
+    float* Yh = V + 16 * tiles * d->Cin;
+    float* slab = Yh + 16 * tiles * d->Cout;
+    float* dU = slab + (size_t)16 * splits * d->Cin * d->Cout;
+    {
+        const long long total = tiles * (d->Cin / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(x), V, d->B, d->H, d->W, d->Cin / 4,
+                           d->pad_mode == MMH_PAD_REFLECT ? 1 : 0);
+        const long long total2 = tiles * (d->Cout / 4);
+        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, st,
+                           static_cast<const float*>(dy), Yh, d->B, d->H, d->W, d->Cout / 4);
+        if (int rc = mmh::check_launch("wino transforms")) return rc;
+    }
+    WgradKP p{};
+    Gather& g = p.g;
+    g.src = V;
+    g.src_bytes = (unsigned)((size_t)tiles * d->Cin * sizeof(float));
+    g.srcH = 1; g.srcW = (int)tiles; g.src_cs = (unsigned)d->Cin;
+    g.PH = 1; g.PW = (int)tiles; g.TH = 1; g.TW = 1;
+    g.C4 = d->Cin / 4;
+    g.ap_h = 0; g.at_h = 0; g.a0_h = 0; g.ap_w = 1; g.at_w = 0; g.a0_w = 0;
+    g.shift = 0; g.reflect = 0; g.chunk_major = 0; g.cw = 1;
+    p.dy = Yh;
+    p.dy_bytes = (unsigned)((size_t)tiles * d->Cout * sizeof(float));
+    p.dy_cs = (unsigned)d->Cout;
+    p.slab = slab;
+    p.Mrows = d->Cin; p.N = d->Cout; p.P = (int)tiles;
+    p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(tiles, splits), BK) * BK);
+    p.nsplit = splits;
+    p.src_bs = tiles * d->Cin; p.dy_bs = tiles * d->Cout;
+    {
+        const bool b256 = g_wgrad_bn256 && p.N % 256 == 0;
+        const int BNsel = b256 ? 256 : (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32));
+        dim3 grid((p.N + BNsel - 1) / BNsel, (p.Mrows + BM - 1) / BM, 16 * splits);
+        int rc;
+        if (b256) rc = launch_wgrad_grid_t<256, 2, 2>(p, grid, st);
+        else if (p.N > 64) rc = launch_wgrad_grid_t<128, 2, 2>(p, grid, st);
+        else if (p.N > 32) rc = launch_wgrad_grid_t<64, 2, 2>(p, grid, st);
+        else rc = launch_wgrad_grid_t<32, 4, 1>(p, grid, st);
+        if (rc) return rc;
+    }
+    const int64_t n4 = (int64_t)d->Cin * d->Cout / 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(16 * n4, 256), 4096)), dim3(256),
+                       0, st, slab, dU, 16 * n4, splits, 0, n4);
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)mmh::cdiv(n4, 256)), dim3(256), 0, st, dU,
+                       static_cast<float*>(dw), n4, accumulate);
+    return mmh::check_launch("wino wgrad");
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mmh_conv2d_fprop_wino": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmh_conv2d_dgrad_wino_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_dgrad_wino": (_i, [_DP, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_conv2d_wgrad_wino_ws_bytes": (_sz, [_DP]),
+    "mmh_conv2d_wgrad_wino": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_convT2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -141,6 +141,22 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect):
     return dx
 
 
+def raw_conv_wgrad_wino(x, dy, reflect):
+    """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd F(2x2,3x3)."""
+    _chk(x, "x"); _chk(dy, "dy")
+    B, H, W_, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    nbytes = L.load().mmh_conv2d_wgrad_wino_ws_bytes(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("winograd path not applicable to this shape")
+    ws = _ws(nbytes, x)
+    dw = _empty((3, 3, Cin, Cout), x)
+    L.call("mmh_conv2d_wgrad_wino", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+           _stream())
+    return dw
+
+
 def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape

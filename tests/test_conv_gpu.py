@@ -191,3 +191,6 @@ def test_winograd_fprop(case, act, dev):
         dx = ops.raw_conv_dgrad_wino(dy, w, x.shape, refl)
         _, dxr, _, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
         assert R.rel_l1(dx, dxr) < 2e-5, ("winograd dgrad", R.rel_l1(dx, dxr))
+        dw = ops.raw_conv_wgrad_wino(x, dy, refl)
+        _, _, dwr, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
+        assert R.rel_l1(dw, dwr) < 2e-5, ("winograd wgrad", R.rel_l1(dw, dwr))

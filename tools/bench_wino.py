@@ -21,6 +21,13 @@ for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256), (256, 64,
     r1, r2 = [], []
     for _ in range(5):
         r1.append(timeit(gd)); r2.append(timeit(gw))
+    hd = lambda: ops.raw_conv_wgrad(x, dy, 3, 1, 1, True)
+    hw = lambda: ops.raw_conv_wgrad_wino(x, dy, True)
+    hd(); hw(); torch.cuda.synchronize()
+    r3, r4 = [], []
+    for _ in range(5):
+        r3.append(timeit(hd)); r4.append(timeit(hw))
+    print(f"{Cin}->{Cout}@{H}: wgrad direct {statistics.median(r3):.3f} ms | winograd {statistics.median(r4):.3f} ms | speedup {statistics.median(r3)/statistics.median(r4):.2f}x", flush=True)
     print(f"{Cin}->{Cout}@{H}: dgrad direct {statistics.median(r1):.3f} ms | winograd {statistics.median(r2):.3f} ms | speedup {statistics.median(r1)/statistics.median(r2):.2f}x", flush=True)
     rd, rw = [], []
     for _ in range(5):
