@@ -41,13 +41,18 @@ def synthetic_batch_gpu(B, H, W, seed, dev):
 
 
 class KernelTimer:
-    """HIP-event brackets around every launch of one kernel shape during the timed region."""
+    """HIP-event brackets around every launch of ONE kernel shape during the timed region: either
+    the direct implicit-GEMM fprop matching `match` (conv desc fields) or, with Winograd on, the
+    batched Winograd-domain GEMM with (tiles, K, N) == `gemm`."""
 
-    def __init__(self, match):
-        self.match, self.pairs, self.enabled = match, [], False
+    def __init__(self, match, gemm=None):
+        self.match, self.gemm, self.pairs, self.enabled = match, gemm, [], False
 
     def want(self, d):
-        return self.enabled and all(getattr(d, k) == v for k, v in self.match.items())
+        return self.enabled and self.gemm is None and all(getattr(d, k) == v for k, v in self.match.items())
+
+    def want_gemm(self, tiles, K, N):
+        return self.enabled and self.gemm == (tiles, K, N)
 
     def bracket(self):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -150,6 +155,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-winograd", action="store_true",
+                    help="direct implicit-GEMM kernels for every conv (default: Winograd F(2x2,3x3) for the "
+                         "fp32 3x3 stride-1 convs with >= 256x256 channels)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE.json configs[1] (default); bf16 = bf16 MFMA compute, fp32 master "
                          "weights/accumulate/HBM tensors (the --opt_level O1 path; configs[2]/[4] precision)")
@@ -176,6 +184,8 @@ def main():
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     from mmhand_amd import ops
+    if a.no_winograd:
+        ops.USE_WINOGRAD = False
     from mmhand_amd.mmhand_model import MMHandModel
     from mmhand_amd.options import default_train_opt
     opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="bench", local_rank=local,
@@ -189,7 +199,10 @@ def main():
 
     # dominant kernel: the 3x3 reflect-pad 512->512 conv fprop at 64x64 (PATBlock streams 2/3)
     hs = H // 4
-    timer = KernelTimer(dict(Cin=512, Cout=512, kh=3, stride=1, H=hs, W=hs))
+    wino = ops.USE_WINOGRAD and a.dtype == "f32"
+    tiles = a.batch * (hs // 2) * (hs // 2)
+    timer = KernelTimer(dict(Cin=512, Cout=512, kh=3, stride=1, H=hs, W=hs),
+                        gemm=(tiles, 512, 512) if wino else None)
     ops.fprop_timer = timer
 
     def barrier():
@@ -216,11 +229,19 @@ def main():
     if rank == 0:
         imgs_per_s = world * a.batch * a.steps / dt
         k_ms, k_n = timer.mean_ms()
+        if wino:      # 16 x [tiles x 512] . [512 x 512]: the arithmetic this launch really does
+            k_flop = 16 * 2.0 * tiles * 512 * 512
+            k_name = ("conv_igemm_batched_kernel<256,2,2,false>: the 16 Winograd-domain GEMMs "
+                      f"[{tiles}x512].[512x512] of the 3x3 512->512 fprop @64x64")
+        else:
+            k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
+            k_name = (("conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
+                       "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tj) and a.batch == 32 and a.size == 256 and a.dtype == "f32":
-            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
-        k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
+            tjd = json.load(open(tj))
+            traffic = tjd.get("winograd_gemm" if wino else "direct", {}).get("hbm_bytes_per_launch")
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         line = {
             "metric": "256x256 hand images/sec (G+D step)", "value": round(imgs_per_s, 3),
@@ -228,7 +249,8 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"RHD-shaped {H}x{W}, per-GPU batch {a.batch}, "
-                       f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}, G(9 PATBlocks,"
+                       f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}"
+                       f"{' (Winograd F(2x2,3x3) on the 3x3 stack)' if wino else ''}, G(9 PATBlocks,"
                        f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}"},
             "step_mfma_frac": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world
@@ -236,9 +258,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic,
-                         "kernel": ("conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
-                                    "conv_igemm_kernel<128,2,2,false>") + " fprop 3x3 512->512 @64x64 "
-                                   f"(B={a.batch}): {k_flop / 1e9:.1f} GFLOP/launch, {k_ms:.3f} ms avg "
+                         "kernel": f"{k_name} (B={a.batch}): {k_flop / 1e9:.1f} GFLOP/launch, {k_ms:.3f} ms avg "
                                    f"over {k_n} launches in the timed region"},
             "losses": {k: round(v, 5) for k, v in losses.items()},
         }

@@ -92,6 +92,14 @@ int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* 
  * transformed input and product planes (mmh_conv2d_fprop_wino_ws_bytes).            */
 int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U,
                      mmh_stream_t s);
+/* The three stages of mmh_conv2d_fprop_wino, individually launchable (V: [16][tiles][C],
+ * tiles = B*(H/2)*(W/2); M = V[xi] . U[xi] as 16 batched GEMMs in one launch).              */
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, void* V,
+                   mmh_stream_t s);
+int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
+                  mmh_stream_t s);
+int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,
+                    int act, mmh_stream_t s);
 size_t mmh_conv2d_fprop_wino_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U,
                           const void* bias, void* y, int act, void* ws, size_t ws_bytes,

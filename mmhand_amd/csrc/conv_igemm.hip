@@ -1877,6 +1877,31 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
     return do_dgrad(d, dy, w, nullptr, dx, dx_cs, MMH_ACT_NONE, mmh::as_stream(s));
 }
 
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, void* V, mmh_stream_t s) {
+    MMH_REQUIRE(x && V && B > 0 && H >= 4 && W >= 4 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
+                "mmh_wino_input: bad arguments");
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 4, reflect);
+    return mmh::check_launch("wino_input_kernel");
+}
+
+int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, mmh_stream_t s) {
+    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0, "mmh_wino_gemm: bad arguments");
+    return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
+                     K, N, mmh::as_stream(s));
+}
+
+int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act,
+                    mmh_stream_t s) {
+    MMH_REQUIRE(M && y && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "mmh_wino_output: bad arguments");
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(M), static_cast<float*>(y), static_cast<const float*>(bias), B,
+                       H, W, C / 4, act);
+    return mmh::check_launch("wino_output_kernel");
+}
+
 int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U, mmh_stream_t s) {
     MMH_REQUIRE(w && U && Cin > 0 && Cout > 0, "mmh_wino_weights: bad arguments");
     hipLaunchKernelGGL(wino_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),

@@ -42,6 +42,9 @@ SIGNATURES = {
     "mmh_conv2d_dgrad_folded_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_dgrad_folded": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmh_wino_weights": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_input": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmh_conv2d_fprop_wino_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_fprop_wino": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "mmh_conv2d_dgrad_wino_ws_bytes": (_sz, [_DP]),

@@ -14,6 +14,7 @@ are physical [kh, kw, Cin, Cout]; the nn.Parameter objects the modules expose
 are permuted *views* of them with the reference's logical OIHW / IOHW shape.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -93,6 +94,17 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
 
 
 _wino_cache = {}
+# Winograd F(2x2,3x3) for the fp32 3x3 / stride-1 / pad-1 convs with >= 256x256 channel pairs
+# (1.25-1.6x over the direct implicit GEMM on MI355X; slower below that).  MMH_WINOGRAD=0 or
+# ops.USE_WINOGRAD = False selects the direct kernels everywhere.
+USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
+
+
+def _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+    return (USE_WINOGRAD and not bf16 and k == 3 and stride == 1 and pad == 1 and H % 2 == 0
+            and W_ % 2 == 0 and H >= 4 and W_ >= 4 and Cin % 32 == 0 and Cout % 32 == 0
+            and Cin * Cout >= 256 * 256)
+
 
 
 def wino_weights(w, flip_transpose=False):
@@ -110,18 +122,25 @@ def wino_weights(w, flip_transpose=False):
 
 
 def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE):
-    """fp32 3x3 / stride 1 / pad 1 conv by Winograd F(2x2,3x3)."""
+    """fp32 3x3 / stride 1 / pad 1 conv by Winograd F(2x2,3x3): input transform, 16 batched GEMMs
+    (one launch), output transform (+bias, activation)."""
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape
     Cout = w.shape[3]
-    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
-    nbytes = L.load().mmh_conv2d_fprop_wino_ws_bytes(C.byref(d))
-    if nbytes == 0:
-        raise RuntimeError("winograd path not applicable to this shape")
-    ws = _ws(nbytes, x)
+    tiles = B * (H // 2) * (W_ // 2)
+    U = wino_weights(w)
+    V = _empty((16, tiles, Cin), x)
+    M = _empty((16, tiles, Cout), x)
     y = _empty((B, H, W_, Cout), x)
-    L.call("mmh_conv2d_fprop_wino", C.byref(d), _ptr(x), _ptr(wino_weights(w)), _ptr(bias), _ptr(y), act,
-           _ptr(ws), ws.numel() * 4, _stream())
+    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), _ptr(V), _stream())
+    if fprop_timer is not None and fprop_timer.want_gemm(tiles, Cin, Cout):
+        e0, e1 = fprop_timer.bracket()      # HIP events around the GEMM launch only (bench.py roofline)
+        e0.record()
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, _stream())
+        e1.record()
+    else:
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, _stream())
+    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, _stream())
     return y
 
 
@@ -162,6 +181,8 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     B, H, W_, Cin = x.shape
     k, _, wc, Cout = w.shape
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
+    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+        return raw_conv_fprop_wino(x, w, bias, reflect, act)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
     if bf16:
@@ -181,6 +202,8 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False):
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     k, _, _, Cout = w.shape
+    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+        return raw_conv_dgrad_wino(dy, w, x_shape, reflect)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16 and Cout % 64 == 0:
         d.dtype = L.BF16
@@ -197,6 +220,8 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
+    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+        return raw_conv_wgrad_wino(x, dy, reflect)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16:
         d.dtype = L.BF16
