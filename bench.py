@@ -51,8 +51,8 @@ class KernelTimer:
     def want(self, d):
         return self.enabled and self.gemm is None and all(getattr(d, k) == v for k, v in self.match.items())
 
-    def want_gemm(self, tiles, K, N):
-        return self.enabled and self.gemm == (tiles, K, N)
+    def want_gemm(self, P, tiles, K, N):
+        return self.enabled and self.gemm == (P, tiles, K, N)
 
     def bracket(self):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -199,10 +199,12 @@ def main():
 
     # dominant kernel: the 3x3 reflect-pad 512->512 conv fprop at 64x64 (PATBlock streams 2/3)
     hs = H // 4
-    wino = ops.USE_WINOGRAD and a.dtype == "f32"
-    tiles = a.batch * (hs // 2) * (hs // 2)
+    wtile = ops._wino_tile(a.batch, hs, hs, 512, 512, 3, 1, 1, a.dtype == "bf16")
+    wino = wtile > 0
+    planes = (wtile + 2) ** 2
+    tiles = a.batch * (hs // max(wtile, 1)) ** 2
     timer = KernelTimer(dict(Cin=512, Cout=512, kh=3, stride=1, H=hs, W=hs),
-                        gemm=(tiles, 512, 512) if wino else None)
+                        gemm=(planes, tiles, 512, 512) if wino else None)
     ops.fprop_timer = timer
 
     def barrier():
@@ -229,10 +231,10 @@ def main():
     if rank == 0:
         imgs_per_s = world * a.batch * a.steps / dt
         k_ms, k_n = timer.mean_ms()
-        if wino:      # 16 x [tiles x 512] . [512 x 512]: the arithmetic this launch really does
-            k_flop = 16 * 2.0 * tiles * 512 * 512
-            k_name = ("conv_igemm_batched_kernel<256,2,2,false>: the 16 Winograd-domain GEMMs "
-                      f"[{tiles}x512].[512x512] of the 3x3 512->512 fprop @64x64")
+        if wino:      # P x [tiles x 512] . [512 x 512]: the arithmetic this launch really does
+            k_flop = planes * 2.0 * tiles * 512 * 512
+            k_name = (f"conv_igemm_batched_kernel<128,2,2,false>: the {planes} Winograd-domain GEMMs "
+                      f"[{tiles}x512].[512x512] (F({wtile}x{wtile},3x3)) of the 3x3 512->512 fprop @{hs}x{hs}")
         else:
             k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
             k_name = (("conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
@@ -250,7 +252,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"RHD-shaped {H}x{W}, per-GPU batch {a.batch}, "
                        f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}"
-                       f"{' (Winograd F(2x2,3x3) on the 3x3 stack)' if wino else ''}, G(9 PATBlocks,"
+                       f"{f' (Winograd F({wtile}x{wtile},3x3) on the 3x3 stack)' if wino else ''}, G(9 PATBlocks,"
                        f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}"},
             "step_mfma_frac": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world

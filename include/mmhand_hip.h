@@ -86,36 +86,36 @@ size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* w,
                             void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
 
-/* Winograd F(2x2,3x3) fprop for fp32 3x3 / stride 1 / pad 1 convs (even H, W; dense tensors):
- * 2.25x fewer multiplications than the direct implicit GEMM.  U = mmh_wino_weights(w):
- * [16][Cin][Cout] (flip_transpose=1 gives the dgrad filter [16][Cout][Cin]).  ws holds the
- * transformed input and product planes (mmh_conv2d_fprop_wino_ws_bytes).            */
-int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U,
-                     mmh_stream_t s);
-/* The three stages of mmh_conv2d_fprop_wino, individually launchable (V: [16][tiles][C],
- * tiles = B*(H/2)*(W/2); M = V[xi] . U[xi] as 16 batched GEMMs in one launch).              */
-int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, void* V,
-                   mmh_stream_t s);
+/* ---- Winograd for the fp32 3x3 / stride 1 / pad 1 convs (the PATBlock / ResnetBlock stack) ----
+ * y = A^T[(G g G^T) . (B^T d B)]A with tile = 2 (F(2x2,3x3): 16 planes, 2.25x fewer
+ * multiplications than the direct implicit GEMM) or tile = 4 (F(4x4,3x3): 36 planes, 4x fewer;
+ * fp32 error 2e-6 relative at K = 512).  tiles = B*(H/tile)*(W/tile); planes P = (tile+2)^2.
+ *   U  [P][K][N]     = mmh_wino_weights(w)  (flip_transpose=1: the dgrad filter [P][Cout][Cin])
+ *   V  [P][tiles][C] = mmh_wino_input(x)    (reflect or zero padding folded into the gather)
+ *   M  [P][tiles][N] = mmh_wino_gemm(V, U)  (P batched GEMMs, one launch)
+ *   y                = mmh_wino_output(M)   (+bias, activation)
+ * dgrad: the same three stages on dy with zero padding and the flipped filter give g on the
+ *        real domain; mmh_conv2d_dgrad_border adds the eight reflect-border terms.
+ * wgrad: Yh = mmh_wino_dy(dy) = A dY A^T; dU = mmh_wino_wgrad_gemm(V, Yh) (P split-K GEMMs over
+ *        the tiles, deterministic slab reduction); dw = mmh_wino_dw(dU) = G^T dU G.          */
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile,
+                     void* U, mmh_stream_t s);
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile,
+                   void* V, mmh_stream_t s);
+int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, void* Yh,
+                mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
-                  mmh_stream_t s);
+                  int nbatch, mmh_stream_t s);
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,
-                    int act, mmh_stream_t s);
-size_t mmh_conv2d_fprop_wino_ws_bytes(const mmh_conv_desc* d);
-int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U,
-                          const void* bias, void* y, int act, void* ws, size_t ws_bytes,
-                          mmh_stream_t s);
-
-/* Winograd dgrad (folded): Ut = mmh_wino_weights(w, flip_transpose=1); `w` (fp32, plain)
- * is still needed for the eight reflect-border terms.                                */
-size_t mmh_conv2d_dgrad_wino_ws_bytes(const mmh_conv_desc* d);
-int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut,
-                          const void* w, void* dx, void* ws, size_t ws_bytes,
-                          mmh_stream_t s);
-
-/* Winograd wgrad: dw = G^T [ sum_tiles (B^T d B) . (A dY A^T) ] G.                     */
-size_t mmh_conv2d_wgrad_wino_ws_bytes(const mmh_conv_desc* d);
-int mmh_conv2d_wgrad_wino(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
-                          void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
+                    int act, int tile, mmh_stream_t s);
+size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);
+int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout,
+                        int nbatch, void* ws, size_t ws_bytes, void* dU, mmh_stream_t s);
+int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate,
+                mmh_stream_t s);
+size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx,
+                            void* ws, size_t ws_bytes, mmh_stream_t s);
 
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the

@@ -1690,6 +1690,239 @@ __global__ void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// Winograd F(4x4, 3x3): 36 multiplications per 4x4 output tile (2.25 per output instead of 9):
+// 4x fewer MFMA flops than the direct kernel and a transformed tensor only 2.25x the input
+// (F(2x2,3x3): 4x).  Same pipeline: 36 batched GEMMs between the transforms.  Matrices are the
+// standard ones for interpolation points {0, +-1, +-2, inf}; fp32 error with K = 512 is 2e-6
+// relative (checked against fp64 direct convolution).  One thread per (tile, 2 channels).
+// ---------------------------------------------------------------------------
+struct F2 { float x, y; };
+__device__ __forceinline__ F2 operator+(F2 a, F2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ F2 operator-(F2 a, F2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ F2 operator*(float k, F2 a) { return {k * a.x, k * a.y}; }
+
+// out[0..5] = B^T in[0..5]
+__device__ __forceinline__ void w4_bt(const F2* in, F2* out) {
+    out[0] = 4.f * in[0] - 5.f * in[2] + in[4];
+    out[1] = in[3] + in[4] - 4.f * (in[1] + in[2]);
+    out[2] = 4.f * (in[1] - in[2]) - in[3] + in[4];
+    out[3] = 2.f * (in[3] - in[1]) - in[2] + in[4];
+    out[4] = 2.f * (in[1] - in[3]) - in[2] + in[4];
+    out[5] = 4.f * in[1] - 5.f * in[3] + in[5];
+}
+// out[0..3] = A^T in[0..5]
+__device__ __forceinline__ void w4_at(const F2* in, F2* out) {
+    const F2 a = in[1] + in[2], b = in[1] - in[2], c = in[3] + in[4], d = in[3] - in[4];
+    out[0] = in[0] + a + c;
+    out[1] = b + 2.f * d;
+    out[2] = a + 4.f * c;
+    out[3] = b + 8.f * d + in[5];
+}
+// out[0..5] = A in[0..3]
+__device__ __forceinline__ void w4_a(const F2* in, F2* out) {
+    out[0] = in[0];
+    out[1] = in[0] + in[1] + in[2] + in[3];
+    out[2] = in[0] - in[1] + in[2] - in[3];
+    out[3] = in[0] + 2.f * in[1] + 4.f * in[2] + 8.f * in[3];
+    out[4] = in[0] - 2.f * in[1] + 4.f * in[2] - 8.f * in[3];
+    out[5] = in[3];
+}
+// out[0..5] = G in[0..2]
+__device__ __forceinline__ void w4_g(const float* in, float* out) {
+    out[0] = 0.25f * in[0];
+    out[1] = (-1.f / 6.f) * (in[0] + in[1] + in[2]);
+    out[2] = (-1.f / 6.f) * (in[0] - in[1] + in[2]);
+    out[3] = (1.f / 24.f) * in[0] + (1.f / 12.f) * in[1] + (1.f / 6.f) * in[2];
+    out[4] = (1.f / 24.f) * in[0] - (1.f / 12.f) * in[1] + (1.f / 6.f) * in[2];
+    out[5] = in[2];
+}
+// out[0..2] = G^T in[0..5]
+__device__ __forceinline__ void w4_gt(const F2* in, F2* out) {
+    out[0] = 0.25f * in[0] - (1.f / 6.f) * (in[1] + in[2]) + (1.f / 24.f) * (in[3] + in[4]);
+    out[1] = (1.f / 6.f) * (in[2] - in[1]) + (1.f / 12.f) * (in[3] - in[4]);
+    out[2] = (1.f / 6.f) * (in[3] + in[4] - in[1] - in[2]) + in[5];
+}
+
+__global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                     int flip_transpose) {
+    const int total = Cin * Cout;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i / Cout, co = i - ci * Cout;
+    float g[3][3], t[6][3], col[3], o6[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ka = flip_transpose ? 2 - a : a, kb = flip_transpose ? 2 - b : b;
+            g[a][b] = w[((size_t)(ka * 3 + kb) * Cin + ci) * Cout + co];
+        }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        col[0] = g[0][b]; col[1] = g[1][b]; col[2] = g[2][b];
+        w4_g(col, o6);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) t[a][b] = o6[a];
+    }
+    const size_t plane = (size_t)Cin * Cout;
+    const size_t o = flip_transpose ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        w4_g(t[a], o6);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * plane + o] = o6[b];
+    }
+}
+
+__global__ void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
+                                   int C2, int reflect) {
+    const int TH = H / 4, TW = W / 4;
+    const long long tiles = (long long)B * TH * TW;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const F2* xin = reinterpret_cast<const F2*>(x);
+    F2 d[6][6], t[6][6], colv[6], o6[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        int hh = 4 * ty - 1 + r;
+        bool okh = true;
+        if (reflect) { hh = hh < 0 ? -hh : hh; hh = hh >= H ? 2 * (H - 1) - hh : hh; }
+        else okh = hh >= 0 && hh < H;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int ww = 4 * tx - 1 + q;
+            bool ok = okh;
+            if (reflect) { ww = ww < 0 ? -ww : ww; ww = ww >= W ? 2 * (W - 1) - ww : ww; }
+            else ok = ok && ww >= 0 && ww < W;
+            d[r][q] = ok ? xin[(((long long)b * H + hh) * W + ww) * C2 + c] : F2{0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) colv[r] = d[r][q];
+        w4_bt(colv, o6);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t[r][q] = o6[r];
+    }
+    const long long plane = tiles * C2;
+    F2* out = reinterpret_cast<F2*>(V) + tile * C2 + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        w4_bt(t[r], o6);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[(long long)(r * 6 + q) * plane] = o6[q];
+    }
+}
+
+__global__ void wino4_output_kernel(const float* __restrict__ M, float* __restrict__ y,
+                                    const float* __restrict__ bias, int B, int H, int W, int C2, int act) {
+    const int TH = H / 4, TW = W / 4;
+    const long long tiles = (long long)B * TH * TW;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const long long plane = tiles * C2;
+    const F2* in = reinterpret_cast<const F2*>(M) + tile * C2 + c;
+    F2 m[6][6], s4[4][6], colv[6], o4[4];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) m[r][q] = in[(long long)(r * 6 + q) * plane];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) colv[r] = m[r][q];
+        w4_at(colv, o4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s4[r][q] = o4[r];
+    }
+    const F2 bv = bias ? reinterpret_cast<const F2*>(bias)[c] : F2{0.f, 0.f};
+    F2* yo = reinterpret_cast<F2*>(y);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        w4_at(s4[r], o4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            F2 v = o4[q] + bv;
+            v.x = apply_act(v.x, act); v.y = apply_act(v.y, act);
+            yo[(((long long)b * H + 4 * ty + r) * W + 4 * tx + q) * C2 + c] = v;
+        }
+    }
+}
+
+// Yhat[36][tile][C] = A dY A^T for the 4x4 output-gradient tile
+__global__ void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Yh, int B, int H, int W,
+                                int C2) {
+    const int TH = H / 4, TW = W / 4;
+    const long long tiles = (long long)B * TH * TW;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const F2* in = reinterpret_cast<const F2*>(dy);
+    F2 yv[4][4], t[6][4], colv[4], o6[6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yv[r][q] = in[(((long long)b * H + 4 * ty + r) * W + 4 * tx + q) * C2 + c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colv[r] = yv[r][q];
+        w4_a(colv, o6);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t[r][q] = o6[r];
+    }
+    const long long plane = tiles * C2;
+    F2* out = reinterpret_cast<F2*>(Yh) + tile * C2 + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        w4_a(t[r], o6);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[(long long)(r * 6 + q) * plane] = o6[q];
+    }
+}
+
+// dw[3][3][Cin][Cout] (+)= G^T dU G, dU: [36][Cin][Cout]
+__global__ void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int64_t plane2,
+                                int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane2) return;
+    const F2* in = reinterpret_cast<const F2*>(dU) + i;
+    F2 u[6][6], t[3][6], colv[6], o3[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) u[a][b] = in[(int64_t)(a * 6 + b) * plane2];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) colv[a] = u[a][b];
+        w4_gt(colv, o3);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a][b] = o3[a];
+    }
+    F2* out = reinterpret_cast<F2*>(dw) + i;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        w4_gt(t[a], o3);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            F2 v = o3[b];
+            if (accumulate) v = v + out[(int64_t)(a * 3 + b) * plane2];
+            out[(int64_t)(a * 3 + b) * plane2] = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ Winograd host side
 template <int BN, int WM, int WN, bool NMAJOR>
 int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
@@ -1702,8 +1935,11 @@ int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
     return mmh::check_launch("conv_igemm_batched_kernel");
 }
 
+int g_wino_bn256 = 0;   // 128-wide tiles: 3-5 % faster than 256 for these short-K GEMMs (more workgroups per CU)
+
 // 16 x ( [tiles x K] . [K x N] ): V [16][tiles][K], U [16][K][N] -> M [16][tiles][N]
-int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st) {
+int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st,
+              int nbatch = 16) {
     MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
     BatchKP bp{};
     ConvKP& p = bp.p;
@@ -1727,20 +1963,14 @@ int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K,
     p.act = MMH_ACT_NONE;
     bp.src_bs = tiles * K; bp.w_bs = (long long)K * N; bp.out_bs = tiles * N;
     {
-        const int bn = (N % 256 == 0) ? 256 : 128;
+        const int bn = (N % 256 == 0 && g_wino_bn256) ? 256 : 128;
         const int gx = (N + bn - 1) / bn, gy = (p.M + BM - 1) / BM;
         p.xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
     }
-    if (N % 256 == 0) return launch_batched_t<256, 2, 2, false>(bp, 16, st);
-    if (N > 64) return launch_batched_t<128, 2, 2, false>(bp, 16, st);
-    if (N > 32) return launch_batched_t<64, 2, 2, false>(bp, 16, st);
-    return launch_batched_t<32, 4, 1, false>(bp, 16, st);
-}
-
-bool wino_ok(const mmh_conv_desc* d) {
-    return d->dtype == MMH_F32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
-           d->H % 2 == 0 && d->W % 2 == 0 && d->H >= 4 && d->W >= 4 && d->x_cs == d->Cin &&
-           d->y_cs == d->Cout && d->Cin % 32 == 0;
+    if (N % 256 == 0 && g_wino_bn256) return launch_batched_t<256, 2, 2, false>(bp, nbatch, st);
+    if (N > 64) return launch_batched_t<128, 2, 2, false>(bp, nbatch, st);
+    if (N > 32) return launch_batched_t<64, 2, 2, false>(bp, nbatch, st);
+    return launch_batched_t<32, 4, 1, false>(bp, nbatch, st);
 }
 
 // Split-K factor: fill whole rounds of the 512 resident workgroups (256 CUs x 2 per CU, LDS
@@ -1855,6 +2085,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
     if (!strcmp(key, "conv_cw")) { g_conv_cw = value; return 0; }
     if (!strcmp(key, "conv_bn256")) { g_conv_bn256 = value; return 0; }
+    if (!strcmp(key, "wino_bn256")) { g_wino_bn256 = value; return 0; }
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
@@ -1877,186 +2108,160 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
     return do_dgrad(d, dy, w, nullptr, dx, dx_cs, MMH_ACT_NONE, mmh::as_stream(s));
 }
 
-int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, void* V, mmh_stream_t s) {
-    MMH_REQUIRE(x && V && B > 0 && H >= 4 && W >= 4 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0,
-                "mmh_wino_input: bad arguments");
-    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
-                       static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 4, reflect);
-    return mmh::check_launch("wino_input_kernel");
-}
+// ---- Winograd stages (tile = 2: F(2x2,3x3), 16 planes; tile = 4: F(4x4,3x3), 36 planes) ----
+static int wino_planes(int tile) { return tile == 4 ? 36 : 16; }
 
-int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, mmh_stream_t s) {
-    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0, "mmh_wino_gemm: bad arguments");
-    return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
-                     K, N, mmh::as_stream(s));
-}
-
-int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act,
-                    mmh_stream_t s) {
-    MMH_REQUIRE(M && y && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "mmh_wino_output: bad arguments");
-    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
-                       static_cast<const float*>(M), static_cast<float*>(y), static_cast<const float*>(bias), B,
-                       H, W, C / 4, act);
-    return mmh::check_launch("wino_output_kernel");
-}
-
-int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, void* U, mmh_stream_t s) {
-    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0, "mmh_wino_weights: bad arguments");
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
-                       static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, void* U, mmh_stream_t s) {
+    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0 && (tile == 2 || tile == 4), "mmh_wino_weights: bad arguments");
+    if (tile == 4)
+        hipLaunchKernelGGL(wino4_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+    else
+        hipLaunchKernelGGL(wino_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
     return mmh::check_launch("wino_weights_kernel");
 }
 
-size_t mmh_conv2d_fprop_wino_ws_bytes(const mmh_conv_desc* d) {
-    if (!d || !wino_ok(d)) return 0;
-    const size_t tiles = (size_t)d->B * (d->H / 2) * (d->W / 2);
-    return 16 * tiles * (size_t)(d->Cin + d->Cout) * sizeof(float);
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, void* V, mmh_stream_t s) {
+    MMH_REQUIRE(x && V && B > 0 && (tile == 2 || tile == 4) && H >= tile + 2 && W >= tile + 2 &&
+                    H % tile == 0 && W % tile == 0 && C % 4 == 0, "mmh_wino_input: bad arguments");
+    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    if (tile == 4) {
+        const long long total = tiles * (C / 2);
+        hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 2, reflect);
+    } else {
+        const long long total = tiles * (C / 4);
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 4, reflect);
+    }
+    return mmh::check_launch("wino_input_kernel");
 }
 
-int mmh_conv2d_fprop_wino(const mmh_conv_desc* d, const void* x, const void* U, const void* bias, void* y,
-                          int act, void* ws, size_t ws_bytes, mmh_stream_t s) {
-    if (int rc = validate(d)) return rc;
-    MMH_REQUIRE(wino_ok(d), "mmh_conv2d_fprop_wino: needs fp32 3x3 stride 1 pad 1, even H,W, Cin %% 32 == 0");
-    MMH_REQUIRE(x && U && y && ws && ws_bytes >= mmh_conv2d_fprop_wino_ws_bytes(d),
-                "mmh_conv2d_fprop_wino: NULL buffer or workspace too small");
-    hipStream_t st = mmh::as_stream(s);
-    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
-    float* V = static_cast<float*>(ws);
-    float* Mo = V + 16 * tiles * d->Cin;
-    {
-        const long long total = tiles * (d->Cin / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float*>(x), V, d->B, d->H, d->W, d->Cin / 4,
-                           d->pad_mode == MMH_PAD_REFLECT ? 1 : 0);
-        if (int rc = mmh::check_launch("wino_input_kernel")) return rc;
+int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, void* Yh, mmh_stream_t s) {
+    MMH_REQUIRE(dy && Yh && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0,
+                "mmh_wino_dy: bad arguments");
+    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    if (tile == 4) {
+        const long long total = tiles * (C / 2);
+        hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(dy), static_cast<float*>(Yh), B, H, W, C / 2);
+    } else {
+        const long long total = tiles * (C / 4);
+        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(dy), static_cast<float*>(Yh), B, H, W, C / 4);
     }
-    if (int rc = wino_gemm(V, static_cast<const float*>(U), Mo, tiles, d->Cin, d->Cout, st)) return rc;
-    {
-        const long long total = tiles * (d->Cout / 4);
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Mo,
-                           static_cast<float*>(y), static_cast<const float*>(bias), d->B, d->H, d->W,
-                           d->Cout / 4, act);
-        return mmh::check_launch("wino_output_kernel");
-    }
+    return mmh::check_launch("wino_dy_kernel");
 }
 
-// Winograd dgrad: the zero-padded correlation of dy with the flipped filter (U' from
-// mmh_wino_weights(flip_transpose=1)) gives g on the real domain; reflect padding then adds the
-// eight border terms exactly as the direct path does.
-size_t mmh_conv2d_dgrad_wino_ws_bytes(const mmh_conv_desc* d) {
-    if (!d || !wino_ok(d)) return 0;
-    const size_t tiles = (size_t)d->B * (d->H / 2) * (d->W / 2);
-    size_t b = 16 * tiles * (size_t)(d->Cin + d->Cout) * sizeof(float);
-    if (d->pad_mode == MMH_PAD_REFLECT) b += reflect1_ws_bytes(d);
-    return b;
+int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, int nbatch,
+                  mmh_stream_t s) {
+    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0 && nbatch > 0, "mmh_wino_gemm: bad arguments");
+    return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
+                     K, N, mmh::as_stream(s), nbatch);
 }
 
-int mmh_conv2d_dgrad_wino(const mmh_conv_desc* d, const void* dy, const void* Ut, const void* w, void* dx,
-                          void* ws, size_t ws_bytes, mmh_stream_t s) {
-    if (int rc = validate(d)) return rc;
-    MMH_REQUIRE(wino_ok(d), "mmh_conv2d_dgrad_wino: needs fp32 3x3 stride 1 pad 1, even H,W, dense tensors");
-    MMH_REQUIRE(dy && Ut && w && dx && ws && ws_bytes >= mmh_conv2d_dgrad_wino_ws_bytes(d),
-                "mmh_conv2d_dgrad_wino: NULL buffer or workspace too small");
-    MMH_REQUIRE(d->Cout % 32 == 0, "mmh_conv2d_dgrad_wino: Cout %% 32 != 0");
-    hipStream_t st = mmh::as_stream(s);
-    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
-    float* V = static_cast<float*>(ws);
-    float* Mo = V + 16 * tiles * d->Cout;
-    float* border = Mo + 16 * tiles * d->Cin;
-    {
-        const long long total = tiles * (d->Cout / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float*>(dy), V, d->B, d->H, d->W, d->Cout / 4, 0);
-        if (int rc = mmh::check_launch("wino_input_kernel")) return rc;
+int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,
+                    mmh_stream_t s) {
+    MMH_REQUIRE(M && y && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0,
+                "mmh_wino_output: bad arguments");
+    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    if (tile == 4) {
+        const long long total = tiles * (C / 2);
+        hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           mmh::as_stream(s), static_cast<const float*>(M), static_cast<float*>(y),
+                           static_cast<const float*>(bias), B, H, W, C / 2, act);
+    } else {
+        const long long total = tiles * (C / 4);
+        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           mmh::as_stream(s), static_cast<const float*>(M), static_cast<float*>(y),
+                           static_cast<const float*>(bias), B, H, W, C / 4, act);
     }
-    if (int rc = wino_gemm(V, static_cast<const float*>(Ut), Mo, tiles, d->Cout, d->Cin, st)) return rc;
-    {
-        const long long total = tiles * (d->Cin / 4);
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Mo,
-                           static_cast<float*>(dx), static_cast<const float*>(nullptr), d->B, d->H, d->W,
-                           d->Cin / 4, MMH_ACT_NONE);
-        if (int rc = mmh::check_launch("wino_output_kernel")) return rc;
-    }
-    if (d->pad_mode == MMH_PAD_REFLECT) return do_dgrad_reflect1(d, dy, w, dx, border, st, false);
-    return 0;
+    return mmh::check_launch("wino_output_kernel");
 }
 
-// Winograd wgrad: dU[xi] = V[xi]^T . Yhat[xi] (16 batched split-K GEMMs over the tiles), then
-// dw = G^T dU G.
-static int wino_wgrad_splits(const mmh_conv_desc* d, long long tiles) {
-    const int bn = (g_wgrad_bn256 && d->Cout % 256 == 0) ? 256 : 128;
-    const int per = ((d->Cin + BM - 1) / BM) * ((d->Cout + bn - 1) / bn) * 16;
-    int s = std::max(1, g_wgrad_slots / per);
+// dU[xi][Cin][Cout] = sum over tiles V[xi][tile][Cin] * Yh[xi][tile][Cout]: nbatch split-K GEMMs in one
+// launch, fixed-order slab reduction (deterministic).
+static int wino_wgrad_splits(int Cin, int Cout, long long tiles, int nbatch) {
+    const int bn = (g_wgrad_bn256 && Cout % 256 == 0) ? 256 : 128;
+    const int per = ((Cin + BM - 1) / BM) * ((Cout + bn - 1) / bn) * nbatch;
+    const int s = std::max(1, g_wgrad_slots / per);
     const long long maxs = std::max<long long>(1, tiles / (8 * BK));
     return (int)std::min<long long>(s, maxs);
 }
 
-size_t mmh_conv2d_wgrad_wino_ws_bytes(const mmh_conv_desc* d) {
-    if (!d || !wino_ok(d)) return 0;
-    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
-    const int splits = wino_wgrad_splits(d, tiles);
-    return (size_t)(16 * tiles * (d->Cin + d->Cout) + (size_t)16 * (splits + 1) * d->Cin * d->Cout) * sizeof(float);
+size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch) {
+    if (tiles <= 0 || Cin <= 0 || Cout <= 0 || nbatch <= 0) return 0;
+    return (size_t)nbatch * wino_wgrad_splits(Cin, Cout, tiles, nbatch) * Cin * Cout * sizeof(float);
 }
 
-int mmh_conv2d_wgrad_wino(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
-                          size_t ws_bytes, int accumulate, mmh_stream_t s) {
-    if (int rc = validate(d)) return rc;
-    MMH_REQUIRE(wino_ok(d) && d->Cout % 32 == 0, "mmh_conv2d_wgrad_wino: needs fp32 3x3 stride 1 pad 1, even H,W");
-    MMH_REQUIRE(x && dy && dw && ws && ws_bytes >= mmh_conv2d_wgrad_wino_ws_bytes(d),
-                "mmh_conv2d_wgrad_wino: NULL buffer or workspace too small");
+int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout, int nbatch, void* ws,
+                        size_t ws_bytes, void* dU, mmh_stream_t s) {
+    MMH_REQUIRE(V && Yh && ws && dU && tiles > 0 && Cin % 4 == 0 && Cout % 4 == 0,
+                "mmh_wino_wgrad_gemm: bad arguments");
+    MMH_REQUIRE(ws_bytes >= mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, nbatch),
+                "mmh_wino_wgrad_gemm: workspace too small");
+    MMH_REQUIRE(tiles * (long long)std::max(Cin, Cout) < (1ll << 30), "mmh_wino_wgrad_gemm: tensor too large");
     hipStream_t st = mmh::as_stream(s);
-    const long long tiles = (long long)d->B * (d->H / 2) * (d->W / 2);
-    const int splits = wino_wgrad_splits(d, tiles);
-    float* V = static_cast<float*>(ws);
-    float* Yh = V + 16 * tiles * d->Cin;
-    float* slab = Yh + 16 * tiles * d->Cout;
-    float* dU = slab + (size_t)16 * splits * d->Cin * d->Cout;
-    {
-        const long long total = tiles * (d->Cin / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float*>(x), V, d->B, d->H, d->W, d->Cin / 4,
-                           d->pad_mode == MMH_PAD_REFLECT ? 1 : 0);
-        const long long total2 = tiles * (d->Cout / 4);
-        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, st,
-                           static_cast<const float*>(dy), Yh, d->B, d->H, d->W, d->Cout / 4);
-        if (int rc = mmh::check_launch("wino transforms")) return rc;
-    }
+    const int splits = wino_wgrad_splits(Cin, Cout, tiles, nbatch);
     WgradKP p{};
     Gather& g = p.g;
-    g.src = V;
-    g.src_bytes = (unsigned)((size_t)tiles * d->Cin * sizeof(float));
-    g.srcH = 1; g.srcW = (int)tiles; g.src_cs = (unsigned)d->Cin;
+    g.src = static_cast<const float*>(V);
+    g.src_bytes = (unsigned)((size_t)tiles * Cin * sizeof(float));
+    g.srcH = 1; g.srcW = (int)tiles; g.src_cs = (unsigned)Cin;
     g.PH = 1; g.PW = (int)tiles; g.TH = 1; g.TW = 1;
-    g.C4 = d->Cin / 4;
+    g.C4 = Cin / 4;
     g.ap_h = 0; g.at_h = 0; g.a0_h = 0; g.ap_w = 1; g.at_w = 0; g.a0_w = 0;
     g.shift = 0; g.reflect = 0; g.chunk_major = 0; g.cw = 1;
-    p.dy = Yh;
-    p.dy_bytes = (unsigned)((size_t)tiles * d->Cout * sizeof(float));
-    p.dy_cs = (unsigned)d->Cout;
-    p.slab = slab;
-    p.Mrows = d->Cin; p.N = d->Cout; p.P = (int)tiles;
+    p.dy = static_cast<const float*>(Yh);
+    p.dy_bytes = (unsigned)((size_t)tiles * Cout * sizeof(float));
+    p.dy_cs = (unsigned)Cout;
+    p.slab = static_cast<float*>(ws);
+    p.Mrows = Cin; p.N = Cout; p.P = (int)tiles;
     p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(tiles, splits), BK) * BK);
     p.nsplit = splits;
-    p.src_bs = tiles * d->Cin; p.dy_bs = tiles * d->Cout;
-    {
-        const bool b256 = g_wgrad_bn256 && p.N % 256 == 0;
-        const int BNsel = b256 ? 256 : (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32));
-        dim3 grid((p.N + BNsel - 1) / BNsel, (p.Mrows + BM - 1) / BM, 16 * splits);
-        int rc;
-        if (b256) rc = launch_wgrad_grid_t<256, 2, 2>(p, grid, st);
-        else if (p.N > 64) rc = launch_wgrad_grid_t<128, 2, 2>(p, grid, st);
-        else if (p.N > 32) rc = launch_wgrad_grid_t<64, 2, 2>(p, grid, st);
-        else rc = launch_wgrad_grid_t<32, 4, 1>(p, grid, st);
-        if (rc) return rc;
+    p.src_bs = tiles * Cin; p.dy_bs = tiles * Cout;
+    const bool b256 = g_wgrad_bn256 && p.N % 256 == 0;
+    const int BNsel = b256 ? 256 : (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32));
+    dim3 grid((p.N + BNsel - 1) / BNsel, (p.Mrows + BM - 1) / BM, nbatch * splits);
+    int rc;
+    if (b256) rc = launch_wgrad_grid_t<256, 2, 2>(p, grid, st);
+    else if (p.N > 64) rc = launch_wgrad_grid_t<128, 2, 2>(p, grid, st);
+    else if (p.N > 32) rc = launch_wgrad_grid_t<64, 2, 2>(p, grid, st);
+    else rc = launch_wgrad_grid_t<32, 4, 1>(p, grid, st);
+    if (rc) return rc;
+    const int64_t n4 = (int64_t)Cin * Cout / 4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
+                       dim3(256), 0, st, p.slab, static_cast<float*>(dU), nbatch * n4, splits, 0, n4);
+    return mmh::check_launch("wino wgrad gemm");
+}
+
+int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate, mmh_stream_t s) {
+    MMH_REQUIRE(dU && dw && Cin % 4 == 0 && Cout % 4 == 0 && (tile == 2 || tile == 4), "mmh_wino_dw: bad arguments");
+    if (tile == 4) {
+        const int64_t n2 = (int64_t)Cin * Cout / 2;
+        hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)mmh::cdiv(n2, 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(dU), static_cast<float*>(dw), n2, accumulate);
+    } else {
+        const int64_t n4 = (int64_t)Cin * Cout / 4;
+        hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)mmh::cdiv(n4, 256)), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(dU), static_cast<float*>(dw), n4, accumulate);
     }
-    const int64_t n4 = (int64_t)d->Cin * d->Cout / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(16 * n4, 256), 4096)), dim3(256),
-                       0, st, slab, dU, 16 * n4, splits, 0, n4);
-    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)mmh::cdiv(n4, 256)), dim3(256), 0, st, dU,
-                       static_cast<float*>(dw), n4, accumulate);
-    return mmh::check_launch("wino wgrad");
+    return mmh::check_launch("wino_dw_kernel");
+}
+
+// The eight reflect-border terms of a 3x3 / pad 1 dgrad, added into dx (whose main term came
+// from the Winograd path).  ws: mmh_conv2d_dgrad_border_ws_bytes.
+size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d) { return d ? reflect1_ws_bytes(d) : 0; }
+
+int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
+                            size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == MMH_PAD_REFLECT &&
+                    d->H >= 3 && d->W >= 3 && d->x_cs == d->Cin,
+                "mmh_conv2d_dgrad_border: needs a dense 3x3 stride-1 reflect-pad-1 conv");
+    MMH_REQUIRE(dy && w && dx && ws && ws_bytes >= reflect1_ws_bytes(d), "mmh_conv2d_dgrad_border: bad buffers");
+    return do_dgrad_reflect1(d, dy, w, dx, ws, mmh::as_stream(s), false);
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

@@ -94,85 +94,103 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
 
 
 _wino_cache = {}
-# Winograd F(2x2,3x3) for the fp32 3x3 / stride-1 / pad-1 convs with >= 256x256 channel pairs
-# (1.25-1.6x over the direct implicit GEMM on MI355X; slower below that).  MMH_WINOGRAD=0 or
-# ops.USE_WINOGRAD = False selects the direct kernels everywhere.
+# Winograd for the fp32 3x3 / stride-1 / pad-1 convs with >= 256x256 channel pairs: F(4x4,3x3)
+# when H and W are multiples of 4 (4x fewer multiplications than the direct implicit GEMM), else
+# F(2x2,3x3) (2.25x fewer).  Slower than the direct kernel below that size (transform-bound).
+# MMH_WINOGRAD=0 or ops.USE_WINOGRAD = False selects the direct kernels everywhere;
+# ops.WINOGRAD_TILE = 2 forces F(2x2,3x3).
 USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
+WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "4"))
 
 
-def _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
-    return (USE_WINOGRAD and not bf16 and k == 3 and stride == 1 and pad == 1 and H % 2 == 0
-            and W_ % 2 == 0 and H >= 4 and W_ >= 4 and Cin % 32 == 0 and Cout % 32 == 0
-            and Cin * Cout >= 256 * 256)
+def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+    """0 = direct kernel, else the Winograd output-tile size (2 or 4)."""
+    if not (USE_WINOGRAD and not bf16 and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0
+            and Cout % 32 == 0):
+        return 0
+    # measured on MI355X at B=32: F(4,3) wins from 64x64 channels up (1.1-2.8x), F(2,3) only from
+    # 256x256 up (1.25-1.6x; transform-bound below)
+    if WINOGRAD_TILE == 4 and H % 4 == 0 and W_ % 4 == 0 and H >= 8 and W_ >= 8 and Cin * Cout >= 64 * 64:
+        return 4
+    if H % 2 == 0 and W_ % 2 == 0 and H >= 4 and W_ >= 4 and Cin * Cout >= 256 * 256:
+        return 2
+    return 0
 
 
-
-def wino_weights(w, flip_transpose=False):
-    """Winograd-domain filter U [16,K,N] of a physical 3x3 weight (cached per weights epoch)."""
-    key = (w.data_ptr(), bool(flip_transpose))
+def wino_weights(w, tile, flip_transpose=False):
+    """Winograd-domain filter U [P,K,N] of a physical 3x3 weight (cached per weights epoch)."""
+    key = (w.data_ptr(), tile, bool(flip_transpose))
     ent = _wino_cache.get(key)
     if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
         _, _, cin, cout = w.shape
-        U = torch.empty((16, cout, cin) if flip_transpose else (16, cin, cout), dtype=torch.float32,
+        P = (tile + 2) ** 2
+        U = torch.empty((P, cout, cin) if flip_transpose else (P, cin, cout), dtype=torch.float32,
                         device=w.device)
-        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), _ptr(U), _stream())
+        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, _ptr(U), _stream())
         ent = (_weights_epoch[0], tuple(w.shape), U)
         _wino_cache[key] = ent
     return ent[2]
 
 
-def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE):
-    """fp32 3x3 / stride 1 / pad 1 conv by Winograd F(2x2,3x3): input transform, 16 batched GEMMs
-    (one launch), output transform (+bias, activation)."""
-    _chk(x, "x"); _chk(w, "w")
+def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False):
+    """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation)."""
     B, H, W_, Cin = x.shape
-    Cout = w.shape[3]
-    tiles = B * (H // 2) * (W_ // 2)
-    U = wino_weights(w)
-    V = _empty((16, tiles, Cin), x)
-    M = _empty((16, tiles, Cout), x)
+    P = (tile + 2) ** 2
+    tiles = B * (H // tile) * (W_ // tile)
+    V = _empty((P, tiles, Cin), x)
+    M = _empty((P, tiles, Cout), x)
     y = _empty((B, H, W_, Cout), x)
-    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), _ptr(V), _stream())
-    if fprop_timer is not None and fprop_timer.want_gemm(tiles, Cin, Cout):
+    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+    if time_it and fprop_timer is not None and fprop_timer.want_gemm(P, tiles, Cin, Cout):
         e0, e1 = fprop_timer.bracket()      # HIP events around the GEMM launch only (bench.py roofline)
         e0.record()
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, _stream())
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, _stream())
         e1.record()
     else:
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, _stream())
-    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, _stream())
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, _stream())
+    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, _stream())
     return y
 
 
-def raw_conv_dgrad_wino(dy, w, x_shape, reflect):
-    """fp32 3x3 / stride 1 / pad 1 dgrad (folded) by Winograd F(2x2,3x3)."""
+def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4):
+    """fp32 3x3 / stride 1 / pad 1 conv by Winograd."""
+    _chk(x, "x"); _chk(w, "w")
+    return _wino_conv(x, wino_weights(w, tile), bias, w.shape[3], reflect, act, tile, time_it=True)
+
+
+def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
+    """fp32 3x3 / stride 1 / pad 1 dgrad (folded) by Winograd: the zero-padded correlation of dy
+    with the flipped filter gives g on the real domain; reflect padding adds the eight border
+    terms exactly as the direct path does."""
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
-    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
-    nbytes = L.load().mmh_conv2d_dgrad_wino_ws_bytes(C.byref(d))
-    if nbytes == 0:
-        raise RuntimeError("winograd path not applicable to this shape")
-    ws = _ws(nbytes, dy)
-    dx = _empty((B, H, W_, Cin), dy)
-    L.call("mmh_conv2d_dgrad_wino", C.byref(d), _ptr(dy), _ptr(wino_weights(w, True)), _ptr(w), _ptr(dx),
-           _ptr(ws), ws.numel() * 4, _stream())
+    dx = _wino_conv(dy, wino_weights(w, tile, True), None, Cin, False, L.ACT_NONE, tile)
+    if reflect:
+        d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
+        ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
+        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4,
+               _stream())
     return dx
 
 
-def raw_conv_wgrad_wino(x, dy, reflect):
-    """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd F(2x2,3x3)."""
+def raw_conv_wgrad_wino(x, dy, reflect, tile=4):
+    """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd: dw = G^T [sum_tiles (B^T d B).(A dY A^T)] G."""
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
-    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
-    nbytes = L.load().mmh_conv2d_wgrad_wino_ws_bytes(C.byref(d))
-    if nbytes == 0:
-        raise RuntimeError("winograd path not applicable to this shape")
-    ws = _ws(nbytes, x)
-    dw = _empty((3, 3, Cin, Cout), x)
-    L.call("mmh_conv2d_wgrad_wino", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+    P = (tile + 2) ** 2
+    tiles = B * (H // tile) * (W_ // tile)
+    V = _empty((P, tiles, Cin), x)
+    Yh = _empty((P, tiles, Cout), x)
+    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+    L.call("mmh_wino_dy", _ptr(dy), B, H, W_, Cout, tile, _ptr(Yh), _stream())
+    ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), x)
+    dU = _empty((P, Cin, Cout), x)
+    L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
+    dw = _empty((3, 3, Cin, Cout), x)
+    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
     return dw
 
 
@@ -181,8 +199,9 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     B, H, W_, Cin = x.shape
     k, _, wc, Cout = w.shape
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
-    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
-        return raw_conv_fprop_wino(x, w, bias, reflect, act)
+    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
+    if wt:
+        return raw_conv_fprop_wino(x, w, bias, reflect, act, wt)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
     if bf16:
@@ -202,8 +221,9 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False):
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     k, _, _, Cout = w.shape
-    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
-        return raw_conv_dgrad_wino(dy, w, x_shape, reflect)
+    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
+    if wt:
+        return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16 and Cout % 64 == 0:
         d.dtype = L.BF16
@@ -220,8 +240,9 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
-    if _wino_applies(B, H, W_, Cin, Cout, k, stride, pad, bf16):
-        return raw_conv_wgrad_wino(x, dy, reflect)
+    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
+    if wt:
+        return raw_conv_wgrad_wino(x, dy, reflect, wt)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16:
         d.dtype = L.BF16

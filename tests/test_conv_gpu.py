@@ -173,24 +173,27 @@ def test_reflect1_dgrad_border_terms(hw, dev):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, True), (1, 12, 20, 256, 256, True), (2, 8, 8, 64, 128, False),
-                                  (3, 4, 6, 32, 64, True), (1, 16, 16, 512, 256, True)])
+                                  (3, 4, 8, 32, 64, True), (1, 16, 16, 512, 256, True), (2, 8, 12, 96, 32, False)])
+@pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("act", [0, 1])
-def test_winograd_fprop(case, act, dev):
-    """Winograd F(2x2,3x3) fprop == direct convolution (fp64 oracle) within fp32 rounding."""
+def test_winograd_all_passes(case, tile, act, dev):
+    """Winograd F(2x2,3x3) / F(4x4,3x3) fprop, dgrad (reflect border terms included) and wgrad ==
+    direct convolution (fp64 oracle) within fp32 rounding."""
     from mmhand_amd import ops
     B, H, W, Cin, Cout, refl = case
+    if tile == 4 and (H % 4 or W % 4 or H < 8 or W < 8):
+        pytest.skip("F(4x4,3x3) needs H, W multiples of 4")
     x = _mk((B, H, W, Cin), 1, dev)
     w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
     bias = _mk((Cout,), 3, dev)
     ops.bump_weights_epoch()
-    y = ops.raw_conv_fprop_wino(x, w, bias, refl, act)
+    y = ops.raw_conv_fprop_wino(x, w, bias, refl, act, tile)
     yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 1, refl, act)
-    assert R.rel_l1(y, yr) < 2e-5, R.rel_l1(y, yr)
+    assert R.rel_l1(y, yr) < 2e-5, ("winograd fprop", tile, R.rel_l1(y, yr))
     if act == 0:
         dy = _mk(tuple(y.shape), 4, dev)
-        dx = ops.raw_conv_dgrad_wino(dy, w, x.shape, refl)
-        _, dxr, _, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
-        assert R.rel_l1(dx, dxr) < 2e-5, ("winograd dgrad", R.rel_l1(dx, dxr))
-        dw = ops.raw_conv_wgrad_wino(x, dy, refl)
-        _, _, dwr, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
-        assert R.rel_l1(dw, dwr) < 2e-5, ("winograd wgrad", R.rel_l1(dw, dwr))
+        dx = ops.raw_conv_dgrad_wino(dy, w, x.shape, refl, tile)
+        dw = ops.raw_conv_wgrad_wino(x, dy, refl, tile)
+        _, dxr, dwr, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
+        assert R.rel_l1(dx, dxr) < 2e-5, ("winograd dgrad", tile, R.rel_l1(dx, dxr))
+        assert R.rel_l1(dw, dwr) < 2e-5, ("winograd wgrad", tile, R.rel_l1(dw, dwr))

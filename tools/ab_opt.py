@@ -16,7 +16,8 @@ for (H, Cin, Cout, k, s, p, refl) in [(64, 512, 512, 3, 1, 1, True), (64, 256, 2
     y = ops.raw_conv_fprop(x, w, None, s, p, refl, 0); dy = torch.randn_like(y)
     flop = 2.0 * y.numel() * Cin * k * k
     for name, fn in (("fprop", lambda: ops.raw_conv_fprop(x, w, None, s, p, refl, 0)),
-                     ("dgrad", lambda: ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl))):
+                     ("dgrad", lambda: ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl)),
+                     ("wgrad", lambda: ops.raw_conv_wgrad(x, dy, k, s, p, refl))):
         res = {v: [] for v in vals}
         for v in vals:
             lib.check(L.mmh_set_option(key.encode(), v), "set"); fn()

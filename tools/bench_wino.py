@@ -12,17 +12,19 @@ def timeit(fn, iters=3):
 for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256), (256, 64, 64)]:
     x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
     fl = 2.0 * B * H * H * Cin * Cout * 9
+    ops.USE_WINOGRAD = False
     fd = lambda: ops.raw_conv_fprop(x, w, None, 1, 1, True, 0)
-    fw = lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0)
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    fw = lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0, T)
     y = fd(); dy = torch.randn_like(y)
     gd = lambda: ops.raw_conv_dgrad(dy, w, x.shape, 1, 1, True)
-    gw = lambda: ops.raw_conv_dgrad_wino(dy, w, x.shape, True)
+    gw = lambda: ops.raw_conv_dgrad_wino(dy, w, x.shape, True, T)
     fd(); fw(); gd(); gw(); torch.cuda.synchronize()
     r1, r2 = [], []
     for _ in range(5):
         r1.append(timeit(gd)); r2.append(timeit(gw))
     hd = lambda: ops.raw_conv_wgrad(x, dy, 3, 1, 1, True)
-    hw = lambda: ops.raw_conv_wgrad_wino(x, dy, True)
+    hw = lambda: ops.raw_conv_wgrad_wino(x, dy, True, T)
     hd(); hw(); torch.cuda.synchronize()
     r3, r4 = [], []
     for _ in range(5):
