@@ -141,8 +141,12 @@ def infer_main(a):
         "config": {"workload": f"STB-shaped {a.size}x{a.size}, batch {B}, "
                    f"{'bf16 MFMA / fp32 storage' if a.dtype == 'bf16' else 'fp32'}, Generator forward only "
                    "(eval BatchNorm folded into convs, hipGraph replay)"},
-        "step_mfma_frac": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 /
-                                (PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF), 4)}),
+        # direct-convolution-equivalent rate: BASELINE.json's 611.68 GFLOP/image forward count x images/s,
+        # over the dense MFMA peak.  Winograd executes 2.25-4x fewer multiplications on the 3x3
+        # stack, so this can exceed 1.0; it is a throughput yardstick, not a utilisation.
+        "direct_equiv_tflops": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3, 1),
+        "direct_equiv_frac_of_peak": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 /
+                                           (PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF), 4)}),
         flush=True)
 
 
@@ -255,8 +259,14 @@ def main():
                        f"{f' (Winograd F({wtile}x{wtile},3x3) on the 3x3 stack)' if wino else ''}, G(9 PATBlocks,"
                        f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}"},
-            "step_mfma_frac": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world
-                                    / 1e3 / peak, 4),
+            # direct-convolution-equivalent rate per GPU: BASELINE.json's GFLOP/image/step count x
+            # images/s.  Winograd executes 2.25-4x fewer multiplications on the 3x3 stack, so the
+            # fraction can exceed 1.0: a throughput yardstick against BASELINE.md's bound, not a
+            # utilisation (the utilisation figure is roofline.frac).
+            "direct_equiv_tflops": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world / 1e3, 1),
+            "direct_equiv_frac_of_peak": round(GFLOP_PER_IMAGE_STEP * (H * W / 65536.0) * imgs_per_s / world
+                                               / 1e3 / peak, 4),
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic,

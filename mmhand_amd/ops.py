@@ -101,6 +101,9 @@ _wino_cache = {}
 # ops.WINOGRAD_TILE = 2 forces F(2x2,3x3).
 USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
 WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "4"))
+# keep the forward pass's transformed input for the wgrad pass (2.25x the activation's bytes per
+# eligible conv at F(4,3), one input transform less per conv and step); MMH_WINOGRAD_KEEP_INPUT=0 re-transforms
+KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
 
 
 def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16):
@@ -132,8 +135,9 @@ def wino_weights(w, tile, flip_transpose=False):
     return ent[2]
 
 
-def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False):
-    """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation)."""
+def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False):
+    """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
+    keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor)."""
     B, H, W_, Cin = x.shape
     P = (tile + 2) ** 2
     tiles = B * (H // tile) * (W_ // tile)
@@ -149,13 +153,14 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False):
     else:
         L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, _stream())
     L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, _stream())
-    return y
+    return (y, V) if keep_V else y
 
 
-def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4):
+def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=False):
     """fp32 3x3 / stride 1 / pad 1 conv by Winograd."""
     _chk(x, "x"); _chk(w, "w")
-    return _wino_conv(x, wino_weights(w, tile), bias, w.shape[3], reflect, act, tile, time_it=True)
+    return _wino_conv(x, wino_weights(w, tile), bias, w.shape[3], reflect, act, tile, time_it=True,
+                      keep_V=keep_V)
 
 
 def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
@@ -174,22 +179,28 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
     return dx
 
 
-def raw_conv_wgrad_wino(x, dy, reflect, tile=4):
-    """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd: dw = G^T [sum_tiles (B^T d B).(A dY A^T)] G."""
-    _chk(x, "x"); _chk(dy, "dy")
-    B, H, W_, Cin = x.shape
-    Cout = dy.shape[3]
+def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None):
+    """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd: dw = G^T [sum_tiles (B^T d B).(A dY A^T)] G.
+    V = the transformed input kept by the forward pass (x is then unused and may be None)."""
+    _chk(dy, "dy")
+    B, H, W_, Cout = dy.shape
     P = (tile + 2) ** 2
     tiles = B * (H // tile) * (W_ // tile)
-    V = _empty((P, tiles, Cin), x)
-    Yh = _empty((P, tiles, Cout), x)
-    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+    if V is None:
+        _chk(x, "x")
+        Cin = x.shape[3]
+        V = _empty((P, tiles, Cin), x)
+        L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+    else:
+        Cin = V.shape[2]
+        assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous()
+    Yh = _empty((P, tiles, Cout), dy)
     L.call("mmh_wino_dy", _ptr(dy), B, H, W_, Cout, tile, _ptr(Yh), _stream())
-    ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), x)
-    dU = _empty((P, Cin, Cout), x)
+    ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), dy)
+    dU = _empty((P, Cin, Cout), dy)
     L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
-    dw = _empty((3, 3, Cin, Cout), x)
+    dw = _empty((3, 3, Cin, Cout), dy)
     L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
     return dw
 
@@ -322,8 +333,18 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False):
-        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act, bf16)
+        B, H, W_, Cin = x.shape
+        wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
         ctx.cfg = (stride, pad, reflect, act, bias is not None, bf16)
+        ctx.x_shape = tuple(x.shape)
+        ctx.wino_V = 0
+        if wt and KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
+            # the wgrad pass contracts the same transformed input: keep it instead of x
+            y, V = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, keep_V=True)
+            ctx.wino_V = wt
+            ctx.save_for_backward(V, w, y if act != L.ACT_NONE else None)
+            return y
+        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act, bf16)
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
         return y
 
@@ -336,9 +357,12 @@ class Conv2dFn(torch.autograd.Function):
             g = raw_act_bwd(g, y, act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = raw_conv_dgrad(g, w, x.shape, stride, pad, reflect, bf16)
+            dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16)
         if ctx.needs_input_grad[1]:
-            dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
+            if ctx.wino_V:
+                dw = raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x)
+            else:
+                dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
         return dx, dw, db, None, None, None, None, None
