@@ -463,6 +463,201 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_batched_kernel(const BatchK
 }
 
 // ---------------------------------------------------------------------------
+// Winograd-domain GEMMs, dedicated kernel: P planes of C[M x N] = A[M x K] . B[K x N], all three
+// row-major and dense (V [P][tiles][K], U [P][K][N] -> M [P][tiles][N]).  Same MFMA tiling and
+// LDS layout as conv_igemm_body, but
+//   * plain row/column addressing (no tap / reflect / stride arithmetic): one add per k-step;
+//   * PERSISTENT workgroups: the contraction is short (K = 64..512 channels = 2..16 k-steps), so a
+//     one-tile-per-workgroup launch spends a third of its life filling the pipeline and storing
+//     the tile.  Here each workgroup walks a list of tiles with ONE software pipeline running
+//     across tile boundaries: the loads of the next tile's first k-step are in flight while the
+//     current tile's accumulators are stored;
+//   * XCD-aware work list: XCD x owns a contiguous range of (plane, row tile, column tile) items
+//     with the column tile fastest, and its resident workgroups take consecutive items, so the
+//     column tiles of one A row panel and the whole B plane are served by one L2.
+// Requires K % 32 == 0 and N % 32 == 0; the M tail is handled by the buffer range check (loads
+// return 0, stores are dropped), whole column groups past N are skipped.
+// ---------------------------------------------------------------------------
+struct WinoGemmKP {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, K, N, P;
+    int MT, NT;         // row / column tiles per plane
+    int W;              // work items = P * MT * NT
+    int Wx;             // items per XCD
+    int nb;             // workgroups per XCD (grid = 8 * nb)
+};
+
+template <int BN>
+__global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
+    constexpr int WTM = 64, WTN = BN / 2;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NB = BN / 32;
+    constexpr int ASZ = BM * LDA;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;
+    float* const Bs = smem + ASZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = tid & 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wend = min(p.W, (xcd + 1) * p.Wx);
+    int wc = xcd * p.Wx + slot;             // item being computed
+    if (wc >= wend) return;
+    const int KS = p.K / BK;
+    const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u;
+    const unsigned b_bytes = (unsigned)p.K * (unsigned)p.N * 4u;
+    const unsigned c_bytes = (unsigned)p.M * (unsigned)p.N * 4u;
+    const unsigned a_step = BK * 4u, b_step = (unsigned)BK * (unsigned)p.N * 4u;
+
+    // loader state (runs one k-step ahead of the MFMAs, possibly already in the next item)
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned a_off[4], b_off[NB];
+    auto setup_load = [&](int w) {
+        const int nt = w % p.NT;
+        const int t = w / p.NT;
+        const int mt = t % p.MT;
+        const int xi = t / p.MT;
+        rsA = make_rsrc(p.A + (size_t)xi * p.M * p.K, a_bytes);
+        rsB = make_rsrc(p.B + (size_t)xi * p.K * p.N, b_bytes);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mt * BM + (tid >> 3) + 32 * i;
+            a_off[i] = ((unsigned)m * (unsigned)p.K + grp * 4u) * 4u;   // m >= M: beyond num_records -> 0
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            const int krow = idx / (BN / 4);
+            const int n = nt * BN + 4 * (idx - krow * (BN / 4));
+            b_off[i] = n < p.N ? ((unsigned)krow * (unsigned)p.N + (unsigned)n) * 4u : OOB;
+        }
+    };
+    float4 ra[4], rb[NB];
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = bload4(rsA, a_off[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = bload4(rsB, b_off[i]);
+    };
+    auto advance_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_off[i] += a_step;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_off[i] = b_off[i] == OOB ? OOB : b_off[i] + b_step;
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * LDA + grp * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[(tid + 256 * i) * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    setup_load(wc);
+    issue_loads();
+    store_tiles();
+    __syncthreads();
+    for (;;) {
+        for (int ks = 0; ks < KS; ++ks) {
+            bool more = true;
+            if (ks + 1 < KS) advance_k();
+            else {
+                more = wc + p.nb < wend;
+                if (more) setup_load(wc + p.nb);
+            }
+            if (more) issue_loads();
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                float4 av[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    av[i] = *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
+                float bsc[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const float a = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (ks == KS - 1) {
+                // tile done: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Rows past M
+                // land beyond num_records and are dropped by the buffer range check; whole 32-column
+                // groups past N (N % 32 == 0) are skipped by a wave-uniform test.
+                const int nt = wc % p.NT;
+                const int t = wc / p.NT;
+                const int mt = t % p.MT;
+                const int xi = t / p.MT;
+                const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+                    p.C + (size_t)xi * p.M * p.N, 0, c_bytes, 0x00020000);
+                const unsigned n4 = (unsigned)p.N * 4u;
+                const int ncol0 = nt * BN + wn * WTN;
+                unsigned vbase = (unsigned)(mt * BM + wm * WTM + 4 * h) * n4 + (unsigned)(ncol0 + l31) * 4u;
+                asm volatile("" : "+v"(vbase));     // keep the store addressing inside this block (no hoisting)
+                // the scalar offset of a buffer store is not range-checked: use it only for tiles fully inside M
+                if (mt * BM + BM <= p.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (ncol0 + j * 32 < p.N) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    __builtin_amdgcn_raw_buffer_store_b32(
+                                        __float_as_uint(acc[i][j][r]), rsC, vbase + j * 128u,
+                                        (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n4, 0);
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (ncol0 + j * 32 < p.N) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    __builtin_amdgcn_raw_buffer_store_b32(
+                                        __float_as_uint(acc[i][j][r]), rsC,
+                                        vbase + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n4 + j * 128u, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
+        wc += p.nb;
+        if (wc >= wend) break;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (fp32).  y = A^T[(G g G^T) . (B^T d B)]A:
 // 16 multiplications per 2x2 output tile instead of 36, i.e. 2.25x fewer MFMA flops than the
 // direct implicit GEMM.  Three kernels around the batched GEMM above:
@@ -1936,11 +2131,38 @@ int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
 }
 
 int g_wino_bn256 = 0;   // 128-wide tiles: 3-5 % faster than 256 for these short-K GEMMs (more workgroups per CU)
+int g_wino_gemm_v2 = 1; // dedicated persistent kernel (wino_gemm_kernel) when K % 32 == 0 and N >= 64
+int g_wino_gemm_occ = 3;   // resident workgroups per CU the persistent grid is sized for
+
+template <int BN>
+static int launch_wino_gemm_t(const WinoGemmKP& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)(BM * LDA + BK * BN) * sizeof(float);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(wino_gemm_kernel<BN>, lds);
+    if (ready != 0) return ready;
+    hipLaunchKernelGGL((wino_gemm_kernel<BN>), dim3(8 * p.nb), dim3(256), lds, st, p);
+    return mmh::check_launch("wino_gemm_kernel");
+}
+
+static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st,
+                        int nbatch) {
+    WinoGemmKP p{};
+    p.A = V; p.B = U; p.C = Mo;
+    p.M = (int)tiles; p.K = K; p.N = N; p.P = nbatch;
+    const int bn = N > 64 ? 128 : 64;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (N + bn - 1) / bn;
+    p.W = nbatch * p.MT * p.NT;
+    p.Wx = (p.W + 7) / 8;
+    p.nb = std::min(p.Wx, 32 * g_wino_gemm_occ);   // 32 CUs per XCD
+    return bn == 128 ? launch_wino_gemm_t<128>(p, st) : launch_wino_gemm_t<64>(p, st);
+}
 
 // 16 x ( [tiles x K] . [K x N] ): V [16][tiles][K], U [16][K][N] -> M [16][tiles][N]
 int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st,
               int nbatch = 16) {
     MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
+    if (g_wino_gemm_v2 && K % BK == 0 && N >= 64 && N % 32 == 0) return wino_gemm_v2(V, U, Mo, tiles, K, N, st, nbatch);
     BatchKP bp{};
     ConvKP& p = bp.p;
     Gather& g = p.g;
@@ -2092,6 +2314,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
     if (!strcmp(key, "wgrad_bn256")) { g_wgrad_bn256 = value; return 0; }
+    if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
+    if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_slots")) { g_wino_wgrad_slots = value; return 0; }
     return mmh::fail("mmh_set_option: unknown key '%s'", key);

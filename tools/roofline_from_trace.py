@@ -12,7 +12,27 @@ for r in csv.DictReader(open(f)):
         acc[wg].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(f"kernel: {pat}\ntrace:  {f.split('/')[-1]}")
 print(f"{'workgroups (x,y,z)':>22s} {'launches':>9s} {'mean us':>10s} {'min us':>10s} {'max us':>10s} {'total ms':>10s}")
+def two_means(v):
+    """1-D 2-means: the same grid can carry two contraction lengths (K = 256 or 512 channels)."""
+    lo, hi = min(v), max(v)
+    for _ in range(20):
+        a = [x for x in v if abs(x - lo) <= abs(x - hi)]
+        b = [x for x in v if abs(x - lo) > abs(x - hi)]
+        if not a or not b:
+            return [v]
+        lo, hi = statistics.mean(a), statistics.mean(b)
+    return [a, b]
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     print(f"{str(k):>22s} {len(v):9d} {statistics.mean(v):10.1f} {min(v):10.1f} {max(v):10.1f} {sum(v)/1e3:10.1f}")
-print("workgroups (4, 1024, 1) = 4 column tiles x 1024 row tiles = the 3x3 512->512 fprop at 64x64, B=32:\n"
-      "618.5 GFLOP per launch; bench.py's roofline.achieved = 618.5 GFLOP / its HIP-event mean.")
+    if "batched" in pat and max(v) > 1.5 * min(v):
+        for c in two_means(v):
+            print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
+if "batched" in pat:
+    print("workgroups (4, 64, 36) = 4 column tiles x 64 row tiles x 36 Winograd planes = [8192x512].[512x512] per\n"
+          "plane: the F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches both have this\n"
+          "shape); 154.6 GFLOP per launch; bench.py's roofline.achieved = 154.6 GFLOP / its HIP-event mean over the\n"
+          "fprop launches.  The same grid also carries the dgrad of the 512->256 convs ([8192x256].[256x512], half\n"
+          "the contraction): per step 32 launches with K=512 (upper duration cluster) and 16 with K=256 (lower).")
+else:
+    print("workgroups (4, 1024, 1) = 4 column tiles x 1024 row tiles = the 3x3 512->512 fprop at 64x64, B=32:\n"
+          "618.5 GFLOP per launch; bench.py's roofline.achieved = 618.5 GFLOP / its HIP-event mean.")
