@@ -239,10 +239,22 @@ int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight,
                double denom, const void* gscalar, void* da, mmh_stream_t s);
 
 /* ---- Adam (torch.optim.Adam, MMHandModel.py:90-98) over a flat buffer ------
- * step is the 1-based step count; no weight decay, no amsgrad.             */
+ * step is the 1-based step count; no weight decay, no amsgrad.
+ * skip_flag (device int32, may be NULL): when *skip_flag != 0 the launch leaves
+ * p, m and v untouched - the `if not self.overflow: optimizer.step()` of
+ * MMHandModel.py:316-328 decided on the device, without a host round trip.  */
 int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, int step,
-                  float grad_scale, mmh_stream_t s);
+                  float grad_scale, const void* skip_flag, mmh_stream_t s);
+
+/* ---- overflow detection (MMHandModel.loss_backward, MMHandModel.py:294-308) --
+ * *flag_out = (flag_in ? *flag_in : 0) | any(!isfinite(g[0..n))).  flag_in carries
+ * the sticky `self.overflow` of the steps already taken this iteration.  Run on
+ * the flat gradient buffer AFTER the data-parallel all-reduce: a non-finite
+ * value on any rank is non-finite in the sum on every rank, which is the
+ * flag all-reduce of reduce_tensor (MMHandModel.py:381-384) for free.       */
+int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in,
+                       void* flag_out, mmh_stream_t s);
 
 /* ---- layout: NCHW (any strides) <-> padded NHWC, with channel concat -------
  * replaces torch.cat at MMHandModel.py:216-220,238,242,278-289.            */

@@ -1088,7 +1088,25 @@ struct WgradKP {
     int dbg;                // timing-only ablation bits (results wrong)
     int nsplit;             // splits per batch: blockIdx.z = batch * nsplit + split
     long long src_bs, dy_bs;   // element strides between batches (Winograd: 16 planes)
+    int xcd_remap;          // grid size % 8 == 0: XCD x works on a contiguous range of (z, y, x) ids
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs.  With the remap, XCD x takes the contiguous
+// logical range [x*T/8, (x+1)*T/8) in order, so the column/row tiles of one (plane, split) -
+// which read the same two panels - are resident on ONE XCD and share its L2.
+__device__ __forceinline__ void wgrad_block_ids(const WgradKP& p, int& bx, int& by, int& bz) {
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int total = gx * gy * (int)gridDim.z;
+        const int L = bx + gx * (by + gy * bz);
+        const int Lg = (L & 7) * (total >> 3) + (L >> 3);
+        bx = Lg % gx;
+        const int t = Lg / gx;
+        by = t % gy;
+        bz = t / gy;
+    }
+}
 
 template <int BN, int WAVES_M, int WAVES_N, bool DBUF>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
@@ -1107,9 +1125,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int batch = blockIdx.z / p.nsplit, split = blockIdx.z - batch * p.nsplit;
+    int bx, by, bz;
+    wgrad_block_ids(p, bx, by, bz);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int batch = bz / p.nsplit, split = bz - batch * p.nsplit;
     const int pbeg = split * p.pix_per_split;
     const int pend = min(p.P, pbeg + p.pix_per_split);
     const int PHW = g.PH * g.PW;
@@ -1243,7 +1263,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradKP p) {
         }
     }
 
-    float* slab = p.slab + (size_t)blockIdx.z * (size_t)p.Mrows * p.N;
+    float* slab = p.slab + (size_t)bz * (size_t)p.Mrows * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1295,9 +1315,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    const int batch = blockIdx.z / p.nsplit, split = blockIdx.z - batch * p.nsplit;
+    int bx, by, bz;
+    wgrad_block_ids(p, bx, by, bz);
+    const int m0 = by * BM;
+    const int n0 = bx * BN;
+    const int batch = bz / p.nsplit, split = bz - batch * p.nsplit;
     const int pbeg = split * p.pix_per_split;
     const int pend = min(p.P, pbeg + p.pix_per_split);
     const int PHW = g.PH * g.PW;
@@ -1402,7 +1424,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
         }
     }
 
-    float* slab = p.slab + (size_t)blockIdx.z * (size_t)p.Mrows * p.N;
+    float* slab = p.slab + (size_t)bz * (size_t)p.Mrows * p.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2199,6 +2221,7 @@ int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K,
 // bound) so the last round is not a mostly empty tail; keep >= 8 k-steps per split.
 int g_wgrad_slots = 768;   // tuning knob (mmh_set_option "wgrad_slots")
 int g_wgrad_bn256 = 1;     // 128x256 wgrad tile when Cout % 256 == 0
+int g_wgrad_xcd = 1;     // XCD-contiguous workgroup order for the batched Winograd wgrad GEMMs
 int g_wino_wgrad_bn256 = 0;   // 128-wide tiles measured faster for the batched Winograd wgrad GEMMs
 int g_wino_wgrad_slots = 2304;   // 3 waves of blocks: measured 20-29 % faster than 768 on the 512- and 256-channel shapes
 
@@ -2314,6 +2337,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
     if (!strcmp(key, "wgrad_bn256")) { g_wgrad_bn256 = value; return 0; }
+    if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
@@ -2452,6 +2476,7 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
     const bool b256 = g_wino_wgrad_bn256 && p.N % 256 == 0;
     const int BNsel = b256 ? 256 : (p.N > 64 ? 128 : (p.N > 32 ? 64 : 32));
     dim3 grid((p.N + BNsel - 1) / BNsel, (p.Mrows + BM - 1) / BM, nbatch * splits);
+    p.xcd_remap = (g_wgrad_xcd && (grid.x * grid.y * grid.z) % 8 == 0) ? 1 : 0;
     int rc;
     if (b256) rc = launch_wgrad_grid_t<256, 2, 2>(p, grid, st);
     else if (p.N > 64) rc = launch_wgrad_grid_t<128, 2, 2>(p, grid, st);

@@ -495,7 +495,8 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
                             float b2, float eps, float step_size, float inv_sqrt_bc2,
-                            float gscale) {
+                            float gscale, const int* __restrict__ skip) {
+    if (skip && *skip) return;      // a gradient of this iteration was not finite: leave p, m, v alone
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -507,6 +508,24 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
         float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
         p[i] = p[i] - step_size * (mm / denom);
     }
+}
+
+// flag |= any(!isfinite(g)): the exponent field of inf/nan is all ones
+__global__ void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n4, int64_t n,
+                                      int* __restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t k = i; k < n4; k += stride) {
+        const float4 v = ld4(g, k);
+        bad |= (__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u;
+        bad |= (__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u;
+        bad |= (__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u;
+        bad |= (__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u;
+    }
+    for (int64_t k = 4 * n4 + i; k < n; k += stride)
+        bad |= (__float_as_uint(g[k]) & 0x7f800000u) == 0x7f800000u;
+    if (bad) *flag = 1;     // every writer stores the same value
 }
 
 // ------------------------------------------------------------------ layout
@@ -903,15 +922,28 @@ int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight, double den
     return mmh::check_launch("l1_bwd");
 }
 
+int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in, void* flag_out, mmh_stream_t s) {
+    MMH_REQUIRE(g && flag_out && n > 0, "mmh_grad_nonfinite: bad arguments");
+    MMH_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "mmh_grad_nonfinite: g must be 16-byte aligned");
+    hipStream_t st = mmh::as_stream(s);
+    hipError_t e = flag_in ? hipMemcpyAsync(flag_out, flag_in, sizeof(int), hipMemcpyDeviceToDevice, st)
+                           : hipMemsetAsync(flag_out, 0, sizeof(int), st);
+    if (e != hipSuccess) return mmh::fail("mmh_grad_nonfinite: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(TPB), 0, st,
+                       static_cast<const float*>(g), n / 4, n, static_cast<int*>(flag_out));
+    return mmh::check_launch("grad_nonfinite");
+}
+
 int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int step, float grad_scale, mmh_stream_t s) {
+                  float beta2, float eps, int step, float grad_scale, const void* skip_flag,
+                  mmh_stream_t s) {
     MMH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "mmh_adam_step: bad arguments");
     const double bc1 = 1.0 - std::pow((double)beta1, step);
     const double bc2 = 1.0 - std::pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, mmh::as_stream(s),
                        static_cast<float*>(p), static_cast<const float*>(g), static_cast<float*>(m),
                        static_cast<float*>(v), n, beta1, beta2, eps, (float)((double)lr / bc1),
-                       (float)(1.0 / std::sqrt(bc2)), grad_scale);
+                       (float)(1.0 / std::sqrt(bc2)), grad_scale, static_cast<const int*>(skip_flag));
     return mmh::check_launch("adam");
 }
 

@@ -66,12 +66,15 @@ class FlatAdam(torch.optim.Optimizer):
         self.net.flat_grad.zero_()
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, skip_flag=None):
+        """skip_flag: int32 device scalar; when it is non-zero the kernel leaves p, m, v untouched.
+        The caller takes the step back from step_count once the flag has reached the host
+        (MMHandModel._settle_overflow), as apex does not count a skipped step."""
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
-                      self.grad_scale)
+                      self.grad_scale, skip_flag)
         ops.bump_weights_epoch()
 
     def state_dict(self):
@@ -240,8 +243,20 @@ class MMHandModel(torch.nn.Module):
             self.dp = self.world > 1 or (os.environ.get("MMH_FORCE_DP") == "1" and dist.is_initialized())
             if self.dp:
                 self._init_data_parallel()
+            self.skipped_steps = 0
+            if opt.continue_train:
+                self.load_train_state()
         self.comm_stream = torch.cuda.Stream(self.device) if getattr(self, "dp", False) else None
         self._pending = None
+        if self.isTrain:
+            # overflow skip (models/MMHandModel.py:294-330) decided on the device: one sticky int32
+            # flag per optimizer step of an iteration, order G, D_PP x DG_ratio, D_PB x DG_ratio
+            self._nflags = 1 + 2 * opt.DG_ratio
+            self._flags = torch.zeros(self._nflags, dtype=torch.int32, device=self.device)
+            self._flags_host = torch.zeros(self._nflags, dtype=torch.int32).pin_memory()
+            self._flags_event = None
+            self.skipped_steps = getattr(self, "skipped_steps", 0)   # optimizer steps skipped so far
+            self.last_overflow = False      # did the last settled iteration skip anything
 
     # ------------------------------------------------------------------ data parallel
     def _init_data_parallel(self):
@@ -383,33 +398,74 @@ class MMHandModel(torch.nn.Module):
         fake_PP = self.fake_PP_pool.query(fake_now)
         self.loss_D_PP = self.backward_D_basic(self.netD_PP, real_PP, fake_PP).detach()
 
+    # ------------------------------------------------------------------ overflow skip
+    def _guarded_step(self, optimizer, k):
+        """`if not self.overflow: optimizer.step()` (models/MMHandModel.py:316-328) without a host
+        round trip: flag k = flag k-1 | any(!isfinite(grad)), and the Adam launch is a no-op when
+        it is set.  Called after the gradient all-reduce, so every rank sees the same flag (a
+        non-finite term makes the sum non-finite everywhere): reduce_tensor (:381-384) for free."""
+        ops.grad_nonfinite(optimizer.net.flat_grad, self._flags[k:k + 1],
+                           self._flags[k - 1:k] if k > 0 else None)
+        optimizer.step(skip_flag=self._flags[k:k + 1])
+
+    def _settle_overflow(self):
+        """Fetch the flags of the previous iteration (copied to pinned memory when it ended, long
+        finished by now) and take skipped steps back from the Adam step counts."""
+        if self._flags_event is None:
+            return
+        self._flags_event.synchronize()
+        self._flags_event = None
+        f = self._flags_host.tolist()
+        r = self.opt.DG_ratio
+        per_opt = ((self.optimizer_G, f[0:1]), (self.optimizer_D_PP, f[1:1 + r]),
+                   (self.optimizer_D_PB, f[1 + r:1 + 2 * r]))
+        for o, fl in per_opt:
+            o.step_count -= sum(1 for x in fl if x)
+        self.skipped_steps += sum(1 for x in f if x)
+        self.last_overflow = any(f)
+        if self.last_overflow:
+            self.pprint("non-finite gradient: skipped %d optimizer step(s)" % sum(1 for x in f if x))
+
     # ------------------------------------------------------------------ the step
     def optimize_parameters(self):
-        """models/MMHandModel.py:310-330.  Order of effects is the reference's; the generator's
-        gradient all-reduce and Adam are deferred behind the discriminator steps, which do not
-        read generator parameters."""
+        """models/MMHandModel.py:310-330.  Order of effects is the reference's; under data
+        parallelism the generator's gradient all-reduce runs beneath the first discriminator
+        forward+backward (which reads no generator parameter) and its Adam follows it there."""
+        self._settle_overflow()
+        r = self.opt.DG_ratio
         self.forward()
         self.optimizer_G.zero_grad()
         self.backward_G()
         work_G = self._allreduce_async(self.netG)
         if work_G is None:
-            self.optimizer_G.step()
+            self._guarded_step(self.optimizer_G, 0)
 
-        for _ in range(self.opt.DG_ratio):
+        def finish_G():
+            # data parallel: the 285 MB all-reduce ran under the first discriminator
+            # forward+backward; its (global) flag must head the chain before any D step is decided
+            nonlocal work_G
+            if work_G is not None:
+                self._wait(work_G)
+                self._guarded_step(self.optimizer_G, 0)
+                work_G = None
+
+        for i in range(r):
             self.optimizer_D_PP.zero_grad()
             self.backward_D_PP()
             self._wait(self._allreduce_async(self.netD_PP))
-            self.optimizer_D_PP.step()
+            finish_G()
+            self._guarded_step(self.optimizer_D_PP, 1 + i)
 
-        for _ in range(self.opt.DG_ratio):
+        for i in range(r):
             self.optimizer_D_PB.zero_grad()
             self.backward_D_PB()
             self._wait(self._allreduce_async(self.netD_PB))
-            self.optimizer_D_PB.step()
-
-        if work_G is not None:
-            self._wait(work_G)
-            self.optimizer_G.step()
+            finish_G()
+            self._guarded_step(self.optimizer_D_PB, 1 + r + i)
+        finish_G()
+        self._flags_host.copy_(self._flags, non_blocking=True)
+        self._flags_event = torch.cuda.Event()
+        self._flags_event.record()
         self.overflow = False
 
     # ------------------------------------------------------------------ reporting / io
@@ -447,6 +503,43 @@ class MMHandModel(torch.nn.Module):
         self.save_network(self.netG, "netG", label, self.gpu_ids)
         self.save_network(self.netD_PB, "netD_PB", label, self.gpu_ids)
         self.save_network(self.netD_PP, "netD_PP", label, self.gpu_ids)
+        self.save_train_state(label)
+
+    def save_train_state(self, label):
+        """<label>_net_amp.pth — the file the reference's distributed runs fill with apex's
+        loss-scaler state (models/base_model.py:54-56).  There is no loss scaler here (fp32 / bf16);
+        the file carries what a resumed run needs instead: the three Adam states (step count and the
+        flat exp_avg / exp_avg_sq buffers, in flatten_parameters() order) and the skipped-step
+        count.  The learning-rate schedule is positioned by --epoch_count as in the reference
+        (network_utils.py:92-95), so scheduler state is not stored.  The reference's loader feeds
+        any *amp* file to amp.load_state_dict inside try/except, so it ignores this one."""
+        if not self.master:
+            return
+        self._settle_overflow()
+        os.makedirs(self.save_dir, exist_ok=True)
+        state = {"format": "mmhand_amd.train_state.v1", "skipped_steps": self.skipped_steps,
+                 "optimizers": {}}
+        for name in ("optimizer_G", "optimizer_D_PB", "optimizer_D_PP"):
+            sd = getattr(self, name).state_dict()
+            state["optimizers"][name] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
+        torch.save(state, os.path.join(self.save_dir, "%s_net_amp.pth" % label))
+
+    def load_train_state(self):
+        path = os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_net_amp.pth" % self.opt.which_epoch)
+        if not os.path.exists(path):
+            return False
+        state = torch.load(path, map_location="cpu")
+        if not isinstance(state, dict) or state.get("format") != "mmhand_amd.train_state.v1":
+            return False        # a real apex amp file: nothing to restore without a loss scaler
+        for name, sd in state["optimizers"].items():
+            o = getattr(self, name)
+            if sd["exp_avg"].numel() != o.exp_avg.numel():
+                raise RuntimeError(f"{path}: {name} state has {sd['exp_avg'].numel()} elements, "
+                                   f"the network has {o.exp_avg.numel()}")
+            o.load_state_dict(sd)
+        self.skipped_steps = int(state.get("skipped_steps", 0))
+        self.pprint("restored optimizer state (Adam step %d)" % self.optimizer_G.step_count)
+        return True
 
     def load_network(self):
         """models/base_model.py:60-80: load every <which_epoch>_net_<name>.pth in the run dir."""

@@ -703,12 +703,24 @@ def nhwc_to_nchw_view(t, Cc=None):
 
 
 # --------------------------------------------------------------------------- optimiser
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    """torch.optim.Adam.step (models/MMHandModel.py:90-98) on flat buffers, one launch."""
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, skip_flag=None):
+    """torch.optim.Adam.step (models/MMHandModel.py:90-98) on flat buffers, one launch.
+    skip_flag: int32 device scalar; non-zero makes the launch a no-op (overflow skip)."""
     for t in (p, g, m, v):
         _chk(t)
+    if skip_flag is not None:
+        assert skip_flag.dtype == torch.int32 and skip_flag.is_cuda
     L.call("mmh_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
-           float(beta2), float(eps), int(step), float(grad_scale), _stream())
+           float(beta2), float(eps), int(step), float(grad_scale), _ptr(skip_flag), _stream())
+
+
+def grad_nonfinite(g, flag_out, flag_in=None):
+    """flag_out = (flag_in or 0) | any(!isfinite(g)) on the device (MMHandModel.loss_backward,
+    models/MMHandModel.py:294-308); int32 one-element tensors."""
+    _chk(g)
+    for f in (flag_out, flag_in):
+        assert f is None or (f.dtype == torch.int32 and f.is_cuda and f.numel() == 1)
+    L.call("mmh_grad_nonfinite", _ptr(g), g.numel(), _ptr(flag_in), _ptr(flag_out), _stream())
 
 
 # --------------------------------------------------------------------------- pose maps

@@ -157,7 +157,8 @@ def test_checkpoint_roundtrip(dev, tmp_path):
     m = MMHandModel(opt)
     m.save("latest")
     files = sorted(os.listdir(os.path.join(str(tmp_path), opt.name)))
-    assert files == ["latest_net_netD_PB.pth", "latest_net_netD_PP.pth", "latest_net_netG.pth"]
+    assert files == ["latest_net_amp.pth", "latest_net_netD_PB.pth", "latest_net_netD_PP.pth",
+                     "latest_net_netG.pth"]
     sd = torch.load(os.path.join(str(tmp_path), opt.name, "latest_net_netG.pth"))
     assert sd["model.stream1_down.1.weight"].shape == (S["ngf"], 3, 7, 7)
     opt2 = _small_opt("batch", checkpoints_dir=str(tmp_path), continue_train=True)
