@@ -12,22 +12,29 @@ for r in csv.DictReader(open(f)):
         acc[wg].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(f"kernel: {pat}\ntrace:  {f.split('/')[-1]}")
 print(f"{'workgroups (x,y,z)':>22s} {'launches':>9s} {'mean us':>10s} {'min us':>10s} {'max us':>10s} {'total ms':>10s}")
-def two_means(v):
-    """1-D 2-means: the same grid can carry two contraction lengths (K = 256 or 512 channels)."""
-    lo, hi = min(v), max(v)
-    for _ in range(20):
-        a = [x for x in v if abs(x - lo) <= abs(x - hi)]
-        b = [x for x in v if abs(x - lo) > abs(x - hi)]
-        if not a or not b:
-            return [v]
-        lo, hi = statistics.mean(a), statistics.mean(b)
-    return [a, b]
+def clusters(v, gap=1.12):
+    """Split sorted durations where two neighbours differ by more than `gap`x: one grid can carry
+    several GEMM shapes (the persistent Winograd kernel always launches 8 x 96 workgroups)."""
+    v = sorted(v)
+    out = [[v[0]]]
+    for x in v[1:]:
+        if x > out[-1][-1] * gap:
+            out.append([])
+        out[-1].append(x)
+    return out
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     print(f"{str(k):>22s} {len(v):9d} {statistics.mean(v):10.1f} {min(v):10.1f} {max(v):10.1f} {sum(v)/1e3:10.1f}")
-    if "batched" in pat and max(v) > 1.5 * min(v):
-        for c in two_means(v):
-            print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
-if "batched" in pat:
+    if ("batched" in pat or "wino_gemm" in pat) and max(v) > 1.5 * min(v):
+        for c in clusters(v):
+            if len(c) >= 5:
+                print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
+if "wino_gemm" in pat:
+    print("wino_gemm_kernel is persistent: every launch has 8 XCDs x 96 workgroups, whatever the GEMM shape, so\n"
+          "shapes are told apart by duration.  The slowest cluster (~1.17 ms) is 36 x [8192x512].[512x512] = the\n"
+          "F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches are the same GEMM):\n"
+          "154.6 GFLOP per launch; bench.py's roofline.achieved = 154.6 GFLOP / its HIP-event mean over the fprop\n"
+          "launches.  The other clusters: 512->256 / 256->512 (77.3 GFLOP) and 256->256 (38.7 GFLOP) convs.")
+elif "batched" in pat:
     print("workgroups (4, 64, 36) = 4 column tiles x 64 row tiles x 36 Winograd planes = [8192x512].[512x512] per\n"
           "plane: the F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches both have this\n"
           "shape); 154.6 GFLOP per launch; bench.py's roofline.achieved = 154.6 GFLOP / its HIP-event mean over the\n"
