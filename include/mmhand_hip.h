@@ -238,6 +238,22 @@ int mmh_l1_fwd(const void* a, const void* b, int64_t n, float weight,
 int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight,
                double denom, const void* gscalar, void* da, mmh_stream_t s);
 
+/* ---- thin 7x7 convolutions (at most 4 output channels) on the vector ALU -----
+ * The Generator head ReflectionPad2d(3)+Conv2d(64,3,7)+Tanh (models/Generator.py:255-259)
+ * and the dgrad of the Discriminator stems (models/Discriminator.py:79-84) with respect
+ * to the generated image only, i.e. the first <= 4 of their input channels
+ * (MMHandModel.backward_G, models/MMHandModel.py:236-261: P2 / H1 carry no gradient).
+ * A 32-wide MFMA tile wastes 7/8 of the matrix core on 4 columns; see conv_thin.hip.
+ * fprop: d->Cout == 4, d->Cin % 4 == 0, 7x7 / stride 1 / pad 3 (reflect or zero), fp32;
+ *        w [7][7][Cin][4]; same result as mmh_conv2d_fprop.
+ * dgrad: writes channels [0,4) of dx (pixel stride d->x_cs) and leaves the others alone;
+ *        w is the conv's full weight [7][7][d->Cin][d->Cout]; ws from the _ws_bytes query. */
+int mmh_conv7_thin_fprop(const mmh_conv_desc* d, const void* x, const void* w,
+                         const void* bias, void* y, int act, mmh_stream_t s);
+size_t mmh_conv7_thin_dgrad_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
+                         void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
+
 /* ---- Adam (torch.optim.Adam, MMHandModel.py:90-98) over a flat buffer ------
  * step is the 1-based step count; no weight decay, no amsgrad.
  * skip_flag (device int32, may be NULL): when *skip_flag != 0 the launch leaves

@@ -347,9 +347,10 @@ class MMHandModel(torch.nn.Module):
     def backward_G(self):
         o = self.opt
         with _frozen(self.netD_PB, self.netD_PP):
-            pred_fake_PB = self.netD_PB.forward_nhwc(self._cat_PB(self.fake_nhwc, True))
+            nc = o.H_input_nc     # only the generated image inside the concat carries a gradient
+            pred_fake_PB = self.netD_PB.forward_nhwc(self._cat_PB(self.fake_nhwc, True), dx_channels=nc)
             self.loss_G_GAN_PB = self.criterionGAN(pred_fake_PB, True)
-            pred_fake_PP = self.netD_PP.forward_nhwc(self._cat_PP(self.fake_nhwc))
+            pred_fake_PP = self.netD_PP.forward_nhwc(self._cat_PP(self.fake_nhwc), dx_channels=nc)
             self.loss_G_GAN_PP = self.criterionGAN(pred_fake_PP, True)
             if self.criterionL1 is not None:
                 losses = self.criterionL1(self.fake_nhwc, self.x_H2)

@@ -200,8 +200,8 @@ class _Net(nn.Module):
         return self
 
     # -- functional layers
-    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE):
-        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16)
+    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0):
+        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels)
 
     def convT(self, cp, x):
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16)
@@ -353,9 +353,11 @@ class Discriminator(_Net):
             self._conv(cb, i2, dim, dim, 3)
             self._normp(cb, i2 + 1, dim)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, dx_channels=0):
+        """dx_channels > 0: the caller needs the gradient of only the first dx_channels input
+        channels (the generated image inside cat(fake, P2) / cat(fake, H1))."""
         m = self.model
-        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True), True)
+        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels), True)
         for i in range(self.n_down):
             y = self.normact(m, 5 + 3 * i, self.conv(m[4 + 3 * i], y, 2, 1, False), True)
         base = 4 + 3 * self.n_down

@@ -104,6 +104,9 @@ WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "4"))
 # keep the forward pass's transformed input for the wgrad pass (2.25x the activation's bytes per
 # eligible conv at F(4,3), one input transform less per conv and step); MMH_WINOGRAD_KEEP_INPUT=0 re-transforms
 KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
+# 7x7 convs with <= 4 output columns (Generator head fprop, Discriminator-stem dgrad towards the
+# generated image) on the vector-ALU kernel of conv_thin.hip; MMH_THIN=0 keeps them on the MFMA path
+USE_THIN = os.environ.get("MMH_THIN", "1") != "0"
 
 
 def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16):
@@ -215,6 +218,10 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         return raw_conv_fprop_wino(x, w, bias, reflect, act, wt)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
+    if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 4 == 0:
+        # the Generator head (64 -> 3): 4 output columns waste an MFMA tile; fp32 vector-ALU kernel
+        L.call("mmh_conv7_thin_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
+        return y
     if bf16:
         d.dtype = L.BF16
         w = bf16_weights(w)[1]
@@ -228,10 +235,28 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     return y
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False):
+def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
+    """dgrad of a 7x7 / stride 1 / pad 3 conv for the first 4 input channels only (the others are
+    returned as zeros): the Discriminator stems seen from the generated image."""
+    _chk(dy, "dy"); _chk(w, "w")
+    B, H, W_, Cin = x_shape
+    Cout = w.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, 7, 1, 3, reflect)
+    dx = torch.zeros((B, H, W_, Cin), dtype=torch.float32, device=dy.device)
+    ws = _ws(L.load().mmh_conv7_thin_dgrad_ws_bytes(C.byref(d)), dy)
+    L.call("mmh_conv7_thin_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, _stream())
+    return dx
+
+
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0):
+    """dx_channels > 0: only the first dx_channels input channels need a gradient (the caller
+    ignores the rest, which may come back as zeros)."""
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     k, _, _, Cout = w.shape
+    if (USE_THIN and 0 < dx_channels <= 4 and k == 7 and stride == 1 and pad == 3 and Cout % 4 == 0
+            and Cin >= 4):
+        return raw_conv_dgrad_thin(dy, w, x_shape, reflect)
     wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
     if wt:
         return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt)
@@ -332,8 +357,9 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False):
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0):
         B, H, W_, Cin = x.shape
+        ctx.dx_channels = dx_channels
         wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
         ctx.cfg = (stride, pad, reflect, act, bias is not None, bf16)
         ctx.x_shape = tuple(x.shape)
@@ -357,7 +383,7 @@ class Conv2dFn(torch.autograd.Function):
             g = raw_act_bwd(g, y, act)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16)
+            dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
             if ctx.wino_V:
                 dw = raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x)
@@ -365,7 +391,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):

@@ -54,6 +54,51 @@ def test_conv2d_fprop_dgrad_wgrad(case, dev):
     assert R.rel_l1(db, dbr) < TOL, ("bias grad", R.rel_l1(db, dbr))
 
 
+# thin 7x7 convs (conv_thin.hip): (B, H, W, Cin, Cout, reflect) — tile-aligned, ragged (rows past a
+# 16-row tile, columns past a 64-column tile), image smaller than the tile, zero padding
+THIN_CASES = [
+    (2, 16, 16, 64, 4, True), (1, 20, 70, 64, 4, True), (2, 37, 130, 8, 4, True), (1, 8, 8, 16, 4, False),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+@pytest.mark.parametrize("act", [0, 2])
+def test_thin_conv7_fprop(case, act, dev):
+    """Generator head (7x7, 4 output columns, Tanh) on the vector-ALU kernel vs the fp64 oracle."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((7, 7, Cin, Cout), 2, dev) * 0.05
+    bias = _mk((Cout,), 3, dev)
+    assert ops.USE_THIN
+    y = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, act)
+    yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 3, refl, act)
+    assert R.rel_l1(y, yr) < TOL, R.rel_l1(y, yr)
+
+
+# (B, H, W, Cin, Cout, reflect): Discriminator stems D_PP (6 -> 8 channels) and D_PB (24)
+THIN_DGRAD_CASES = [
+    (2, 16, 16, 8, 64, True), (1, 20, 70, 24, 64, True), (2, 37, 66, 8, 32, True), (1, 12, 12, 24, 16, False),
+]
+
+
+@pytest.mark.parametrize("case", THIN_DGRAD_CASES)
+def test_thin_conv7_dgrad_first_channels(case, dev):
+    """dgrad of a Discriminator stem restricted to the generated image's channels: channels [0,4)
+    equal the full dgrad of the fp64 oracle, the remaining channels come back as zeros."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    w = _mk((7, 7, Cin, Cout), 2, dev) * 0.05
+    dy = _mk((B, H, W, Cout), 4, dev)
+    dx = ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), 1, 3, refl, dx_channels=3)
+    x = _mk((B, H, W, Cin), 1, dev)
+    _, dxr, _, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 3, refl)
+    assert R.rel_l1(dx[..., :4], dxr[..., :4]) < TOL, R.rel_l1(dx[..., :4], dxr[..., :4])
+    assert not dx[..., 4:].any()
+    full = ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), 1, 3, refl)      # MFMA path, all channels
+    assert R.rel_l1(full, dxr) < TOL
+
+
 @pytest.mark.parametrize("act", [1, 2])
 def test_conv2d_epilogue_act(act, dev):
     from mmhand_amd import ops
@@ -107,7 +152,7 @@ BF16_CASES = [
     (1, 16, 16, 44, 64, 7, 1, 3, True),      # pose stem
     (2, 16, 16, 4, 64, 3, 1, 1, False),      # VGG conv1
     (2, 9, 11, 24, 64, 7, 1, 3, True),       # D_PB stem, ragged M
-    (2, 10, 12, 64, 4, 7, 1, 3, True),       # head: dgrad falls back to fp32
+    (2, 10, 12, 64, 4, 7, 1, 3, True),       # head: fprop (thin kernel) and dgrad are fp32
     (2, 16, 16, 64, 64, 3, 1, 1, True),
     (1, 12, 20, 256, 256, 3, 1, 1, True),
     (2, 8, 8, 512, 256, 3, 1, 1, True),
@@ -134,9 +179,10 @@ def test_conv2d_bf16_mfma_path(case, dev):
     rb = lambda t: t.cpu().bfloat16().float()
     yr, dxr, dwr, _ = R.conv2d_grads(rb(x), rb(w), bias.cpu(), rb(dy), s, p, refl)
     yf, dxf, dwf, _ = R.conv2d_grads(x.cpu(), w.cpu(), bias.cpu(), dy.cpu(), s, p, refl)
-    # dgrad with Cout not a multiple of 64 keeps the fp32 kernel; fprop always runs in bf16
-    # (flat (tap, ci) contraction for the small-Cin stems)
-    y_ref = yr
+    # dgrad with Cout not a multiple of 64 keeps the fp32 kernel; fprop runs in bf16 (flat
+    # (tap, ci) contraction for the small-Cin stems) except the 4-column head, which is on the
+    # fp32 vector-ALU kernel of conv_thin.hip in both precisions
+    y_ref = yf if (k == 7 and Cout == 4) else yr
     dx_ref = dxr if Cout % 64 == 0 else dxf
     assert R.rel_l1(y, y_ref) < 5e-5, ("fprop vs matching-precision oracle", R.rel_l1(y, y_ref))
     assert R.rel_l1(dx, dx_ref) < 5e-5, ("dgrad vs matching-precision oracle", R.rel_l1(dx, dx_ref))
