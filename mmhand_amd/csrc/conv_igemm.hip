@@ -658,6 +658,153 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
 }
 
 // ---------------------------------------------------------------------------
+// Winograd-domain wgrad GEMMs, dedicated kernel: slab[xi][split][Cin x Cout] = V[xi][t0:t1]^T . Yh[xi][t0:t1]
+// (contraction over a range of tiles).  The TN counterpart of wino_gemm_kernel: same 128x128x32
+// block tile, plain addressing (one add per k-step; the end of a split's tile range is enforced by
+// the buffer descriptor's num_records, so the last k-step needs no mask), persistent workgroups
+// with one software pipeline across work items, XCD-contiguous work list with the 128x128 output
+// tiles of one (plane, split) - which read the same two panels - adjacent.  Requires
+// Cin % 128 == 0 and Cout % 128 == 0; the generic conv_wgrad_kernel covers the rest.
+// ---------------------------------------------------------------------------
+struct WinoWgradKP {
+    const float* V;
+    const float* Y;
+    float* slab;            // [P][S][Cin][Cout]
+    int T;                  // tiles per plane
+    int Cin, Cout, P, S;
+    int t_per_split;        // multiple of BK
+    int MT, NT;
+    int W, Wx, nb;          // work items, items per XCD, workgroups per XCD
+};
+
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) wino_wgrad_gemm_kernel(const WinoWgradKP p) {
+    constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int ASZ = BK * LDW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As = smem;             // [k = tile][128 ci], row pitch LDW
+    float* const Bs = smem + ASZ;       // [k = tile][128 co]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wend = min(p.W, (xcd + 1) * p.Wx);
+    int wc = xcd * p.Wx + slot;
+    if (wc >= wend) return;
+    const unsigned a_step = (unsigned)BK * (unsigned)p.Cin * 4u, b_step = (unsigned)BK * (unsigned)p.Cout * 4u;
+    const int krow = tid >> 5, kcol = (tid & 31) * 4;
+
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned a_off, b_off;              // row krow of the current k-step; rows +8, +16, +24 via the immediate
+    auto item_ksteps = [&](int w) {
+        const int split = (w / (p.MT * p.NT)) % p.S;
+        const int t0 = split * p.t_per_split;
+        const int t1 = min(p.T, t0 + p.t_per_split);
+        return t1 > t0 ? (t1 - t0 + BK - 1) / BK : 0;
+    };
+    auto setup_load = [&](int w) {
+        const int nt = w % p.NT;
+        int t = w / p.NT;
+        const int mt = t % p.MT; t /= p.MT;
+        const int split = t % p.S;
+        const int xi = t / p.S;
+        const int t0 = split * p.t_per_split;
+        const int t1 = min(p.T, t0 + p.t_per_split);
+        // descriptors end at the split's last tile: rows past it read as zeros
+        rsA = make_rsrc(p.V + (size_t)xi * p.T * p.Cin, (unsigned)t1 * (unsigned)p.Cin * 4u);
+        rsB = make_rsrc(p.Y + (size_t)xi * p.T * p.Cout, (unsigned)t1 * (unsigned)p.Cout * 4u);
+        a_off = ((unsigned)(t0 + krow) * (unsigned)p.Cin + (unsigned)(mt * BM + kcol)) * 4u;
+        b_off = ((unsigned)(t0 + krow) * (unsigned)p.Cout + (unsigned)(nt * BN + kcol)) * 4u;
+    };
+    float4 ra[4], rb[4];
+    auto issue_loads = [&]() {
+        const unsigned a8 = 8u * (unsigned)p.Cin * 4u, b8 = 8u * (unsigned)p.Cout * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = bload4(rsA, a_off + i * a8);
+            rb[i] = bload4(rsB, b_off + i * b8);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(krow + 8 * i) * LDW + kcol]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[(krow + 8 * i) * BN + kcol]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    setup_load(wc);
+    issue_loads();
+    store_tiles();
+    __syncthreads();
+    for (;;) {
+        const int KS = item_ksteps(wc);     // >= 1 by construction of the host-side split
+        for (int ks = 0; ks < KS; ++ks) {
+            bool more = true;
+            if (ks + 1 < KS) { a_off += a_step; b_off += b_step; }
+            else {
+                more = wc + p.nb < wend;
+                if (more) setup_load(wc + p.nb);
+            }
+            if (more) issue_loads();
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[(2 * kk + h) * LDW + wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[(2 * kk + h) * BN + wn * WTN + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+                const int nt = wc % p.NT;
+                int t = wc / p.NT;
+                const int mt = t % p.MT; t /= p.MT;     // t = xi * S + split: the slab index
+                const unsigned sl_bytes = (unsigned)p.Cin * (unsigned)p.Cout * 4u;
+                const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+                    p.slab + (size_t)t * p.Cin * p.Cout, 0, sl_bytes, 0x00020000);
+                const unsigned n4 = (unsigned)p.Cout * 4u;
+                unsigned vbase = (unsigned)(mt * BM + wm * WTM + 4 * h) * n4 + (unsigned)(nt * BN + wn * WTN + l31) * 4u;
+                asm volatile("" : "+v"(vbase));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rsC, vbase + j * 128u,
+                                                                  (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n4, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
+        wc += p.nb;
+        if (wc >= wend) break;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (fp32).  y = A^T[(G g G^T) . (B^T d B)]A:
 // 16 multiplications per 2x2 output tile instead of 36, i.e. 2.25x fewer MFMA flops than the
 // direct implicit GEMM.  Three kernels around the batched GEMM above:
@@ -2221,6 +2368,8 @@ int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K,
 // bound) so the last round is not a mostly empty tail; keep >= 8 k-steps per split.
 int g_wgrad_slots = 768;   // tuning knob (mmh_set_option "wgrad_slots")
 int g_wgrad_bn256 = 1;     // 128x256 wgrad tile when Cout % 256 == 0
+int g_wino_wgrad_v2 = 1;   // dedicated persistent kernel when Cin, Cout % 128 == 0
+int g_wino_wgrad_occ = 3;  // 3 | 4 resident workgroups per CU (4 = 128-VGPR build)
 int g_wgrad_xcd = 1;     // XCD-contiguous workgroup order for the batched Winograd wgrad GEMMs
 int g_wino_wgrad_bn256 = 0;   // 128-wide tiles measured faster for the batched Winograd wgrad GEMMs
 int g_wino_wgrad_slots = 2304;   // 3 waves of blocks: measured 20-29 % faster than 768 on the 512- and 256-channel shapes
@@ -2338,6 +2487,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
     if (!strcmp(key, "wgrad_bn256")) { g_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wgrad_xcd")) { g_wgrad_xcd = value; return 0; }
+    if (!strcmp(key, "wino_wgrad_v2")) { g_wino_wgrad_v2 = value; return 0; }
+    if (!strcmp(key, "wino_wgrad_occ")) { g_wino_wgrad_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
@@ -2456,6 +2607,34 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
     MMH_REQUIRE(tiles * (long long)std::max(Cin, Cout) < (1ll << 30), "mmh_wino_wgrad_gemm: tensor too large");
     hipStream_t st = mmh::as_stream(s);
     const int splits = wino_wgrad_splits(Cin, Cout, tiles, nbatch);
+    if (g_wino_wgrad_v2 && Cin % BM == 0 && Cout % 128 == 0) {
+        WinoWgradKP q{};
+        q.V = static_cast<const float*>(V); q.Y = static_cast<const float*>(Yh); q.slab = static_cast<float*>(ws);
+        q.T = (int)tiles; q.Cin = Cin; q.Cout = Cout; q.P = nbatch;
+        q.t_per_split = (int)(mmh::cdiv(mmh::cdiv(tiles, splits), BK) * BK);
+        q.S = (int)mmh::cdiv(tiles, q.t_per_split);       // every split owns at least one tile
+        q.MT = Cin / BM; q.NT = Cout / 128;
+        q.W = nbatch * q.S * q.MT * q.NT;
+        q.Wx = (q.W + 7) / 8;
+        const int occ = g_wino_wgrad_occ == 4 ? 4 : 3;
+        q.nb = std::min(q.Wx, 32 * occ);
+        constexpr size_t lds = (size_t)(BK * LDW + BK * 128) * sizeof(float);
+        static int ready3 = -1, ready4 = -1;
+        if (occ == 4) {
+            if (ready4 != 0) ready4 = allow_lds(wino_wgrad_gemm_kernel<4>, lds);
+            if (ready4 != 0) return ready4;
+            hipLaunchKernelGGL(wino_wgrad_gemm_kernel<4>, dim3(8 * q.nb), dim3(256), lds, st, q);
+        } else {
+            if (ready3 != 0) ready3 = allow_lds(wino_wgrad_gemm_kernel<3>, lds);
+            if (ready3 != 0) return ready3;
+            hipLaunchKernelGGL(wino_wgrad_gemm_kernel<3>, dim3(8 * q.nb), dim3(256), lds, st, q);
+        }
+        if (int rc = mmh::check_launch("wino_wgrad_gemm_kernel")) return rc;
+        const int64_t n4 = (int64_t)Cin * Cout / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
+                           dim3(256), 0, st, q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4);
+        return mmh::check_launch("wino wgrad gemm");
+    }
     WgradKP p{};
     Gather& g = p.g;
     g.src = static_cast<const float*>(V);

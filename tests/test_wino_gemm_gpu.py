@@ -32,3 +32,35 @@ def test_wino_gemm_matches_fp64_product(shape, v2):
     ref = torch.bmm(V.double().cpu(), U.double().cpu())
     rel = (out.double().cpu() - ref).abs().sum() / ref.abs().sum()
     assert rel < TOL, rel
+
+
+# (planes, tiles, Cin, Cout): split tails (tiles not a multiple of 32), a single k-step, many splits
+WGRAD_SHAPES = [(36, 32, 128, 128), (36, 200, 128, 256), (16, 1000, 256, 128), (36, 4096, 256, 256),
+                (36, 37, 128, 128), (4, 8192, 512, 512), (36, 300, 64, 96)]
+
+
+@pytest.mark.parametrize("v2", [0, 1])
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_wino_wgrad_gemm_matches_fp64_product(shape, v2):
+    """dU[xi] = V[xi]^T . Yh[xi] (contraction over tiles, split-K + fixed-order slab reduction):
+    the persistent TN kernel (v2, channel counts % 128 == 0) and the generic wgrad kernel."""
+    from mmhand_amd import lib
+    P, T, Cin, Cout = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P * 1000 + T)
+    V = torch.randn(P, T, Cin, generator=g).to(dev)
+    Y = torch.randn(P, T, Cout, generator=g).to(dev)
+    L = lib.load()
+    lib.check(L.mmh_set_option(b"wino_wgrad_v2", v2), "mmh_set_option")
+    try:
+        nws = L.mmh_wino_wgrad_gemm_ws_bytes(T, Cin, Cout, P)
+        ws = torch.full((nws // 4 + 4,), float("nan"), device=dev)
+        dU = torch.full((P, Cin, Cout), 7.0, device=dev)
+        lib.call("mmh_wino_wgrad_gemm", V.data_ptr(), Y.data_ptr(), T, Cin, Cout, P, ws.data_ptr(), nws,
+                 dU.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    finally:
+        lib.check(L.mmh_set_option(b"wino_wgrad_v2", 1), "mmh_set_option")
+    ref = torch.bmm(V.double().cpu().transpose(1, 2), Y.double().cpu())
+    rel = (dU.double().cpu() - ref).abs().sum() / ref.abs().sum()
+    assert rel < 5e-6, rel       # fp32 accumulation over up to 8192 tiles
