@@ -2140,10 +2140,15 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
 }
 
 __global__ void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
-                                   int C2, int reflect) {
+                                   int C2, int reflect, int xcd_remap) {
     const int TH = H / 4, TW = W / 4;
     const long long tiles = (long long)B * TH * TW;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // workgroups are dealt round-robin over the 8 XCDs: give XCD x a contiguous range of tiles, so
+    // that the 6x6 windows of neighbouring tiles (2 shared rows / columns each) meet in ONE L2
+    // instead of being fetched from HBM once per XCD (measured: FETCH_SIZE 2.0x -> see profiles/)
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    long long i = (long long)blk * blockDim.x + threadIdx.x;
     if (i >= tiles * C2) return;
     const int c = (int)(i % C2);
     const long long tile = i / C2;
@@ -2300,6 +2305,7 @@ int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
 }
 
 int g_wino_bn256 = 0;   // 128-wide tiles: 3-5 % faster than 256 for these short-K GEMMs (more workgroups per CU)
+int g_wino_xcd = 1;     // XCD-contiguous tile order in the input transform (halo rows meet in one L2)
 int g_wino_gemm_v2 = 1; // dedicated persistent kernel (wino_gemm_kernel) when K % 32 == 0 and N >= 64
 int g_wino_gemm_occ = 3;   // resident workgroups per CU the persistent grid is sized for
 
@@ -2490,6 +2496,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_wgrad_v2")) { g_wino_wgrad_v2 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_occ")) { g_wino_wgrad_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
+    if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_slots")) { g_wino_wgrad_slots = value; return 0; }
@@ -2531,8 +2538,10 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
     const long long tiles = (long long)B * (H / tile) * (W / tile);
     if (tile == 4) {
         const long long total = tiles * (C / 2);
-        hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
-                           static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 2, reflect);
+        const unsigned nblk = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(nblk), dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 2, reflect,
+                           (g_wino_xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
     } else {
         const long long total = tiles * (C / 4);
         hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
