@@ -114,8 +114,10 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
 int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate,
                 mmh_stream_t s);
 size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d);
+/* phase 1 = the eight border GEMMs (dy, w -> ws; independent of dx, so the caller may run
+ * them on a second stream beside the Winograd transforms), 2 = add ws into dx, 3 = both. */
 int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx,
-                            void* ws, size_t ws_bytes, mmh_stream_t s);
+                            void* ws, size_t ws_bytes, int phase, mmh_stream_t s);
 
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the

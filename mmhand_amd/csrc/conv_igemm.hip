@@ -1906,8 +1906,9 @@ size_t reflect1_ws_bytes(const mmh_conv_desc* d) {
     return (size_t)d->B * (2 * d->W + 2 * d->H + 4) * d->Cin * sizeof(float);
 }
 
+// phase: bit 0 = the GEMMs (border pieces into ws, main term into dx), bit 1 = border_add (ws -> dx)
 int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
-                      hipStream_t st, bool with_main = true) {
+                      hipStream_t st, bool with_main = true, int phase = 3) {
     const int H = d->H, W = d->W, C = d->Cin;
     const bool bf16 = d->dtype == MMH_BF16;
     float* rows = static_cast<float*>(ws);                       // [B][2][W][C]
@@ -1972,7 +1973,9 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     if (bf16) MMH_REQUIRE(bf16_ok(main), "bf16 dgrad needs Cout %% 64 == 0 (Cout=%d)", d->Cout);
     if (with_main) mp.p[n++] = main;      // else: the main term was produced by the Winograd path
     mp.n = n;
-    int rc;
+    int rc = 0;
+    if (!(phase & 1)) {
+    } else
     if (!bf16 && g_conv_bn256 == 2 && C % 256 == 0) {   // measured: no gain for the [n][k] weight tile
         if (with_main) mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
         rc = launch_multi_t<256, 2, 2>(mp, false, st);
@@ -1980,6 +1983,7 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);
     else rc = launch_multi_t<32, 4, 1>(mp, bf16, st);
     if (rc) return rc;
+    if (!(phase & 2)) return 0;
     const int nr = (H - 2 == 1) ? 1 : 2, nc = (W - 2 == 1) ? 1 : 2;
     const int64_t total = (int64_t)d->B * (nr * W + (H - nr) * nc) * (C / 4);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
@@ -2696,13 +2700,15 @@ int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accum
 size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d) { return d ? reflect1_ws_bytes(d) : 0; }
 
 int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
-                            size_t ws_bytes, mmh_stream_t s) {
+                            size_t ws_bytes, int phase, mmh_stream_t s) {
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == MMH_PAD_REFLECT &&
                     d->H >= 3 && d->W >= 3 && d->x_cs == d->Cin,
                 "mmh_conv2d_dgrad_border: needs a dense 3x3 stride-1 reflect-pad-1 conv");
-    MMH_REQUIRE(dy && w && dx && ws && ws_bytes >= reflect1_ws_bytes(d), "mmh_conv2d_dgrad_border: bad buffers");
-    return do_dgrad_reflect1(d, dy, w, dx, ws, mmh::as_stream(s), false);
+    MMH_REQUIRE(phase >= 1 && phase <= 3, "mmh_conv2d_dgrad_border: phase must be 1 (GEMMs), 2 (add) or 3 (both)");
+    MMH_REQUIRE(dy && w && (dx || !(phase & 2)) && ws && ws_bytes >= reflect1_ws_bytes(d),
+                "mmh_conv2d_dgrad_border: bad buffers");
+    return do_dgrad_reflect1(d, dy, w, dx, ws, mmh::as_stream(s), false, phase);
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

@@ -50,7 +50,7 @@ SIGNATURES = {
     "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "mmh_wino_dw": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mmh_conv2d_dgrad_border_ws_bytes": (_sz, [_DP]),
-    "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv7_thin_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv7_thin_dgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv7_thin_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),

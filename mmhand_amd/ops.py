@@ -169,7 +169,9 @@ def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=Fals
 def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
     """fp32 3x3 / stride 1 / pad 1 dgrad (folded) by Winograd: the zero-padded correlation of dy
     with the flipped filter gives g on the real domain; reflect padding adds the eight border
-    terms exactly as the direct path does."""
+    terms exactly as the direct path does.  (Running the border GEMMs on a second stream beside
+    the transforms was measured 2.6 % SLOWER per step than in line: the two cross-stream waits
+    per conv cost more than the ~100 us of latency-bound GEMMs they hide.)"""
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
@@ -177,7 +179,7 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
     if reflect:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
-        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4,
+        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
                _stream())
     return dx
 
