@@ -1906,6 +1906,7 @@ size_t reflect1_ws_bytes(const mmh_conv_desc* d) {
     return (size_t)d->B * (2 * d->W + 2 * d->H + 4) * d->Cin * sizeof(float);
 }
 
+int g_border_bn64 = 1;  // border-only dgrad launches (Winograd path): 64-wide tiles
 // phase: bit 0 = the GEMMs (border pieces into ws, main term into dx), bit 1 = border_add (ws -> dx)
 int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
                       hipStream_t st, bool with_main = true, int phase = 3) {
@@ -1979,8 +1980,8 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     if (!bf16 && g_conv_bn256 == 2 && C % 256 == 0) {   // measured: no gain for the [n][k] weight tile
         if (with_main) mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
         rc = launch_multi_t<256, 2, 2>(mp, false, st);
-    } else if (C > 64) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
-    else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);
+    } else if (C > 64 && !(g_border_bn64 && !with_main && !bf16)) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
+    else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);   // border-only: narrower tiles, 2x the workgroups
     else rc = launch_multi_t<32, 4, 1>(mp, bf16, st);
     if (rc) return rc;
     if (!(phase & 2)) return 0;
@@ -2501,6 +2502,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_wgrad_occ")) { g_wino_wgrad_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
     if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
+    if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_slots")) { g_wino_wgrad_slots = value; return 0; }
