@@ -97,20 +97,26 @@ int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* 
  * dgrad: the same three stages on dy with zero padding and the flipped filter give g on the
  *        real domain; mmh_conv2d_dgrad_border adds the eight reflect-border terms.
  * wgrad: Yh = mmh_wino_dy(dy) = A dY A^T; dU = mmh_wino_wgrad_gemm(V, Yh) (P split-K GEMMs over
- *        the tiles, deterministic slab reduction); dw = mmh_wino_dw(dU) = G^T dU G.          */
-int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile,
+ *        the tiles, deterministic slab reduction); dw = mmh_wino_dw(dU) = G^T dU G.
+ * dtype = MMH_F32: every Winograd-domain tensor is fp32 (tile 2 or 4).
+ * dtype = MMH_BF16 (tile 2 only; the --opt_level O1/O2 path): U, V, M and Yh are bf16 in HBM,
+ *        transforms compute in fp32 and round once, the GEMMs run on the bf16 MFMA with fp32
+ *        accumulation; x, y, dy, dU, dw, bias stay fp32.  bf16 U is [P][N][K] (contraction index
+ *        contiguous).  Needs K % 64 == 0, N % 32 == 0 (wgrad: Cin, Cout % 128 == 0).        */
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, int dtype,
                      void* U, mmh_stream_t s);
-int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile,
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype,
                    void* V, mmh_stream_t s);
-int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, void* Yh,
+int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh,
                 mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
-                  int nbatch, mmh_stream_t s);
+                  int nbatch, int dtype, mmh_stream_t s);
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,
-                    int act, int tile, mmh_stream_t s);
+                    int act, int tile, int dtype, mmh_stream_t s);
 size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);
 int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout,
-                        int nbatch, void* ws, size_t ws_bytes, void* dU, mmh_stream_t s);
+                        int nbatch, int dtype, void* ws, size_t ws_bytes, void* dU,
+                        mmh_stream_t s);
 int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate,
                 mmh_stream_t s);
 size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d);

@@ -26,6 +26,28 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+    return r;
+}
+// 4-channel element access of the Winograd-domain tensors: fp32 (float4) or bf16 (8 bytes, RNE)
+template <bool BF>
+__device__ __forceinline__ void wst4(void* base, long long idx4, float4 v) {
+    if (BF) reinterpret_cast<bf16x4*>(base)[idx4] = to_bf16x4(v);
+    else reinterpret_cast<float4*>(base)[idx4] = v;
+}
+template <bool BF>
+__device__ __forceinline__ float4 wld4(const void* base, long long idx4) {
+    if (BF) {
+        const bf16x4 r = reinterpret_cast<const bf16x4*>(base)[idx4];
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    return reinterpret_cast<const float4*>(base)[idx4];
+}
 
 constexpr int BM = 128;   // rows (pixels, or (tap,ci) for wgrad) per workgroup
 constexpr int BK = 32;    // contraction depth per k-step
@@ -813,10 +835,12 @@ __global__ void __launch_bounds__(256, OCC) wino_wgrad_gemm_kernel(const WinoWgr
 //   (16 GEMMs)    : M[xi][tile][N] = V[xi] . U[xi]
 //   wino_output   : y tile = A^T M A (+bias, activation)
 // ---------------------------------------------------------------------------
-__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin,
+template <bool BF>
+__global__ void wino_weights_kernel(const float* __restrict__ w, void* __restrict__ Uv, int Cin,
                                     int Cout, int flip_transpose) {
-    // w: [3][3][Cin][Cout].  U: [16][K][N] with (K,N) = (Cin,Cout), or (Cout,Cin) with the taps
-    // flipped when flip_transpose (the dgrad filter).
+    // w: [3][3][Cin][Cout].  fp32 U: [16][K][N] with (K,N) = (Cin,Cout), or (Cout,Cin) with the taps
+    // flipped when flip_transpose (the dgrad filter).  bf16 U: [16][N][K] (contraction index
+    // contiguous, what the bf16 MFMA operand reads want): [Cout][Cin], or [Cin][Cout] flipped.
     const int total = Cin * Cout;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -838,13 +862,16 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
         t[3][b] = g[2][b];
     }
     const size_t plane = (size_t)Cin * Cout;
-    const size_t o = flip_transpose ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
+    const size_t o = (flip_transpose != 0) != BF ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        U[(size_t)(a * 4 + 0) * plane + o] = t[a][0];
-        U[(size_t)(a * 4 + 1) * plane + o] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-        U[(size_t)(a * 4 + 2) * plane + o] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-        U[(size_t)(a * 4 + 3) * plane + o] = t[a][2];
+        const float u4[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                             t[a][2]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (BF) static_cast<__bf16*>(Uv)[(size_t)(a * 4 + b) * plane + o] = (__bf16)u4[b];
+            else static_cast<float*>(Uv)[(size_t)(a * 4 + b) * plane + o] = u4[b];
+        }
     }
 }
 
@@ -852,7 +879,8 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // V[xi][tile][C]: one thread per (tile, 4 channels).  Padding 1, reflect or zero.
-__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H,
+template <bool BF>
+__global__ void wino_input_kernel(const float* __restrict__ x, void* __restrict__ V, int B, int H,
                                   int W, int C4, int reflect) {
     const int TH = H / 2, TW = W / 2;
     const long long tiles = (long long)B * TH * TW;
@@ -890,18 +918,19 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
         t[3][q] = f4sub(d[1][q], d[3][q]);
     }
     const long long plane = tiles * C4;
-    float4* out = reinterpret_cast<float4*>(V) + tile * C4 + c;
+    const long long o = tile * C4 + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        out[(long long)(r * 4 + 0) * plane] = f4sub(t[r][0], t[r][2]);
-        out[(long long)(r * 4 + 1) * plane] = f4add(t[r][1], t[r][2]);
-        out[(long long)(r * 4 + 2) * plane] = f4sub(t[r][2], t[r][1]);
-        out[(long long)(r * 4 + 3) * plane] = f4sub(t[r][1], t[r][3]);
+        wst4<BF>(V, (long long)(r * 4 + 0) * plane + o, f4sub(t[r][0], t[r][2]));
+        wst4<BF>(V, (long long)(r * 4 + 1) * plane + o, f4add(t[r][1], t[r][2]));
+        wst4<BF>(V, (long long)(r * 4 + 2) * plane + o, f4sub(t[r][2], t[r][1]));
+        wst4<BF>(V, (long long)(r * 4 + 3) * plane + o, f4sub(t[r][1], t[r][3]));
     }
 }
 
 // y[b, 2ty+i, 2tx+j, :] = (A^T M A)[i][j] (+ bias, act).  One thread per (tile, 4 channels).
-__global__ void wino_output_kernel(const float* __restrict__ M, float* __restrict__ y,
+template <bool BF>
+__global__ void wino_output_kernel(const void* __restrict__ M, float* __restrict__ y,
                                    const float* __restrict__ bias, int B, int H, int W, int C4,
                                    int act) {
     const int TH = H / 2, TW = W / 2;
@@ -915,12 +944,11 @@ __global__ void wino_output_kernel(const float* __restrict__ M, float* __restric
     const int ty = (int)((tile / TW) % TH);
     const int b = (int)(tile / ((long long)TW * TH));
     const long long plane = tiles * C4;
-    const float4* in = reinterpret_cast<const float4*>(M) + tile * C4 + c;
     float4 m[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[r][q] = in[(long long)(r * 4 + q) * plane];
+        for (int q = 0; q < 4; ++q) m[r][q] = wld4<BF>(M, (long long)(r * 4 + q) * plane + tile * C4 + c);
     float4 s[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -949,16 +977,9 @@ __global__ void wino_output_kernel(const float* __restrict__ M, float* __restric
 // Accumulation and output are fp32.  k-step = 64 channels of one tap; needs channels % 64 == 0
 // (the 3x3 stacks; the small-Cin stems keep the fp32 kernel).
 // ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK16 = 64;     // contraction depth per k-step (bf16 kernel)
 constexpr int LDH = 72;      // LDS row pitch in bf16 elements (144 B: conflict-free ds_read_b128)
 
-__device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
-    bf16x4 r;
-    r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
-    return r;
-}
 
 template <int BN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int bx, const int by,
@@ -1586,6 +1607,306 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
         }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 Winograd-domain GEMMs (F(2x2,3x3) under --opt_level O1/O2): V, U, M, Yhat are bf16 in HBM,
+// products accumulate in fp32 on v_mfma_f32_32x32x16_bf16.
+//
+// wino_gemm_bf16_kernel: P planes of C[M x N] = A[M x K] . B[N x K]^T, both operands with the
+// contraction index contiguous (V [P][tiles][K], U [P][N][K]), so both MFMA operands are one
+// ds_read_b128 per lane from [row][LDH] LDS tiles.  Same persistent / XCD-aware structure as
+// wino_gemm_kernel; k-step = 64.  The fp32 accumulators leave as bf16: each lane swaps with its
+// neighbour (DPP quad_perm) so that even lanes store the (n, n+1) pair of one row and odd lanes
+// the pair of the next row - 4-byte stores, 64 contiguous bytes per row and half-wave.
+// Requires K % 64 == 0 and N % 32 == 0.
+// ---------------------------------------------------------------------------
+struct WinoGemmBfKP {
+    const __bf16* A;
+    const __bf16* B;
+    __bf16* C;
+    int M, K, N, P;
+    int MT, NT, W, Wx, nb;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBfKP p) {
+    constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* const As = reinterpret_cast<__bf16*>(smem);     // [128][LDH]
+    __bf16* const Bs = As + BM * LDH;                       // [128][LDH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int chunk = tid & 7, lrow = tid >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wend = min(p.W, (xcd + 1) * p.Wx);
+    int wc = xcd * p.Wx + slot;
+    if (wc >= wend) return;
+    const int KS = p.K / BK16;
+    const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 2u;
+    const unsigned b_bytes = (unsigned)p.N * (unsigned)p.K * 2u;
+    const unsigned c_bytes = (unsigned)p.M * (unsigned)p.N * 2u;
+
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned a_off[4], b_off[4];
+    auto setup_load = [&](int w) {
+        const int nt = w % p.NT;
+        const int t = w / p.NT;
+        const int mt = t % p.MT;
+        const int xi = t / p.MT;
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A) + (size_t)xi * p.M * p.K, 0, a_bytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.B) + (size_t)xi * p.N * p.K, 0, b_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // rows past M / N start beyond num_records: the loads return zeros
+            a_off[i] = ((unsigned)(mt * BM + lrow + 32 * i) * (unsigned)p.K + chunk * 8u) * 2u;
+            b_off[i] = ((unsigned)(nt * BN + lrow + 32 * i) * (unsigned)p.K + chunk * 8u) * 2u;
+        }
+    };
+    uint4 ra[4], rb[4];
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i], 0, 0));
+            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], 0, 0));
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&As[(lrow + 32 * i) * LDH + chunk * 8]) = ra[i];
+            *reinterpret_cast<uint4*>(&Bs[(lrow + 32 * i) * LDH + chunk * 8]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    setup_load(wc);
+    issue_loads();
+    store_tiles();
+    __syncthreads();
+    for (;;) {
+        for (int ks = 0; ks < KS; ++ks) {
+            bool more = true;
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a_off[i] += BK16 * 2u; b_off[i] += BK16 * 2u; }
+            } else {
+                more = wc + p.nb < wend;
+                if (more) setup_load(wc + p.nb);
+            }
+            if (more) issue_loads();
+#pragma unroll
+            for (int s16 = 0; s16 < BK16 / 16; ++s16) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 32 + l31) * LDH + s16 * 16 + h * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + j * 32 + l31) * LDH + s16 * 16 + h * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+                const int nt = wc % p.NT;
+                const int t = wc / p.NT;
+                const int mt = t % p.MT;
+                const int xi = t / p.MT;
+                const __amdgpu_buffer_rsrc_t rsC =
+                    __builtin_amdgcn_make_buffer_rsrc(p.C + (size_t)xi * p.M * p.N, 0, c_bytes, 0x00020000);
+                const unsigned n2 = (unsigned)p.N * 2u;     // bytes per row
+                const int odd = l31 & 1;
+                const int ncol0 = nt * BN + wn * WTN;
+                // even lanes store (n, n+1) of row m, odd lanes (n-1, n) of row m+1; rows past M fall
+                // beyond num_records (the row term stays in the range-checked vector offset)
+                unsigned vbase = (unsigned)(mt * BM + wm * WTM + 4 * h + odd) * n2 + (unsigned)(ncol0 + (l31 & ~1)) * 2u;
+                asm volatile("" : "+v"(vbase));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (ncol0 + j * 32 < p.N) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) {
+                                const float x0 = acc[i][j][r], x1 = acc[i][j][r + 1];
+                                const float y0 = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x0), 0xB1, 0xF, 0xF, true));
+                                const float y1 = __builtin_bit_cast(
+                                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x1), 0xB1, 0xF, 0xF, true));
+                                const unsigned v = odd ? pack_bf16x2(y1, x1) : pack_bf16x2(x0, y0);
+                                const unsigned rd = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n2;
+                                __builtin_amdgcn_raw_buffer_store_b32(v, rsC, vbase + rd + j * 64u, 0, 0);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
+        wc += p.nb;
+        if (wc >= wend) break;
+    }
+}
+
+// wino_wgrad_gemm_bf16_kernel: slab[xi][split][Cin x Cout] (fp32) = V[xi][t0:t1]^T . Yh[xi][t0:t1], bf16
+// operands with the contraction index (tile) as the SLOW dimension: tiles sit in LDS as
+// [tile][channel] and both MFMA operands are read transposed (ds_read_b64_tr_b16, tr_frag).
+// Persistent / XCD-aware like wino_wgrad_gemm_kernel; k-step = 64 tiles.  Cin, Cout % 128 == 0.
+struct WinoWgradBfKP {
+    const __bf16* V;
+    const __bf16* Y;
+    float* slab;
+    int T, Cin, Cout, P, S, t_per_split, MT, NT, W, Wx, nb;
+};
+
+__global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const WinoWgradBfKP p) {
+    constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* const As = reinterpret_cast<__bf16*>(smem);     // [BKP tiles][LDT]
+    __bf16* const Bs = As + BKP * LDT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wend = min(p.W, (xcd + 1) * p.Wx);
+    int wc = xcd * p.Wx + slot;
+    if (wc >= wend) return;
+    const int krow = tid >> 4, kchunk = tid & 15;       // 16 tile rows x 16 chunks of 8 channels per pass
+    const unsigned a_step = (unsigned)BKP * (unsigned)p.Cin * 2u, b_step = (unsigned)BKP * (unsigned)p.Cout * 2u;
+
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned a_off, b_off;
+    auto item_ksteps = [&](int w) {
+        const int split = (w / (p.MT * p.NT)) % p.S;
+        const int t0 = split * p.t_per_split;
+        const int t1 = min(p.T, t0 + p.t_per_split);
+        return t1 > t0 ? (t1 - t0 + BKP - 1) / BKP : 0;
+    };
+    auto setup_load = [&](int w) {
+        const int nt = w % p.NT;
+        int t = w / p.NT;
+        const int mt = t % p.MT; t /= p.MT;
+        const int split = t % p.S;
+        const int xi = t / p.S;
+        const int t0 = split * p.t_per_split;
+        const int t1 = min(p.T, t0 + p.t_per_split);
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.V) + (size_t)xi * p.T * p.Cin, 0,
+                                                (unsigned)t1 * (unsigned)p.Cin * 2u, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Y) + (size_t)xi * p.T * p.Cout, 0,
+                                                (unsigned)t1 * (unsigned)p.Cout * 2u, 0x00020000);
+        a_off = ((unsigned)(t0 + krow) * (unsigned)p.Cin + (unsigned)(mt * BM + kchunk * 8)) * 2u;
+        b_off = ((unsigned)(t0 + krow) * (unsigned)p.Cout + (unsigned)(nt * BN + kchunk * 8)) * 2u;
+    };
+    uint4 ra[4], rb[4];
+    auto issue_loads = [&]() {
+        const unsigned a16 = 16u * (unsigned)p.Cin * 2u, b16 = 16u * (unsigned)p.Cout * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off + i * a16, 0, 0));
+            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off + i * b16, 0, 0));
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&As[(krow + 16 * i) * LDT + kchunk * 8]) = ra[i];
+            *reinterpret_cast<uint4*>(&Bs[(krow + 16 * i) * LDT + kchunk * 8]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    setup_load(wc);
+    issue_loads();
+    store_tiles();
+    __syncthreads();
+    for (;;) {
+        const int KS = item_ksteps(wc);
+        for (int ks = 0; ks < KS; ++ks) {
+            bool more = true;
+            if (ks + 1 < KS) { a_off += a_step; b_off += b_step; }
+            else {
+                more = wc + p.nb < wend;
+                if (more) setup_load(wc + p.nb);
+            }
+            if (more) issue_loads();
+#pragma unroll
+            for (int s16 = 0; s16 < BKP / 16; ++s16) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = tr_frag(As, s16 * 16, wm * WTM + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(Bs, s16 * 16, wn * WTN + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (ks == KS - 1) {
+                const int nt = wc % p.NT;
+                int t = wc / p.NT;
+                const int mt = t % p.MT; t /= p.MT;
+                const unsigned sl_bytes = (unsigned)p.Cin * (unsigned)p.Cout * 4u;
+                const __amdgpu_buffer_rsrc_t rsC =
+                    __builtin_amdgcn_make_buffer_rsrc(p.slab + (size_t)t * p.Cin * p.Cout, 0, sl_bytes, 0x00020000);
+                const unsigned n4 = (unsigned)p.Cout * 4u;
+                unsigned vbase = (unsigned)(mt * BM + wm * WTM + 4 * h) * n4 + (unsigned)(nt * BN + wn * WTN + l31) * 4u;
+                asm volatile("" : "+v"(vbase));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rsC, vbase + j * 128u,
+                                                                  (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n4, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+            __syncthreads();
+            if (more) store_tiles();
+            __syncthreads();
+        }
+        wc += p.nb;
+        if (wc >= wend) break;
+    }
+}
+
 // dw[i] (+)= sum_z slab[z][i], fixed order -> deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                    int64_t n4_total, int splits, int accumulate, int64_t n4) {
@@ -1994,7 +2315,8 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
 }
 
 // Yhat[xi][tile][C] = A dY A^T for the 2x2 output-gradient tile (Winograd wgrad).
-__global__ void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Yh, int B, int H, int W,
+template <bool BF>
+__global__ void wino_dy_kernel(const float* __restrict__ dy, void* __restrict__ Yh, int B, int H, int W,
                                int C4) {
     const int TH = H / 2, TW = W / 2;
     const long long tiles = (long long)B * TH * TW;
@@ -2013,13 +2335,13 @@ __global__ void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__
     float4 t[4][2] = {{y00, y01}, {f4add(y00, y10), f4add(y01, y11)}, {f4sub(y00, y10), f4sub(y01, y11)},
                       {f4sub(z, y10), f4sub(z, y11)}};
     const long long plane = tiles * C4;
-    float4* out = reinterpret_cast<float4*>(Yh) + tile * C4 + c;
+    const long long o = tile * C4 + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        out[(long long)(r * 4 + 0) * plane] = t[r][0];
-        out[(long long)(r * 4 + 1) * plane] = f4add(t[r][0], t[r][1]);
-        out[(long long)(r * 4 + 2) * plane] = f4sub(t[r][0], t[r][1]);
-        out[(long long)(r * 4 + 3) * plane] = f4sub(z, t[r][1]);
+        wst4<BF>(Yh, (long long)(r * 4 + 0) * plane + o, t[r][0]);
+        wst4<BF>(Yh, (long long)(r * 4 + 1) * plane + o, f4add(t[r][0], t[r][1]));
+        wst4<BF>(Yh, (long long)(r * 4 + 2) * plane + o, f4sub(t[r][0], t[r][1]));
+        wst4<BF>(Yh, (long long)(r * 4 + 3) * plane + o, f4sub(z, t[r][1]));
     }
 }
 
@@ -2312,6 +2634,7 @@ int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
 int g_wino_bn256 = 0;   // 128-wide tiles: 3-5 % faster than 256 for these short-K GEMMs (more workgroups per CU)
 int g_wino_xcd = 1;     // XCD-contiguous tile order in the input transform (halo rows meet in one L2)
 int g_wino_gemm_v2 = 1; // dedicated persistent kernel (wino_gemm_kernel) when K % 32 == 0 and N >= 64
+int g_wino_bf16_occ = 3;   // resident workgroups per CU the bf16 Winograd GEMM grids are sized for
 int g_wino_gemm_occ = 3;   // resident workgroups per CU the persistent grid is sized for
 
 template <int BN>
@@ -2504,6 +2827,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
+    if (!strcmp(key, "wino_bf16_occ")) { g_wino_bf16_occ = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_slots")) { g_wino_wgrad_slots = value; return 0; }
     return mmh::fail("mmh_set_option: unknown key '%s'", key);
@@ -2527,20 +2851,30 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
 // ---- Winograd stages (tile = 2: F(2x2,3x3), 16 planes; tile = 4: F(4x4,3x3), 36 planes) ----
 static int wino_planes(int tile) { return tile == 4 ? 36 : 16; }
 
-int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, void* U, mmh_stream_t s) {
-    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0 && (tile == 2 || tile == 4), "mmh_wino_weights: bad arguments");
+static bool wino_dtype_ok(int dtype, int tile) { return dtype == MMH_F32 || (dtype == MMH_BF16 && tile == 2); }
+
+int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, int dtype, void* U,
+                     mmh_stream_t s) {
+    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0 && (tile == 2 || tile == 4) && wino_dtype_ok(dtype, tile),
+                "mmh_wino_weights: bad arguments (bf16 needs tile 2)");
+    const dim3 grid((Cin * Cout + 255) / 256);
     if (tile == 4)
-        hipLaunchKernelGGL(wino4_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+        hipLaunchKernelGGL(wino4_weights_kernel, grid, dim3(256), 0, mmh::as_stream(s),
                            static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+    else if (dtype == MMH_BF16)
+        hipLaunchKernelGGL(wino_weights_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(w), U, Cin, Cout, flip_transpose);
     else
-        hipLaunchKernelGGL(wino_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, mmh::as_stream(s),
-                           static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+        hipLaunchKernelGGL(wino_weights_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(w), U, Cin, Cout, flip_transpose);
     return mmh::check_launch("wino_weights_kernel");
 }
 
-int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, void* V, mmh_stream_t s) {
+int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype, void* V,
+                   mmh_stream_t s) {
     MMH_REQUIRE(x && V && B > 0 && (tile == 2 || tile == 4) && H >= tile + 2 && W >= tile + 2 &&
-                    H % tile == 0 && W % tile == 0 && C % 4 == 0, "mmh_wino_input: bad arguments");
+                    H % tile == 0 && W % tile == 0 && C % 4 == 0 && wino_dtype_ok(dtype, tile),
+                "mmh_wino_input: bad arguments");
     const long long tiles = (long long)B * (H / tile) * (W / tile);
     if (tile == 4) {
         const long long total = tiles * (C / 2);
@@ -2550,14 +2884,20 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
                            (g_wino_xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
     } else {
         const long long total = tiles * (C / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
-                           static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C / 4, reflect);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_input_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(x), V, B, H, W, C / 4, reflect);
+        else
+            hipLaunchKernelGGL(wino_input_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(x), V, B, H, W, C / 4, reflect);
     }
     return mmh::check_launch("wino_input_kernel");
 }
 
-int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, void* Yh, mmh_stream_t s) {
-    MMH_REQUIRE(dy && Yh && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0,
+int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh, mmh_stream_t s) {
+    MMH_REQUIRE(dy && Yh && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0 &&
+                    wino_dtype_ok(dtype, tile),
                 "mmh_wino_dy: bad arguments");
     const long long tiles = (long long)B * (H / tile) * (W / tile);
     if (tile == 4) {
@@ -2566,22 +2906,51 @@ int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, void* Yh, 
                            static_cast<const float*>(dy), static_cast<float*>(Yh), B, H, W, C / 2);
     } else {
         const long long total = tiles * (C / 4);
-        hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
-                           static_cast<const float*>(dy), static_cast<float*>(Yh), B, H, W, C / 4);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_dy_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(dy), Yh, B, H, W, C / 4);
+        else
+            hipLaunchKernelGGL(wino_dy_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(dy), Yh, B, H, W, C / 4);
     }
     return mmh::check_launch("wino_dy_kernel");
 }
 
-int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, int nbatch,
+static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tiles, int K, int N, int nbatch,
+                          hipStream_t st) {
+    MMH_REQUIRE(K % BK16 == 0 && N % 32 == 0, "mmh_wino_gemm (bf16): needs K %% 64 == 0 and N %% 32 == 0");
+    MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
+    WinoGemmBfKP p{};
+    p.A = static_cast<const __bf16*>(V); p.B = static_cast<const __bf16*>(U); p.C = static_cast<__bf16*>(Mo);
+    p.M = (int)tiles; p.K = K; p.N = N; p.P = nbatch;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (N + 127) / 128;
+    p.W = nbatch * p.MT * p.NT;
+    p.Wx = (p.W + 7) / 8;
+    p.nb = std::min(p.Wx, 32 * g_wino_bf16_occ);
+    constexpr size_t lds = (size_t)(2 * BM * LDH) * sizeof(__bf16);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel, lds);
+    if (ready != 0) return ready;
+    hipLaunchKernelGGL(wino_gemm_bf16_kernel, dim3(8 * p.nb), dim3(256), lds, st, p);
+    return mmh::check_launch("wino_gemm_bf16_kernel");
+}
+
+int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, int nbatch, int dtype,
                   mmh_stream_t s) {
-    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0 && nbatch > 0, "mmh_wino_gemm: bad arguments");
+    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0 && nbatch > 0 &&
+                    (dtype == MMH_F32 || dtype == MMH_BF16),
+                "mmh_wino_gemm: bad arguments");
+    if (dtype == MMH_BF16) return wino_gemm_bf16(V, U, M, tiles, K, N, nbatch, mmh::as_stream(s));
     return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
                      K, N, mmh::as_stream(s), nbatch);
 }
 
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,
-                    mmh_stream_t s) {
-    MMH_REQUIRE(M && y && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0,
+                    int dtype, mmh_stream_t s) {
+    MMH_REQUIRE(M && y && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0 &&
+                    wino_dtype_ok(dtype, tile),
                 "mmh_wino_output: bad arguments");
     const long long tiles = (long long)B * (H / tile) * (W / tile);
     if (tile == 4) {
@@ -2591,9 +2960,13 @@ int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int 
                            static_cast<const float*>(bias), B, H, W, C / 2, act);
     } else {
         const long long total = tiles * (C / 4);
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           mmh::as_stream(s), static_cast<const float*>(M), static_cast<float*>(y),
-                           static_cast<const float*>(bias), B, H, W, C / 4, act);
+        const dim3 grid((unsigned)((total + 255) / 256));
+        if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s), M,
+                               static_cast<float*>(y), static_cast<const float*>(bias), B, H, W, C / 4, act);
+        else
+            hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s), M,
+                               static_cast<float*>(y), static_cast<const float*>(bias), B, H, W, C / 4, act);
     }
     return mmh::check_launch("wino_output_kernel");
 }
@@ -2613,15 +2986,38 @@ size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch
     return (size_t)nbatch * wino_wgrad_splits(Cin, Cout, tiles, nbatch) * Cin * Cout * sizeof(float);
 }
 
-int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout, int nbatch, void* ws,
-                        size_t ws_bytes, void* dU, mmh_stream_t s) {
-    MMH_REQUIRE(V && Yh && ws && dU && tiles > 0 && Cin % 4 == 0 && Cout % 4 == 0,
+int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout, int nbatch, int dtype,
+                        void* ws, size_t ws_bytes, void* dU, mmh_stream_t s) {
+    MMH_REQUIRE(V && Yh && ws && dU && tiles > 0 && Cin % 4 == 0 && Cout % 4 == 0 &&
+                    (dtype == MMH_F32 || dtype == MMH_BF16),
                 "mmh_wino_wgrad_gemm: bad arguments");
     MMH_REQUIRE(ws_bytes >= mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, nbatch),
                 "mmh_wino_wgrad_gemm: workspace too small");
     MMH_REQUIRE(tiles * (long long)std::max(Cin, Cout) < (1ll << 30), "mmh_wino_wgrad_gemm: tensor too large");
     hipStream_t st = mmh::as_stream(s);
     const int splits = wino_wgrad_splits(Cin, Cout, tiles, nbatch);
+    if (dtype == MMH_BF16) {
+        MMH_REQUIRE(Cin % BM == 0 && Cout % 128 == 0, "mmh_wino_wgrad_gemm (bf16): needs Cin, Cout %% 128 == 0");
+        WinoWgradBfKP q{};
+        q.V = static_cast<const __bf16*>(V); q.Y = static_cast<const __bf16*>(Yh); q.slab = static_cast<float*>(ws);
+        q.T = (int)tiles; q.Cin = Cin; q.Cout = Cout; q.P = nbatch;
+        q.t_per_split = (int)(mmh::cdiv(mmh::cdiv(tiles, splits), BKP) * BKP);
+        q.S = (int)mmh::cdiv(tiles, q.t_per_split);
+        q.MT = Cin / BM; q.NT = Cout / 128;
+        q.W = nbatch * q.S * q.MT * q.NT;
+        q.Wx = (q.W + 7) / 8;
+        q.nb = std::min(q.Wx, 32 * g_wino_bf16_occ);
+        constexpr size_t lds = (size_t)(2 * BKP * LDT) * sizeof(__bf16);
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(wino_wgrad_gemm_bf16_kernel, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL(wino_wgrad_gemm_bf16_kernel, dim3(8 * q.nb), dim3(256), lds, st, q);
+        if (int rc = mmh::check_launch("wino_wgrad_gemm_bf16_kernel")) return rc;
+        const int64_t n4 = (int64_t)Cin * Cout / 4;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
+                           dim3(256), 0, st, q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4);
+        return mmh::check_launch("wino wgrad gemm (bf16)");
+    }
     if (g_wino_wgrad_v2 && Cin % BM == 0 && Cout % 128 == 0) {
         WinoWgradKP q{};
         q.V = static_cast<const float*>(V); q.Y = static_cast<const float*>(Yh); q.slab = static_cast<float*>(ws);

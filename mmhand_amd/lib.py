@@ -41,13 +41,13 @@ SIGNATURES = {
     "mmh_conv2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv2d_dgrad_folded_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_dgrad_folded": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mmh_wino_weights": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "mmh_wino_input": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mmh_wino_dy": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
-    "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmh_wino_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_input": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_dy": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mmh_wino_wgrad_gemm_ws_bytes": (_sz, [_i64, _i, _i, _i]),
-    "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "mmh_wino_dw": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mmh_conv2d_dgrad_border_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),

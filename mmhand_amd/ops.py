@@ -107,13 +107,26 @@ KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
 # 7x7 convs with <= 4 output columns (Generator head fprop, Discriminator-stem dgrad towards the
 # generated image) on the vector-ALU kernel of conv_thin.hip; MMH_THIN=0 keeps them on the MFMA path
 USE_THIN = os.environ.get("MMH_THIN", "1") != "0"
+# --opt_level O1/O2: the 3x3 stride-1 convs with channels % 128 == 0 on bf16 Winograd F(2x2,3x3)
+USE_WINOGRAD_BF16 = os.environ.get("MMH_WINOGRAD_BF16", "1") != "0"
 
 
-def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16):
+# bf16 Winograd engages per pass where it was measured faster than the direct bf16 kernel at B=32,
+# 64x64 (tools/bench_wino_bf16.py): fprop 512->512 1.50x, 512->256 1.13x, 256->256 0.90x; dgrad
+# 1.31x / 0.97x / 0.83x; wgrad 1.91x / 1.49x / 1.34x.  Minimum Cin*Cout per pass:
+WINO_BF16_MIN = {"fprop": 512 * 256, "dgrad": 512 * 512, "wgrad": 0}
+
+
+def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
     """0 = direct kernel, else the Winograd output-tile size (2 or 4)."""
-    if not (USE_WINOGRAD and not bf16 and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0
-            and Cout % 32 == 0):
+    if not (USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cout % 32 == 0):
         return 0
+    if bf16:
+        # bf16 MFMA path: F(2x2,3x3) with bf16 Winograd-domain tensors (F(4x4,3x3) would amplify
+        # the bf16 rounding ~8x: 2e-2 vs 4e-3 relative); the bf16 GEMM kernels need channels % 128
+        ok = (USE_WINOGRAD_BF16 and H % 2 == 0 and W_ % 2 == 0 and H >= 4 and W_ >= 4
+              and Cin % 128 == 0 and Cout % 128 == 0 and Cin * Cout >= WINO_BF16_MIN[op])
+        return 2 if ok else 0
     # measured on MI355X at B=32: F(4,3) wins from 64x64 channels up (1.1-2.8x), F(2,3) only from
     # 256x256 up (1.25-1.6x; transform-bound below)
     if WINOGRAD_TILE == 4 and H % 4 == 0 and W_ % 4 == 0 and H >= 8 and W_ >= 8 and Cin * Cout >= 64 * 64:
@@ -123,50 +136,56 @@ def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16):
     return 0
 
 
-def wino_weights(w, tile, flip_transpose=False):
-    """Winograd-domain filter U [P,K,N] of a physical 3x3 weight (cached per weights epoch)."""
-    key = (w.data_ptr(), tile, bool(flip_transpose))
+def wino_weights(w, tile, flip_transpose=False, bf16=False):
+    """Winograd-domain filter of a physical 3x3 weight (cached per weights epoch): fp32 U [P,K,N],
+    bf16 U [P,N,K] (contraction index contiguous)."""
+    key = (w.data_ptr(), tile, bool(flip_transpose), bool(bf16))
     ent = _wino_cache.get(key)
     if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
         _, _, cin, cout = w.shape
         P = (tile + 2) ** 2
-        U = torch.empty((P, cout, cin) if flip_transpose else (P, cin, cout), dtype=torch.float32,
-                        device=w.device)
-        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, _ptr(U), _stream())
+        kn = (cout, cin) if flip_transpose else (cin, cout)        # (K, N)
+        U = torch.empty((P, kn[1], kn[0]) if bf16 else (P, kn[0], kn[1]),
+                        dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, L.BF16 if bf16 else L.F32,
+               _ptr(U), _stream())
         ent = (_weights_epoch[0], tuple(w.shape), U)
         _wino_cache[key] = ent
     return ent[2]
 
 
-def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False):
+def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
-    keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor)."""
+    keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor).
+    bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32."""
     B, H, W_, Cin = x.shape
     P = (tile + 2) ** 2
     tiles = B * (H // tile) * (W_ // tile)
-    V = _empty((P, tiles, Cin), x)
-    M = _empty((P, tiles, Cout), x)
+    dt = L.BF16 if bf16 else L.F32
+    wd = torch.bfloat16 if bf16 else torch.float32
+    V = torch.empty((P, tiles, Cin), dtype=wd, device=x.device)
+    M = torch.empty((P, tiles, Cout), dtype=wd, device=x.device)
     y = _empty((B, H, W_, Cout), x)
-    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, dt, _ptr(V), _stream())
     if time_it and fprop_timer is not None and fprop_timer.want_gemm(P, tiles, Cin, Cout):
         e0, e1 = fprop_timer.bracket()      # HIP events around the GEMM launch only (bench.py roofline)
         e0.record()
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, _stream())
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
         e1.record()
     else:
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, _stream())
-    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, _stream())
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
+    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _stream())
     return (y, V) if keep_V else y
 
 
-def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=False):
-    """fp32 3x3 / stride 1 / pad 1 conv by Winograd."""
+def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=False, bf16=False):
+    """3x3 / stride 1 / pad 1 conv by Winograd (fp32, or bf16 Winograd-domain tensors with tile 2)."""
     _chk(x, "x"); _chk(w, "w")
-    return _wino_conv(x, wino_weights(w, tile), bias, w.shape[3], reflect, act, tile, time_it=True,
-                      keep_V=keep_V)
+    return _wino_conv(x, wino_weights(w, tile, False, bf16), bias, w.shape[3], reflect, act, tile, time_it=True,
+                      keep_V=keep_V, bf16=bf16)
 
 
-def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
+def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
     """fp32 3x3 / stride 1 / pad 1 dgrad (folded) by Winograd: the zero-padded correlation of dy
     with the flipped filter gives g on the real domain; reflect padding adds the eight border
     terms exactly as the direct path does.  (Running the border GEMMs on a second stream beside
@@ -175,35 +194,41 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4):
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
-    dx = _wino_conv(dy, wino_weights(w, tile, True), None, Cin, False, L.ACT_NONE, tile)
+    dx = _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, bf16=bf16)
     if reflect:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
+        wb = w
+        if bf16 and Cout % 64 == 0:         # border GEMMs on the bf16 MFMA too
+            d.dtype = L.BF16
+            wb = bf16_weights(w)[0]
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
-        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
+        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(wb), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
                _stream())
     return dx
 
 
-def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None):
+def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
     """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd: dw = G^T [sum_tiles (B^T d B).(A dY A^T)] G.
     V = the transformed input kept by the forward pass (x is then unused and may be None)."""
     _chk(dy, "dy")
     B, H, W_, Cout = dy.shape
     P = (tile + 2) ** 2
     tiles = B * (H // tile) * (W_ // tile)
+    dt = L.BF16 if bf16 else L.F32
+    wd = torch.bfloat16 if bf16 else torch.float32
     if V is None:
         _chk(x, "x")
         Cin = x.shape[3]
-        V = _empty((P, tiles, Cin), x)
-        L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, _ptr(V), _stream())
+        V = torch.empty((P, tiles, Cin), dtype=wd, device=dy.device)
+        L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, dt, _ptr(V), _stream())
     else:
         Cin = V.shape[2]
-        assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous()
-    Yh = _empty((P, tiles, Cout), dy)
-    L.call("mmh_wino_dy", _ptr(dy), B, H, W_, Cout, tile, _ptr(Yh), _stream())
+        assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous() and V.dtype == wd
+    Yh = torch.empty((P, tiles, Cout), dtype=wd, device=dy.device)
+    L.call("mmh_wino_dy", _ptr(dy), B, H, W_, Cout, tile, dt, _ptr(Yh), _stream())
     ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), dy)
     dU = _empty((P, Cin, Cout), dy)
-    L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, _ptr(ws), ws.numel() * 4, _ptr(dU),
+    L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, dt, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
     dw = _empty((3, 3, Cin, Cout), dy)
     L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
@@ -217,7 +242,7 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     assert wc == Cin, f"weight Cin {wc} != x channels {Cin}"
     wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
     if wt:
-        return raw_conv_fprop_wino(x, w, bias, reflect, act, wt)
+        return raw_conv_fprop_wino(x, w, bias, reflect, act, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
     if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 4 == 0:
@@ -259,9 +284,9 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     if (USE_THIN and 0 < dx_channels <= 4 and k == 7 and stride == 1 and pad == 3 and Cout % 4 == 0
             and Cin >= 4):
         return raw_conv_dgrad_thin(dy, w, x_shape, reflect)
-    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
+    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "dgrad")
     if wt:
-        return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt)
+        return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16 and Cout % 64 == 0:
         d.dtype = L.BF16
@@ -278,9 +303,9 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
-    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16)
+    wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "wgrad")
     if wt:
-        return raw_conv_wgrad_wino(x, dy, reflect, wt)
+        return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16:
         d.dtype = L.BF16
@@ -368,7 +393,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.wino_V = 0
         if wt and KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
             # the wgrad pass contracts the same transformed input: keep it instead of x
-            y, V = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, keep_V=True)
+            y, V = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, keep_V=True, bf16=bf16)
             ctx.wino_V = wt
             ctx.save_for_backward(V, w, y if act != L.ACT_NONE else None)
             return y
@@ -388,7 +413,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
             if ctx.wino_V:
-                dw = raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x)
+                dw = raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x, bf16=bf16)
             else:
                 dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:

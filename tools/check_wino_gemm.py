@@ -12,7 +12,7 @@ for v2 in (0, 1):
     for (P, M, K, N) in shapes:
         V = torch.randn(P, M, K, device=dev); U = torch.randn(P, K, N, device=dev)
         out = torch.full((P, M, N), 7.0, device=dev)
-        lib.call("mmh_wino_gemm", V.data_ptr(), U.data_ptr(), out.data_ptr(), M, K, N, P, torch.cuda.current_stream().cuda_stream)
+        lib.call("mmh_wino_gemm", V.data_ptr(), U.data_ptr(), out.data_ptr(), M, K, N, P, lib.F32, torch.cuda.current_stream().cuda_stream)
         ref = torch.bmm(V.double(), U.double())
         err = (out.double() - ref).abs()
         rel = err.sum() / ref.abs().sum()
