@@ -62,6 +62,10 @@ class KernelTimer:
 
     def mean_ms(self):
         ts = [a.elapsed_time(b) for a, b in self.pairs]
+        if os.environ.get("MMH_BENCH_TIMER_DEBUG") == "1":
+            st = sorted(ts)
+            print(f"[timer] n={len(ts)} min={st[0]:.3f} med={st[len(st) // 2]:.3f} max={st[-1]:.3f} "
+                  f"first8={[round(t, 3) for t in ts[:8]]}", file=sys.stderr, flush=True)
         return sum(ts) / len(ts), len(ts)
 
 
@@ -216,9 +220,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(a.warmup):
         model.optimize_parameters()
     barrier()
+    # a generation-2 collection of the interpreter (tens of ms with the autograd graphs alive) in
+    # the middle of an iteration starves the GPU queue; collect now, then keep the collector off
+    # inside the timed region, as mmhand_amd/train.py does between its periodic collections
+    gc.collect()
+    if os.environ.get("MMH_BENCH_GC") != "1":
+        gc.disable()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -226,6 +237,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    gc.enable()
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -253,8 +253,8 @@ class MMHandModel(torch.nn.Module):
             # flag per optimizer step of an iteration, order G, D_PP x DG_ratio, D_PB x DG_ratio
             self._nflags = 1 + 2 * opt.DG_ratio
             self._flags = torch.zeros(self._nflags, dtype=torch.int32, device=self.device)
-            self._flags_host = torch.zeros(self._nflags, dtype=torch.int32).pin_memory()
-            self._flags_event = None
+            self._flags_free = [torch.zeros(self._nflags, dtype=torch.int32).pin_memory() for _ in range(3)]
+            self._flags_pending = []        # [(event, pinned host copy)] of iterations not settled yet
             self.skipped_steps = getattr(self, "skipped_steps", 0)   # optimizer steps skipped so far
             self.last_overflow = False      # did the last settled iteration skip anything
 
@@ -409,23 +409,27 @@ class MMHandModel(torch.nn.Module):
                            self._flags[k - 1:k] if k > 0 else None)
         optimizer.step(skip_flag=self._flags[k:k + 1])
 
-    def _settle_overflow(self):
-        """Fetch the flags of the previous iteration (copied to pinned memory when it ended, long
-        finished by now) and take skipped steps back from the Adam step counts."""
-        if self._flags_event is None:
-            return
-        self._flags_event.synchronize()
-        self._flags_event = None
-        f = self._flags_host.tolist()
-        r = self.opt.DG_ratio
-        per_opt = ((self.optimizer_G, f[0:1]), (self.optimizer_D_PP, f[1:1 + r]),
-                   (self.optimizer_D_PB, f[1 + r:1 + 2 * r]))
-        for o, fl in per_opt:
-            o.step_count -= sum(1 for x in fl if x)
-        self.skipped_steps += sum(1 for x in f if x)
-        self.last_overflow = any(f)
-        if self.last_overflow:
-            self.pprint("non-finite gradient: skipped %d optimizer step(s)" % sum(1 for x in f if x))
+    def _settle_overflow(self, drain=False):
+        """Fetch the overflow flags of finished iterations (copied to pinned memory when each ended)
+        and take skipped steps back from the Adam step counts.  The newest iteration is left
+        pending unless `drain`, so the host may run a full iteration ahead of the GPU: the flags it
+        waits for here are two iterations old and long complete.  Consequence: after an overflow
+        the Adam step counts are corrected one iteration late, i.e. the single iteration that
+        follows a skipped step uses t+1 in its bias correction (apex would use t)."""
+        while len(self._flags_pending) > (0 if drain else 1):
+            ev, host = self._flags_pending.pop(0)
+            ev.synchronize()
+            f = host.tolist()
+            self._flags_free.append(host)
+            r = self.opt.DG_ratio
+            per_opt = ((self.optimizer_G, f[0:1]), (self.optimizer_D_PP, f[1:1 + r]),
+                       (self.optimizer_D_PB, f[1 + r:1 + 2 * r]))
+            for o, fl in per_opt:
+                o.step_count -= sum(1 for x in fl if x)
+            self.skipped_steps += sum(1 for x in f if x)
+            self.last_overflow = any(f)
+            if self.last_overflow:
+                self.pprint("non-finite gradient: skipped %d optimizer step(s)" % sum(1 for x in f if x))
 
     # ------------------------------------------------------------------ the step
     def optimize_parameters(self):
@@ -464,9 +468,11 @@ class MMHandModel(torch.nn.Module):
             finish_G()
             self._guarded_step(self.optimizer_D_PB, 1 + r + i)
         finish_G()
-        self._flags_host.copy_(self._flags, non_blocking=True)
-        self._flags_event = torch.cuda.Event()
-        self._flags_event.record()
+        host = self._flags_free.pop()
+        host.copy_(self._flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._flags_pending.append((ev, host))
         self.overflow = False
 
     # ------------------------------------------------------------------ reporting / io
@@ -514,9 +520,9 @@ class MMHandModel(torch.nn.Module):
         count.  The learning-rate schedule is positioned by --epoch_count as in the reference
         (network_utils.py:92-95), so scheduler state is not stored.  The reference's loader feeds
         any *amp* file to amp.load_state_dict inside try/except, so it ignores this one."""
+        self._settle_overflow(drain=True)
         if not self.master:
             return
-        self._settle_overflow()
         os.makedirs(self.save_dir, exist_ok=True)
         state = {"format": "mmhand_amd.train_state.v1", "skipped_steps": self.skipped_steps,
                  "optimizers": {}}

@@ -32,6 +32,11 @@ def main(argv=None):
     model.pprint("model [%s] was created" % model.name())
     log_name = os.path.join(opt.checkpoints_dir, opt.name, "loss_log.txt")
     total_steps = 0
+    # the interpreter's generation-2 collections (tens of ms with autograd graphs alive) would land
+    # in the middle of an iteration and starve the GPU queue: collect at the points that
+    # synchronise with the device anyway (loss printing, end of epoch)
+    import gc
+    gc.disable()
     for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
         epoch_start = time.time()
         epoch_iter = 0
@@ -49,10 +54,12 @@ def main(argv=None):
                 print(msg)
                 with open(log_name, "a") as f:
                     f.write("%s\n" % msg)
+                gc.collect()
             if total_steps % opt.save_latest_freq == 0 and model.master:
                 print("saving the latest model (epoch %d, total_steps %d)" % (epoch, total_steps))
                 model.save("latest")
         loader.set_epoch(epoch)
+        gc.collect()
         if epoch % opt.save_epoch_freq == 0 and model.master:
             print("saving the model at the end of epoch %d, iters %d" % (epoch, total_steps))
             model.save("latest")
