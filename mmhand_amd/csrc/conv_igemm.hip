@@ -1633,28 +1633,33 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+template <int BKS>
 __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBfKP p) {
     constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int LDB = BKS + 8;          // row pitch (bf16): 144 B / 272 B, conflict-free ds_read_b128
+    constexpr int CPR = BKS / 8;          // 16-byte chunks per row
+    constexpr int NLD = BM * CPR / 256;   // loads per thread and operand per k-step
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* const As = reinterpret_cast<__bf16*>(smem);     // [128][LDH]
-    __bf16* const Bs = As + BM * LDH;                       // [128][LDH]
+    __bf16* const As = reinterpret_cast<__bf16*>(smem);     // [128][LDB]
+    __bf16* const Bs = As + BM * LDB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int chunk = tid & 7, lrow = tid >> 3;
+    const int chunk = tid % CPR, lrow = tid / CPR;
+    constexpr int RPP = 256 / CPR;        // rows covered per pass
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wend = min(p.W, (xcd + 1) * p.Wx);
     int wc = xcd * p.Wx + slot;
     if (wc >= wend) return;
-    const int KS = p.K / BK16;
+    const int KS = p.K / BKS;
     const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 2u;
     const unsigned b_bytes = (unsigned)p.N * (unsigned)p.K * 2u;
     const unsigned c_bytes = (unsigned)p.M * (unsigned)p.N * 2u;
 
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    unsigned a_off[4], b_off[4];
+    unsigned a_off[NLD], b_off[NLD];
     auto setup_load = [&](int w) {
         const int nt = w % p.NT;
         const int t = w / p.NT;
@@ -1663,24 +1668,24 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
         rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A) + (size_t)xi * p.M * p.K, 0, a_bytes, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.B) + (size_t)xi * p.N * p.K, 0, b_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // rows past M / N start beyond num_records: the loads return zeros
-            a_off[i] = ((unsigned)(mt * BM + lrow + 32 * i) * (unsigned)p.K + chunk * 8u) * 2u;
-            b_off[i] = ((unsigned)(nt * BN + lrow + 32 * i) * (unsigned)p.K + chunk * 8u) * 2u;
+        for (int i = 0; i < NLD; ++i) {   // rows past M / N start beyond num_records: the loads return zeros
+            a_off[i] = ((unsigned)(mt * BM + lrow + RPP * i) * (unsigned)p.K + chunk * 8u) * 2u;
+            b_off[i] = ((unsigned)(nt * BN + lrow + RPP * i) * (unsigned)p.K + chunk * 8u) * 2u;
         }
     };
-    uint4 ra[4], rb[4];
+    uint4 ra[NLD], rb[NLD];
     auto issue_loads = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i], 0, 0));
             rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], 0, 0));
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(&As[(lrow + 32 * i) * LDH + chunk * 8]) = ra[i];
-            *reinterpret_cast<uint4*>(&Bs[(lrow + 32 * i) * LDH + chunk * 8]) = rb[i];
+        for (int i = 0; i < NLD; ++i) {
+            *reinterpret_cast<uint4*>(&As[(lrow + RPP * i) * LDB + chunk * 8]) = ra[i];
+            *reinterpret_cast<uint4*>(&Bs[(lrow + RPP * i) * LDB + chunk * 8]) = rb[i];
         }
     };
 
@@ -1701,21 +1706,21 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
             bool more = true;
             if (ks + 1 < KS) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a_off[i] += BK16 * 2u; b_off[i] += BK16 * 2u; }
+                for (int i = 0; i < NLD; ++i) { a_off[i] += BKS * 2u; b_off[i] += BKS * 2u; }
             } else {
                 more = wc + p.nb < wend;
                 if (more) setup_load(wc + p.nb);
             }
             if (more) issue_loads();
 #pragma unroll
-            for (int s16 = 0; s16 < BK16 / 16; ++s16) {
+            for (int s16 = 0; s16 < BKS / 16; ++s16) {
                 bf16x8 af[TM], bfr[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 32 + l31) * LDH + s16 * 16 + h * 8]);
+                    af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WTM + i * 32 + l31) * LDB + s16 * 16 + h * 8]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + j * 32 + l31) * LDH + s16 * 16 + h * 8]);
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WTN + j * 32 + l31) * LDB + s16 * 16 + h * 8]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2634,6 +2639,7 @@ int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
 int g_wino_bn256 = 0;   // 128-wide tiles: 3-5 % faster than 256 for these short-K GEMMs (more workgroups per CU)
 int g_wino_xcd = 1;     // XCD-contiguous tile order in the input transform (halo rows meet in one L2)
 int g_wino_gemm_v2 = 1; // dedicated persistent kernel (wino_gemm_kernel) when K % 32 == 0 and N >= 64
+int g_wino_bf16_bk = 64;   // k-step of the bf16 NT GEMM: 64 | 128
 int g_wino_bf16_occ = 3;   // resident workgroups per CU the bf16 Winograd GEMM grids are sized for
 int g_wino_gemm_occ = 3;   // resident workgroups per CU the persistent grid is sized for
 
@@ -2828,6 +2834,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_bf16_occ")) { g_wino_bf16_occ = value; return 0; }
+    if (!strcmp(key, "wino_bf16_bk")) { g_wino_bf16_bk = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
     if (!strcmp(key, "wino_wgrad_slots")) { g_wino_wgrad_slots = value; return 0; }
     return mmh::fail("mmh_set_option: unknown key '%s'", key);
@@ -2928,12 +2935,21 @@ static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tile
     p.NT = (N + 127) / 128;
     p.W = nbatch * p.MT * p.NT;
     p.Wx = (p.W + 7) / 8;
-    p.nb = std::min(p.Wx, 32 * g_wino_bf16_occ);
-    constexpr size_t lds = (size_t)(2 * BM * LDH) * sizeof(__bf16);
-    static int ready = -1;
-    if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel, lds);
-    if (ready != 0) return ready;
-    hipLaunchKernelGGL(wino_gemm_bf16_kernel, dim3(8 * p.nb), dim3(256), lds, st, p);
+    if (g_wino_bf16_bk == 128 && K % 128 == 0) {
+        p.nb = std::min(p.Wx, 32 * 2);
+        constexpr size_t lds = (size_t)(2 * BM * (128 + 8)) * sizeof(__bf16);
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<128>, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL(wino_gemm_bf16_kernel<128>, dim3(8 * p.nb), dim3(256), lds, st, p);
+    } else {
+        p.nb = std::min(p.Wx, 32 * g_wino_bf16_occ);
+        constexpr size_t lds = (size_t)(2 * BM * (64 + 8)) * sizeof(__bf16);
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<64>, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL(wino_gemm_bf16_kernel<64>, dim3(8 * p.nb), dim3(256), lds, st, p);
+    }
     return mmh::check_launch("wino_gemm_bf16_kernel");
 }
 
