@@ -210,7 +210,7 @@ def main():
     wtile = ops._wino_tile(a.batch, hs, hs, 512, 512, 3, 1, 1, a.dtype == "bf16")
     wino = wtile > 0
     planes = (wtile + 2) ** 2
-    tiles = a.batch * (hs // max(wtile, 1)) ** 2
+    tiles = a.batch * (-(-hs // max(wtile, 1))) ** 2      # F(6x6,3x3) tiles are ragged: ceil
     timer = KernelTimer(dict(Cin=512, Cout=512, kh=3, stride=1, H=hs, W=hs),
                         gemm=(planes, tiles, 512, 512) if wino else None)
     ops.fprop_timer = timer

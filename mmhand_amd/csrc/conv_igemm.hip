@@ -2856,15 +2856,26 @@ int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void
 }
 
 // ---- Winograd stages (tile = 2: F(2x2,3x3), 16 planes; tile = 4: F(4x4,3x3), 36 planes) ----
-static int wino_planes(int tile) { return tile == 4 ? 36 : 16; }
+static int wino_planes(int tile) { return (tile + 2) * (tile + 2); }
+static bool wino_tile_ok(int tile) { return tile == 2 || tile == 4 || tile == 6; }
+// tiles per image side: F(6x6,3x3) tiles are ragged (any size), the others need divisibility
+static bool wino_hw_ok(int H, int W, int tile) {
+    return tile == 6 ? (H >= 4 && W >= 4) : (H >= tile + 2 && W >= tile + 2 && H % tile == 0 && W % tile == 0);
+}
+static long long wino_tiles(int B, int H, int W, int tile) {
+    return (long long)B * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
+}
 
 static bool wino_dtype_ok(int dtype, int tile) { return dtype == MMH_F32 || (dtype == MMH_BF16 && tile == 2); }
 
 int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, int dtype, void* U,
                      mmh_stream_t s) {
-    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0 && (tile == 2 || tile == 4) && wino_dtype_ok(dtype, tile),
-                "mmh_wino_weights: bad arguments (bf16 needs tile 2)");
+    MMH_REQUIRE(w && U && Cin > 0 && Cout > 0 && wino_tile_ok(tile) && wino_dtype_ok(dtype, tile),
+                "mmh_wino_weights: bad arguments (tile 2 | 4 | 6; bf16 needs tile 2)");
     const dim3 grid((Cin * Cout + 255) / 256);
+    if (tile == 6)
+        return mmh::wino6_weights(static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose,
+                                  mmh::as_stream(s));
     if (tile == 4)
         hipLaunchKernelGGL(wino4_weights_kernel, grid, dim3(256), 0, mmh::as_stream(s),
                            static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
@@ -2879,10 +2890,13 @@ int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int t
 
 int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype, void* V,
                    mmh_stream_t s) {
-    MMH_REQUIRE(x && V && B > 0 && (tile == 2 || tile == 4) && H >= tile + 2 && W >= tile + 2 &&
-                    H % tile == 0 && W % tile == 0 && C % 4 == 0 && wino_dtype_ok(dtype, tile),
+    MMH_REQUIRE(x && V && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
+                    wino_dtype_ok(dtype, tile),
                 "mmh_wino_input: bad arguments");
-    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    const long long tiles = wino_tiles(B, H, W, tile);
+    if (tile == 6)
+        return mmh::wino6_input(static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C, reflect, g_wino_xcd,
+                                mmh::as_stream(s));
     if (tile == 4) {
         const long long total = tiles * (C / 2);
         const unsigned nblk = (unsigned)((total + 255) / 256);
@@ -2903,10 +2917,12 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
 }
 
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh, mmh_stream_t s) {
-    MMH_REQUIRE(dy && Yh && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0 &&
+    MMH_REQUIRE(dy && Yh && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
                     wino_dtype_ok(dtype, tile),
                 "mmh_wino_dy: bad arguments");
-    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    const long long tiles = wino_tiles(B, H, W, tile);
+    if (tile == 6)
+        return mmh::wino6_dy(static_cast<const float*>(dy), static_cast<float*>(Yh), B, H, W, C, mmh::as_stream(s));
     if (tile == 4) {
         const long long total = tiles * (C / 2);
         hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mmh::as_stream(s),
@@ -2965,10 +2981,13 @@ int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, i
 
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,
                     int dtype, mmh_stream_t s) {
-    MMH_REQUIRE(M && y && B > 0 && (tile == 2 || tile == 4) && H % tile == 0 && W % tile == 0 && C % 4 == 0 &&
+    MMH_REQUIRE(M && y && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
                     wino_dtype_ok(dtype, tile),
                 "mmh_wino_output: bad arguments");
-    const long long tiles = (long long)B * (H / tile) * (W / tile);
+    const long long tiles = wino_tiles(B, H, W, tile);
+    if (tile == 6)
+        return mmh::wino6_output(static_cast<const float*>(M), static_cast<float*>(y), static_cast<const float*>(bias),
+                                 B, H, W, C, act, mmh::as_stream(s));
     if (tile == 4) {
         const long long total = tiles * (C / 2);
         hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -3096,7 +3115,10 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
 }
 
 int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate, mmh_stream_t s) {
-    MMH_REQUIRE(dU && dw && Cin % 4 == 0 && Cout % 4 == 0 && (tile == 2 || tile == 4), "mmh_wino_dw: bad arguments");
+    MMH_REQUIRE(dU && dw && Cin % 4 == 0 && Cout % 4 == 0 && wino_tile_ok(tile), "mmh_wino_dw: bad arguments");
+    if (tile == 6)
+        return mmh::wino6_dw(static_cast<const float*>(dU), static_cast<float*>(dw), Cin, Cout, accumulate,
+                             mmh::as_stream(s));
     if (tile == 4) {
         const int64_t n2 = (int64_t)Cin * Cout / 2;
         hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)mmh::cdiv(n2, 256)), dim3(256), 0, mmh::as_stream(s),

@@ -1,0 +1,317 @@
+// Winograd F(6x6, 3x3) transforms (fp32): 64 multiplications per 6x6 output tile instead of 324,
+// i.e. 5.06x fewer MFMA flops than the direct 3x3 convolution and 21 % fewer than F(4x4,3x3), and
+// a Winograd domain of 64/36 = 1.78x the activation instead of 2.25x.  Interpolation points
+// 0, +-1, +-2, +-1/2, inf (the standard matrices).  fp32 rounding error measured against fp64:
+// 5e-6 relative L1 at K = 512 (F(4x4,3x3): 2.4e-6, direct fp32: 2.4e-7) - far inside the 1e-3 bar.
+//
+// Tiles are RAGGED: TH = ceil(H/6), TW = ceil(W/6); the input transform reads zeros beyond the
+// (reflect- or zero-) padded image, the output transform writes only pixels inside it, the
+// output-gradient transform reads zeros outside it.  So every H, W >= 2 is eligible.
+//
+//   U  [64][K][N]      = G g G^T              wino6_weights   (flip_transpose: dgrad filter)
+//   V  [64][tiles][C]  = B^T d B              wino6_input     (8x8 window, stride 6, pad 1)
+//   y                  = A^T M A (+bias, act) wino6_output
+//   Yh [64][tiles][C]  = A dY A^T             wino6_dy        (wgrad)
+//   dw [3][3][Cin][Cout] = G^T dU G           wino6_dw
+// One thread per (tile, 2 channels), like the F(4x4,3x3) kernels in conv_igemm.hip.
+#include "common.h"
+
+namespace {
+
+struct F2 { float x, y; };
+__device__ __forceinline__ F2 operator+(F2 a, F2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ F2 operator-(F2 a, F2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ F2 operator*(float k, F2 a) { return {k * a.x, k * a.y}; }
+
+__device__ __forceinline__ float act6(float v, int act) {
+    if (act == MMH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MMH_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// out[0..7] = B^T in[0..7]
+template <typename T>
+__device__ __forceinline__ void w6_bt(const T* d, T* o) {
+    const T e1 = d[2] - 4.25f * d[4] + d[6], f1 = d[1] - 4.25f * d[3] + d[5];
+    const T e2 = 0.25f * d[2] - 1.25f * d[4] + d[6], f2 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+    const T e3 = 4.f * d[2] - 5.f * d[4] + d[6], f3 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+    o[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+    o[1] = e1 + f1; o[2] = e1 - f1;
+    o[3] = e2 + f2; o[4] = e2 - f2;
+    o[5] = e3 + f3; o[6] = e3 - f3;
+    o[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+}
+// out[0..5] = A^T in[0..7]
+template <typename T>
+__device__ __forceinline__ void w6_at(const T* m, T* y) {
+    const T s1 = m[1] + m[2], t1 = m[1] - m[2], s2 = m[3] + m[4], t2 = m[3] - m[4], s3 = m[5] + m[6],
+            t3 = m[5] - m[6];
+    y[0] = m[0] + s1 + s2 + s3;
+    y[1] = t1 + 2.f * t2 + 0.5f * t3;
+    y[2] = s1 + 4.f * s2 + 0.25f * s3;
+    y[3] = t1 + 8.f * t2 + 0.125f * t3;
+    y[4] = s1 + 16.f * s2 + 0.0625f * s3;
+    y[5] = t1 + 32.f * t2 + 0.03125f * t3 + m[7];
+}
+// out[0..7] = A in[0..5]
+template <typename T>
+__device__ __forceinline__ void w6_a(const T* y, T* o) {
+    const T e = y[0] + y[2] + y[4], f = y[1] + y[3] + y[5];
+    const T e2 = y[0] + 4.f * y[2] + 16.f * y[4], f2 = 2.f * y[1] + 8.f * y[3] + 32.f * y[5];
+    const T e3 = y[0] + 0.25f * y[2] + 0.0625f * y[4], f3 = 0.5f * y[1] + 0.125f * y[3] + 0.03125f * y[5];
+    o[0] = y[0];
+    o[1] = e + f; o[2] = e - f;
+    o[3] = e2 + f2; o[4] = e2 - f2;
+    o[5] = e3 + f3; o[6] = e3 - f3;
+    o[7] = y[5];
+}
+// out[0..7] = G in[0..2]
+__device__ __forceinline__ void w6_g(const float* g, float* o) {
+    const float a = (-2.f / 9.f) * (g[0] + g[2]), b = (-2.f / 9.f) * g[1];
+    const float c = (1.f / 90.f) * g[0] + (2.f / 45.f) * g[2], d = (1.f / 45.f) * g[1];
+    const float e = (32.f / 45.f) * g[0] + (8.f / 45.f) * g[2], f = (16.f / 45.f) * g[1];
+    o[0] = g[0];
+    o[1] = a + b; o[2] = a - b;
+    o[3] = c + d; o[4] = c - d;
+    o[5] = e + f; o[6] = e - f;
+    o[7] = g[2];
+}
+// out[0..2] = G^T in[0..7]
+template <typename T>
+__device__ __forceinline__ void w6_gt(const T* u, T* w) {
+    const T s1 = u[1] + u[2], t1 = u[1] - u[2], s2 = u[3] + u[4], t2 = u[3] - u[4], s3 = u[5] + u[6],
+            t3 = u[5] - u[6];
+    w[0] = u[0] + (-2.f / 9.f) * s1 + (1.f / 90.f) * s2 + (32.f / 45.f) * s3;
+    w[1] = (-2.f / 9.f) * t1 + (1.f / 45.f) * t2 + (16.f / 45.f) * t3;
+    w[2] = (-2.f / 9.f) * s1 + (2.f / 45.f) * s2 + (8.f / 45.f) * s3 + u[7];
+}
+
+__global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                     int flip_transpose) {
+    const int total = Cin * Cout;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = i / Cout, co = i - ci * Cout;
+    float g[3][3], t[8][3], col[3], o8[8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ka = flip_transpose ? 2 - a : a, kb = flip_transpose ? 2 - b : b;
+            g[a][b] = w[((size_t)(ka * 3 + kb) * Cin + ci) * Cout + co];
+        }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        col[0] = g[0][b]; col[1] = g[1][b]; col[2] = g[2][b];
+        w6_g(col, o8);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) t[a][b] = o8[a];
+    }
+    const size_t plane = (size_t)Cin * Cout;
+    const size_t o = flip_transpose ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        w6_g(t[a], o8);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) U[(size_t)(a * 8 + b) * plane + o] = o8[b];
+    }
+}
+
+__global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
+                                                          int H, int W, int C2, int reflect, int xcd_remap) {
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    // XCD-contiguous tile order: neighbouring 8x8 windows (2 shared rows / columns) meet in one L2
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const long long i = (long long)blk * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const F2* xin = reinterpret_cast<const F2*>(x);
+    F2 d[8][8], colv[8], o8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int hh = 6 * ty - 1 + r;
+        bool okh;
+        if (reflect) {      // the padded image is rows -1 .. H; ragged tiles reach beyond it: zeros
+            okh = hh <= H;
+            hh = hh < 0 ? -hh : hh;
+            hh = hh >= H ? 2 * (H - 1) - hh : hh;
+            okh = okh && hh >= 0;
+        } else {
+            okh = hh >= 0 && hh < H;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int ww = 6 * tx - 1 + q;
+            bool ok;
+            if (reflect) {
+                ok = okh && ww <= W;
+                ww = ww < 0 ? -ww : ww;
+                ww = ww >= W ? 2 * (W - 1) - ww : ww;
+                ok = ok && ww >= 0;
+            } else {
+                ok = okh && ww >= 0 && ww < W;
+            }
+            d[r][q] = ok ? xin[(((long long)b * H + hh) * W + ww) * C2 + c] : F2{0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {       // columns, in place
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = d[r][q];
+        w6_bt(colv, o8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
+    }
+    const long long plane = tiles * C2;
+    F2* out = reinterpret_cast<F2*>(V) + tile * C2 + c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        w6_bt(d[r], o8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+    }
+}
+
+__global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ M, float* __restrict__ y,
+                                                           const float* __restrict__ bias, int B, int H, int W,
+                                                           int C2, int act) {
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const long long plane = tiles * C2;
+    const F2* in = reinterpret_cast<const F2*>(M) + tile * C2 + c;
+    F2 s6[6][8], colv[8], o6[6];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {       // columns: 8 planes (r, q) -> 6 rows
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = in[(long long)(r * 8 + q) * plane];
+        w6_at(colv, o6);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s6[r][q] = o6[r];
+    }
+    const F2 bv = bias ? reinterpret_cast<const F2*>(bias)[c] : F2{0.f, 0.f};
+    F2* yo = reinterpret_cast<F2*>(y);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int hh = 6 * ty + r;
+        if (hh >= H) break;
+        w6_at(s6[r], o6);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int ww = 6 * tx + q;
+            if (ww < W) {
+                F2 v = o6[q] + bv;
+                v.x = act6(v.x, act); v.y = act6(v.y, act);
+                yo[(((long long)b * H + hh) * W + ww) * C2 + c] = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__ dy, float* __restrict__ Yh, int B,
+                                                       int H, int W, int C2) {
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const F2* in = reinterpret_cast<const F2*>(dy);
+    F2 t[8][6], colv[6], o8[8];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int ww = 6 * tx + q;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int hh = 6 * ty + r;
+            colv[r] = (hh < H && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : F2{0.f, 0.f};
+        }
+        w6_a(colv, o8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
+    }
+    const long long plane = tiles * C2;
+    F2* out = reinterpret_cast<F2*>(Yh) + tile * C2 + c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        w6_a(t[r], o8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+    }
+}
+
+// dw[3][3][Cin][Cout] (+)= G^T dU G, dU: [64][Cin][Cout]
+__global__ void __launch_bounds__(256) wino6_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int64_t plane2, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane2) return;
+    const F2* in = reinterpret_cast<const F2*>(dU) + i;
+    F2 t[3][8], colv[8], o3[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = in[(int64_t)(r * 8 + q) * plane2];
+        w6_gt(colv, o3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r][q] = o3[r];
+    }
+    F2* out = reinterpret_cast<F2*>(dw) + i;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        w6_gt(t[a], o3);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            F2 v = o3[b];
+            if (accumulate) v = v + out[(int64_t)(a * 3 + b) * plane2];
+            out[(int64_t)(a * 3 + b) * plane2] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace mmh {
+
+int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st) {
+    hipLaunchKernelGGL(wino6_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st, w, U, Cin, Cout,
+                       flip_transpose);
+    return check_launch("wino6_weights_kernel");
+}
+
+int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    const unsigned nblk = (unsigned)((tiles * (C / 2) + 255) / 256);
+    hipLaunchKernelGGL(wino6_input_kernel, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C / 2, reflect,
+                       (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
+    return check_launch("wino6_input_kernel");
+}
+
+int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    hipLaunchKernelGGL(wino6_output_kernel, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, M, y,
+                       bias, B, H, W, C / 2, act);
+    return check_launch("wino6_output_kernel");
+}
+
+int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    hipLaunchKernelGGL(wino6_dy_kernel, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, dy, Yh, B, H,
+                       W, C / 2);
+    return check_launch("wino6_dy_kernel");
+}
+
+int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st) {
+    const int64_t n2 = (int64_t)Cin * Cout / 2;
+    hipLaunchKernelGGL(wino6_dw_kernel, dim3((unsigned)cdiv(n2, 256)), dim3(256), 0, st, dU, dw, n2, accumulate);
+    return check_launch("wino6_dw_kernel");
+}
+
+}  // namespace mmh

@@ -54,6 +54,36 @@ def test_conv2d_fprop_dgrad_wgrad(case, dev):
     assert R.rel_l1(db, dbr) < TOL, ("bias grad", R.rel_l1(db, dbr))
 
 
+# Winograd F(6x6,3x3) with ragged tiles: (B, H, W, Cin, Cout, reflect) — sizes that are / are not
+# multiples of 6, odd sizes, one tile per side
+WINO6_CASES = [
+    (2, 16, 16, 64, 128, True), (1, 12, 20, 256, 256, True), (2, 13, 17, 128, 128, True),
+    (1, 24, 18, 128, 64, False), (2, 12, 12, 64, 64, False), (1, 37, 12, 32, 32, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO6_CASES)
+def test_conv_winograd_f6x6(case, dev, monkeypatch):
+    """All three passes through F(6x6,3x3) (forced) against the fp64 oracle."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    monkeypatch.setattr(ops, "WINOGRAD_TILE", 6)
+    monkeypatch.setattr(ops, "WINO6_MIN", 0)
+    assert ops._wino_tile(B, H, W, Cin, Cout, 3, 1, 1, False) == 6
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    y = ops.raw_conv_fprop(x, w, bias, 1, 1, refl, 1)
+    dy = _mk(tuple(y.shape), 4, dev)
+    dx = ops.raw_conv_dgrad(dy, w, x.shape, 1, 1, refl)
+    dw = ops.raw_conv_wgrad(x, dy, 3, 1, 1, refl)
+    yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 1, refl, 1)
+    _, dxr, dwr, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
+    assert R.rel_l1(y, yr) < TOL, ("fprop", R.rel_l1(y, yr))
+    assert R.rel_l1(dx, dxr) < TOL, ("dgrad", R.rel_l1(dx, dxr))
+    assert R.rel_l1(dw, dwr) < TOL, ("wgrad", R.rel_l1(dw, dwr))
+
+
 # thin 7x7 convs (conv_thin.hip): (B, H, W, Cin, Cout, reflect) — tile-aligned, ragged (rows past a
 # 16-row tile, columns past a 64-column tile), image smaller than the tile, zero padding
 THIN_CASES = [
