@@ -2831,6 +2831,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_wgrad_occ")) { g_wino_wgrad_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
     if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
+    if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_bf16_occ")) { g_wino_bf16_occ = value; return 0; }

@@ -117,6 +117,14 @@ __global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restr
     }
 }
 
+__device__ __forceinline__ float zero_of(float) { return 0.f; }
+__device__ __forceinline__ F2 zero_of(F2) { return F2{0.f, 0.f}; }
+__device__ __forceinline__ float act_of(float v, int act) { return act6(v, act); }
+__device__ __forceinline__ F2 act_of(F2 v, int act) { return F2{act6(v.x, act), act6(v.y, act)}; }
+
+// T = F2: one thread per (tile, 2 channels); T = float: per (tile, channel) - half the registers,
+// twice the waves per SIMD (C2 is the channel count in units of T)
+template <typename T>
 __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
                                                           int H, int W, int C2, int reflect, int xcd_remap) {
     const int TH = (H + 5) / 6, TW = (W + 5) / 6;
@@ -129,8 +137,8 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     const int c = (int)(i % C2);
     const long long tile = i / C2;
     const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
-    const F2* xin = reinterpret_cast<const F2*>(x);
-    F2 d[8][8], colv[8], o8[8];
+    const T* xin = reinterpret_cast<const T*>(x);
+    T d[8][8], colv[8], o8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         int hh = 6 * ty - 1 + r;
@@ -155,7 +163,7 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
             } else {
                 ok = okh && ww >= 0 && ww < W;
             }
-            d[r][q] = ok ? xin[(((long long)b * H + hh) * W + ww) * C2 + c] : F2{0.f, 0.f};
+            d[r][q] = ok ? xin[(((long long)b * H + hh) * W + ww) * C2 + c] : zero_of(T{});
         }
     }
 #pragma unroll
@@ -167,7 +175,7 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
         for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
     }
     const long long plane = tiles * C2;
-    F2* out = reinterpret_cast<F2*>(V) + tile * C2 + c;
+    T* out = reinterpret_cast<T*>(V) + tile * C2 + c;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         w6_bt(d[r], o8);
@@ -176,6 +184,7 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ M, float* __restrict__ y,
                                                            const float* __restrict__ bias, int B, int H, int W,
                                                            int C2, int act) {
@@ -187,8 +196,8 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
     const long long tile = i / C2;
     const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
     const long long plane = tiles * C2;
-    const F2* in = reinterpret_cast<const F2*>(M) + tile * C2 + c;
-    F2 s6[6][8], colv[8], o6[6];
+    const T* in = reinterpret_cast<const T*>(M) + tile * C2 + c;
+    T s6[6][8], colv[8], o6[6];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {       // columns: 8 planes (r, q) -> 6 rows
 #pragma unroll
@@ -197,8 +206,8 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 6; ++r) s6[r][q] = o6[r];
     }
-    const F2 bv = bias ? reinterpret_cast<const F2*>(bias)[c] : F2{0.f, 0.f};
-    F2* yo = reinterpret_cast<F2*>(y);
+    const T bv = bias ? reinterpret_cast<const T*>(bias)[c] : zero_of(T{});
+    T* yo = reinterpret_cast<T*>(y);
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int hh = 6 * ty + r;
@@ -208,14 +217,13 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
         for (int q = 0; q < 6; ++q) {
             const int ww = 6 * tx + q;
             if (ww < W) {
-                F2 v = o6[q] + bv;
-                v.x = act6(v.x, act); v.y = act6(v.y, act);
-                yo[(((long long)b * H + hh) * W + ww) * C2 + c] = v;
+                yo[(((long long)b * H + hh) * W + ww) * C2 + c] = act_of(o6[q] + bv, act);
             }
         }
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__ dy, float* __restrict__ Yh, int B,
                                                        int H, int W, int C2) {
     const int TH = (H + 5) / 6, TW = (W + 5) / 6;
@@ -225,22 +233,22 @@ __global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__
     const int c = (int)(i % C2);
     const long long tile = i / C2;
     const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
-    const F2* in = reinterpret_cast<const F2*>(dy);
-    F2 t[8][6], colv[6], o8[8];
+    const T* in = reinterpret_cast<const T*>(dy);
+    T t[8][6], colv[6], o8[8];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int ww = 6 * tx + q;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int hh = 6 * ty + r;
-            colv[r] = (hh < H && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : F2{0.f, 0.f};
+            colv[r] = (hh < H && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : zero_of(T{});
         }
         w6_a(colv, o8);
 #pragma unroll
         for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
     }
     const long long plane = tiles * C2;
-    F2* out = reinterpret_cast<F2*>(Yh) + tile * C2 + c;
+    T* out = reinterpret_cast<T*>(Yh) + tile * C2 + c;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         w6_a(t[r], o8);
@@ -286,25 +294,39 @@ int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpos
     return check_launch("wino6_weights_kernel");
 }
 
+int g_wino6_vec = 0x0;   // bit 0 / 1 / 2: input / output / dy transform works on 2 channels per thread
+
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st) {
     const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
-    const unsigned nblk = (unsigned)((tiles * (C / 2) + 255) / 256);
-    hipLaunchKernelGGL(wino6_input_kernel, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C / 2, reflect,
-                       (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
+    const int cpt = (g_wino6_vec & 1) ? 2 : 1;
+    const unsigned nblk = (unsigned)((tiles * (C / cpt) + 255) / 256);
+    const int remap = (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0;
+    if (cpt == 2)
+        hipLaunchKernelGGL(wino6_input_kernel<F2>, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C / 2, reflect, remap);
+    else
+        hipLaunchKernelGGL(wino6_input_kernel<float>, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C, reflect, remap);
     return check_launch("wino6_input_kernel");
 }
 
 int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, hipStream_t st) {
     const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
-    hipLaunchKernelGGL(wino6_output_kernel, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, M, y,
-                       bias, B, H, W, C / 2, act);
+    if (g_wino6_vec & 2)
+        hipLaunchKernelGGL(wino6_output_kernel<F2>, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, M,
+                           y, bias, B, H, W, C / 2, act);
+    else
+        hipLaunchKernelGGL(wino6_output_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, M, y,
+                           bias, B, H, W, C, act);
     return check_launch("wino6_output_kernel");
 }
 
 int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t st) {
     const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
-    hipLaunchKernelGGL(wino6_dy_kernel, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, dy, Yh, B, H,
-                       W, C / 2);
+    if (g_wino6_vec & 4)
+        hipLaunchKernelGGL(wino6_dy_kernel<F2>, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, dy, Yh,
+                           B, H, W, C / 2);
+    else
+        hipLaunchKernelGGL(wino6_dy_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, dy, Yh, B,
+                           H, W, C);
     return check_launch("wino6_dy_kernel");
 }
 

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mmhand_amd import ops, lib
 key = sys.argv[1]; vals = [int(v) for v in sys.argv[2:]]
-L = lib.load(); dev = torch.device("cuda:0"); B = 32
+L = lib.load(); dev = torch.device("cuda:0"); B = 32; TILE = int(os.environ.get("TILE", "6"))
 def timeit(fn, iters=3):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -14,9 +14,9 @@ def timeit(fn, iters=3):
 for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256)]:
     x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
     dy = torch.randn(B, H, H, Cout, device=dev)
-    for name, fn in (("fprop", lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0, 4)),
-                     ("dgrad", lambda: ops.raw_conv_dgrad_wino(dy, w, x.shape, True, 4)),
-                     ("wgrad", lambda: ops.raw_conv_wgrad_wino(x, dy, True, 4))):
+    for name, fn in (("fprop", lambda: ops.raw_conv_fprop_wino(x, w, None, True, 0, TILE)),
+                     ("dgrad", lambda: ops.raw_conv_dgrad_wino(dy, w, x.shape, True, TILE)),
+                     ("wgrad", lambda: ops.raw_conv_wgrad_wino(x, dy, True, TILE))):
         res = {v: [] for v in vals}
         for v in vals:
             lib.check(L.mmh_set_option(key.encode(), v), "set"); fn()
