@@ -88,8 +88,10 @@ int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* 
 
 /* ---- Winograd for the fp32 3x3 / stride 1 / pad 1 convs (the PATBlock / ResnetBlock stack) ----
  * y = A^T[(G g G^T) . (B^T d B)]A with tile = 2 (F(2x2,3x3): 16 planes, 2.25x fewer
- * multiplications than the direct implicit GEMM) or tile = 4 (F(4x4,3x3): 36 planes, 4x fewer;
- * fp32 error 2e-6 relative at K = 512).  tiles = B*(H/tile)*(W/tile); planes P = (tile+2)^2.
+ * multiplications than the direct implicit GEMM), tile = 4 (F(4x4,3x3): 36 planes, 4x fewer;
+ * fp32 error 2.4e-6 relative at K = 512) or tile = 6 (F(6x6,3x3): 64 planes, 5.06x fewer, 5e-6;
+ * ragged tiles: any H, W >= 4).  tiles = B*ceil(H/tile)*ceil(W/tile) (tile 2, 4: H, W % tile
+ * == 0); planes P = (tile+2)^2.
  *   U  [P][K][N]     = mmh_wino_weights(w)  (flip_transpose=1: the dgrad filter [P][Cout][Cin])
  *   V  [P][tiles][C] = mmh_wino_input(x)    (reflect or zero padding folded into the gather)
  *   M  [P][tiles][N] = mmh_wino_gemm(V, U)  (P batched GEMMs, one launch)

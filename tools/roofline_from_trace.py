@@ -30,10 +30,11 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
                 print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
 if "wino_gemm" in pat:
     print("wino_gemm_kernel is persistent: every launch has 8 XCDs x 96 workgroups, whatever the GEMM shape, so\n"
-          "shapes are told apart by duration.  The slowest cluster (~1.17 ms) is 36 x [8192x512].[512x512] = the\n"
-          "F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches are the same GEMM):\n"
-          "154.6 GFLOP per launch; bench.py's roofline.achieved = 154.6 GFLOP / its HIP-event mean over the fprop\n"
-          "launches.  The other clusters: 512->256 / 256->512 (77.3 GFLOP) and 256->256 (38.7 GFLOP) convs.")
+          "shapes are told apart by duration.  The slowest cluster is the Winograd-domain GEMM set of a 3x3\n"
+          "512->512 conv at 64x64, B=32 (fprop and dgrad launches are the same GEMM): F(6x6,3x3) = 64 x\n"
+          "[3872x512].[512x512] = 129.9 GFLOP per launch (F(4x4,3x3), MMH_WINOGRAD_TILE=4: 36 x [8192x512].[512x512]\n"
+          "= 154.6 GFLOP); bench.py's roofline.achieved = that FLOP count / its HIP-event mean over the fprop\n"
+          "launches.  The other clusters: 512->256 / 256->512 and 256->256 convs (1/2 and 1/4 of the FLOPs).")
 elif "batched" in pat:
     print("workgroups (4, 64, 36) = 4 column tiles x 64 row tiles x 36 Winograd planes = [8192x512].[512x512] per\n"
           "plane: the F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches both have this\n"
