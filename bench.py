@@ -164,8 +164,8 @@ def main():
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true",
-                    help="direct implicit-GEMM kernels for every conv (default: Winograd F(2x2,3x3) for the "
-                         "fp32 3x3 stride-1 convs with >= 256x256 channels)")
+                    help="direct implicit-GEMM kernels for every conv (default: Winograd F(6x6,3x3) for the "
+                         "fp32 3x3 stride-1 convs with >= 128x128 channels, F(2x2,3x3) in bf16)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE.json configs[1] (default); bf16 = bf16 MFMA compute, fp32 master "
                          "weights/accumulate/HBM tensors (the --opt_level O1 path; configs[2]/[4] precision)")

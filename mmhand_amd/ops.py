@@ -94,16 +94,18 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
 
 
 _wino_cache = {}
-# Winograd for the fp32 3x3 / stride-1 / pad-1 convs with >= 256x256 channel pairs: F(4x4,3x3)
-# when H and W are multiples of 4 (4x fewer multiplications than the direct implicit GEMM), else
-# F(2x2,3x3) (2.25x fewer).  Slower than the direct kernel below that size (transform-bound).
+# Winograd for the fp32 3x3 / stride-1 / pad-1 convs: F(6x6,3x3) (ragged tiles, any H and W;
+# 5.06x fewer multiplications than the direct implicit GEMM, fp32 error 5e-6) from 128x128 channel
+# pairs up, F(4x4,3x3) (4x fewer, H and W multiples of 4) from 64x64, F(2x2,3x3) (2.25x fewer)
+# for even sizes from 256x256.  Below those sizes the direct kernel is faster (transform-bound).
 # MMH_WINOGRAD=0 or ops.USE_WINOGRAD = False selects the direct kernels everywhere;
-# ops.WINOGRAD_TILE = 2 forces F(2x2,3x3).
+# MMH_WINOGRAD_TILE / ops.WINOGRAD_TILE = 4 | 2 caps the tile size.
 USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
 WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "6"))
 WINO6_MIN = 128 * 128      # F(6x6,3x3) from this Cin*Cout up (64 planes of filter transform per conv)
-# keep the forward pass's transformed input for the wgrad pass (2.25x the activation's bytes per
-# eligible conv at F(4,3), one input transform less per conv and step); MMH_WINOGRAD_KEEP_INPUT=0 re-transforms
+# keep the forward pass's transformed input for the wgrad pass (1.78x the activation's bytes per
+# eligible conv at F(6,3), 2.25x at F(4,3); one input transform less per conv and step);
+# MMH_WINOGRAD_KEEP_INPUT=0 re-transforms
 KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
 # 7x7 convs with <= 4 output columns (Generator head fprop, Discriminator-stem dgrad towards the
 # generated image) on the vector-ALU kernel of conv_thin.hip; MMH_THIN=0 keeps them on the MFMA path
@@ -119,7 +121,7 @@ WINO_BF16_MIN = {"fprop": 512 * 256, "dgrad": 512 * 512, "wgrad": 0}
 
 
 def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
-    """0 = direct kernel, else the Winograd output-tile size (2 or 4)."""
+    """0 = direct kernel, else the Winograd output-tile size (2, 4 or 6)."""
     if not (USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cout % 32 == 0):
         return 0
     if bf16:
@@ -133,7 +135,7 @@ def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
     # multiplications and a 21 % smaller Winograd domain than F(4,3)
     if WINOGRAD_TILE == 6 and H >= 12 and W_ >= 12 and Cin * Cout >= WINO6_MIN:
         return 6
-    if WINOGRAD_TILE in (4, 6) and H % 4 == 0 and W_ % 4 == 0 and H >= 8 and W_ >= 8 and Cin * Cout >= 64 * 64:
+    if WINOGRAD_TILE >= 4 and H % 4 == 0 and W_ % 4 == 0 and H >= 8 and W_ >= 8 and Cin * Cout >= 64 * 64:
         return 4
     if H % 2 == 0 and W_ % 2 == 0 and H >= 4 and W_ >= 4 and Cin * Cout >= 256 * 256:
         return 2
