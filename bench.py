@@ -189,6 +189,10 @@ def main():
     force_dp = os.environ.get("MMH_FORCE_DP") == "1" and "RANK" in os.environ
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: RCCL's socket bootstrap on the loopback interface (the container hostname
+            # may not resolve); the data path is xGMI / P2P regardless
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     from mmhand_amd import ops

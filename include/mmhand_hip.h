@@ -111,6 +111,10 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
                    void* V, mmh_stream_t s);
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh,
                 mmh_stream_t s);
+/* Both backward transforms of dy in one pass (tile 6, fp32): V = mmh_wino_input(dy, zero pad) for
+ * the dgrad GEMMs and Yh = mmh_wino_dy(dy) for the wgrad GEMMs; dy is read once. */
+int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* V,
+                      void* Yh, mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
                   int nbatch, int dtype, mmh_stream_t s);
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,

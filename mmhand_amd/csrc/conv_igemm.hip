@@ -2917,6 +2917,14 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
     return mmh::check_launch("wino_input_kernel");
 }
 
+int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* V, void* Yh,
+                      mmh_stream_t s) {
+    MMH_REQUIRE(dy && V && Yh && B > 0 && tile == 6 && dtype == MMH_F32 && wino_hw_ok(H, W, tile) && C % 4 == 0,
+                "mmh_wino_input_dy: needs tile 6, fp32");
+    return mmh::wino6_input_dy(static_cast<const float*>(dy), static_cast<float*>(V), static_cast<float*>(Yh), B, H, W,
+                               C, g_wino_xcd, mmh::as_stream(s));
+}
+
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh, mmh_stream_t s) {
     MMH_REQUIRE(dy && Yh && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
                     wino_dtype_ok(dtype, tile),

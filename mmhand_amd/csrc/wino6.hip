@@ -257,6 +257,70 @@ __global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__
     }
 }
 
+// Backward of one conv needs BOTH transforms of dy: V' = B^T d B of the zero-padded 8x8 window (the
+// dgrad GEMM operand) and Yh = A dY A^T of the 6x6 tile inside it (the wgrad GEMM operand).  One
+// kernel loads the window once (one read of dy instead of two).
+template <typename T>
+__global__ void __launch_bounds__(256) wino6_input_dy_kernel(const float* __restrict__ dy, float* __restrict__ V,
+                                                             float* __restrict__ Yh, int B, int H, int W, int C2,
+                                                             int xcd_remap) {
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const long long i = (long long)blk * blockDim.x + threadIdx.x;
+    if (i >= tiles * C2) return;
+    const int c = (int)(i % C2);
+    const long long tile = i / C2;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    const T* in = reinterpret_cast<const T*>(dy);
+    T d[8][8], colv[8], o8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int hh = 6 * ty - 1 + r;
+        const bool okh = hh >= 0 && hh < H;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ww = 6 * tx - 1 + q;
+            d[r][q] = (okh && ww >= 0 && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : zero_of(T{});
+        }
+    }
+    const long long plane = tiles * C2;
+    {   // Yh from the inner 6x6 tile (rows / columns 1..6 of the window)
+        T t[8][6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) colv[r] = d[r + 1][q + 1];
+            w6_a(colv, o8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
+        }
+        T* out = reinterpret_cast<T*>(Yh) + tile * C2 + c;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            w6_a(t[r], o8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = d[r][q];
+        w6_bt(colv, o8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
+    }
+    T* out = reinterpret_cast<T*>(V) + tile * C2 + c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        w6_bt(d[r], o8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+    }
+}
+
 // dw[3][3][Cin][Cout] (+)= G^T dU G, dU: [64][Cin][Cout]
 __global__ void __launch_bounds__(256) wino6_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int64_t plane2, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -328,6 +392,14 @@ int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t
         hipLaunchKernelGGL(wino6_dy_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, dy, Yh, B,
                            H, W, C);
     return check_launch("wino6_dy_kernel");
+}
+
+int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    const unsigned nblk = (unsigned)((tiles * C + 255) / 256);
+    hipLaunchKernelGGL(wino6_input_dy_kernel<float>, dim3(nblk), dim3(256), 0, st, dy, V, Yh, B, H, W, C,
+                       (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
+    return check_launch("wino6_input_dy_kernel");
 }
 
 int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st) {

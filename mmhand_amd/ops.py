@@ -110,6 +110,8 @@ KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
 # 7x7 convs with <= 4 output columns (Generator head fprop, Discriminator-stem dgrad towards the
 # generated image) on the vector-ALU kernel of conv_thin.hip; MMH_THIN=0 keeps them on the MFMA path
 USE_THIN = os.environ.get("MMH_THIN", "1") != "0"
+# F(6x6,3x3) backward: both transforms of dy (dgrad and wgrad operands) from one read of dy
+FUSE_WINO6_BWD = os.environ.get("MMH_FUSE_WINO6_BWD", "1") != "0"
 # --opt_level O1/O2: the 3x3 stride-1 convs with channels % 128 == 0 on bf16 Winograd F(2x2,3x3)
 USE_WINOGRAD_BF16 = os.environ.get("MMH_WINOGRAD_BF16", "1") != "0"
 
@@ -239,6 +241,39 @@ def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
     dw = _empty((3, 3, Cin, Cout), dy)
     L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
     return dw
+
+
+def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
+    """dgrad and wgrad of a 3x3 / stride 1 / pad 1 conv by Winograd F(6x6,3x3) with ONE pass over
+    dy for both of its transforms (mmh_wino_input_dy).  V = the forward pass's transformed input.
+    Returns (dx, dw)."""
+    _chk(dy, "dy"); _chk(w, "w")
+    B, H, W_, Cin = x_shape
+    Cout = w.shape[3]
+    P, tile = 64, 6
+    tiles = B * (-(-H // tile)) * (-(-W_ // tile))
+    assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous() and V.dtype == torch.float32
+    Vd = _empty((P, tiles, Cout), dy)
+    Yh = _empty((P, tiles, Cout), dy)
+    L.call("mmh_wino_input_dy", _ptr(dy), B, H, W_, Cout, tile, L.F32, _ptr(Vd), _ptr(Yh), _stream())
+    # dgrad: correlation with the flipped filter, then the reflect-border terms
+    M = _empty((P, tiles, Cin), dy)
+    L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
+    dx = _empty((B, H, W_, Cin), dy)
+    L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, _stream())
+    if reflect:
+        d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
+        ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
+        L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
+               _stream())
+    # wgrad
+    ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), dy)
+    dU = _empty((P, Cin, Cout), dy)
+    L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, L.F32, _ptr(ws), ws.numel() * 4, _ptr(dU),
+           _stream())
+    dw = _empty((3, 3, Cin, Cout), dy)
+    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
+    return dx, dw
 
 
 def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
@@ -415,6 +450,12 @@ class Conv2dFn(torch.autograd.Function):
         if act != L.ACT_NONE:
             g = raw_act_bwd(g, y, act)
         dx = dw = db = None
+        if (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6):
+            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x)      # x is the saved V here
+            if has_bias and ctx.needs_input_grad[2]:
+                db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
+            return dx, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:

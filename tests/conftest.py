@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Every rendezvous in the suite is on 127.0.0.1: pin gloo / RCCL bootstrap to the loopback
+# interface so that neither tries to resolve the container hostname (which may not resolve and
+# then stalls for minutes before falling back).  Inherited by the spawned rank processes.
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -84,6 +84,29 @@ def test_conv_winograd_f6x6(case, dev, monkeypatch):
     assert R.rel_l1(dw, dwr) < TOL, ("wgrad", R.rel_l1(dw, dwr))
 
 
+@pytest.mark.parametrize("case", WINO6_CASES[:4])
+def test_conv_winograd_f6x6_fused_backward(case, dev, monkeypatch):
+    """Conv2dFn backward through mmh_wino_input_dy (one read of dy for the dgrad and wgrad
+    operands) equals the two separate F(6x6,3x3) passes bit for bit, and the fp64 oracle to 2e-5."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    monkeypatch.setattr(ops, "WINOGRAD_TILE", 6)
+    monkeypatch.setattr(ops, "WINO6_MIN", 0)
+    x0 = _mk((B, H, W, Cin), 1, dev)
+    w0 = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    dy = _mk((B, H, W, Cout), 4, dev)
+    got = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "FUSE_WINO6_BWD", fuse)
+        x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+        y = ops.Conv2dFn.apply(x, w, None, 1, 1, refl, 0)
+        y.backward(dy)
+        got[fuse] = (x.grad.clone(), w.grad.clone())
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+    _, dxr, dwr, _ = R.conv2d_grads(x0.cpu(), w0.cpu(), None, dy.cpu(), 1, 1, refl)
+    assert R.rel_l1(got[True][0], dxr) < TOL and R.rel_l1(got[True][1], dwr) < TOL
+
+
 # thin 7x7 convs (conv_thin.hip): (B, H, W, Cin, Cout, reflect) — tile-aligned, ragged (rows past a
 # 16-row tile, columns past a 64-column tile), image smaller than the tile, zero padding
 THIN_CASES = [
