@@ -2134,13 +2134,19 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
 
 // Gradient w.r.t. the conv input.  out: [B, OH, OW, Cin] with channel stride out_cs, where
 // (OH,OW) is the padded domain for reflect mode and (H,W) otherwise.
+int g_dgrad_s2_multi = 1;   // stride-2 dgrad / ConvTranspose fprop: 4 parity classes in one multi-piece launch
+template <int BN, int WM, int WN>
+int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st);
+
 int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx,
              int dx_cs, int act, hipStream_t st) {
     const int s = d->stride;
     const int off = d->pad_mode == MMH_PAD_REFLECT ? d->pad : 0;  // padded-domain origin shift
     const int OH = d->H + 2 * off, OW = d->W + 2 * off;
     MMH_REQUIRE(s == 1 || (OH % 2 == 0 && OW % 2 == 0), "stride-2 dgrad needs even H,W");
-    // one launch per output parity class (1 class for stride 1, 4 for stride 2)
+    ConvKP classes[4];
+    int ncls = 0;
+    // one piece per output parity class (1 class for stride 1, 4 for stride 2)
     for (int ch = 0; ch < s; ++ch)
         for (int cw = 0; cw < s; ++cw) {
             // real coordinate hi = ph*s + ch - off; taps with (hi + pad - kh) % s == 0
@@ -2175,6 +2181,10 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
             p.out_linear = s == 1;
             p.act = act;
             if (TH == 0 || TW == 0) p.nk = 0;  // no tap reaches this class: writes zeros
+            if (s == 2 && d->dtype != MMH_BF16 && g_dgrad_s2_multi) {   // collected, launched once below
+                classes[ncls++] = p;
+                continue;
+            }
             int rc;
             if (d->dtype == MMH_BF16) {
                 // w is the prepared bf16 tensor [taps][Cin][Cout]
@@ -2188,6 +2198,18 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
                 rc = launch_conv<true>(p, st);
             if (rc) return rc;
         }
+    if (ncls) {
+        // The four parity classes of a stride-2 dgrad have 1, 2, 2 and 4 taps: short contractions
+        // whose separate launches each pay a pipeline fill and a tail.  One multi-piece launch,
+        // heaviest class first, keeps the chip full across class boundaries.
+        MultiKP mp{};
+        const int order[4] = {3, 1, 2, 0};      // (ch,cw) = (1,1) has the most taps for k3 / pad 1
+        for (int i = 0; i < ncls; ++i) mp.p[mp.n++] = classes[ncls == 4 ? order[i] : i];
+        const int C = d->Cin;
+        if (C > 64) return launch_multi_t<128, 2, 2>(mp, false, st);
+        if (C > 32) return launch_multi_t<64, 2, 2>(mp, false, st);
+        return launch_multi_t<32, 4, 1>(mp, false, st);
+    }
     return 0;
 }
 
@@ -2831,6 +2853,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_wgrad_occ")) { g_wino_wgrad_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_v2")) { g_wino_gemm_v2 = value; return 0; }
     if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
+    if (!strcmp(key, "dgrad_s2_multi")) { g_dgrad_s2_multi = value; return 0; }
     if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
