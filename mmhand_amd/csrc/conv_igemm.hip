@@ -844,7 +844,10 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, void* __restric
     const int total = Cin * Cout;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int ci = i / Cout, co = i - ci * Cout;
+    // thread -> (ci, co) with the output's fastest index fastest (coalesced plane stores): fp32 U is
+    // [K][N] = [Cin][Cout] (or [Cout][Cin] flipped), bf16 U the transpose of that
+    const bool co_fast = (flip_transpose != 0) == BF;
+    const int ci = co_fast ? i / Cout : i % Cin, co = co_fast ? i - (i / Cout) * Cout : i / Cin;
     float g[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -2467,7 +2470,8 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, float* __restr
     const int total = Cin * Cout;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int ci = i / Cout, co = i - ci * Cout;
+    // thread -> (ci, co) with the output's fastest index fastest (coalesced plane stores)
+    const int ci = flip_transpose ? i % Cin : i / Cout, co = flip_transpose ? i / Cin : i - (i / Cout) * Cout;
     float g[3][3], t[6][3], col[3], o6[6];
 #pragma unroll
     for (int a = 0; a < 3; ++a)

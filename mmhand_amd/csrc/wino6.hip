@@ -91,7 +91,9 @@ __global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restr
     const int total = Cin * Cout;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int ci = i / Cout, co = i - ci * Cout;
+    // thread -> (ci, co) with the OUTPUT's fastest index fastest: 64 coalesced plane stores per
+    // thread (the 9 filter reads are the strided side when the output is transposed)
+    const int ci = flip_transpose ? i % Cin : i / Cout, co = flip_transpose ? i / Cin : i - (i / Cout) * Cout;
     float g[3][3], t[8][3], col[3], o8[8];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
