@@ -293,7 +293,8 @@ typedef struct mmh_plane_src {
     int32_t C;                       /* channels taken from this source     */
     int64_t sb, sc, sh, sw;          /* element strides                     */
 } mmh_plane_src;
-/* dir 0: gather srcs -> nhwc[B,H,W,Cd] (channels beyond sum(C) zeroed).
+/* Cd % 4 == 0, nhwc 16-byte aligned.
+ * dir 0: gather srcs -> nhwc[B,H,W,Cd] (channels beyond sum(C) zeroed).
  * dir 1: scatter nhwc -> srcs (backward of dir 0 / NHWC->NCHW export).     */
 int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B,
                   int H, int W, int Cd, int dir, mmh_stream_t s);

@@ -552,29 +552,49 @@ struct PackArgs {
 };
 __global__ void pack_nhwc_kernel(PackArgs a, float* __restrict__ nhwc, int B, int H, int W, int Cd,
                                  int dir) {
+    // one thread per pixel; the NHWC side moves as float4 (Cd % 4 == 0): 16-byte lanes instead of
+    // Cd scalar stores 4*Cd bytes apart
     const int64_t total = (int64_t)B * H * W;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
-        int w = (int)(i % W);
-        int64_t t = i / W;
-        int hh = (int)(t % H);
-        int b = (int)(t / H);
-        float* px = nhwc + i * Cd;
-        int c0 = 0;
-        for (int k = 0; k < a.nsrc; ++k) {
-            const mmh_plane_src& s = a.s[k];
-            float* sp = static_cast<float*>(s.ptr);
-            if (sp) {
-                const int64_t base = b * s.sb + hh * s.sh + w * s.sw;
-                if (dir == 0) for (int c = 0; c < s.C; ++c) px[c0 + c] = sp[base + c * s.sc];
-                else          for (int c = 0; c < s.C; ++c) sp[base + c * s.sc] = px[c0 + c];
-            } else if (dir == 0) {
-                for (int c = 0; c < s.C; ++c) px[c0 + c] = 0.f;
+        const int w = (int)(i % W);
+        const int64_t t = i / W;
+        const int hh = (int)(t % H);
+        const int b = (int)(t / H);
+        float4* px = reinterpret_cast<float4*>(nhwc + i * Cd);
+        // element address of packed channel c in its source plane set, or null (zero fill / skipped)
+        auto chan = [&](int c) -> float* {
+            int c0 = 0;
+            for (int k = 0; k < a.nsrc; ++k) {
+                const mmh_plane_src& s = a.s[k];
+                if (c < c0 + s.C) {
+                    float* sp = static_cast<float*>(s.ptr);
+                    return sp ? sp + b * s.sb + hh * s.sh + w * s.sw + (int64_t)(c - c0) * s.sc : nullptr;
+                }
+                c0 += s.C;
             }
-            c0 += s.C;
+            return nullptr;
+        };
+        for (int g4 = 0; g4 < Cd / 4; ++g4) {
+            if (dir == 0) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* q = chan(4 * g4 + e);
+                    v[e] = q ? *q : 0.f;
+                }
+                px[g4] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const float4 r = px[g4];
+                const float v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* q = chan(4 * g4 + e);
+                    if (q) *q = v[e];
+                }
+            }
         }
-        if (dir == 0) for (int c = c0; c < Cd; ++c) px[c] = 0.f;
     }
 }
 
@@ -966,8 +986,9 @@ int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr,
 
 int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B, int H, int W, int Cd,
                   int dir, mmh_stream_t s) {
-    MMH_REQUIRE(srcs && nhwc && nsrc >= 1 && nsrc <= 4 && B > 0 && H > 0 && W > 0 && Cd > 0,
-                "mmh_pack_nhwc: bad arguments");
+    MMH_REQUIRE(srcs && nhwc && nsrc >= 1 && nsrc <= 4 && B > 0 && H > 0 && W > 0 && Cd > 0 && Cd % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(nhwc) & 15) == 0,
+                "mmh_pack_nhwc: bad arguments (Cd %% 4 == 0, 16-byte aligned NHWC buffer)");
     PackArgs a{};
     a.nsrc = nsrc;
     int tot = 0;
