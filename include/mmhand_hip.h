@@ -267,6 +267,11 @@ int mmh_conv7_thin_fprop(const mmh_conv_desc* d, const void* x, const void* w,
 size_t mmh_conv7_thin_dgrad_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
                          void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
+/* wgrad of the head (d->Cout == 4, d->Cin % 64 == 0): dw [7][7][Cin][4] (+)= sum over pixels;
+ * per-workgroup partial sums in ws, added in a fixed order (deterministic).              */
+size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
+                         void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
 
 /* ---- Adam (torch.optim.Adam, MMHandModel.py:90-98) over a flat buffer ------
  * step is the 1-based step count; no weight decay, no amsgrad.

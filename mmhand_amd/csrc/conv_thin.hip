@@ -187,6 +187,131 @@ __global__ void thin_reflect_fold_kernel(const float* __restrict__ dxp, float* _
     }
 }
 
+// ---------------------------------------------------------------------------
+// wgrad of the same thin conv (the Generator head): dw[kh][kw][ci][0..3] = sum over pixels of
+// x[pix + tap][ci] * dy[pix][0..3].  As a GEMM it has N = 4 columns (3.9 ms on a 32-wide MFMA
+// tile).  Here: one workgroup per (image, 32-column strip, 64-channel chunk) walks down the strip;
+// 7 waves = the 7 tap rows kh, lane = input channel; each thread keeps its 7 kw x 4 co = 28 sums
+// in registers.  Input rows live in an 8-slot LDS ring (one new row per step, loaded while the
+// previous step computes); a thread reads the 38 staged inputs of its row once and slides the
+// 7-wide window over them in registers: 38 + 32 LDS reads per 448 packed FMAs.
+// Partial sums per workgroup go to `slab`, thin_wgrad_reduce_kernel adds them in a fixed order.
+// ---------------------------------------------------------------------------
+constexpr int WGW = 32;                 // strip width (output columns per workgroup)
+constexpr int WGC = WGW + 6;            // staged input columns
+
+struct ThinWgKP {
+    const float* x;
+    unsigned x_bytes;
+    const float* dy;
+    unsigned dy_bytes;
+    float* slab;                        // [nblk][49][64][4]
+    int B, H, W, Cin, x_cs, dy_cs, reflect;
+    int strips, chunks;
+};
+
+__global__ void __launch_bounds__(448) thin_wgrad7_kernel(const ThinWgKP p) {
+    __shared__ float ring[8][WGC][64];
+    __shared__ float4 dyrow[2][WGW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, kh = tid >> 6;
+    int t = blockIdx.x;
+    const int chunk = t % p.chunks; t /= p.chunks;
+    const int strip = t % p.strips;
+    const int b = t / p.strips;
+    const int w0 = strip * WGW;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+    // staging: input row `ir` (may be outside [0,H): reflected or zero) -> ring slot (ir + 3) & 7
+    constexpr int NF4 = WGC * 16;       // float4 per staged row (38 pixels x 16 groups of 4 channels)
+    auto row_off = [&](int ir, int idx) -> unsigned {    // byte offset of staged float4 `idx` of input row ir
+        const int px = idx >> 4, c4 = idx & 15;
+        int iw = w0 + px - 3;
+        bool ok = idx < NF4;
+        if (p.reflect) {
+            ir = ir < 0 ? -ir : ir; ir = ir >= p.H ? 2 * (p.H - 1) - ir : ir;
+            iw = iw < 0 ? -iw : iw; iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+        }
+        ok = ok && ir >= 0 && ir < p.H && iw >= 0 && iw < p.W;
+        return ok ? (unsigned)(((b * p.H + ir) * p.W + iw) * p.x_cs + chunk * 64 + c4 * 4) * 4u : OOBT;
+    };
+    float4 st[2];
+    float4 sd = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_row = [&](int ir, int orow) {     // input row ir and the dy row of output row orow -> registers
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, row_off(ir, tid + 448 * i), 0, 0);
+            st[i] = __builtin_bit_cast(float4, v);
+        }
+        if (tid < WGW) {
+            const int ow = w0 + tid;
+            const unsigned off = (orow < p.H && ow < p.W) ? (unsigned)(((b * p.H + orow) * p.W + ow) * p.dy_cs) * 4u : OOBT;
+            sd = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+        }
+    };
+    auto store_row = [&](int ir, int orow) {
+        float* slot = &ring[(ir + 3) & 7][0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 448 * i;
+            if (idx < NF4) *reinterpret_cast<float4*>(slot + (idx >> 4) * 64 + (idx & 15) * 4) = st[i];
+        }
+        if (tid < WGW) dyrow[orow & 1][tid] = sd;
+    };
+
+    f2 acc[7][2];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { acc[k][0] = (f2){0.f, 0.f}; acc[k][1] = (f2){0.f, 0.f}; }
+
+    // prologue: input rows -3 .. 2 (slots 0..5); row 3 and dy row 0 complete step 0
+    for (int ir = -3; ir <= 2; ++ir) { load_row(ir, p.H); store_row(ir, 1); }   // dy slot 1 gets zeros (unused)
+    load_row(3, 0);
+    store_row(3, 0);
+    __syncthreads();
+    for (int r = 0; r < p.H; ++r) {
+        if (r + 1 < p.H) load_row(r + 4, r + 1);        // next step's new row, in flight during the FMAs
+        const float* xr = &ring[(r + kh) & 7][0][lane];  // input row r + kh - 3
+        float xv[WGC];
+#pragma unroll
+        for (int c = 0; c < WGC; ++c) xv[c] = xr[c * 64];
+#pragma unroll
+        for (int c = 0; c < WGW; ++c) {
+            const float4 d4 = dyrow[r & 1][c];
+            const f2 d01 = (f2){d4.x, d4.y}, d23 = (f2){d4.z, d4.w};
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                const f2 xb = (f2){xv[c + kw], xv[c + kw]};
+                acc[kw][0] = __builtin_elementwise_fma(xb, d01, acc[kw][0]);
+                acc[kw][1] = __builtin_elementwise_fma(xb, d23, acc[kw][1]);
+            }
+        }
+        if (r + 1 < p.H) store_row(r + 4, r + 1);       // slot (r + 7) & 7 is not read in step r
+        __syncthreads();
+    }
+    float* out = p.slab + ((size_t)blockIdx.x * 49 + kh * 7) * 256 + lane * 4;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw)
+        *reinterpret_cast<float4*>(out + kw * 256) = make_float4(acc[kw][0].x, acc[kw][0].y, acc[kw][1].x, acc[kw][1].y);
+}
+
+// dw[tap][chunk*64 + ci][0..3] (+)= sum over (image, strip) of slab[(b, strip, chunk)][tap][ci][0..3]
+__global__ void thin_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nbs, int chunks,
+                                         int Cin, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // float4 index into [49][Cin]
+    if (i >= 49 * Cin) return;
+    const int tap = i / Cin, ci = i - tap * Cin;
+    const int chunk = ci >> 6, cl = ci & 63;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nbs; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (((size_t)(k * chunks + chunk) * 49 + tap) * 64 + cl) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(dw) + i;
+    if (accumulate) { const float4 v = *o; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    *o = s;
+}
+
 int launch_thin(ThinKP& p, hipStream_t st) {
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
@@ -265,6 +390,39 @@ int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, 
         return mmh::check_launch("thin_reflect_fold_kernel");
     }
     return 0;
+}
+
+size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d) {
+    if (!thin_shape_ok(d) || d->Cin % 64) return 0;
+    const size_t nblk = (size_t)d->B * ((d->W + WGW - 1) / WGW) * (d->Cin / 64);
+    return nblk * 49 * 64 * 4 * sizeof(float);
+}
+
+int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws, size_t ws_bytes,
+                         int accumulate, mmh_stream_t s) {
+    MMH_REQUIRE(thin_shape_ok(d), "mmh_conv7_thin_wgrad: needs a 7x7 / stride 1 / pad 3 fp32 conv");
+    MMH_REQUIRE(d->Cout == 4 && d->Cin % 64 == 0 && d->Cin > 0 && d->x_cs >= d->Cin && d->x_cs % 4 == 0 && d->y_cs >= 4 &&
+                    d->y_cs % 4 == 0,
+                "mmh_conv7_thin_wgrad: needs Cout == 4 and Cin %% 64 == 0");
+    MMH_REQUIRE(x && dy && dw && ws && ws_bytes >= mmh_conv7_thin_wgrad_ws_bytes(d), "mmh_conv7_thin_wgrad: bad buffers");
+    const long long xb = (long long)d->B * d->H * d->W * d->x_cs * 4, yb = (long long)d->B * d->H * d->W * d->y_cs * 4;
+    MMH_REQUIRE(xb < (1ll << 32) - 64 && yb < (1ll << 32) - 64, "mmh_conv7_thin_wgrad: tensors too large for 32-bit offsets");
+    hipStream_t st = mmh::as_stream(s);
+    ThinWgKP p{};
+    p.x = static_cast<const float*>(x); p.x_bytes = (unsigned)xb;
+    p.dy = static_cast<const float*>(dy); p.dy_bytes = (unsigned)yb;
+    p.slab = static_cast<float*>(ws);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
+    p.reflect = d->pad_mode == MMH_PAD_REFLECT;
+    p.strips = (d->W + WGW - 1) / WGW;
+    p.chunks = d->Cin / 64;
+    const int nblk = d->B * p.strips * p.chunks;
+    hipLaunchKernelGGL(thin_wgrad7_kernel, dim3(nblk), dim3(448), 0, st, p);
+    if (int rc = mmh::check_launch("thin_wgrad7_kernel")) return rc;
+    const int n4 = 49 * d->Cin;
+    hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st, p.slab, static_cast<float*>(dw),
+                       d->B * p.strips, p.chunks, d->Cin, accumulate);
+    return mmh::check_launch("thin_wgrad_reduce_kernel");
 }
 
 }  // extern "C"

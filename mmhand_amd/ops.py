@@ -348,6 +348,13 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     if wt:
         return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 64 == 0:
+        # the Generator head: 4 output columns; fp32 vector-ALU kernel (also under --opt_level O1/O2)
+        ws = _ws(L.load().mmh_conv7_thin_wgrad_ws_bytes(C.byref(d)), x)
+        dw = _empty((k, k, Cin, Cout), x)
+        L.call("mmh_conv7_thin_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+               _stream())
+        return dw
     if bf16:
         d.dtype = L.BF16
     assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
