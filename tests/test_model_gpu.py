@@ -115,6 +115,58 @@ def test_generator_eval_mode_matches_oracle(dev):
     assert R.rel_l1(out, ref) < TOL
 
 
+@pytest.mark.parametrize("wino", [True, False])
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_wide_channels_vs_oracle(norm, wino, dev, monkeypatch):
+    """ngf 32 -> PATBlock channels 128 / 256 at 12x12.  wino: every 3x3 conv of the stack runs on
+    Winograd F(6x6,3x3) (fused backward transforms), the stems and head on the direct / thin
+    kernels; else the direct kernels everywhere.  Output and every parameter gradient against the
+    fp64 oracle.
+
+    Tolerances.  Output: 2e-5 both ways.  Gradients, direct kernels: 1e-3, relaxed only where the
+    problem itself is ill-conditioned (the oracle's own fp32 run further than 1e-4 from its fp64
+    run).  Gradients, Winograd: 2e-2.  Each Winograd conv is within 3e-6 sigma of fp64 per output
+    channel (the direct kernel: 4e-7 sigma) and the network output within 5e-6, but parameter
+    gradients are far more sensitive to forward perturbations than the output is (ReLU masks and
+    the norm layers' nearly cancelling backward sums): measured up to 9e-3 on stem weight
+    gradients at toy sizes with batch statistics over 288 samples, and a median of 5e-3 between
+    the Winograd and the direct kernels on the full-size Generator (tools/grad_noise.py) - the
+    level at which any two fp32 convolution implementations differ on this network.
+    MMH_WINOGRAD=0 selects the direct kernels when gradient-level parity matters more than speed."""
+    from mmhand_amd import ops
+    from mmhand_amd.networks import Generator
+    monkeypatch.setattr(ops, "USE_WINOGRAD", wino)
+    assert ops._wino_tile(2, 12, 12, 256, 128, 3, 1, 1, False) == (6 if wino else 0)
+    net = Generator([3, 42, 6], 3, 32, norm, False, 2)
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    net.flatten_parameters()
+    b = O.synthetic_batch(2, 48, 48, seed=11)
+    # dense pose planes: at 12x12 the sparse synthetic heat maps leave InstanceNorm planes of the
+    # pose stream with almost no variance (the fp32 and fp64 oracles then differ by 8e-3)
+    pose = torch.rand(2, 42, 48, 48, generator=torch.Generator().manual_seed(12))
+    g_in = [b["H1"], pose, torch.cat((b["D1"], b["D2"]), 1)]
+    probe = torch.randn(2, 3, 48, 48, generator=torch.Generator().manual_seed(3))
+    out = net([t.to(dev) for t in g_in])
+    (out * probe.to(dev)).sum().backward()
+    og = {}
+    for dt in (torch.float64, torch.float32):
+        onet = O._Net({k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}, norm, False)
+        ref = O.generator_forward(onet, [t.to(dt) for t in g_in], 2)
+        (ref * probe.to(dt)).sum().backward()
+        og[dt] = dict((k, t.grad) for k, t in onet.named_parameters())
+        if dt == torch.float64:
+            assert R.rel_l1(out, ref.detach()) < 2e-5, R.rel_l1(out, ref.detach())
+    grads = logical_grads(net)
+    for k, g in grads.items():
+        if RC.is_null_grad_bias("G", k, norm) or og[torch.float64].get(k) is None:
+            continue
+        cond = R.rel_l1(og[torch.float32][k], og[torch.float64][k])
+        e = R.rel_l1(g, og[torch.float64][k])
+        assert e < max(2e-2 if wino else TOL, 10 * cond), (k, e, cond)
+
+
 def _small_opt(norm, dev_index=0, **kw):
     from mmhand_amd.options import default_train_opt
     args = dict(batchSize=S["B"], ngf=S["ngf"], ndf=S["ndf"], n_layers_D=S["n_layers_D"],
