@@ -72,3 +72,49 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_pat
     for k, v in ref_sd.items():
         if v.is_floating_point() and not is_null_grad_bias("G", k, norm):
             assert torch.allclose(r0["sd"][k], v, atol=2e-4 + 1e-3 * v.abs().max().item()), k
+
+
+def _worker_overflow(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    from oracle import mmhand_ref as O
+    from mmhand_amd.mmhand_model import MMHandModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    random.seed(0)
+    full = O.synthetic_batch(4, 32, 32, seed=7)
+    shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
+    model = MMHandModel(_opt("instance", 2, True))
+    model.set_input(shard)
+    model.optimize_parameters()                                  # clean iteration
+    snap = {n: getattr(model, n).flat_param.clone() for n in ("netG", "netD_PP", "netD_PB")}
+    if rank == 0:                                                # ONLY rank 0 overflows
+        orig = model.backward_G
+
+        def poisoned():
+            orig()
+            model.netG.flat_grad[11] = float("inf")
+        model.backward_G = poisoned
+    model.optimize_parameters()
+    model._settle_overflow(drain=True)
+    torch.cuda.synchronize()
+    unchanged = {n: bool(torch.equal(getattr(model, n).flat_param, snap[n])) for n in snap}
+    torch.save({"unchanged": unchanged, "skipped": model.skipped_steps,
+                "steps": [o.step_count for o in model.optimizers],
+                "G": model.netG.flat_param.detach().cpu()}, os.path.join(tmp, f"ovf{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_skips_the_step_on_every_rank(dev, tmp_path):
+    """The overflow flag needs no collective of its own: it is computed on the all-reduced gradients,
+    and a non-finite value on ONE rank is non-finite in the sum on every rank (reduce_tensor of
+    models/MMHandModel.py:381-384).  Rank 0 alone poisons its generator gradient; both ranks must
+    skip all three optimizer steps of that iteration and stay identical replicas."""
+    mp.spawn(_worker_overflow, args=(2, 29623, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "ovf0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "ovf1.pt"))
+    for r in (r0, r1):
+        assert r["unchanged"] == {"netG": True, "netD_PP": True, "netD_PB": True}, r["unchanged"]
+        assert r["skipped"] == 3 and r["steps"] == [1, 1, 1], (r["skipped"], r["steps"])
+    assert torch.equal(r0["G"], r1["G"])
