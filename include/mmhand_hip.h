@@ -195,13 +195,18 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count,
 /* out = dropout(relu(x*scale[g][c] + shift[g][c])) (+ residual).  scale and
  * shift are [groups][C].  Dropout keeps an element when the counter-based
  * hash of (seed, element index) < keep threshold and scales by 1/(1-p);
- * if mask != NULL (uint8 per element, test hook) it is used instead.       */
+ * if mask != NULL (uint8 per element, test hook) it is used instead.
+ * keep_bits != NULL (uint8 per 4 channels): bit e = lane e survived ReLU / dropout -
+ * all the backward needs of `out`, at 1/16 of its bytes.                    */
 int mmh_scale_shift_act(const void* x, const void* scale, const void* shift,
                         const void* residual, void* out, int groups,
                         int64_t rows_per_group, int C, int relu, float drop_p,
-                        uint64_t seed, const void* mask, mmh_stream_t s);
+                        uint64_t seed, const void* mask, void* keep_bits,
+                        mmh_stream_t s);
 
 /* Backward of norm+relu+dropout.  dz = g * (relu||drop ? (out>0)/(1-p) : 1).
+ * masked: 0 = no ReLU / dropout (`out` unused), 1 = `out` is the fp32 forward output,
+ * 2 = `out` is the keep_bits array written by mmh_scale_shift_act.
  * reduce: s1[g][c] = sum dz, s2[g][c] = sum dz*xhat, xhat = (x-mean)*invstd.
  * apply:  dx = gamma*invstd*(dz - s1/count - xhat*s2/count).               */
 size_t mmh_norm_bwd_ws_bytes(int groups, int64_t rows_per_group, int C);

@@ -173,7 +173,7 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
                                        const float* __restrict__ residual, float* __restrict__ out,
                                        int64_t n4, int64_t rows_per_group, int C4, int relu,
                                        float drop_p, uint64_t seed,
-                                       const uint8_t* __restrict__ mask) {
+                                       const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits) {
     const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,6 +196,8 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
                 r[e] = keep ? r[e] * dsc : 0.f;
             }
         }
+        if (keep_bits)      // what the backward needs of `out`: which lanes survived ReLU / dropout
+            keep_bits[i] = (uint8_t)((r[0] > 0.f) | ((r[1] > 0.f) << 1) | ((r[2] > 0.f) << 2) | ((r[3] > 0.f) << 3));
         if (residual) {
             float4 q = ld4(residual, i);
             r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
@@ -233,7 +235,11 @@ __global__ void col_reduce_partial(const float* __restrict__ a, const float* __r
             float4 g = *reinterpret_cast<const float4*>(a + off);
             float gv[4] = {g.x, g.y, g.z, g.w};
             if (MODE == 1) {
-                if (masked) {
+                if (masked == 2) {      // 4 keep bits per float4 (mmh_scale_shift_act keep_bits)
+                    const unsigned kb = reinterpret_cast<const uint8_t*>(outv)[off >> 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[e] = (kb >> e) & 1u ? gv[e] * dsc : 0.f;
+                } else if (masked) {
                     float4 o = *reinterpret_cast<const float4*>(outv + off);
                     gv[0] = o.x > 0.f ? gv[0] * dsc : 0.f;
                     gv[1] = o.y > 0.f ? gv[1] * dsc : 0.f;
@@ -330,7 +336,11 @@ __global__ void norm_bwd_apply_kernel(const float* __restrict__ g, const float* 
         float4 a1 = ld4(s1, gi), a2 = ld4(s2, gi);
         float4 gm = gamma ? ld4(gamma, c4) : make_float4(1.f, 1.f, 1.f, 1.f);
         float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-        if (masked) {
+        if (masked == 2) {
+            const unsigned kb = reinterpret_cast<const uint8_t*>(outv)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = (kb >> e) & 1u ? gv[e] * dsc : 0.f;
+        } else if (masked) {
             float4 o = ld4(outv, i);
             gv[0] = o.x > 0.f ? gv[0] * dsc : 0.f;
             gv[1] = o.y > 0.f ? gv[1] * dsc : 0.f;
@@ -788,7 +798,7 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count, const void
 
 int mmh_scale_shift_act(const void* x, const void* scale, const void* shift, const void* residual,
                         void* out, int groups, int64_t rows, int C, int relu, float drop_p,
-                        uint64_t seed, const void* mask, mmh_stream_t s) {
+                        uint64_t seed, const void* mask, void* keep_bits, mmh_stream_t s) {
     if (int rc = check_cols("mmh_scale_shift_act", C)) return rc;
     MMH_REQUIRE(x && scale && shift && out && groups > 0 && rows > 0, "mmh_scale_shift_act: bad arguments");
     MMH_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu),
@@ -798,7 +808,7 @@ int mmh_scale_shift_act(const void* x, const void* scale, const void* shift, con
                        static_cast<const float*>(x), static_cast<const float*>(scale),
                        static_cast<const float*>(shift), static_cast<const float*>(residual),
                        static_cast<float*>(out), n4, rows, C / 4, relu, drop_p, seed,
-                       static_cast<const uint8_t*>(mask));
+                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits));
     return mmh::check_launch("scale_shift_act");
 }
 

@@ -536,14 +536,17 @@ def raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var, m
     return scale, shift, invstd
 
 
-def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask):
+def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=False):
+    """keep_bits: also return the uint8 [B,H,W,C/4] array of surviving-lane bits (4 per byte), the
+    only thing the norm backward needs of `out`."""
     B, H, W_, Cc = x.shape
     groups = scale.shape[0]
     rows = (B // groups) * H * W_
     out = torch.empty_like(x)
+    kb = torch.empty((B, H, W_, Cc // 4), dtype=torch.uint8, device=x.device) if keep_bits else None
     L.call("mmh_scale_shift_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
-           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _stream())
-    return out
+           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _stream())
+    return (out, kb) if keep_bits else out
 
 
 def _sync_stats(mean, m2, rows, group):
@@ -579,21 +582,25 @@ class NormActFn(torch.autograd.Function):
             mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
         scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
                                                  running_var)
-        out = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask)
+        masked = bool(relu or drop_p > 0)
+        if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
+            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True)
+        else:
+            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask), None
         ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
                    residual is not None)
-        ctx.save_for_backward(x, out, mean, invstd, gamma)
+        ctx.save_for_backward(x, kb, mean, invstd, gamma)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, out, mean, invstd, gamma = ctx.saved_tensors
+        x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
         groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         if has_res and relu:
             raise RuntimeError("NormActFn: residual together with ReLU is not on the reference path")
         g = g.contiguous()
         Cc = x.shape[3]
-        masked = int(relu or drop_p > 0)
+        masked = 2 if (relu or drop_p > 0) else 0
         ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
         s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
         L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
