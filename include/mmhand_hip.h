@@ -117,8 +117,11 @@ int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int 
                       void* Yh, mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
                   int nbatch, int dtype, mmh_stream_t s);
+/* stats (tile 6, fp32; may be NULL): [B][tiles per image][3][C] floats = per (image, tile, channel)
+ * the count, mean and M2 of the tile's outputs - the partial-statistics layout that
+ * mmh_norm_stats_merge reduces, so the InstanceNorm after the conv does not re-read y. */
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,
-                    int act, int tile, int dtype, mmh_stream_t s);
+                    int act, int tile, int dtype, void* stats, mmh_stream_t s);
 size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);
 int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout,
                         int nbatch, int dtype, void* ws, size_t ws_bytes, void* dU,
@@ -181,6 +184,11 @@ size_t mmh_norm_stats_ws_bytes(int groups, int64_t rows_per_group, int C);
 int mmh_norm_stats(const void* x, int groups, int64_t rows_per_group, int C,
                    int cs, void* mean, void* m2, void* ws, size_t ws_bytes,
                    mmh_stream_t s);
+
+/* Chan merge of `chunks` partial (count, mean, M2) triples per (group, channel), laid out
+ * [groups][chunks][3][C] (what mmh_wino_output(stats) writes): the second stage of mmh_norm_stats. */
+int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, void* mean,
+                         void* m2, mmh_stream_t s);
 
 /* scale = gamma*rsqrt(m2/count+eps), shift = beta - mean*scale, invstd.
  * gamma/beta may be NULL (affine=False).  If running_mean != NULL (batch

@@ -3016,14 +3016,15 @@ int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, i
 }
 
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,
-                    int dtype, mmh_stream_t s) {
+                    int dtype, void* stats, mmh_stream_t s) {
     MMH_REQUIRE(M && y && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
                     wino_dtype_ok(dtype, tile),
                 "mmh_wino_output: bad arguments");
     const long long tiles = wino_tiles(B, H, W, tile);
+    MMH_REQUIRE(!stats || (tile == 6 && dtype == MMH_F32), "mmh_wino_output: statistics need tile 6, fp32");
     if (tile == 6)
         return mmh::wino6_output(static_cast<const float*>(M), static_cast<float*>(y), static_cast<const float*>(bias),
-                                 B, H, W, C, act, mmh::as_stream(s));
+                                 B, H, W, C, act, static_cast<float*>(stats), mmh::as_stream(s));
     if (tile == 4) {
         const long long total = tiles * (C / 2);
         hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -107,17 +107,34 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
     const bool ok = i < groups * C;
     const int grp = ok ? i / C : 0, c = ok ? i - grp * C : 0;
     double na = 0, ma = 0, qa = 0;
-    if (ok)
-        for (int k = kl; k < chunks; k += 8) {
-            const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
-            double nb = ws[o], mb = ws[o + C], qb = ws[o + 2 * C];
-            if (nb > 0) {
-                double nt = na + nb, d = mb - ma;
-                ma += d * (nb / nt);
-                qa += qb + d * d * (na * nb / nt);
-                na = nt;
-            }
+    auto merge = [&](double nb, double mb, double qb) {
+        if (nb > 0) {
+            double nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
         }
+    };
+    if (ok) {
+        // 4 partial triples per iteration: their loads do not depend on the running merge, so 12 are
+        // in flight instead of a load -> divide -> load chain (121 tiles per plane after a Winograd
+        // conv); the merge ORDER is unchanged (k ascending per lane)
+        int k = kl;
+        for (; k + 24 < chunks; k += 32) {
+            float nb[4], mb[4], qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t o = ((int64_t)(grp * chunks + k + 8 * u) * 3) * C + c;
+                nb[u] = ws[o]; mb[u] = ws[o + C]; qb[u] = ws[o + 2 * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) merge(nb[u], mb[u], qb[u]);
+        }
+        for (; k < chunks; k += 8) {
+            const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
+            merge(ws[o], ws[o + C], ws[o + 2 * C]);
+        }
+    }
     sh[0][kl][cl] = na; sh[1][kl][cl] = ma; sh[2][kl][cl] = qa;
     __syncthreads();
     if (kl == 0 && ok) {
@@ -778,6 +795,15 @@ int mmh_norm_stats(const void* x, int groups, int64_t rows, int C, int cs, void*
                        static_cast<const float*>(ws), groups, C, g.chunks, static_cast<float*>(mean),
                        static_cast<float*>(m2));
     return mmh::check_launch("norm_stats");
+}
+
+int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, void* mean, void* m2,
+                         mmh_stream_t s) {
+    MMH_REQUIRE(partials && mean && m2 && groups > 0 && chunks > 0 && C > 0, "mmh_norm_stats_merge: bad arguments");
+    hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(partials), groups, C, chunks, static_cast<float*>(mean),
+                       static_cast<float*>(m2));
+    return mmh::check_launch("norm_stats_merge");
 }
 
 int mmh_norm_finalize(const void* mean, const void* m2, double count, const void* gamma,

@@ -186,10 +186,17 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     }
 }
 
+__device__ __forceinline__ void stat_add(float v, float& n, float& s) { n += 1.f; s += v; }
+__device__ __forceinline__ void stat_add(F2, float&, float&) {}
+
+// stats (T = float only): per (image, tile, channel) the count, mean and M2 of the tile's valid
+// outputs, in the partial layout of norm_stats_partial (pointwise.hip) with chunk = tile index
+// inside the image, so the InstanceNorm that follows the conv merges 121 partials per plane
+// instead of re-reading the plane.
 template <typename T>
 __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ M, float* __restrict__ y,
                                                            const float* __restrict__ bias, int B, int H, int W,
-                                                           int C2, int act) {
+                                                           int C2, int act, float* __restrict__ stats) {
     const int TH = (H + 5) / 6, TW = (W + 5) / 6;
     const long long tiles = (long long)B * TH * TW;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,18 +217,35 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
     }
     const T bv = bias ? reinterpret_cast<const T*>(bias)[c] : zero_of(T{});
     T* yo = reinterpret_cast<T*>(y);
+    T vals[6][6];
+    float n = 0.f, sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const int hh = 6 * ty + r;
-        if (hh >= H) break;
         w6_at(s6[r], o6);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int ww = 6 * tx + q;
-            if (ww < W) {
-                yo[(((long long)b * H + hh) * W + ww) * C2 + c] = act_of(o6[q] + bv, act);
+            vals[r][q] = act_of(o6[q] + bv, act);
+            if (hh < H && ww < W) {
+                yo[(((long long)b * H + hh) * W + ww) * C2 + c] = vals[r][q];
+                stat_add(vals[r][q], n, sum);
             }
         }
+    }
+    if (stats && sizeof(T) == 4) {
+        const float mean = sum / n;         // n >= 1: a tile always holds at least one pixel of the image
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (6 * ty + r < H && 6 * tx + q < W) {
+                    const float d = *reinterpret_cast<const float*>(&vals[r][q]) - mean;
+                    m2 += d * d;
+                }
+        float* o = stats + ((long long)(b * (TH * TW) + ty * TW + tx) * 3) * C2 + c;
+        o[0] = n; o[C2] = mean; o[2 * C2] = m2;
     }
 }
 
@@ -374,14 +398,15 @@ int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflec
     return check_launch("wino6_input_kernel");
 }
 
-int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, hipStream_t st) {
+int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, float* stats,
+                 hipStream_t st) {
     const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
-    if (g_wino6_vec & 2)
+    if ((g_wino6_vec & 2) && !stats)
         hipLaunchKernelGGL(wino6_output_kernel<F2>, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, M,
-                           y, bias, B, H, W, C / 2, act);
+                           y, bias, B, H, W, C / 2, act, nullptr);
     else
         hipLaunchKernelGGL(wino6_output_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, M, y,
-                           bias, B, H, W, C, act);
+                           bias, B, H, W, C, act, stats);
     return check_launch("wino6_output_kernel");
 }
 

@@ -162,7 +162,13 @@ def wino_weights(w, tile, flip_transpose=False, bf16=False):
     return ent[2]
 
 
-def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False):
+# Per-tile output statistics of the last Winograd F(6x6,3x3) conv outputs, keyed by the output's
+# data pointer: NormActFn (instance norm) picks them up instead of re-reading the conv output.
+FUSE_NORM_STATS = os.environ.get("MMH_FUSE_NORM_STATS", "1") != "0"
+_pending_stats = {}
+
+
+def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
     keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor).
     bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32."""
@@ -182,7 +188,13 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
         e1.record()
     else:
         L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
-    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _stream())
+    stats = None
+    if want_stats and FUSE_NORM_STATS and tile == 6 and not bf16 and act == L.ACT_NONE:
+        stats = _empty((B, tiles // B, 3, Cout), x)
+    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _ptr(stats), _stream())
+    if stats is not None:
+        _pending_stats.clear()              # only the most recent conv output can be the norm's input
+        _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
     return (y, V) if keep_V else y
 
 
@@ -190,7 +202,7 @@ def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=Fals
     """3x3 / stride 1 / pad 1 conv by Winograd (fp32, or bf16 Winograd-domain tensors with tile 2)."""
     _chk(x, "x"); _chk(w, "w")
     return _wino_conv(x, wino_weights(w, tile, False, bf16), bias, w.shape[3], reflect, act, tile, time_it=True,
-                      keep_V=keep_V, bf16=bf16)
+                      keep_V=keep_V, bf16=bf16, want_stats=True)
 
 
 def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
@@ -260,7 +272,7 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
     M = _empty((P, tiles, Cin), dy)
     L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
     dx = _empty((B, H, W_, Cin), dy)
-    L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, _stream())
+    L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, _stream())
     if reflect:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
@@ -516,9 +528,19 @@ def set_dropout_seed(seed):
 
 
 def raw_norm_stats(x, groups):
-    """mean, M2 per (group, channel); groups = B (instance) or 1 (batch)."""
+    """mean, M2 per (group, channel); groups = B (instance) or 1 (batch).  For instance norm right
+    after a Winograd F(6x6,3x3) conv the per-tile partials written by its output transform are
+    merged instead of reading x again."""
     B, H, W_, Cc = x.shape
     rows = (B // groups) * H * W_
+    pend = _pending_stats.pop(x.data_ptr(), None)
+    _pending_stats.clear()      # an entry is only ever valid for the norm call right after its conv
+    if pend is not None and groups == B and pend[1] == tuple(x.shape):
+        stats = pend[0]
+        mean = _empty((groups, Cc), x)
+        m2 = _empty((groups, Cc), x)
+        L.call("mmh_norm_stats_merge", _ptr(stats), groups, stats.shape[1], Cc, _ptr(mean), _ptr(m2), _stream())
+        return mean, m2, rows
     ws = _ws(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc), x)
     mean = _empty((groups, Cc), x)
     m2 = _empty((groups, Cc), x)
