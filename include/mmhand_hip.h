@@ -265,6 +265,14 @@ int mmh_l1_fwd(const void* a, const void* b, int64_t n, float weight,
 int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight,
                double denom, const void* gscalar, void* da, mmh_stream_t s);
 
+/* MSE mean (F.mse_loss, the --percep_is_l1 0 branch of losses/L1_plus_perceptualLoss.py:68-71):
+ * out = weight * sum (a-b)^2 / denom;  da = gscalar[0] * weight/denom * 2 (a-b)            */
+int mmh_mse_fwd(const void* a, const void* b, int64_t n, float weight,
+                double denom, void* out, void* ws, size_t ws_bytes,
+                mmh_stream_t s);
+int mmh_mse_bwd(const void* a, const void* b, int64_t n, float weight,
+                double denom, const void* gscalar, void* da, mmh_stream_t s);
+
 /* ---- thin 7x7 convolutions (at most 4 output channels) on the vector ALU -----
  * The Generator head ReflectionPad2d(3)+Conv2d(64,3,7)+Tanh (models/Generator.py:255-259)
  * and the dgrad of the Discriminator stems (models/Discriminator.py:79-84) with respect

@@ -471,7 +471,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return r;  // valid in thread 0
 }
 
-// MODE 0: BCE-with-logits vs constant target; MODE 1: |a-b|
+// MODE 0: BCE-with-logits vs constant target; MODE 1: |a-b|; MODE 2: (a-b)^2
 template <int MODE>
 __global__ void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                     int64_t n, float target, float* __restrict__ partial) {
@@ -489,9 +489,13 @@ __global__ void loss_partial_kernel(const float* __restrict__ a, const float* __
                 float x = xs[e];
                 acc += fmaxf(x, 0.f) - x * target + log1pf(__expf(-fabsf(x)));
             }
-        } else {
+        } else if (MODE == 1) {
             float4 w = ld4(b, i);
             acc += fabsf(v.x - w.x) + fabsf(v.y - w.y) + fabsf(v.z - w.z) + fabsf(v.w - w.w);
+        } else {
+            float4 w = ld4(b, i);
+            const float d0 = v.x - w.x, d1 = v.y - w.y, d2 = v.z - w.z, d3 = v.w - w.w;
+            acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
     }
     float r = block_sum(acc, sh);
@@ -531,6 +535,19 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
         float4 v = ld4(a, i), w = ld4(b, i), r;
         r.x = kk * sgn(v.x - w.x); r.y = kk * sgn(v.y - w.y);
         r.z = kk * sgn(v.z - w.z); r.w = kk * sgn(v.w - w.w);
+        st4(da, i, r);
+    }
+}
+
+__global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n4,
+                               float k, const float* __restrict__ gs, float* __restrict__ da) {
+    const float kk = 2.f * k * gs[0];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 v = ld4(a, i), w = ld4(b, i), r;
+        r.x = kk * (v.x - w.x); r.y = kk * (v.y - w.y);
+        r.z = kk * (v.z - w.z); r.w = kk * (v.w - w.w);
         st4(da, i, r);
     }
 }
@@ -956,8 +973,12 @@ static int loss_fwd(int mode, const void* a, const void* b, int64_t n, float tar
     if (mode == 0)
         hipLaunchKernelGGL((loss_partial_kernel<0>), dim3(blocks), dim3(TPB), 0, st,
                            static_cast<const float*>(a), nullptr, n, target, static_cast<float*>(ws));
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL((loss_partial_kernel<1>), dim3(blocks), dim3(TPB), 0, st,
+                           static_cast<const float*>(a), static_cast<const float*>(b), n, 0.f,
+                           static_cast<float*>(ws));
+    else
+        hipLaunchKernelGGL((loss_partial_kernel<2>), dim3(blocks), dim3(TPB), 0, st,
                            static_cast<const float*>(a), static_cast<const float*>(b), n, 0.f,
                            static_cast<float*>(ws));
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, static_cast<const float*>(ws),
@@ -993,6 +1014,22 @@ int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight, double den
                        (float)((double)weight / denom), static_cast<const float*>(gscalar),
                        static_cast<float*>(da));
     return mmh::check_launch("l1_bwd");
+}
+
+int mmh_mse_fwd(const void* a, const void* b, int64_t n, float weight, double denom, void* out,
+                void* ws, size_t ws_bytes, mmh_stream_t s) {
+    MMH_REQUIRE(b != nullptr, "mmh_mse_fwd: NULL buffer");
+    return loss_fwd(2, a, b, n, 0.f, weight, denom, out, ws, ws_bytes, s);
+}
+
+int mmh_mse_bwd(const void* a, const void* b, int64_t n, float weight, double denom,
+                const void* gscalar, void* da, mmh_stream_t s) {
+    MMH_REQUIRE(a && b && gscalar && da && n > 0 && n % 4 == 0 && denom > 0, "mmh_mse_bwd: bad arguments");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(a), static_cast<const float*>(b), n / 4,
+                       (float)((double)weight / denom), static_cast<const float*>(gscalar),
+                       static_cast<float*>(da));
+    return mmh::check_launch("mse_bwd");
 }
 
 int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in, void* flag_out, mmh_stream_t s) {

@@ -71,6 +71,16 @@ class InferenceGenerator:
             f[("up", i)] = _fold(up[3 * i], up[3 * i + 1], transposed=True)
         f[("head",)] = _fold(up[3 * n.n_down + 1], None)
         self.f = f
+        self._graph = None              # a re-fold (BN recalibration) invalidates a captured graph
+        ops.bump_weights_epoch()        # ... and every derived copy of the previous folded weights
+
+    def refold(self):
+        """Call after the network's weights or BN running statistics changed."""
+        if self.folded:
+            self._build_folded()
+        else:
+            self._graph = None
+            ops.bump_weights_epoch()
 
     def _forward_folded(self, x1, x2, x3):
         n, f = self.net, self.f
@@ -130,4 +140,8 @@ class InferenceGenerator:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_out = self._eager(self._static_in)
+        # the captured launches read the derived weights (bf16 copies, Winograd-domain filters) made
+        # during the warm-up: hold them for as long as the graph lives (ops drops its cache at every
+        # weights-epoch bump)
+        self._derived = (dict(ops._wino_cache), dict(ops._bf16_cache))
         self._graph, self._key = g, key

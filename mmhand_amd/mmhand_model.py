@@ -125,9 +125,9 @@ class L1PlusPerceptualLoss:
     STD = (0.229, 0.224, 0.225)
 
     def __init__(self, lambda_L1, lambda_perceptual, vgg, percep_is_l1=1):
-        if percep_is_l1 != 1:
-            raise NotImplementedError("percep_is_l1=0 (MSE) is not on the shipped path")
         self.lambda_L1, self.lambda_perceptual, self.vgg = lambda_L1, lambda_perceptual, vgg
+        # L1_plus_perceptualLoss.py:64-71: L1 on the VGG features when percep_is_l1 == 1, else MSE
+        self.percep_fn = ops.L1MeanFn if percep_is_l1 == 1 else ops.MSEMeanFn
         dev = next(vgg.parameters()).device
         sc = [0.5 / s for s in self.STD] + [0.0]
         sh = [(0.5 - m) / s for m, s in zip(self.MEAN, self.STD)] + [0.0]
@@ -143,7 +143,7 @@ class L1PlusPerceptualLoss:
         f = self.features(fake)
         with torch.no_grad():
             r = self.features(real)
-        loss_p = ops.L1MeanFn.apply(f, r, self.lambda_perceptual, float(f.numel()))
+        loss_p = self.percep_fn.apply(f, r, self.lambda_perceptual, float(f.numel()))
         return loss_l1 + loss_p, loss_l1, loss_p
 
 
@@ -186,6 +186,12 @@ class MMHandModel(torch.nn.Module):
         self.world = dist.get_world_size() if (getattr(opt, "distributed", False)
                                                and dist.is_initialized()) else 1
         seed = getattr(opt, "seed", 49)
+        # dropout masks: an independent stream per rank, as each reference rank has its own RNG
+        # (the weights are seeded identically on every rank and broadcast from rank 0).  ImagePool
+        # draws from Python's global `random`, exactly as util/image_pool.py does; seed it from the
+        # caller (random.seed) when a reproducible pool history is wanted.
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        ops.set_dropout_seed((int(seed) * 0x9E3779B97F4A7C15 + 0x5EED0001 + rank * 0xD1B54A32D192ED03) % (1 << 64))
         norm = get_norm_layer(opt.norm)
         input_nc = [opt.H_input_nc, opt.P_input_nc * 2, opt.D_input_nc * 2]
         self.netG = Generator(input_nc, opt.output_nc, opt.ngf, norm, not opt.no_dropout,
@@ -219,13 +225,28 @@ class MMHandModel(torch.nn.Module):
             self.fake_PB_pool = ImagePool(opt.pool_size)
             self.criterionGAN = GANLoss()
             if opt.L1_type == "l1_plus_perL1":
+                if getattr(opt, "perceptual_layers", 3) != 3:
+                    # the reference slices vgg19.features up to (and including) this index
+                    # (L1_plus_perceptualLoss.py:24-27); only its shipped value is built here
+                    raise NotImplementedError("--perceptual_layers %r: only 3 (vgg19.features[0:4]) is built"
+                                              % (opt.perceptual_layers,))
                 self.vgg = VGGHead().to(self.device)
                 self.vgg.bf16 = self.bf16
                 vgg_path = getattr(opt, "vgg_weights", None)
                 if vgg_path:
                     self.vgg.load_state_dict(torch.load(vgg_path, map_location="cpu"))
+                    self.vgg_source = "file:" + os.path.abspath(vgg_path)
+                elif getattr(opt, "vgg_random_init", False):
+                    self.vgg.init_random()
+                    self.vgg_source = "random-init (seed 1234): NOT the reference's pretrained objective"
+                    self.pprint("WARNING: perceptual loss on RANDOM vgg19.features[0:4] weights "
+                                "(--vgg_random_init); the reference uses torchvision's pretrained VGG19")
                 else:
-                    self.vgg.init_random()     # torchvision weights are not shipped offline
+                    raise RuntimeError(
+                        "--L1_type l1_plus_perL1 needs torchvision's pretrained vgg19.features[0:4] "
+                        "(losses/L1_plus_perceptualLoss.py:22), which cannot be downloaded here: pass "
+                        "--vgg_weights <state_dict file with 0.weight/0.bias/2.weight/2.bias, or the "
+                        "torchvision 'features.' keys>, or opt in to random weights with --vgg_random_init")
                 self.criterionL1 = L1PlusPerceptualLoss(opt.lambda_A, opt.lambda_B, self.vgg,
                                                         opt.percep_is_l1)
             elif opt.L1_type == "origin":
@@ -269,6 +290,7 @@ class MMHandModel(torch.nn.Module):
                 dist.broadcast(b, 0)
             if net.norm == "batch":
                 net.sync_group = dist.group.WORLD
+        ops.bump_weights_epoch()        # the broadcast rewrote every weight in place
         for o in self.optimizers:
             o.grad_scale = 1.0 / self.world
 
@@ -507,6 +529,9 @@ class MMHandModel(torch.nn.Module):
             torch.save(OrderedDict((k, v.cpu()) for k, v in network.state_dict().items()), path)
 
     def save(self, label):
+        """Call on EVERY rank (mmhand_amd/train.py does): the overflow flags are settled on the same
+        schedule everywhere, so the Adam step counts stay identical across ranks; only the master
+        writes files."""
         self.save_network(self.netG, "netG", label, self.gpu_ids)
         self.save_network(self.netD_PB, "netD_PB", label, self.gpu_ids)
         self.save_network(self.netD_PP, "netD_PP", label, self.gpu_ids)

@@ -401,6 +401,11 @@ class VGGHead(nn.Module):
         return type(sd)((k.replace("net.", "", 1), v) for k, v in sd.items())
 
     def load_state_dict(self, sd, strict=True):
+        """Accepts {'0.weight','0.bias','2.weight','2.bias'} or a torchvision vgg19 state_dict
+        ('features.0.weight', ...; later layers and the classifier are ignored)."""
+        if any(k.startswith("features.") for k in sd):
+            sd = {k[len("features."):]: v for k, v in sd.items()
+                  if k.startswith("features.") and k.split(".")[1] in ("0", "2")}
         return super().load_state_dict({"net." + k: v for k, v in sd.items()}, strict)
 
     def forward_nhwc(self, x):

@@ -15,6 +15,7 @@ are permuted *views* of them with the reference's logical OIHW / IOHW shape.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -52,24 +53,57 @@ def _ws(nbytes, like):
 
 # --------------------------------------------------------------------------- conv
 fprop_timer = None   # optional bench hook: object with want(desc) / bracket() -> (event, event)
+# optional bench hook: dict kind -> executed FLOPs ("mfma": matrix-core convolution arithmetic that the
+# launches really perform - Winograd-domain GEMMs count their own multiplications, not the direct
+# algorithm's; "valu": the thin 7x7 convs on the vector ALU).  None = not counting.
+flop_meter = None
+
+
+def _count(kind, flops):
+    if flop_meter is not None:
+        flop_meter[kind] = flop_meter.get(kind, 0.0) + float(flops)
+
+
+def _count_desc(kind, d):
+    if flop_meter is not None:
+        _count(kind, 2.0 * d.B * d.Ho * d.Wo * d.Cin * d.Cout * d.kh * d.kw)
 
 # bf16 MFMA path ("--opt_level O1/O2": the reference's apex AMP mixed precision becomes bf16
 # compute with fp32 master weights, fp32 accumulation and fp32 tensors in HBM).  The bf16 weight
 # copies are rebuilt lazily whenever the weights epoch moves (optimizer step, load_state_dict).
 _weights_epoch = [0]
 _bf16_cache = {}
+_wino_cache = {}
 
 
 def bump_weights_epoch():
+    """Every derived copy of every weight (bf16 copies, Winograd-domain filters) is stale after an
+    optimizer step / load_state_dict / broadcast: drop them all, so dead tensors' copies are freed
+    too.  Entries additionally hold a weak reference to the tensor object they were made from - a new
+    tensor that happens to land on a freed tensor's address never hits a stale entry."""
     _weights_epoch[0] += 1
+    _bf16_cache.clear()
+    _wino_cache.clear()
+
+
+def _cache_get(cache, key, w):
+    ent = cache.get(key)
+    if ent is not None and ent[0] == _weights_epoch[0] and ent[1]() is w:
+        return ent[2]
+    return None
+
+
+def _cache_put(cache, key, w, value):
+    cache[key] = (_weights_epoch[0], weakref.ref(w), value)
+    return value
 
 
 def bf16_weights(w):
     """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) bf16 copies of a physical fp32 weight; for
     Cin % 64 != 0 the second entry is w_flat [Cout, Kpad] (flat (tap, ci) contraction index)."""
-    key = w.data_ptr()
-    ent = _bf16_cache.get(key)
-    if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _cache_get(_bf16_cache, key, w)
+    if ent is None:
         k, _, cin, cout = w.shape
         wp = torch.empty((k, k, cin, cout), dtype=torch.bfloat16, device=w.device)
         if cin % 64 == 0:
@@ -80,9 +114,8 @@ def bf16_weights(w):
             wt = torch.empty((cout, kpad), dtype=torch.bfloat16, device=w.device)
             L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), None, _stream())
             L.call("mmh_prep_weights_bf16_flat", _ptr(w), k * k, cin, cout, _ptr(wt), _stream())
-        ent = (_weights_epoch[0], tuple(w.shape), wp, wt)
-        _bf16_cache[key] = ent
-    return ent[2], ent[3]
+        ent = _cache_put(_bf16_cache, key, w, (wp, wt))
+    return ent
 
 
 def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None):
@@ -93,7 +126,6 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
                       x_cs or Cin, y_cs or Cout, L.F32)
 
 
-_wino_cache = {}
 # Winograd for the fp32 3x3 / stride-1 / pad-1 convs: F(6x6,3x3) (ragged tiles, any H and W;
 # 5.06x fewer multiplications than the direct implicit GEMM, fp32 error 5e-6) from 128x128 channel
 # pairs up, F(4x4,3x3) (4x fewer, H and W multiples of 4) from 64x64, F(2x2,3x3) (2.25x fewer)
@@ -147,9 +179,9 @@ def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
 def wino_weights(w, tile, flip_transpose=False, bf16=False):
     """Winograd-domain filter of a physical 3x3 weight (cached per weights epoch): fp32 U [P,K,N],
     bf16 U [P,N,K] (contraction index contiguous)."""
-    key = (w.data_ptr(), tile, bool(flip_transpose), bool(bf16))
-    ent = _wino_cache.get(key)
-    if ent is None or ent[0] != _weights_epoch[0] or ent[1] != tuple(w.shape):
+    key = (w.data_ptr(), tuple(w.shape), tile, bool(flip_transpose), bool(bf16))
+    U = _cache_get(_wino_cache, key, w)
+    if U is None:
         _, _, cin, cout = w.shape
         P = (tile + 2) ** 2
         kn = (cout, cin) if flip_transpose else (cin, cout)        # (K, N)
@@ -157,9 +189,8 @@ def wino_weights(w, tile, flip_transpose=False, bf16=False):
                         dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
         L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, L.BF16 if bf16 else L.F32,
                _ptr(U), _stream())
-        ent = (_weights_epoch[0], tuple(w.shape), U)
-        _wino_cache[key] = ent
-    return ent[2]
+        _cache_put(_wino_cache, key, w, U)
+    return U
 
 
 # Per-tile output statistics of the last Winograd F(6x6,3x3) conv outputs, keyed by the output's
@@ -180,18 +211,23 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     V = torch.empty((P, tiles, Cin), dtype=wd, device=x.device)
     M = torch.empty((P, tiles, Cout), dtype=wd, device=x.device)
     y = _empty((B, H, W_, Cout), x)
+    timed = time_it and fprop_timer is not None and fprop_timer.want_gemm(P, tiles, Cin, Cout)
+    if timed:       # HIP events on the launch stream (bench.py roofline): the GEMM launch alone, and
+        e0, e1, o0, o1 = fprop_timer.bracket_op()       # the whole op (both transforms + GEMM)
+        o0.record()
     L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, dt, _ptr(V), _stream())
-    if time_it and fprop_timer is not None and fprop_timer.want_gemm(P, tiles, Cin, Cout):
-        e0, e1 = fprop_timer.bracket()      # HIP events around the GEMM launch only (bench.py roofline)
+    if timed:
         e0.record()
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
+    L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
+    if timed:
         e1.record()
-    else:
-        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
+    _count("mfma", 2.0 * P * tiles * Cin * Cout)
     stats = None
     if want_stats and FUSE_NORM_STATS and tile == 6 and not bf16 and act == L.ACT_NONE:
         stats = _empty((B, tiles // B, 3, Cout), x)
     L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _ptr(stats), _stream())
+    if timed:
+        o1.record()
     if stats is not None:
         _pending_stats.clear()              # only the most recent conv output can be the norm's input
         _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
@@ -250,6 +286,7 @@ def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
     dU = _empty((P, Cin, Cout), dy)
     L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, dt, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
+    _count("mfma", 2.0 * P * tiles * Cin * Cout)
     dw = _empty((3, 3, Cin, Cout), dy)
     L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
     return dw
@@ -271,6 +308,7 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
     # dgrad: correlation with the flipped filter, then the reflect-border terms
     M = _empty((P, tiles, Cin), dy)
     L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
+    _count("mfma", 2.0 * 2 * P * tiles * Cin * Cout)       # this GEMM and the wgrad GEMM below
     dx = _empty((B, H, W_, Cin), dy)
     L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, _stream())
     if reflect:
@@ -301,10 +339,12 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
     if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 4 == 0:
         # the Generator head (64 -> 3): 4 output columns waste an MFMA tile; fp32 vector-ALU kernel
         L.call("mmh_conv7_thin_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
+        _count_desc("valu", d)
         return y
     if bf16:
         d.dtype = L.BF16
         w = bf16_weights(w)[1]
+    _count_desc("mfma", d)
     if fprop_timer is not None and fprop_timer.want(d):
         e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
         e0.record()
@@ -325,6 +365,7 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     dx = torch.zeros((B, H, W_, Cin), dtype=torch.float32, device=dy.device)
     ws = _ws(L.load().mmh_conv7_thin_dgrad_ws_bytes(C.byref(d)), dy)
     L.call("mmh_conv7_thin_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, _stream())
+    _count("valu", 2.0 * B * H * W_ * 4 * Cout * 49)
     return dx
 
 
@@ -349,6 +390,7 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     ws = _ws(nbytes, dy) if nbytes else None
     L.call("mmh_conv2d_dgrad_folded", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws),
            ws.numel() * 4 if ws is not None else 0, _stream())
+    _count_desc("mfma", d)
     return dx
 
 
@@ -366,6 +408,7 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
         dw = _empty((k, k, Cin, Cout), x)
         L.call("mmh_conv7_thin_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
                _stream())
+        _count_desc("valu", d)
         return dw
     if bf16:
         d.dtype = L.BF16
@@ -375,6 +418,7 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     dw = _empty((k, k, Cin, Cout), x)
     L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
            ws.numel() * 4, 0, _stream())
+    _count_desc("mfma", d)
     return dw
 
 
@@ -395,6 +439,7 @@ def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False):
         w = bf16_weights(w)[0]
     L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, act,
            _stream())
+    _count_desc("mfma", d)
     return y
 
 
@@ -407,6 +452,7 @@ def raw_convT_dgrad(dy, w, x_shape, bf16=False):
         d.dtype = L.BF16
         w = bf16_weights(w)[1]
     L.call("mmh_convT2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _stream())
+    _count_desc("mfma", d)
     return dx
 
 
@@ -422,6 +468,7 @@ def raw_convT_wgrad(x, dy, bf16=False):
     dw = _empty((3, 3, CoutT, CinT), x)
     L.call("mmh_convT2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
            ws.numel() * 4, 0, _stream())
+    _count_desc("mfma", d)
     return dw
 
 
@@ -596,6 +643,9 @@ class NormActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
                 seed, mask, sync_group):
         _chk(x, "x")
+        if drop_p > 0 and not relu:
+            # the keep bits are (out > 0): exact only behind a ReLU (the reference never drops without one)
+            raise RuntimeError("NormActFn: dropout without a preceding ReLU is not supported")
         B = x.shape[0]
         groups = B if mode == "instance" else 1
         mean, m2, rows = raw_norm_stats(x, groups)
@@ -733,31 +783,51 @@ class BCEWithLogitsConstFn(torch.autograd.Function):
         return dx, None, None
 
 
+def _pair_loss_fwd(kind, ctx, a, b, weight, denom):
+    _chk(a, "a"); _chk(b, "b")
+    n = a.numel()
+    ws = _ws(L.load().mmh_reduce_ws_bytes(n), a)
+    out = _empty((), a)
+    L.call(f"mmh_{kind}_fwd", _ptr(a), _ptr(b), n, float(weight), float(denom), _ptr(out), _ptr(ws),
+           ws.numel() * 4, _stream())
+    ctx.cfg = (float(weight), float(denom))
+    ctx.save_for_backward(a, b)
+    return out
+
+
+def _pair_loss_bwd(kind, ctx, g):
+    a, b = ctx.saved_tensors
+    weight, denom = ctx.cfg
+    g = g.contiguous().float()
+    da = torch.empty_like(a)
+    L.call(f"mmh_{kind}_bwd", _ptr(a), _ptr(b), a.numel(), weight, denom, _ptr(g), _ptr(da), _stream())
+    return da, None, None, None
+
+
 class L1MeanFn(torch.autograd.Function):
     """weight * sum|a-b| / denom (F.l1_loss, losses/L1_plus_perceptualLoss.py:37,66-67).
     ``denom`` is the logical element count (zero pad lanes contribute nothing)."""
 
     @staticmethod
     def forward(ctx, a, b, weight, denom):
-        _chk(a, "a"); _chk(b, "b")
-        n = a.numel()
-        ws = _ws(L.load().mmh_reduce_ws_bytes(n), a)
-        out = _empty((), a)
-        L.call("mmh_l1_fwd", _ptr(a), _ptr(b), n, float(weight), float(denom), _ptr(out), _ptr(ws),
-               ws.numel() * 4, _stream())
-        ctx.cfg = (float(weight), float(denom))
-        ctx.save_for_backward(a, b)
-        return out
+        return _pair_loss_fwd("l1", ctx, a, b, weight, denom)
 
     @staticmethod
     def backward(ctx, g):
-        a, b = ctx.saved_tensors
-        weight, denom = ctx.cfg
-        g = g.contiguous().float()
-        da = torch.empty_like(a)
-        L.call("mmh_l1_bwd", _ptr(a), _ptr(b), a.numel(), weight, denom, _ptr(g), _ptr(da),
-               _stream())
-        return da, None, None, None
+        return _pair_loss_bwd("l1", ctx, g)
+
+
+class MSEMeanFn(torch.autograd.Function):
+    """weight * sum (a-b)^2 / denom (F.mse_loss: the --percep_is_l1 0 branch,
+    losses/L1_plus_perceptualLoss.py:68-71)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, denom):
+        return _pair_loss_fwd("mse", ctx, a, b, weight, denom)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _pair_loss_bwd("mse", ctx, g)
 
 
 # --------------------------------------------------------------------------- layout

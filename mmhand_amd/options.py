@@ -9,8 +9,10 @@ Differences, all deliberate:
     initialises the 'nccl' backend, which is RCCL on ROCm;
   * --opt_level O0 = fp32; O1/O2 (apex AMP in the reference) = bf16 MFMA compute with fp32 master
     weights, accumulation and statistics (no apex, no loss scaling needed);
-  * two additions: --G_n_blocks (the reference hard-codes 9) and --vgg_weights (file with
-    torchvision vgg19.features[0:4] weights; there is no download path offline).
+  * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
+    torchvision vgg19.features[0:4] weights; there is no download path offline) and
+    --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
+    the default --L1_type l1_plus_perL1 refuses to start).
 """
 import argparse
 import os
@@ -57,6 +59,9 @@ _BASE = [
     ("--opt_level", dict(type=str, default="O0", help="O0 fp32 | O1/O2 bf16 MFMA compute")),
     ("--G_n_blocks", dict(type=int, default=9, help="PATBlocks in the generator")),
     ("--vgg_weights", dict(type=str, default=None, help="vgg19.features[0:4] state_dict file")),
+    ("--vgg_random_init", dict(action="store_true",
+                               help="perceptual loss on seeded RANDOM VGG weights (benchmarks / tests; "
+                                    "not the reference's objective)")),
 ]
 _TRAIN = [
     ("--display_freq", dict(type=int, default=100)),
@@ -164,7 +169,8 @@ class TestOptions(BaseOptions):
 
 def default_train_opt(**overrides):
     """Programmatic TrainOptions namespace (defaults of the tables above) for bench/tests.  Never
-    touches the current CUDA device or the process group: the caller owns both."""
+    touches the current CUDA device or the process group: the caller owns both.  Unlike the command
+    line it opts in to --vgg_random_init (bench and tests have no pretrained VGG file)."""
     o = TrainOptions()
     o.initialize()
     opt = o.parser.parse_args([])
@@ -173,6 +179,7 @@ def default_train_opt(**overrides):
     opt.gpu_ids = [lr]
     opt.gpu = lr
     opt.world_size = 1
+    opt.vgg_random_init = True
     for k, v in overrides.items():
         setattr(opt, k, v)
     return opt

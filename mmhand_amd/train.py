@@ -32,11 +32,12 @@ def main(argv=None):
     model.pprint("model [%s] was created" % model.name())
     log_name = os.path.join(opt.checkpoints_dir, opt.name, "loss_log.txt")
     total_steps = 0
-    # the interpreter's generation-2 collections (tens of ms with autograd graphs alive) would land
-    # in the middle of an iteration and starve the GPU queue: collect at the points that
-    # synchronise with the device anyway (loss printing, end of epoch)
+    # the interpreter's generation-2 collections walk everything alive; after the first iteration the
+    # long-lived objects (modules, parameters, pools) are frozen into the permanent generation so a
+    # collection inside an iteration only walks that iteration's autograd graph, and full collections
+    # are run at the points that synchronise with the device anyway (loss printing, end of epoch)
     import gc
-    gc.disable()
+    frozen = False
     for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
         epoch_start = time.time()
         epoch_iter = 0
@@ -46,6 +47,10 @@ def main(argv=None):
             epoch_iter += opt.batchSize
             model.set_input(data)
             model.optimize_parameters()
+            if not frozen:
+                gc.collect()
+                gc.freeze()
+                frozen = True
             if total_steps % opt.print_freq == 0 and model.master:
                 errors = model.get_current_errors()          # float() -> the only D2H sync
                 t = (time.time() - iter_start) / opt.batchSize
@@ -55,13 +60,13 @@ def main(argv=None):
                 with open(log_name, "a") as f:
                     f.write("%s\n" % msg)
                 gc.collect()
-            if total_steps % opt.save_latest_freq == 0 and model.master:
-                print("saving the latest model (epoch %d, total_steps %d)" % (epoch, total_steps))
-                model.save("latest")
+            if total_steps % opt.save_latest_freq == 0:      # every rank: save() settles the overflow
+                model.pprint("saving the latest model (epoch %d, total_steps %d)" % (epoch, total_steps))
+                model.save("latest")                          # flags; only the master writes files
         loader.set_epoch(epoch)
         gc.collect()
-        if epoch % opt.save_epoch_freq == 0 and model.master:
-            print("saving the model at the end of epoch %d, iters %d" % (epoch, total_steps))
+        if epoch % opt.save_epoch_freq == 0:
+            model.pprint("saving the model at the end of epoch %d, iters %d" % (epoch, total_steps))
             model.save("latest")
             model.save(epoch)
         model.pprint("End of epoch %d / %d \t Time Taken: %d sec" %

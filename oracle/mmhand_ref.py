@@ -16,9 +16,10 @@ unchanged.  It follows, function by function:
   pose maps              data/generic_dataset.py:191-217,239-242; util/util.py:94-114
 
 Pinning: the reference ships no tests for this path.  This oracle is pinned against
-the reference's own leaf modules imported from /root/reference in the build container
-(oracle/validate_against_reference.py) and against the golden vectors those modules produced
-(tests/golden/, generated by tests/golden/make_golden.py).  VGG19 pretrained weights and NVIDIA
+the reference's own leaf modules: tests/golden/make_golden.py imports them from /root/reference in
+the build container, asserts that this file reproduces their outputs, gradients and 3-iteration
+step traces, and writes what they produced to tests/golden/*.npz; tests/test_oracle_cpu.py
+re-checks this file against those vectors wherever the tests run.  VGG19 pretrained weights and NVIDIA
 apex are third-party and absent: the perceptual term is checked as an operator on seeded
 VGG-shaped weights, and DDP/SyncBN semantics are pinned to "mean of rank gradients / statistics
 over the global batch" (parity unpinned by the reference for those two).
@@ -202,7 +203,7 @@ class StepOracle:
     def __init__(self, sd_G, sd_DPB, sd_DPP, vgg, norm="batch", use_dropout=False,
                  use_dropout_D=False, n_blocks=9, n_layers_D=3, lr=2e-4, beta1=0.5,
                  lambda_A=10.0, lambda_B=10.0, lambda_GAN=5.0, pool_size=50, DG_ratio=1,
-                 masks=None, rng=random):
+                 masks=None, rng=random, percep_is_l1=1):
         self.G = _Net(sd_G, norm, use_dropout)
         self.DPB = _Net(sd_DPB, norm, use_dropout_D)
         self.DPP = _Net(sd_DPP, norm, use_dropout_D)
@@ -210,6 +211,7 @@ class StepOracle:
         self.n_blocks, self.n_layers_D = n_blocks, n_layers_D
         self.lA, self.lB, self.lG = lambda_A, lambda_B, lambda_GAN
         self.DG_ratio = DG_ratio
+        self.percep_is_l1 = percep_is_l1
         self.masks = masks
         self.opt_G = torch.optim.Adam(self.G.parameters(), lr=lr, betas=(beta1, 0.999))
         self.opt_DPB = torch.optim.Adam(self.DPB.parameters(), lr=lr, betas=(beta1, 0.999))
@@ -241,7 +243,8 @@ class StepOracle:
         self.opt_G.zero_grad()
         g_pb = gan_loss(self._d(self.DPB, torch.cat((fake, batch["P2"]), 1)), True)
         g_pp = gan_loss(self._d(self.DPP, torch.cat((fake, batch["H1"]), 1)), True)
-        l_tot, l_l1, l_p = l1_plus_perceptual(self.vgg, fake, batch["H2"], self.lA, self.lB)
+        l_tot, l_l1, l_p = l1_plus_perceptual(self.vgg, fake, batch["H2"], self.lA, self.lB,
+                                               self.percep_is_l1)
         pair_gan = (g_pb * self.lG + g_pp * self.lG) / 2
         (l_tot + pair_gan).backward()
         self.opt_G.step()

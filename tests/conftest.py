@@ -16,6 +16,10 @@ os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's oneDNN convolutions are fastest at ~16 threads and an order of magnitude slower
+    # at the 128+ threads torch picks by default on the GPU box's 256 logical CPUs (tools/cpu_probe.py)
+    import torch
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
 
 
 @pytest.fixture(scope="session")

@@ -196,6 +196,23 @@ def make_losses():
     print("losses.npz", float(tot), float(l1), float(lp))
 
 
+def make_losses_mse():
+    """The --percep_is_l1 0 branch (losses/L1_plus_perceptualLoss.py:68-71: F.mse_loss on the VGG
+    features) of the reference criterion on the inputs of losses.npz."""
+    vgg_sd = RC.vgg_recipe()
+    crit = ref_criterion(vgg_sd)
+    crit.percep_is_l1 = 0
+    fake = torch.tanh(RC.randn("loss.fake", (2, 3, 32, 32))).requires_grad_(True)
+    real = RC.rand("loss.real", (2, 3, 32, 32))
+    tot, l1, lp = crit(fake, real)
+    tot.backward()
+    ot, ol1, olp = O.l1_plus_perceptual(vgg_sd, fake.detach(), real, 10.0, 10.0, percep_is_l1=0)
+    assert abs(float(ot) - float(tot)) < 1e-5 and abs(float(olp) - float(lp)) < 1e-5
+    np.savez_compressed(os.path.join(HERE, "losses_mse.npz"), total=float(tot), l1=float(l1),
+                        perceptual=float(lp), dfake=fake.grad.numpy())
+    print("losses_mse.npz", float(tot), float(l1), float(lp))
+
+
 def make_adam():
     p = RC.randn("adam.p", (1000,)).requires_grad_(True)
     opt = torch.optim.Adam([p], lr=2e-4, betas=(0.5, 0.999))
@@ -306,6 +323,6 @@ def make_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "adam", "pose", "step"]
+    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "losses_mse", "adam", "pose", "step"]
     for w in which:
         globals()["make_" + w]()

@@ -118,21 +118,14 @@ def test_generator_eval_mode_matches_oracle(dev):
 @pytest.mark.parametrize("wino", [True, False])
 @pytest.mark.parametrize("norm", ["instance", "batch"])
 def test_generator_wide_channels_vs_oracle(norm, wino, dev, monkeypatch):
-    """ngf 32 -> PATBlock channels 128 / 256 at 12x12.  wino: every 3x3 conv of the stack runs on
-    Winograd F(6x6,3x3) (fused backward transforms), the stems and head on the direct / thin
-    kernels; else the direct kernels everywhere.  Output and every parameter gradient against the
-    fp64 oracle.
-
-    Tolerances.  Output: 2e-5 both ways.  Gradients, direct kernels: 1e-3, relaxed only where the
-    problem itself is ill-conditioned (the oracle's own fp32 run further than 1e-4 from its fp64
-    run).  Gradients, Winograd: 2e-2.  Each Winograd conv is within 3e-6 sigma of fp64 per output
-    channel (the direct kernel: 4e-7 sigma) and the network output within 5e-6, but parameter
-    gradients are far more sensitive to forward perturbations than the output is (ReLU masks and
-    the norm layers' nearly cancelling backward sums): measured up to 9e-3 on stem weight
-    gradients at toy sizes with batch statistics over 288 samples, and a median of 5e-3 between
-    the Winograd and the direct kernels on the full-size Generator (tools/grad_noise.py) - the
-    level at which any two fp32 convolution implementations differ on this network.
-    MMH_WINOGRAD=0 selects the direct kernels when gradient-level parity matters more than speed."""
+    """ngf 32 -> PATBlock channels 128 / 256 at 12x12, the smallest feature map F(6x6,3x3) takes
+    (2x2 tiles).  wino: every 3x3 conv of the stack runs on Winograd F(6x6,3x3) (fused backward
+    transforms), the stems and head on the direct / thin kernels; else the direct kernels
+    everywhere.  Output against the fp64 oracle: 2e-5 both ways.  Parameter gradients are gated
+    with a bounded rule at a better-conditioned size (B=4, 64x64: four times the samples per norm
+    plane) in tests/test_winograd_step_gpu.py::test_generator_gradients_winograd_bounded; here,
+    with 144-288 samples per plane, they are held to min(5e-3, max(1e-3, 3*cond)) for the direct
+    kernels and to 1e-2 absolute for the Winograd path (no escape through cond)."""
     from mmhand_amd import ops
     from mmhand_amd.networks import Generator
     monkeypatch.setattr(ops, "USE_WINOGRAD", wino)
@@ -164,7 +157,7 @@ def test_generator_wide_channels_vs_oracle(norm, wino, dev, monkeypatch):
             continue
         cond = R.rel_l1(og[torch.float32][k], og[torch.float64][k])
         e = R.rel_l1(g, og[torch.float64][k])
-        assert e < max(2e-2 if wino else TOL, 10 * cond), (k, e, cond)
+        assert e < (1e-2 if wino else min(5e-3, max(TOL, 3 * cond))), (k, e, cond)
 
 
 def _small_opt(norm, dev_index=0, **kw):
@@ -250,7 +243,7 @@ def test_train_driver_smoke(dev, tmp_path):
     train.main(["--name", "drv", "--checkpoints_dir", str(tmp_path), "--batchSize", "2", "--ngf", "8",
                 "--ndf", "8", "--n_layers_D", "1", "--G_n_blocks", "1", "--fineSize", "64",
                 "--norm", "instance", "--niter", "1", "--niter_decay", "0", "--print_freq", "2",
-                "--synthetic_samples", "4", "--pool_size", "2"])
+                "--synthetic_samples", "4", "--pool_size", "2", "--vgg_random_init"])
     d = os.path.join(str(tmp_path), "drv")
     log = open(os.path.join(d, "loss_log.txt")).read().strip().splitlines()
     assert len(log) == 2 and log[0].startswith("(epoch: 1, iters: 2, time:") and "pair_L1loss:" in log[0]

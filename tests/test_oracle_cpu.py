@@ -87,6 +87,18 @@ def test_losses_match_reference_fixture():
     assert np.allclose(fake.grad.numpy(), fix["dfake"], atol=1e-7)
 
 
+def test_mse_perceptual_branch_matches_reference_fixture():
+    """--percep_is_l1 0 (losses/L1_plus_perceptualLoss.py:68-71)."""
+    fix, mse = _load("losses.npz"), _load("losses_mse.npz")
+    fake = torch.from_numpy(fix["fake"]).requires_grad_(True)
+    tot, l1, lp = O.l1_plus_perceptual(RC.vgg_recipe(), fake, torch.from_numpy(fix["real"]), 10.0, 10.0,
+                                       percep_is_l1=0)
+    assert abs(float(tot) - float(mse["total"])) < 1e-5 and abs(float(lp) - float(mse["perceptual"])) < 1e-5
+    assert abs(float(l1) - float(fix["l1"])) < 1e-6
+    tot.backward()
+    assert np.allclose(fake.grad.numpy(), mse["dfake"], atol=1e-7)
+
+
 def test_pose_maps_bit_exact():
     fix = _load("pose.npz")
     for uv, maps, cords in zip(fix["uv"], fix["maps"], fix["cords"]):

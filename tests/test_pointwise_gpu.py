@@ -138,6 +138,36 @@ def test_losses_vs_reference_fixture(dev):
     assert abs(l.item() - lr.item()) < 1e-4 and R.rel_l1(a.grad, ar.grad) < TOL
 
 
+def test_perceptual_criterion_l1_and_mse_vs_reference_fixture(dev):
+    """L1PlusPerceptualLoss on the HIP kernels (VGG head convs, ImageNet pre-normalisation, L1 and
+    MSE reductions) against the reference criterion's own outputs: --percep_is_l1 1 (losses.npz) and
+    0 (losses_mse.npz, F.mse_loss branch of losses/L1_plus_perceptualLoss.py:68-71)."""
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import L1PlusPerceptualLoss
+    from mmhand_amd.networks import VGGHead
+    from tests.golden import recipe as RC
+    fix = dict(np.load(os.path.join(G, "losses.npz")))
+    vgg = VGGHead()
+    vgg.load_state_dict(RC.vgg_recipe())
+    vgg.to(dev)
+    real = ops.raw_pack([(torch.from_numpy(fix["real"]).to(dev), True, 3)], 2, 32, 32, 4, dev)
+    for is_l1, f in ((1, fix), (0, dict(np.load(os.path.join(G, "losses_mse.npz"))))):
+        fake_nchw = torch.from_numpy(fix["fake"]).to(dev).requires_grad_(True)
+        fake = ops.PackFn.apply(4, fake_nchw, True, 3)
+        tot, l1, lp = L1PlusPerceptualLoss(10.0, 10.0, vgg, is_l1)(fake, real)
+        assert abs(tot.item() - float(f["total"])) < 1e-3 * abs(float(f["total"])), (is_l1, tot.item())
+        assert abs(l1.item() - float(f["l1"])) < 1e-3 * abs(float(f["l1"]))
+        assert abs(lp.item() - float(f["perceptual"])) < 1e-3 * abs(float(f["perceptual"]))
+        tot.backward()
+        assert R.rel_l1(fake_nchw.grad, torch.from_numpy(f["dfake"])) < 1e-3, is_l1
+    a = _mk((2, 16, 16, 4), 1, dev).requires_grad_(True); b = _mk((2, 16, 16, 4), 2, dev)
+    l = ops.MSEMeanFn.apply(a, b, 10.0, float(a.numel()))
+    l.backward()
+    ar = a.detach().cpu().double().requires_grad_(True)
+    lr = 10.0 * F.mse_loss(ar, b.cpu().double()); lr.backward()
+    assert abs(l.item() - lr.item()) < 1e-5 * abs(lr.item()) and R.rel_l1(a.grad, ar.grad) < TOL
+
+
 def test_adam_matches_torch_fixture(dev):
     from mmhand_amd import ops
     fix = dict(np.load(os.path.join(G, "adam.npz")))

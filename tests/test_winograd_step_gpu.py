@@ -1,0 +1,196 @@
+"""Step- and gradient-level parity of the path bench.py measures: every 3x3 stride-1 conv of the
+Generator stack and of the Discriminators' residual blocks on Winograd F(6x6,3x3) (ragged tiles,
+fused backward transforms, InstanceNorm statistics from the output transform).
+
+The reference-generated fixtures (tests/golden, ngf 8 at 32x32) are too small to reach F(6x6,3x3)
+(`_wino_tile` needs 12x12 feature maps and Cin*Cout >= 128^2), so these tests use ngf = ndf = 32
+(PATBlock channels 128 / 256, Discriminator trunk 128) at 64x64 inputs (16x16 feature maps = 3x3
+RAGGED tiles) and compare with the CPU oracle (oracle/mmhand_ref.py, pinned against the reference
+modules by tests/golden/make_golden.py) in fp64 and fp32.  That the Winograd path really ran is
+asserted from the C-ABI calls themselves."""
+import random
+import statistics
+from collections import Counter, OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmhand_ref as O
+from oracle import ops_ref as R
+from tests.golden import recipe as RC
+from tests.test_model_gpu import logical_grads
+
+pytestmark = pytest.mark.gpu
+NGF, SIZE, NB, NLD = 32, 64, 2, 2
+
+
+class _Spy:
+    """Counts C-ABI entry points by (name, winograd tile) while installed on mmhand_amd.lib.call."""
+
+    def __init__(self, monkeypatch):
+        from mmhand_amd import lib, ops
+        self.calls = Counter()
+        real = lib.call
+        tile_arg = {"mmh_wino_input": 6, "mmh_wino_output": 8, "mmh_wino_input_dy": 5, "mmh_wino_dy": 5,
+                    "mmh_wino_dw": 3, "mmh_wino_weights": 4}
+
+        def call(name, *args):
+            t = tile_arg.get(name)
+            self.calls[(name, args[t] if t is not None else None)] += 1
+            if name == "mmh_wino_gemm":
+                self.calls[("gemm_planes", args[6])] += 1
+            return real(name, *args)
+
+        assert ops.L is lib
+        monkeypatch.setattr(lib, "call", call)
+
+    def n(self, name, tile=None):
+        return self.calls[(name, tile)]
+
+
+def _assert_wino6_shapes():
+    from mmhand_amd import ops
+    hs = SIZE // 4
+    for cin, cout in ((4 * NGF, 4 * NGF), (8 * NGF, 8 * NGF), (8 * NGF, 4 * NGF)):      # G stack, D trunk
+        for op in ("fprop", "dgrad", "wgrad"):
+            assert ops._wino_tile(2, hs, hs, cin, cout, 3, 1, 1, False, op) == 6, (cin, cout, op)
+
+
+def _opt(norm, **kw):
+    from mmhand_amd.options import default_train_opt
+    args = dict(batchSize=2, ngf=NGF, ndf=NGF, n_layers_D=NLD, G_n_blocks=NB, norm=norm, no_dropout=True,
+                no_dropout_D=True, pool_size=2, name="wino6", checkpoints_dir="/tmp/mmh_pytest_ckpt",
+                local_rank=0, fineSize=SIZE)
+    args.update(kw)
+    return default_train_opt(**args)
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_optimize_parameters_winograd_vs_oracle(norm, dev, monkeypatch):
+    """3 iterations of optimize_parameters() with F(6x6,3x3) engaged everywhere it engages in the
+    benchmark: six losses per iteration within 1e-3 of the fp64 oracle, the generated image within
+    1e-3 rel-L1, every post-step weight within the bound of the reference-fixture test
+    (tests/test_model_gpu.py::test_optimize_parameters_vs_reference_trace)."""
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    assert ops.USE_WINOGRAD and ops.WINOGRAD_TILE == 6
+    _assert_wino6_shapes()
+    spy = _Spy(monkeypatch)
+    model = MMHandModel(_opt(norm))
+    sds = [OrderedDict((k, v.cpu()) for k, v in n.state_dict().items())
+           for n in (model.netG, model.netD_PB, model.netD_PP)]
+    vgg = OrderedDict((k, v.cpu()) for k, v in model.vgg.state_dict().items())
+    f64 = lambda sd: OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items())
+    orc = O.StepOracle(f64(sds[0]), f64(sds[1]), f64(sds[2]), f64(vgg), norm, False, False, NB, NLD, pool_size=2,
+                       rng=random.Random(49))
+    random.seed(49)
+    for it in range(3):
+        batch = O.synthetic_batch(2, SIZE, SIZE, seed=200 + it)
+        model.set_input(batch)
+        model.optimize_parameters()
+        got = [float(v) for v in model.get_current_errors().values()]
+        want = list(orc.step({k: v.double() for k, v in batch.items()}).values())
+        assert np.allclose(got, want, rtol=1e-3), (it, got, want)
+    assert R.rel_l1(model.fake_p2, orc.fake_p2.detach()) < 1e-3
+    # the path under test really ran: per iteration G has 6*NB convs on F(6x6,3x3) (+ 2*NLD per
+    # Discriminator pass), forward AND fused backward
+    assert spy.n("mmh_wino_input_dy", 6) >= 3 * 6 * NB, spy.calls
+    assert spy.calls[("gemm_planes", 64)] >= 3 * 3 * 6 * NB, spy.calls
+    # F(4x4,3x3) only where the benchmark uses it too (the 64->64 VGG conv); never F(2x2,3x3)
+    assert spy.calls[("gemm_planes", 36)] <= 3 * 3 and spy.calls[("gemm_planes", 16)] == 0, spy.calls
+    for tag, net, onet in (("G", model.netG, orc.G), ("DPB", model.netD_PB, orc.DPB), ("DPP", model.netD_PP, orc.DPP)):
+        osd = onet.state_dict()
+        for k, v in net.state_dict().items():
+            if v.is_floating_point() and not RC.is_null_grad_bias(tag, k, norm):
+                ref = osd[k].float().numpy()
+                assert np.allclose(v.cpu().numpy(), ref, atol=6e-4 + 1e-3 * np.abs(ref).max()), (tag, k)
+
+
+def _generator_grads(norm, wino, sd, g_in, probe, dev):
+    from mmhand_amd import ops
+    from mmhand_amd.networks import Generator
+    ops.USE_WINOGRAD = wino
+    ops.bump_weights_epoch()
+    net = Generator([3, 42, 6], 3, NGF, norm, False, NB)
+    net.load_state_dict(sd)
+    net.to(dev).train()
+    net.flatten_parameters()
+    out = net([t.to(dev) for t in g_in])
+    (out * probe.to(dev)).sum().backward()
+    return out.detach().cpu(), logical_grads(net)
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+def test_generator_gradients_winograd_bounded(norm, dev, monkeypatch):
+    """Parameter gradients of the wide-channel Generator (B=4, 64x64) on both conv paths against the
+    fp64 oracle, with a BOUNDED rule:
+      direct kernels     e <= max(1e-3, 3 * cond), never above 5e-3
+      Winograd F(6x6)    e <= max(1e-3, 3 * e_direct), never above 5e-3
+    cond = distance between the oracle's own fp32 and fp64 gradients of that tensor: what fp32
+    rounding alone does to it on this problem."""
+    from mmhand_amd import ops
+    monkeypatch.setattr(ops, "USE_WINOGRAD", True)
+    _assert_wino6_shapes()
+    B = 4
+    from mmhand_amd.networks import Generator
+    sd = Generator([3, 42, 6], 3, NGF, norm, False, NB).init_weights("normal", 49).state_dict()
+    b = O.synthetic_batch(B, SIZE, SIZE, seed=11)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    probe = torch.randn(B, 3, SIZE, SIZE, generator=torch.Generator().manual_seed(3))
+    og = {}
+    for dt in (torch.float64, torch.float32):
+        onet = O._Net({k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}, norm, False)
+        ref = O.generator_forward(onet, [t.to(dt) for t in g_in], NB)
+        (ref * probe.to(dt)).sum().backward()
+        og[dt] = dict((k, t.grad) for k, t in onet.named_parameters())
+        if dt == torch.float64:
+            ref64 = ref.detach()
+    out_d, gd = _generator_grads(norm, False, sd, g_in, probe, dev)
+    out_w, gw = _generator_grads(norm, True, sd, g_in, probe, dev)
+    assert R.rel_l1(out_d, ref64) < 2e-5 and R.rel_l1(out_w, ref64) < 2e-5
+    rows = []
+    for k in gd:
+        if RC.is_null_grad_bias("G", k, norm) or og[torch.float64].get(k) is None:
+            continue
+        ref = og[torch.float64][k]
+        cond = R.rel_l1(og[torch.float32][k], ref)
+        ed, ew = R.rel_l1(gd[k], ref), R.rel_l1(gw[k], ref)
+        rows.append((k, cond, ed, ew))
+    report = "\n".join(f"{k:55s} cond {c:.1e} direct {d:.1e} wino {w:.1e}" for k, c, d, w in rows)
+    for k, cond, ed, ew in rows:
+        assert ed <= min(5e-3, max(1e-3, 3 * cond)), (k, cond, ed, "\n" + report)
+        assert ew <= min(5e-3, max(1e-3, 3 * ed)), (k, cond, ed, ew, "\n" + report)
+    print("\n" + report)
+
+
+def test_gradient_noise_full_size_generator(dev, monkeypatch):
+    """What tools/grad_noise.py measures, as a gate: on the FULL-size Generator (ngf 64, 9 PATBlocks,
+    256x256, B=2, --norm instance) the F(6x6,3x3) path and the direct kernels agree on the output to
+    5e-5 and on the parameter gradients to a median 1e-2 / 90th percentile 3e-2 relative L1 per
+    tensor - the level at which two fp32 implementations of this network differ (ReLU masks of
+    pre-activations within rounding of zero flip; the norm layers' backward sums nearly cancel)."""
+    from bench import synthetic_batch_gpu
+    from mmhand_amd import ops
+    from mmhand_amd.networks import Generator
+    B = 2
+    b = synthetic_batch_gpu(B, 256, 256, 49, dev)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    probe = torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for wino in (False, True):
+        monkeypatch.setattr(ops, "USE_WINOGRAD", wino)
+        ops.bump_weights_epoch()
+        net = Generator([3, 42, 6], 3, 64, "instance", False, 9).init_weights("normal", 49).to(dev).train()
+        net.flatten_parameters()
+        out = net(g_in)
+        (out * probe).sum().backward()
+        res[wino] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        del net, out
+    rel = lambda a, b_: float((a.double() - b_.double()).abs().sum() / b_.double().abs().sum().clamp_min(1e-30))
+    assert rel(res[True][0], res[False][0]) < 5e-5
+    errs = sorted(rel(res[True][1][n], g) for n, g in res[False][1].items()
+                  if float(g.abs().sum()) > 0 and not RC.is_null_grad_bias("G", n, "instance"))
+    med, p90 = statistics.median(errs), errs[(len(errs) * 9) // 10]
+    print(f"\nfull-size Winograd-vs-direct gradient noise: median {med:.2e}, p90 {p90:.2e}, max {errs[-1]:.2e}")
+    assert med < 1e-2 and p90 < 3e-2, (med, p90, errs[-1])
