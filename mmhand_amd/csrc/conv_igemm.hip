@@ -511,8 +511,16 @@ struct WinoGemmKP {
     int nb;             // workgroups per XCD (grid = 8 * nb)
 };
 
-template <int BN>
-__global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
+// LEVELS = 2: two-level summation over the contraction.  The f32 MFMA chain is a k-ordered fmaf
+// chain, so one accumulator over K = 512 carries a rounding error ~ eps*sqrt(sum_k k); the F(6x6,3x3)
+// output transform (coefficients up to 32 per dimension) then amplifies it - that chain, not the
+// transforms, is 85 % of the F(6x6,3x3) error against fp64 (tools/wino_error_model.py).  With
+// LEVELS = 2 every k-step (32 channels: close to the optimal block sqrt(K)) starts a fresh chain in
+// `part` (C operand = 0) that is folded into `acc` by 64 vector adds: ~3x less accumulated rounding
+// for 64 more VGPRs (2 workgroups per CU instead of 3 at 128-wide tiles).
+constexpr int WINO_FOLD = 1;
+template <int BN, int LEVELS>
+__global__ void __launch_bounds__(256, (LEVELS == 2 && BN == 128) ? 2 : 3) wino_gemm_kernel(const WinoGemmKP p) {
     constexpr int WTM = 64, WTN = BN / 2;
     constexpr int TM = 2, TN = WTN / 32;
     constexpr int NB = BN / 32;
@@ -581,6 +589,7 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
     };
 
     f32x16 acc[TM][TN];
+    f32x16 part[LEVELS == 2 ? TM : 1][LEVELS == 2 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -618,10 +627,23 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
                     for (int i = 0; i < TM; ++i) {
                         const float a = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (LEVELS == 2)
+                                part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    a, bsc[j][e], (kg == 0 && e == 0) ? f32x16{} : part[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
+                        }
                     }
                 }
+            }
+            if constexpr (LEVELS == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += part[i][j][r];
             }
             if (ks == KS - 1) {
                 // tile done: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Rows past M
@@ -2668,14 +2690,20 @@ int g_wino_gemm_v2 = 1; // dedicated persistent kernel (wino_gemm_kernel) when K
 int g_wino_bf16_bk = 64;   // k-step of the bf16 NT GEMM: 64 | 128
 int g_wino_bf16_occ = 3;   // resident workgroups per CU the bf16 Winograd GEMM grids are sized for
 int g_wino_gemm_occ = 3;   // resident workgroups per CU the persistent grid is sized for
+// 2 = two-level summation over the contraction for the F(6x6,3x3) GEMMs (64 planes), whose output
+// transform amplifies accumulated rounding the most: measured 6.7e-6 -> 2.4e-6 relative L1 against
+// fp64 on 512->512 (direct kernel 1.1e-6) for 5-9 % of the GEMM's time; 1 = one chain
+// (mmh_set_option "wino_gemm_levels")
+int g_wino_gemm_levels = 2;
+int g_wino_gemm_bn = 0;       // column-tile width of the persistent GEMM: 0 = auto (128 when N > 64), 64, 128
 
-template <int BN>
+template <int BN, int LEVELS>
 static int launch_wino_gemm_t(const WinoGemmKP& p, hipStream_t st) {
     constexpr size_t lds = (size_t)(BM * LDA + BK * BN) * sizeof(float);
     static int ready = -1;
-    if (ready != 0) ready = allow_lds(wino_gemm_kernel<BN>, lds);
+    if (ready != 0) ready = allow_lds(wino_gemm_kernel<BN, LEVELS>, lds);
     if (ready != 0) return ready;
-    hipLaunchKernelGGL((wino_gemm_kernel<BN>), dim3(8 * p.nb), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((wino_gemm_kernel<BN, LEVELS>), dim3(8 * p.nb), dim3(256), lds, st, p);
     return mmh::check_launch("wino_gemm_kernel");
 }
 
@@ -2684,13 +2712,16 @@ static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long til
     WinoGemmKP p{};
     p.A = V; p.B = U; p.C = Mo;
     p.M = (int)tiles; p.K = K; p.N = N; p.P = nbatch;
-    const int bn = N > 64 ? 128 : 64;
+    const int bn = g_wino_gemm_bn == 64 ? 64 : (N > 64 ? 128 : 64);
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (N + bn - 1) / bn;
     p.W = nbatch * p.MT * p.NT;
     p.Wx = (p.W + 7) / 8;
-    p.nb = std::min(p.Wx, 32 * g_wino_gemm_occ);   // 32 CUs per XCD
-    return bn == 128 ? launch_wino_gemm_t<128>(p, st) : launch_wino_gemm_t<64>(p, st);
+    const bool two = g_wino_gemm_levels == 2 && nbatch == 64 && K > WINO_FOLD * BK;   // nothing to fold below 2 blocks
+    // 32 CUs per XCD; the 128-wide two-level build needs 222 VGPRs: 2 workgroups per CU
+    p.nb = std::min(p.Wx, 32 * ((two && bn == 128) ? std::min(g_wino_gemm_occ, 2) : g_wino_gemm_occ));
+    if (two) return bn == 128 ? launch_wino_gemm_t<128, 2>(p, st) : launch_wino_gemm_t<64, 2>(p, st);
+    return bn == 128 ? launch_wino_gemm_t<128, 1>(p, st) : launch_wino_gemm_t<64, 1>(p, st);
 }
 
 // 16 x ( [tiles x K] . [K x N] ): V [16][tiles][K], U [16][K][N] -> M [16][tiles][N]
@@ -2861,6 +2892,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
+    if (!strcmp(key, "wino_gemm_levels")) { g_wino_gemm_levels = value; return 0; }
+    if (!strcmp(key, "wino_gemm_bn")) { g_wino_gemm_bn = value; return 0; }
     if (!strcmp(key, "wino_bf16_occ")) { g_wino_bf16_occ = value; return 0; }
     if (!strcmp(key, "wino_bf16_bk")) { g_wino_bf16_bk = value; return 0; }
     if (!strcmp(key, "wino_wgrad_bn256")) { g_wino_wgrad_bn256 = value; return 0; }
