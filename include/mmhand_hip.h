@@ -298,19 +298,34 @@ int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, 
  * step is the 1-based step count; no weight decay, no amsgrad.
  * skip_flag (device int32, may be NULL): when *skip_flag != 0 the launch leaves
  * p, m and v untouched - the `if not self.overflow: optimizer.step()` of
- * MMHandModel.py:316-328 decided on the device, without a host round trip.  */
+ * MMHandModel.py:316-328 decided on the device, without a host round trip.
+ * loss_scale (device float, may be NULL): the gradient is additionally divided by
+ * *loss_scale - the unscale step of dynamic loss scaling, read on the device.  */
 int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, int step,
-                  float grad_scale, const void* skip_flag, mmh_stream_t s);
+                  float grad_scale, const void* skip_flag, const void* loss_scale,
+                  mmh_stream_t s);
 
 /* ---- overflow detection (MMHandModel.loss_backward, MMHandModel.py:294-308) --
  * *flag_out = (flag_in ? *flag_in : 0) | any(!isfinite(g[0..n))).  flag_in carries
  * the sticky `self.overflow` of the steps already taken this iteration.  Run on
  * the flat gradient buffer AFTER the data-parallel all-reduce: a non-finite
  * value on any rank is non-finite in the sum on every rank, which is the
- * flag all-reduce of reduce_tensor (MMHandModel.py:381-384) for free.       */
+ * flag all-reduce of reduce_tensor (MMHandModel.py:381-384) for free.
+ * own_out (device int32, may be NULL) = any(!isfinite(g)) of THIS gradient alone: what
+ * apex's per-loss scaler sees when its scale_loss context exits.               */
 int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in,
-                       void* flag_out, mmh_stream_t s);
+                       void* flag_out, void* own_out, mmh_stream_t s);
+
+/* ---- dynamic loss scaling (apex.amp.initialize(..., num_losses=3) + amp.scale_loss,
+ * MMHandModel.py:99-108,294-299): state = {scale, clean steps} (2 device floats).  The
+ * backward runs on loss * scale; mmh_adam_step(loss_scale = state) divides it out again;
+ * then, as apex's LossScaler.update_scale: *overflow != 0 -> scale = max(scale * backoff,
+ * min_scale), clean = 0; else ++clean, and clean == interval -> scale = min(scale * growth,
+ * max_scale), clean = 0.  apex's dynamic defaults: start 2^16, growth 2, backoff 0.5,
+ * interval 2000, max 2^24.                                                           */
+int mmh_loss_scale_update(void* state, const void* overflow, float growth, float backoff,
+                          int interval, float min_scale, float max_scale, mmh_stream_t s);
 
 /* ---- layout: NCHW (any strides) <-> padded NHWC, with channel concat -------
  * replaces torch.cat at MMHandModel.py:216-220,238,242,278-289.            */

@@ -556,8 +556,10 @@ __global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restr
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
                             float b2, float eps, float step_size, float inv_sqrt_bc2,
-                            float gscale, const int* __restrict__ skip) {
+                            float gscale, const int* __restrict__ skip,
+                            const float* __restrict__ loss_scale) {
     if (skip && *skip) return;      // a gradient of this iteration was not finite: leave p, m, v alone
+    if (loss_scale) gscale /= *loss_scale;      // the backward ran on loss * scale (dynamic loss scaling)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -573,7 +575,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 // flag |= any(!isfinite(g)): the exponent field of inf/nan is all ones
 __global__ void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n4, int64_t n,
-                                      int* __restrict__ flag) {
+                                      int* __restrict__ flag, int* __restrict__ own) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
@@ -586,7 +588,32 @@ __global__ void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n4, i
     }
     for (int64_t k = 4 * n4 + i; k < n; k += stride)
         bad |= (__float_as_uint(g[k]) & 0x7f800000u) == 0x7f800000u;
-    if (bad) *flag = 1;     // every writer stores the same value
+    if (bad) {              // every writer stores the same value
+        *flag = 1;
+        if (own) *own = 1;
+    }
+}
+
+// apex.amp's dynamic loss scaler (LossScaler.update_scale): an overflow multiplies the scale by
+// `backoff` and restarts the count of clean steps; `interval` clean steps in a row multiply it by
+// `growth`.  state = {scale, clean steps} as two floats; one thread.
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const int* __restrict__ overflow,
+                                         float growth, float backoff, float interval, float min_scale,
+                                         float max_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float scale = state[0], clean = state[1];
+    if (*overflow) {
+        scale = fmaxf(scale * backoff, min_scale);
+        clean = 0.f;
+    } else {
+        clean += 1.f;
+        if (clean >= interval) {
+            scale = fminf(scale * growth, max_scale);
+            clean = 0.f;
+        }
+    }
+    state[0] = scale;
+    state[1] = clean;
 }
 
 // ------------------------------------------------------------------ layout
@@ -1032,28 +1059,43 @@ int mmh_mse_bwd(const void* a, const void* b, int64_t n, float weight, double de
     return mmh::check_launch("mse_bwd");
 }
 
-int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in, void* flag_out, mmh_stream_t s) {
+int mmh_grad_nonfinite(const void* g, int64_t n, const void* flag_in, void* flag_out, void* own_out,
+                       mmh_stream_t s) {
     MMH_REQUIRE(g && flag_out && n > 0, "mmh_grad_nonfinite: bad arguments");
     MMH_REQUIRE((reinterpret_cast<uintptr_t>(g) & 15) == 0, "mmh_grad_nonfinite: g must be 16-byte aligned");
     hipStream_t st = mmh::as_stream(s);
     hipError_t e = flag_in ? hipMemcpyAsync(flag_out, flag_in, sizeof(int), hipMemcpyDeviceToDevice, st)
                            : hipMemsetAsync(flag_out, 0, sizeof(int), st);
+    if (e == hipSuccess && own_out) e = hipMemsetAsync(own_out, 0, sizeof(int), st);
     if (e != hipSuccess) return mmh::fail("mmh_grad_nonfinite: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid_for(n / 4 + 1, 4096)), dim3(TPB), 0, st,
-                       static_cast<const float*>(g), n / 4, n, static_cast<int*>(flag_out));
+                       static_cast<const float*>(g), n / 4, n, static_cast<int*>(flag_out),
+                       static_cast<int*>(own_out));
     return mmh::check_launch("grad_nonfinite");
+}
+
+int mmh_loss_scale_update(void* state, const void* overflow, float growth, float backoff, int interval,
+                          float min_scale, float max_scale, mmh_stream_t s) {
+    MMH_REQUIRE(state && overflow && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval > 0 &&
+                    min_scale > 0.f && max_scale >= min_scale,
+                "mmh_loss_scale_update: bad arguments");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, mmh::as_stream(s),
+                       static_cast<float*>(state), static_cast<const int*>(overflow), growth, backoff,
+                       (float)interval, min_scale, max_scale);
+    return mmh::check_launch("loss_scale_update");
 }
 
 int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, const void* skip_flag,
-                  mmh_stream_t s) {
+                  const void* loss_scale, mmh_stream_t s) {
     MMH_REQUIRE(p && g && m && v && n > 0 && step >= 1, "mmh_adam_step: bad arguments");
     const double bc1 = 1.0 - std::pow((double)beta1, step);
     const double bc2 = 1.0 - std::pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, mmh::as_stream(s),
                        static_cast<float*>(p), static_cast<const float*>(g), static_cast<float*>(m),
                        static_cast<float*>(v), n, beta1, beta2, eps, (float)((double)lr / bc1),
-                       (float)(1.0 / std::sqrt(bc2)), grad_scale, static_cast<const int*>(skip_flag));
+                       (float)(1.0 / std::sqrt(bc2)), grad_scale, static_cast<const int*>(skip_flag),
+                       static_cast<const float*>(loss_scale));
     return mmh::check_launch("adam");
 }
 

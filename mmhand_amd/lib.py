@@ -85,8 +85,9 @@ SIGNATURES = {
     "mmh_l1_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
     "mmh_mse_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_mse_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
-    "mmh_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp, _vp]),
-    "mmh_grad_nonfinite": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "mmh_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
+    "mmh_grad_nonfinite": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "mmh_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp]),
     "mmh_pack_nhwc": (_i, [C.POINTER(PlaneSrc), _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmh_pose_heatmaps": (_i, [_vp, _i, _i, _i, _d, _vp, _vp]),
     "mmh_map_to_cord": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),

@@ -25,6 +25,9 @@ from .networks import Discriminator, Generator, VGGHead
 from .ops import pad4
 
 
+_LAST_BUCKET_LOG = None      # MMH_DP_LOG=1: the event log of the last data-parallel model (tests)
+
+
 # ----------------------------------------------------------------------------- helpers
 def get_norm_layer(norm_type="instance"):
     """models/network_utils.py:74-84 — returns the tag the networks understand."""
@@ -66,15 +69,16 @@ class FlatAdam(torch.optim.Optimizer):
         self.net.flat_grad.zero_()
 
     @torch.no_grad()
-    def step(self, closure=None, skip_flag=None):
+    def step(self, closure=None, skip_flag=None, loss_scale=None):
         """skip_flag: int32 device scalar; when it is non-zero the kernel leaves p, m, v untouched.
         The caller takes the step back from step_count once the flag has reached the host
-        (MMHandModel._settle_overflow), as apex does not count a skipped step."""
+        (MMHandModel._settle_overflow), as apex does not count a skipped step.
+        loss_scale: fp32 device scalar the gradient is divided by (dynamic loss scaling)."""
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
-                      self.grad_scale, skip_flag)
+                      self.grad_scale, skip_flag, loss_scale)
         ops.bump_weights_epoch()
 
     def state_dict(self):
@@ -213,9 +217,19 @@ class MMHandModel(torch.nn.Module):
             self.load_network()
         for n in nets:
             n.flatten_parameters()
-        # --opt_level O1/O2 (apex AMP in the reference, scripts/mm-train-ratio.sh:7-11) -> bf16 MFMA
-        # compute with fp32 master weights / accumulation / statistics; O0 -> fp32.
-        self.bf16 = str(getattr(opt, "opt_level", "O0")).upper() in ("O1", "O2", "BF16")
+        # --opt_level (apex AMP in the reference, scripts/mm-train-ratio.sh:7-11):
+        #   O0          fp32
+        #   O1 / O2     mixed precision as apex runs it: 16-bit MFMA compute (bf16 here) with fp32
+        #               master weights / accumulation / statistics AND apex's dynamic loss scaling
+        #               (one scaler per loss, num_losses=3): scale -> backward -> overflow check on
+        #               the scaled gradients -> unscale inside Adam -> skip / back off / grow
+        #   BF16        the same bf16 compute without a loss scaler (bf16 has fp32's exponent range)
+        level = str(getattr(opt, "opt_level", "O0")).upper()
+        if level not in ("O0", "O1", "O2", "BF16"):
+            raise ValueError("--opt_level %r: expected O0 | O1 | O2 | BF16 (apex's O3 = pure fp16 weights "
+                             "is 'not recommended' by the reference and not built)" % (opt.opt_level,))
+        self.bf16 = level in ("O1", "O2", "BF16")
+        self.loss_scaling = self.isTrain and level in ("O1", "O2")
         for n in nets:
             n.bf16 = self.bf16
 
@@ -267,13 +281,20 @@ class MMHandModel(torch.nn.Module):
             self.skipped_steps = 0
             if opt.continue_train:
                 self.load_train_state()
-        self.comm_stream = torch.cuda.Stream(self.device) if getattr(self, "dp", False) else None
-        self._pending = None
+        if not getattr(self, "dp", False):
+            self.comm_stream = None
         if self.isTrain:
             # overflow skip (models/MMHandModel.py:294-330) decided on the device: one sticky int32
             # flag per optimizer step of an iteration, order G, D_PP x DG_ratio, D_PB x DG_ratio
             self._nflags = 1 + 2 * opt.DG_ratio
             self._flags = torch.zeros(self._nflags, dtype=torch.int32, device=self.device)
+            # dynamic loss scaling: {scale, clean steps} per loss id (0 = G, 1 = D_PB, 2 = D_PP as
+            # MMHandModel.py:261,281,291 number them) and each step's OWN overflow flag, all on the device
+            self._own = torch.zeros(self._nflags, dtype=torch.int32, device=self.device)
+            if getattr(self, "_scaler", None) is None:
+                self._scaler = torch.tensor([[ops.LOSS_SCALE_INIT, 0.0]] * 3, dtype=torch.float32,
+                                            device=self.device)
+            self.loss_scale_window = ops.LOSS_SCALE_WINDOW
             self._flags_free = [torch.zeros(self._nflags, dtype=torch.int32).pin_memory() for _ in range(3)]
             self._flags_pending = []        # [(event, pinned host copy)] of iterations not settled yet
             self.skipped_steps = getattr(self, "skipped_steps", 0)   # optimizer steps skipped so far
@@ -293,20 +314,17 @@ class MMHandModel(torch.nn.Module):
         ops.bump_weights_epoch()        # the broadcast rewrote every weight in place
         for o in self.optimizers:
             o.grad_scale = 1.0 / self.world
-
-    def _allreduce_async(self, net):
-        """One RCCL all-reduce(SUM) of the flat gradient buffer on the side stream; the 1/world
-        factor is folded into the Adam kernel."""
-        if not self.dp:
-            return None
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            return dist.all_reduce(net.flat_grad, async_op=True)
-
-    @staticmethod
-    def _wait(work):
-        if work is not None:
-            work.wait()
+        # gradient all-reduce: reverse-layer-order buckets of each flat gradient buffer, launched
+        # from autograd hooks on a side stream while the backward pass is still running (dp.py)
+        from .dp import GradBuckets
+        self.comm_stream = torch.cuda.Stream(self.device)
+        self._bucket_log = [] if os.environ.get("MMH_DP_LOG") == "1" else None
+        global _LAST_BUCKET_LOG
+        _LAST_BUCKET_LOG = self._bucket_log
+        self._buckets = {o: GradBuckets(list(o.net.parameters()), o.net.flat_grad, comm_stream=self.comm_stream,
+                                        log=self._bucket_log, name=n)
+                         for n, o in (("G", self.optimizer_G), ("D_PB", self.optimizer_D_PB),
+                                      ("D_PP", self.optimizer_D_PP))}
 
     # ------------------------------------------------------------------ input
     def set_input(self, input):
@@ -386,19 +404,32 @@ class MMHandModel(torch.nn.Module):
             pair_L1loss = self.loss_G_L1
             pair_GANloss = (self.loss_G_GAN_PB * o.lambda_GAN + self.loss_G_GAN_PP * o.lambda_GAN) / 2
             pair_loss = pair_L1loss + pair_GANloss
-            pair_loss.backward()
+            self.loss_backward(pair_loss, 0)
         self.pair_L1loss = pair_L1loss.detach()
         self.pair_GANloss = pair_GANloss.detach()
 
     # ------------------------------------------------------------------ D
-    def backward_D_basic(self, netD, real, fake):
+    def loss_backward(self, loss, loss_id=0):
+        """MMHandModel.loss_backward (models/MMHandModel.py:294-308): with mixed precision the
+        backward runs on loss * scale (amp.scale_loss); the overflow check, the unscale and the
+        scaler update happen at the optimizer step (_guarded_step), all on the device."""
+        if self.loss_scaling:
+            (loss * self._scaler[loss_id, 0]).backward()
+        else:
+            loss.backward()
+
+    def loss_scale(self, loss_id=0):
+        """Current loss scale of loss `loss_id` (synchronises; for logging / tests)."""
+        return float(self._scaler[loss_id, 0])
+
+    def backward_D_basic(self, netD, real, fake, loss_id=0):
         o = self.opt
         pred_real = netD.forward_nhwc(real)
         loss_D_real = self.criterionGAN(pred_real, True) * o.lambda_GAN
         pred_fake = netD.forward_nhwc(fake.detach())
         loss_D_fake = self.criterionGAN(pred_fake, False) * o.lambda_GAN
         loss_D = (loss_D_real + loss_D_fake) * 0.5
-        loss_D.backward()
+        self.loss_backward(loss_D, loss_id)
         return loss_D
 
     def backward_D_PB(self):
@@ -409,7 +440,7 @@ class MMHandModel(torch.nn.Module):
         with torch.no_grad():
             fake_now = self._cat_PB(self.fake_nhwc.detach(), True)
         fake_PB = self.fake_PB_pool.query(fake_now)
-        self.loss_D_PB = self.backward_D_basic(self.netD_PB, real_PB, fake_PB).detach()
+        self.loss_D_PB = self.backward_D_basic(self.netD_PB, real_PB, fake_PB, 1).detach()
 
     def backward_D_PP(self):
         o = self.opt
@@ -419,17 +450,25 @@ class MMHandModel(torch.nn.Module):
         with torch.no_grad():
             fake_now = self._cat_PP(self.fake_nhwc.detach())
         fake_PP = self.fake_PP_pool.query(fake_now)
-        self.loss_D_PP = self.backward_D_basic(self.netD_PP, real_PP, fake_PP).detach()
+        self.loss_D_PP = self.backward_D_basic(self.netD_PP, real_PP, fake_PP, 2).detach()
 
     # ------------------------------------------------------------------ overflow skip
-    def _guarded_step(self, optimizer, k):
+    def _guarded_step(self, optimizer, k, loss_id=0):
         """`if not self.overflow: optimizer.step()` (models/MMHandModel.py:316-328) without a host
         round trip: flag k = flag k-1 | any(!isfinite(grad)), and the Adam launch is a no-op when
         it is set.  Called after the gradient all-reduce, so every rank sees the same flag (a
-        non-finite term makes the sum non-finite everywhere): reduce_tensor (:381-384) for free."""
+        non-finite term makes the sum non-finite everywhere): reduce_tensor (:381-384) for free.
+        With loss scaling the same launches also unscale (Adam divides by the device-resident
+        scale) and update the loss's scaler from this gradient's OWN flag, as apex does when the
+        amp.scale_loss context of that loss exits."""
+        own = self._own[k:k + 1] if self.loss_scaling else None
         ops.grad_nonfinite(optimizer.net.flat_grad, self._flags[k:k + 1],
-                           self._flags[k - 1:k] if k > 0 else None)
-        optimizer.step(skip_flag=self._flags[k:k + 1])
+                           self._flags[k - 1:k] if k > 0 else None, own)
+        if self.loss_scaling:
+            optimizer.step(skip_flag=self._flags[k:k + 1], loss_scale=self._scaler[loss_id])
+            ops.loss_scale_update(self._scaler[loss_id], own, self.loss_scale_window)
+        else:
+            optimizer.step(skip_flag=self._flags[k:k + 1])
 
     def _settle_overflow(self, drain=False):
         """Fetch the overflow flags of finished iterations (copied to pinned memory when each ended)
@@ -455,47 +494,67 @@ class MMHandModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ the step
     def optimize_parameters(self):
-        """models/MMHandModel.py:310-330.  Order of effects is the reference's; under data
-        parallelism the generator's gradient all-reduce runs beneath the first discriminator
-        forward+backward (which reads no generator parameter) and its Adam follows it there."""
+        """models/MMHandModel.py:310-330: one G step, DG_ratio D_PP steps, DG_ratio D_PB steps, each
+        optimizer step skipped once a gradient of the iteration was not finite."""
         self._settle_overflow()
-        r = self.opt.DG_ratio
-        self.forward()
-        self.optimizer_G.zero_grad()
-        self.backward_G()
-        work_G = self._allreduce_async(self.netG)
-        if work_G is None:
-            self._guarded_step(self.optimizer_G, 0)
-
-        def finish_G():
-            # data parallel: the 285 MB all-reduce ran under the first discriminator
-            # forward+backward; its (global) flag must head the chain before any D step is decided
-            nonlocal work_G
-            if work_G is not None:
-                self._wait(work_G)
-                self._guarded_step(self.optimizer_G, 0)
-                work_G = None
-
-        for i in range(r):
-            self.optimizer_D_PP.zero_grad()
-            self.backward_D_PP()
-            self._wait(self._allreduce_async(self.netD_PP))
-            finish_G()
-            self._guarded_step(self.optimizer_D_PP, 1 + i)
-
-        for i in range(r):
-            self.optimizer_D_PB.zero_grad()
-            self.backward_D_PB()
-            self._wait(self._allreduce_async(self.netD_PB))
-            finish_G()
-            self._guarded_step(self.optimizer_D_PB, 1 + r + i)
-        finish_G()
+        if self.dp:
+            self._optimize_parameters_dp()
+        else:
+            r = self.opt.DG_ratio
+            self.forward()
+            self.optimizer_G.zero_grad()
+            self.backward_G()
+            self._guarded_step(self.optimizer_G, 0, 0)
+            for i in range(r):
+                self.optimizer_D_PP.zero_grad()
+                self.backward_D_PP()
+                self._guarded_step(self.optimizer_D_PP, 1 + i, 2)
+            for i in range(r):
+                self.optimizer_D_PB.zero_grad()
+                self.backward_D_PB()
+                self._guarded_step(self.optimizer_D_PB, 1 + r + i, 1)
         host = self._flags_free.pop()
         host.copy_(self._flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._flags_pending.append((ev, host))
         self.overflow = False
+
+    def _optimize_parameters_dp(self):
+        """The same iteration under data parallelism.  Effects land in the reference's order (the
+        flag chain and the optimizer steps run G -> D_PP -> D_PB), but the three backward passes are
+        ENQUEUED back to back: each network's gradient buckets are all-reduced on the side stream
+        from autograd hooks as they complete (dp.GradBuckets), so the Generator's 285 MB travel
+        beneath the rest of its own backward and both discriminator passes, and D_PP's 16 MB beneath
+        D_PB's forward + backward.  That is legal because the discriminator steps read only the
+        already generated, detached image (models/MMHandModel.py:279-289) and the two discriminators
+        share nothing.  A network's step is flushed before that network is used again (DG_ratio > 1)."""
+        r = self.opt.DG_ratio
+        pending = []
+
+        def flush():
+            for bk, o, k, lid in pending:
+                bk.wait()                       # current stream waits for that network's collectives
+                self._guarded_step(o, k, lid)
+            pending.clear()
+
+        def backward_of(o, fn, k, lid):
+            if any(q[1] is o for q in pending):
+                flush()                         # its previous step must land before its next forward
+            bk = self._buckets[o]
+            o.zero_grad()
+            bk.begin()
+            fn()
+            bk.launch_remaining()
+            pending.append((bk, o, k, lid))
+
+        self.forward()
+        backward_of(self.optimizer_G, self.backward_G, 0, 0)
+        for i in range(r):
+            backward_of(self.optimizer_D_PP, self.backward_D_PP, 1 + i, 2)
+        for i in range(r):
+            backward_of(self.optimizer_D_PB, self.backward_D_PB, 1 + r + i, 1)
+        flush()
 
     # ------------------------------------------------------------------ reporting / io
     def get_current_errors(self):
@@ -550,7 +609,10 @@ class MMHandModel(torch.nn.Module):
             return
         os.makedirs(self.save_dir, exist_ok=True)
         state = {"format": "mmhand_amd.train_state.v1", "skipped_steps": self.skipped_steps,
-                 "optimizers": {}}
+                 "optimizers": {},
+                 # {scale, clean steps} of the three dynamic loss scalers: what apex's amp.state_dict()
+                 # holds in this file in the reference (loss_scaler0..2: loss_scale, unskipped)
+                 "loss_scalers": self._scaler.cpu()}
         for name in ("optimizer_G", "optimizer_D_PB", "optimizer_D_PP"):
             sd = getattr(self, name).state_dict()
             state["optimizers"][name] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
@@ -570,6 +632,8 @@ class MMHandModel(torch.nn.Module):
                                    f"the network has {o.exp_avg.numel()}")
             o.load_state_dict(sd)
         self.skipped_steps = int(state.get("skipped_steps", 0))
+        if "loss_scalers" in state:
+            self._scaler = state["loss_scalers"].to(self.device, torch.float32).contiguous()
         self.pprint("restored optimizer state (Adam step %d)" % self.optimizer_G.step_count)
         return True
 

@@ -909,24 +909,40 @@ def nhwc_to_nchw_view(t, Cc=None):
 
 
 # --------------------------------------------------------------------------- optimiser
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, skip_flag=None):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, skip_flag=None, loss_scale=None):
     """torch.optim.Adam.step (models/MMHandModel.py:90-98) on flat buffers, one launch.
-    skip_flag: int32 device scalar; non-zero makes the launch a no-op (overflow skip)."""
+    skip_flag: int32 device scalar; non-zero makes the launch a no-op (overflow skip).
+    loss_scale: fp32 device scalar the gradient is divided by (dynamic loss scaling)."""
     for t in (p, g, m, v):
         _chk(t)
     if skip_flag is not None:
         assert skip_flag.dtype == torch.int32 and skip_flag.is_cuda
+    if loss_scale is not None:
+        assert loss_scale.dtype == torch.float32 and loss_scale.is_cuda
     L.call("mmh_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1),
-           float(beta2), float(eps), int(step), float(grad_scale), _ptr(skip_flag), _stream())
+           float(beta2), float(eps), int(step), float(grad_scale), _ptr(skip_flag), _ptr(loss_scale), _stream())
 
 
-def grad_nonfinite(g, flag_out, flag_in=None):
+def grad_nonfinite(g, flag_out, flag_in=None, own_out=None):
     """flag_out = (flag_in or 0) | any(!isfinite(g)) on the device (MMHandModel.loss_backward,
-    models/MMHandModel.py:294-308); int32 one-element tensors."""
+    models/MMHandModel.py:294-308); own_out = any(!isfinite(g)) alone; int32 one-element tensors."""
     _chk(g)
-    for f in (flag_out, flag_in):
+    for f in (flag_out, flag_in, own_out):
         assert f is None or (f.dtype == torch.int32 and f.is_cuda and f.numel() == 1)
-    L.call("mmh_grad_nonfinite", _ptr(g), g.numel(), _ptr(flag_in), _ptr(flag_out), _stream())
+    L.call("mmh_grad_nonfinite", _ptr(g), g.numel(), _ptr(flag_in), _ptr(flag_out), _ptr(own_out), _stream())
+
+
+# apex.amp dynamic loss scaler defaults (apex/amp/scaler.py: init 2**16, factor 2, window 2000, max 2**24)
+LOSS_SCALE_INIT, LOSS_SCALE_GROWTH, LOSS_SCALE_BACKOFF = 65536.0, 2.0, 0.5
+LOSS_SCALE_WINDOW, LOSS_SCALE_MIN, LOSS_SCALE_MAX = 2000, 1.0, 2.0 ** 24
+
+
+def loss_scale_update(state, overflow, window=None):
+    """state: fp32 [2] = {scale, clean steps}; overflow: int32 [1] (this loss's own flag)."""
+    assert state.dtype == torch.float32 and state.is_cuda and state.numel() == 2 and state.is_contiguous()
+    assert overflow.dtype == torch.int32 and overflow.is_cuda and overflow.numel() == 1
+    L.call("mmh_loss_scale_update", _ptr(state), _ptr(overflow), LOSS_SCALE_GROWTH, LOSS_SCALE_BACKOFF,
+           int(window or LOSS_SCALE_WINDOW), LOSS_SCALE_MIN, LOSS_SCALE_MAX, _stream())
 
 
 # --------------------------------------------------------------------------- pose maps

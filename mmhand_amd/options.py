@@ -8,7 +8,8 @@ Differences, all deliberate:
   * --distributed reads RANK/LOCAL_RANK/WORLD_SIZE from the environment (torchrun) and
     initialises the 'nccl' backend, which is RCCL on ROCm;
   * --opt_level O0 = fp32; O1/O2 (apex AMP in the reference) = bf16 MFMA compute with fp32 master
-    weights, accumulation and statistics (no apex, no loss scaling needed);
+    weights, accumulation and statistics plus apex's dynamic loss scaling (three device-resident
+    scalers, skip / back off / grow); BF16 = the same compute without a scaler;
   * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline) and
     --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
@@ -56,7 +57,8 @@ _BASE = [
     ("--local_rank", dict(type=int, default=0, help="determine which is the master process")),
     ("--distributed", dict(action="store_true", help="one process per GPU, RCCL all-reduce")),
     ("--seed", dict(type=int, default=49, help="manual seed for weight init")),
-    ("--opt_level", dict(type=str, default="O0", help="O0 fp32 | O1/O2 bf16 MFMA compute")),
+    ("--opt_level", dict(type=str, default="O0",
+                         help="O0 fp32 | O1/O2 bf16 MFMA compute + dynamic loss scaling | BF16 (no scaler)")),
     ("--G_n_blocks", dict(type=int, default=9, help="PATBlocks in the generator")),
     ("--vgg_weights", dict(type=str, default=None, help="vgg19.features[0:4] state_dict file")),
     ("--vgg_random_init", dict(action="store_true",

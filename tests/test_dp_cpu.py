@@ -65,6 +65,58 @@ def _w_grad_average(rank, world, port):
     dist.destroy_process_group()
 
 
+def _w_grad_buckets(rank, world, port):
+    """dp.GradBuckets on a 6-layer toy network with flat parameter / gradient buffers: buckets are cut
+    from the END of the flat buffer, each bucket's all-reduce is issued from the autograd hook that
+    completes it - i.e. BEFORE the backward pass has reached the earlier layers - and the result is
+    the sum over ranks of the full flat gradient."""
+    _init(rank, world, port)
+    from mmhand_amd.dp import GradBuckets
+    torch.manual_seed(3)
+    layers = [torch.nn.Linear(16, 16) for _ in range(6)]
+    net = torch.nn.Sequential(*[m for l in layers for m in (l, torch.nn.Tanh())])
+    ps = list(net.parameters())
+    n = sum(p.numel() for p in ps)
+    flat, gflat = torch.zeros(n), torch.zeros(n)
+    off = 0
+    for p in ps:
+        k = p.numel()
+        flat[off:off + k].copy_(p.detach().reshape(-1))
+        p.data = flat[off:off + k].view(p.shape)
+        p.grad = gflat[off:off + k].view(p.shape)
+        off += k
+    log = []
+    bk = GradBuckets(ps, gflat, bucket_bytes=2 * 272 * 4, log=log)       # two layers (w + b) per bucket
+    assert [(s, e) for s, e, _ in bk.buckets] == [(4 * 272, 6 * 272), (2 * 272, 4 * 272), (0, 2 * 272)]
+    x = torch.randn(8, 16, generator=torch.Generator().manual_seed(10 + rank))
+    for it in range(2):                                                   # re-armed per backward pass
+        gflat.zero_()
+        log.clear()
+        bk.begin()
+        net(x).square().mean().backward()
+        bk.launch_remaining()
+        bk.wait()
+        # reference: plain per-rank gradients, summed over ranks
+        ref = torch.autograd.grad(net(x).square().mean(), ps)
+        ref = torch.cat([g.reshape(-1) for g in ref])
+        dist.all_reduce(ref)
+        assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7), (gflat - ref).abs().max()
+        order = [e for e in log if e[0] == "bucket"]
+        assert order == [("bucket", 0), ("bucket", 1), ("bucket", 2)], order
+        # bucket 0 (layers 5, 6) went out before any parameter of layers 1..4 had its gradient
+        first_early = min(i for i, e in enumerate(log) if e[0] == "param" and e[1] < 8)
+        assert log.index(("bucket", 0)) < first_early, log
+        assert log.index(("bucket", 1)) < min(i for i, e in enumerate(log) if e[0] == "param" and e[1] < 4)
+    # a parameter that gets no gradient this pass: finish() still reduces every bucket
+    gflat.zero_()
+    bk.begin()
+    layers[5](x).sum().backward()
+    bk.finish()
+    assert float(gflat[: 5 * 272].abs().sum()) == 0.0 and float(gflat[5 * 272:].abs().sum()) > 0.0
+    bk.remove()
+    dist.destroy_process_group()
+
+
 def _w_options(rank, world, port):
     _init(rank, world, port)
     from mmhand_amd.options import TrainOptions
@@ -76,6 +128,6 @@ def _w_options(rank, world, port):
 
 
 @pytest.mark.parametrize("worker,port", [(_w_sync_stats, 29611), (_w_grad_average, 29612),
-                                          (_w_options, 29613)])
+                                          (_w_options, 29613), (_w_grad_buckets, 29614)])
 def test_world2_gloo(worker, port):
     mp.spawn(worker, args=(2, port), nprocs=2, join=True)

@@ -40,7 +40,7 @@ def _run(norm, batch, distributed):
 
 def _worker(rank, world, port, norm, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", MMH_DP_LOG="1", MMH_BUCKET_MB="0.02")
     sys.path.insert(0, ROOT)
     from oracle import mmhand_ref as O
     torch.cuda.set_device(0)
@@ -48,7 +48,9 @@ def _worker(rank, world, port, norm, tmp):
     full = O.synthetic_batch(4, 32, 32, seed=7)
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
     losses, sd = _run(norm, shard, True)
-    torch.save({"losses": losses, "sd": sd}, os.path.join(tmp, f"rank{rank}.pt"))
+    from mmhand_amd import mmhand_model
+    torch.save({"losses": losses, "sd": sd, "log": list(mmhand_model._LAST_BUCKET_LOG or [])},
+               os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -64,6 +66,17 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_pat
     # replicas stay identical
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    # gradient buckets (20 KB here) went out in reverse layer order DURING the backward pass: the
+    # Generator's first bucket (its last layers) was issued before the gradients of its first
+    # layers existed, and both ranks issued their collectives in the same order
+    log = r0["log"]
+    assert [e for e in log if e[1] == "bucket"] == [e for e in r1["log"] if e[1] == "bucket"]
+    g_buckets = [e[2] for e in log if e[0] == "G" and e[1] == "bucket"]
+    per_iter = max(g_buckets) + 1
+    assert per_iter >= 3 and g_buckets[:per_iter] == list(range(per_iter)), g_buckets
+    first_layer = next(i for i, e in enumerate(log) if e[:2] == ("G", "param") and e[2] == 0)
+    assert log.index(("G", "bucket", 0)) < first_layer
+    assert log.index(("G", "bucket", per_iter - 2)) < first_layer
     # mean of the rank losses == loss on the global batch (losses are means over the batch)
     mean_losses = (np.array(r0["losses"]) + np.array(r1["losses"])) / 2
     if norm == "instance":

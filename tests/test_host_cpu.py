@@ -42,8 +42,9 @@ def test_abi_rejects_bad_arguments_without_gpu(built_lib):
     d = built_lib.ConvDesc(1, 8, 8, 3, 8, 3, 3, 1, 1, 0, 8, 8, 3, 8, 0)   # Cin=3 not %4
     assert l.mmh_conv2d_fprop(ctypes.byref(d), None, None, None, None, 0, None) != 0
     assert b"multiples of 4" in l.mmh_last_error()
-    assert l.mmh_adam_step(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None, None) != 0
-    assert l.mmh_grad_nonfinite(None, 10, None, None, None) != 0
+    assert l.mmh_adam_step(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None, None, None) != 0
+    assert l.mmh_grad_nonfinite(None, 10, None, None, None, None) != 0
+    assert l.mmh_loss_scale_update(None, None, 2.0, 0.5, 2000, 1.0, 2.0 ** 24, None) != 0
 
 
 def test_product_path_never_imports_oracle():

@@ -111,3 +111,85 @@ def test_optimizer_state_checkpoint_roundtrip(dev, tmp_path):
     m2.set_input(_batch(300)); m2.optimize_parameters()
     for n in ("netG", "netD_PP", "netD_PB"):
         assert torch.equal(getattr(m, n).flat_param, getattr(m2, n).flat_param), n
+
+
+def test_loss_scale_update_kernel(dev):
+    """apex LossScaler.update_scale on the device: overflow -> scale * 0.5, clean count reset;
+    `window` clean steps -> scale * 2; bounded by [1, 2^24]."""
+    from mmhand_amd import ops
+    st = torch.tensor([65536.0, 0.0], device=dev)
+    yes = torch.ones(1, dtype=torch.int32, device=dev); no = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.loss_scale_update(st, no, window=3); assert st.tolist() == [65536.0, 1.0]
+    ops.loss_scale_update(st, yes, window=3); assert st.tolist() == [32768.0, 0.0]
+    for _ in range(3):
+        ops.loss_scale_update(st, no, window=3)
+    assert st.tolist() == [65536.0, 0.0]
+    st[0] = 1.0
+    ops.loss_scale_update(st, yes, window=3); assert st.tolist() == [1.0, 0.0]       # floor
+    st[0] = 2.0 ** 24; st[1] = 2.0
+    ops.loss_scale_update(st, no, window=3); assert st.tolist() == [2.0 ** 24, 0.0]  # ceiling
+    # Adam unscales with the device-resident scale: same update as an unscaled gradient
+    g = torch.randn(4096, device=dev)
+    p1 = torch.randn(4096, device=dev); p2 = p1.clone()
+    m1 = torch.zeros_like(p1); v1 = torch.zeros_like(p1); m2 = torch.zeros_like(p1); v2 = torch.zeros_like(p1)
+    sc = torch.tensor([1024.0, 0.0], device=dev)
+    ops.adam_step(p1, g * 1024.0, m1, v1, 2e-4, 0.5, 0.999, 1e-8, 1, 1.0, None, sc)
+    ops.adam_step(p2, g, m2, v2, 2e-4, 0.5, 0.999, 1e-8, 1)
+    assert torch.allclose(p1, p2, rtol=0, atol=1e-9) and torch.allclose(v1, v2, rtol=1e-6, atol=0)
+
+
+def test_opt_level_O1_dynamic_loss_scaling(dev):
+    """--opt_level O1 (the reference's shipped default, scripts/mm-train-ratio.sh:7): apex's dynamic
+    loss scaling around the three backward passes.  A clean iteration leaves the scales at 2^16 and
+    counts one clean step each; a forced overflow in the generator's gradient halves the
+    generator's scale, skips ALL THREE optimizer steps of that iteration (models/MMHandModel.py:
+    316-328: `self.overflow` is sticky) while the two discriminator scalers - whose own backward
+    passes were clean - count a clean step, exactly as apex updates each loss's scaler when its
+    amp.scale_loss context exits; the scales grow again after `window` clean steps; the scaler state
+    travels in <label>_net_amp.pth, the file apex's amp.state_dict() fills in the reference."""
+    from mmhand_amd.mmhand_model import MMHandModel
+    random.seed(49)
+    opt = _small_opt("instance", opt_level="O1", checkpoints_dir="/tmp/mmh_pytest_amp", name="amp")
+    model = MMHandModel(opt)
+    assert model.loss_scaling and model.bf16
+    ref = MMHandModel(_small_opt("instance", opt_level="BF16"))
+    for n in ("netG", "netD_PB", "netD_PP"):
+        getattr(ref, n).load_state_dict(getattr(model, n).state_dict())
+    assert not ref.loss_scaling
+    st = random.getstate()
+    model.set_input(_batch(100)); model.optimize_parameters()
+    random.setstate(st)
+    ref.set_input(_batch(100)); ref.optimize_parameters()
+    assert model._scaler.tolist() == [[65536.0, 1.0]] * 3
+    # scaling by 2^16 and unscaling inside Adam is exact in fp32 (a power of two): same weights
+    for n in ("netG", "netD_PB", "netD_PP"):
+        assert torch.allclose(getattr(model, n).flat_param, getattr(ref, n).flat_param, rtol=0, atol=2e-6), n
+    a = [float(v) for v in model.get_current_errors().values()]
+    b = [float(v) for v in ref.get_current_errors().values()]
+    assert a == pytest.approx(b, rel=1e-5)                      # reported losses are unscaled
+
+    snap = {n: getattr(model, n).flat_param.clone() for n in ("netG", "netD_PP", "netD_PB")}
+    orig = model.backward_G
+
+    def poisoned():
+        orig()
+        model.netG.flat_grad[11] = float("inf")
+    model.backward_G = poisoned
+    model.set_input(_batch(101)); model.optimize_parameters()
+    model.backward_G = orig
+    assert all(torch.equal(getattr(model, n).flat_param, snap[n]) for n in snap)       # all three skipped
+    assert model._scaler.tolist() == [[32768.0, 0.0], [65536.0, 2.0], [65536.0, 2.0]]
+    assert model.loss_scale(0) == 32768.0
+
+    model.loss_scale_window = 3                                  # grow after 3 clean steps
+    model.set_input(_batch(102)); model.optimize_parameters()
+    assert model._scaler.tolist() == [[32768.0, 1.0], [131072.0, 0.0], [131072.0, 0.0]]
+    model._settle_overflow(drain=True)
+    assert model.skipped_steps == 3
+    model.save("latest")
+    opt2 = _small_opt("instance", opt_level="O1", checkpoints_dir="/tmp/mmh_pytest_amp", name="amp",
+                      continue_train=True)
+    m2 = MMHandModel(opt2)
+    assert m2._scaler.tolist() == model._scaler.tolist() and m2.skipped_steps == 3
+    with pytest.raises(ValueError):
+        MMHandModel(_small_opt("instance", opt_level="O3"))
