@@ -563,23 +563,13 @@ class MMHandModel(torch.nn.Module):
                             ("origin_L1", self.loss_originL1), ("perceptual", self.loss_perceptual)])
 
     def get_current_visuals(self):
-        """H1 | P1 | D1 | H2 | P2 | D2 | fake strip as uint8 HxWx3 arrays
-        (models/MMHandModel.py:343-369; pose panels are the max over the 21 maps)."""
-        import numpy as np
-
-        def im(t):
-            a = t[0].detach().float().cpu().numpy()
-            if a.shape[0] == 1:
-                a = np.tile(a, (3, 1, 1))
-            return ((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0).clip(0, 255).astype(np.uint8)
-
-        def pose(t):
-            a = t[0].detach().float().max(0)[0].cpu().numpy()
-            return (np.stack([a] * 3, -1) * 255).clip(0, 255).astype(np.uint8)
-
-        panels = [im(self.input_H1), pose(self.input_P1), im(self.input_D1), im(self.input_H2),
-                  pose(self.input_P2), im(self.input_D2), im(self.fake_p2)]
-        return OrderedDict([("vis", np.concatenate(panels, 1))])
+        """models/MMHandModel.py:343-369: H1 | P1 | D1 | H2 | P2 | D2 | fake strip of sample 0 as one
+        uint8 [H, 7W, 3] array; the pose panels are draw_pose_from_map skeleton drawings
+        (mmhand_amd/visuals.py)."""
+        from . import visuals
+        vis = visuals.visual_strip(self.input_H1, self.input_P1, self.input_D1, self.input_H2, self.input_P2,
+                                   self.input_D2, self.fake_p2)
+        return OrderedDict([("vis", vis)])
 
     def save_network(self, network, network_label, epoch_label, gpu_ids=None):
         if self.master:

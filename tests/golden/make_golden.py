@@ -254,6 +254,17 @@ def make_pose():
     print("pose.npz", np.stack(maps).shape, "nonzero frac", float((np.stack(maps) > 0).mean()))
 
 
+def make_visuals():
+    """labelcolormap(22) and tensor2im from util/util.py (the parts of the visual path that run without
+    cv2: draw_pose_from_cords itself needs cv2.fillConvexPoly / ellipse2Poly and cannot run here)."""
+    from util.util import labelcolormap as ref_cmap, tensor2im as ref_t2i
+    img = RC.rand("vis.img", (2, 3, 16, 16))
+    one = RC.rand("vis.one", (2, 1, 16, 16))
+    np.savez_compressed(os.path.join(HERE, "visuals.npz"), cmap=ref_cmap(22), img=img.numpy(),
+                        img_u8=ref_t2i(img), one=one.numpy(), one_u8=ref_t2i(one))
+    print("visuals.npz", ref_cmap(22)[:4].tolist())
+
+
 def make_step():
     """3 iterations of optimize_parameters on the reference leaf modules (batch & instance norm,
     dropout off: --no_dropout --no_dropout_D, the parity configuration of SURVEY.md §7)."""
@@ -323,6 +334,6 @@ def make_step():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "losses_mse", "adam", "pose", "step"]
+    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "losses_mse", "adam", "pose", "visuals", "step"]
     for w in which:
         globals()["make_" + w]()

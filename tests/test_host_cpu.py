@@ -159,3 +159,51 @@ def test_init_types(kind):
     assert torch.allclose(sd["model.5.bias"], torch.zeros(32)) and abs(sd["model.5.weight"].mean().item() - 1) < 0.02
     with pytest.raises(NotImplementedError):
         d.init_weights("bogus")
+
+
+def test_visuals_colormap_and_tensor2im_match_reference_fixture():
+    """util/util.py labelcolormap(22) / tensor2im outputs stored by tests/golden/make_golden.py."""
+    from mmhand_amd import visuals as V
+    fix = dict(np.load(os.path.join(G, "visuals.npz")))
+    assert np.array_equal(V.labelcolormap(22), fix["cmap"])
+    assert np.array_equal(V.tensor2im(torch.from_numpy(fix["img"])), fix["img_u8"])
+    assert np.array_equal(V.tensor2im(torch.from_numpy(fix["one"])), fix["one_u8"])
+
+
+def test_draw_pose_from_cords_rasterisation():
+    """util/util.py:164-191 restated without cv2 (parity unpinned, see mmhand_amd/visuals.py): the
+    drawing's structure is checked - palm polygon in label 1's colour, each finger bone an ellipse of
+    its own label over it, half axes (length/2, 8) along the bone - plus the two OpenCV primitives on
+    cases with known answers."""
+    from mmhand_amd import visuals as V
+    sq = np.zeros((12, 12), np.uint8)
+    V.fill_convex_poly(sq, [(2, 3), (8, 3), (8, 9), (2, 9)], 7)           # axis-aligned square, inclusive
+    assert sq.sum() == 7 * 7 * 7 and sq[3:10, 2:9].min() == 7
+    tri = np.zeros((10, 10), np.uint8)
+    V.fill_convex_poly(tri, [(0, 0), (8, 0), (0, 8)], 1)
+    assert tri[0, :9].all() and tri[:9, 0].all() and tri[8, 8] == 0 and tri[4, 4] == 1 and tri[5, 5] == 0
+    e = V.ellipse2poly((50, 40), (20, 8), 0)
+    assert tuple(e[0]) == (70, 40) and e[:, 0].max() == 70 and e[:, 0].min() == 30
+    assert e[:, 1].max() == 48 and e[:, 1].min() == 32 and len(e) > 100
+    e90 = V.ellipse2poly((50, 40), (20, 8), 90)
+    assert e90[:, 1].max() == 60 and e90[:, 0].max() == 58
+    # a hand: wrist at the bottom, five fingers fanning up
+    J = np.zeros((21, 2), np.int64)
+    J[0] = (110, 64)
+    for f, x in enumerate((24, 44, 64, 84, 104)):
+        for k in range(4):
+            J[1 + 4 * f + k] = (90 - 20 * k, x)
+    img = V.draw_pose_from_cords(J, (128, 128))
+    cmap = V.labelcolormap(22)
+    assert img.shape == (128, 128, 3) and img.dtype == np.uint8
+    assert tuple(img[100, 64]) == tuple(cmap[1])                         # inside the palm polygon
+    for f, x in enumerate((24, 44, 64, 84, 104)):
+        for k in range(3):                                               # bone k of finger f: label 2 + 3f + k
+            assert tuple(img[80 - 20 * k, x]) == tuple(cmap[2 + 3 * f + k]), (f, k)
+    assert tuple(img[5, 5]) == (0, 0, 0)
+    labels = {tuple(c) for c in img.reshape(-1, 3)}
+    assert labels == {tuple(cmap[i]) for i in range(17)}
+    # vertical bone (length 20): ellipse half axes 10 along y... the reference passes (length/2, 8) with
+    # the bone's angle, so the long axis follows the bone: 8 px to each side across it
+    col = np.all(img[60] == cmap[3], axis=1)                             # row through the middle of finger 0, bone 1
+    assert col[24 - 8] and col[24 + 8] and not col[24 - 10]
