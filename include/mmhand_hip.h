@@ -33,7 +33,7 @@ typedef void* mmh_stream_t; /* a hipStream_t */
 
 enum { MMH_PAD_ZERO = 0, MMH_PAD_REFLECT = 1 };
 enum { MMH_ACT_NONE = 0, MMH_ACT_RELU = 1, MMH_ACT_TANH = 2 };
-enum { MMH_F32 = 0, MMH_BF16 = 1 };
+enum { MMH_F32 = 0, MMH_BF16 = 1, MMH_FP16 = 2 };
 
 /* Geometry of one Conv2d (forward orientation).  For ConvTranspose2d fill it
  * in as the Conv2d whose input-gradient the transposed conv computes. */
@@ -46,7 +46,8 @@ typedef struct mmh_conv_desc {
     int32_t pad_mode;     /* MMH_PAD_ZERO | MMH_PAD_REFLECT (stride 1 only) */
     int32_t Ho, Wo;       /* output (y) spatial size                        */
     int32_t x_cs, y_cs;   /* channel strides of x and y buffers (>= C)      */
-    int32_t dtype;        /* MMH_F32, or MMH_BF16 = bf16 MFMA compute:      */
+    int32_t dtype;        /* MMH_F32, or MMH_BF16 / MMH_FP16 = 16-bit MFMA  */
+                          /* compute (bf16, or IEEE fp16 as apex O1 uses):  */
                           /* x, y, dy, dx stay fp32 in HBM (rounded to bf16 */
                           /* while staged), fp32 accumulate; `w` must then  */
                           /* be a tensor made by mmh_prep_weights_bf16      */
@@ -107,21 +108,33 @@ int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* 
  *        contiguous).  Needs K % 64 == 0, N % 32 == 0 (wgrad: Cin, Cout % 128 == 0).        */
 int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, int dtype,
                      void* U, mmh_stream_t s);
+/* reflect: 0 = zero padding 1, 1 = reflection padding 1, 2 (tile 6, fp32) = zero padding 2 with
+ * tiles over the (H+2) x (W+2) outputs of the full correlation: the first stage of the
+ * REFLECT-FOLD dgrad.  The gradient of a ReflectionPad2d(1) conv lives on the padded domain and
+ * its transpose adds ring row -1 onto row 1 and ring row H onto row H-2; with the tile origin on
+ * the ring, each ring pixel and its partner sit in one 6x6 tile, so mmh_wino_output(fold=1) adds
+ * them in registers: dgrad costs the same 64 GEMMs as fprop and no border terms.  Needs
+ * (H+1) % 6 >= 2 and (W+1) % 6 >= 2 (true for 16, 64, 128: the shapes of the path); tiles =
+ * B*ceil((H+2)/6)*ceil((W+2)/6).                                                           */
 int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype,
                    void* V, mmh_stream_t s);
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh,
                 mmh_stream_t s);
 /* Both backward transforms of dy in one pass (tile 6, fp32): V = mmh_wino_input(dy, zero pad) for
- * the dgrad GEMMs and Yh = mmh_wino_dy(dy) for the wgrad GEMMs; dy is read once. */
+ * the dgrad GEMMs and Yh = mmh_wino_dy(dy) for the wgrad GEMMs; dy is read once.
+ * fold != 0: V is taken on the padded domain as mmh_wino_input(reflect=2) does (needs, besides
+ * its conditions, ceil((H+2)/6) == ceil(H/6) so that V and Yh share one tile grid).           */
 int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* V,
-                      void* Yh, mmh_stream_t s);
+                      void* Yh, int fold, mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
                   int nbatch, int dtype, mmh_stream_t s);
 /* stats (tile 6, fp32; may be NULL): [B][tiles per image][3][C] floats = per (image, tile, channel)
  * the count, mean and M2 of the tile's outputs - the partial-statistics layout that
- * mmh_norm_stats_merge reduces, so the InstanceNorm after the conv does not re-read y. */
+ * mmh_norm_stats_merge reduces, so the InstanceNorm after the conv does not re-read y.
+ * fold != 0 (tile 6, fp32, no bias / act / stats): M is on the padded domain (see mmh_wino_input,
+ * reflect = 2); y receives the reflect-folded gradient on the real H x W domain.               */
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C,
-                    int act, int tile, int dtype, void* stats, mmh_stream_t s);
+                    int act, int tile, int dtype, void* stats, int fold, mmh_stream_t s);
 size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);
 int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout,
                         int nbatch, int dtype, void* ws, size_t ws_bytes, void* dU,
@@ -159,6 +172,11 @@ int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
  * w_t [taps][Cout][Cin] (contraction = Cin, used by fprop).  Either may be NULL. */
 int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout,
                           void* w_plain, void* w_t, mmh_stream_t s);
+/* The same two copies as IEEE fp16 (MMH_FP16; values beyond +-65504 become inf).          */
+int mmh_prep_weights_fp16(const void* w, int taps, int Cin, int Cout,
+                          void* w_plain, void* w_t, mmh_stream_t s);
+int mmh_prep_weights_fp16_flat(const void* w, int taps, int Cin, int Cout,
+                               void* w_flat, mmh_stream_t s);
 /* For fprop of convs whose Cin is not a multiple of 64 (the 7x7 stems): w_flat is
  * [Cout][Kpad] bf16, Kpad = ceil(taps*Cin/64)*64, contraction index k = tap*Cin + ci. */
 int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout,

@@ -26,9 +26,10 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st);
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st);
 int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, float* stats,
-                 hipStream_t st);
+                 int fold, hipStream_t st);
 int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t st);
-int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, hipStream_t st);
+int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, int fold,
+                   hipStream_t st);
 int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);
 extern int g_wino6_vec;
 

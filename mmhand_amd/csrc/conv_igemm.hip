@@ -29,20 +29,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// The 16-bit MFMA kernels serve two element types with one body: bf16 (MMH_BF16) and IEEE fp16
+// (MMH_FP16, the reference's apex O1 precision).  Tiles are carried as 16-bit lanes typed bf16x*;
+// `h16` (a kernel argument, wave-uniform) picks the conversion and the MFMA opcode.
 __device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
     bf16x4 r;
     r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
     return r;
 }
-// 4-channel element access of the Winograd-domain tensors: fp32 (float4) or bf16 (8 bytes, RNE)
-template <bool BF>
+__device__ __forceinline__ bf16x4 to_lp4(float4 v, int h16) {
+    if (h16) {
+        f16x4 r;
+        r[0] = (_Float16)v.x; r[1] = (_Float16)v.y; r[2] = (_Float16)v.z; r[3] = (_Float16)v.w;
+        return __builtin_bit_cast(bf16x4, r);
+    }
+    return to_bf16x4(v);
+}
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int h16) {
+    if (h16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// 4-channel element access of the Winograd-domain tensors: LP = 0 fp32 (float4), 1 bf16, 2 fp16
+// (8 bytes, RNE)
+template <int LP>
 __device__ __forceinline__ void wst4(void* base, long long idx4, float4 v) {
-    if (BF) reinterpret_cast<bf16x4*>(base)[idx4] = to_bf16x4(v);
+    if (LP) reinterpret_cast<bf16x4*>(base)[idx4] = to_lp4(v, LP == 2);
     else reinterpret_cast<float4*>(base)[idx4] = v;
 }
-template <bool BF>
+template <int LP>
 __device__ __forceinline__ float4 wld4(const void* base, long long idx4) {
-    if (BF) {
+    if (LP == 2) {
+        const f16x4 r = reinterpret_cast<const f16x4*>(base)[idx4];
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    if (LP == 1) {
         const bf16x4 r = reinterpret_cast<const bf16x4*>(base)[idx4];
         return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
     }
@@ -91,6 +116,7 @@ struct ConvKP {
     int dbg;                    // timing-only ablation bits (mmh_set_option "conv_dbg"): results wrong
     int xcd_remap;              // remap (blockIdx.y, blockIdx.x) so column tiles of a row tile share an XCD
     int accum;                  // epilogue adds into out instead of overwriting it
+    int h16;                    // 16-bit kernels: 0 = bf16, 1 = fp16 operands
 };
 
 struct KState { int th, tw, c4, j; };   // j: chunk index inside the current tap visit
@@ -857,7 +883,7 @@ __global__ void __launch_bounds__(256, OCC) wino_wgrad_gemm_kernel(const WinoWgr
 //   (16 GEMMs)    : M[xi][tile][N] = V[xi] . U[xi]
 //   wino_output   : y tile = A^T M A (+bias, activation)
 // ---------------------------------------------------------------------------
-template <bool BF>
+template <int BF>
 __global__ void wino_weights_kernel(const float* __restrict__ w, void* __restrict__ Uv, int Cin,
                                     int Cout, int flip_transpose) {
     // w: [3][3][Cin][Cout].  fp32 U: [16][K][N] with (K,N) = (Cin,Cout), or (Cout,Cin) with the taps
@@ -894,7 +920,8 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, void* __restric
                              t[a][2]};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (BF) static_cast<__bf16*>(Uv)[(size_t)(a * 4 + b) * plane + o] = (__bf16)u4[b];
+            if (BF == 2) static_cast<_Float16*>(Uv)[(size_t)(a * 4 + b) * plane + o] = (_Float16)u4[b];
+            else if (BF) static_cast<__bf16*>(Uv)[(size_t)(a * 4 + b) * plane + o] = (__bf16)u4[b];
             else static_cast<float*>(Uv)[(size_t)(a * 4 + b) * plane + o] = u4[b];
         }
     }
@@ -904,7 +931,7 @@ __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // V[xi][tile][C]: one thread per (tile, 4 channels).  Padding 1, reflect or zero.
-template <bool BF>
+template <int BF>
 __global__ void wino_input_kernel(const float* __restrict__ x, void* __restrict__ V, int B, int H,
                                   int W, int C4, int reflect) {
     const int TH = H / 2, TW = W / 2;
@@ -954,7 +981,7 @@ __global__ void wino_input_kernel(const float* __restrict__ x, void* __restrict_
 }
 
 // y[b, 2ty+i, 2tx+j, :] = (A^T M A)[i][j] (+ bias, act).  One thread per (tile, 4 channels).
-template <bool BF>
+template <int BF>
 __global__ void wino_output_kernel(const void* __restrict__ M, float* __restrict__ y,
                                    const float* __restrict__ bias, int B, int H, int W, int C4,
                                    int act) {
@@ -1128,7 +1155,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_bf16x4(ra[i]);
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_lp4(ra[i], p.h16);
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
             *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + 32 * i) * LDH + bgrp * 8]) = rb[i];
@@ -1166,7 +1193,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = mfma16(af[i], bfr[jn], acc[i][jn], p.h16);
         }
         if (!(p.dbg & 2)) {
             __syncthreads();
@@ -1282,6 +1309,7 @@ struct WgradKP {
     int nsplit;             // splits per batch: blockIdx.z = batch * nsplit + split
     long long src_bs, dy_bs;   // element strides between batches (Winograd: 16 planes)
     int xcd_remap;          // grid size % 8 == 0: XCD x works on a contiguous range of (z, y, x) ids
+    int h16;                    // 16-bit kernel: 0 = bf16, 1 = fp16 operands
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs.  With the remap, XCD x takes the contiguous
@@ -1574,12 +1602,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_bf16x4(ra[i]);
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_lp4(ra[i], p.h16);
 #pragma unroll
         for (int i = 0; i < NBD; ++i) {
             const int idx = tid + 256 * i;
             const int prow = idx / (BN / 4), c4 = idx - prow * (BN / 4);
-            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_bf16x4(rb[i]);
+            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_lp4(rb[i], p.h16);
         }
     };
 
@@ -1609,7 +1637,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
             }
             __syncthreads();
             if (more) store_tiles();
@@ -1650,9 +1678,15 @@ struct WinoGemmBfKP {
     __bf16* C;
     int M, K, N, P;
     int MT, NT, W, Wx, nb;
+    int h16;
 };
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+__device__ __forceinline__ unsigned pack_lp2(float lo, float hi, int h16) {
+    if (h16) {
+        f16x2 v;
+        v[0] = (_Float16)lo; v[1] = (_Float16)hi;
+        return __builtin_bit_cast(unsigned, v);
+    }
     bf16x2 v;
     v[0] = (__bf16)lo; v[1] = (__bf16)hi;
     return __builtin_bit_cast(unsigned, v);
@@ -1750,7 +1784,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
             }
             if (ks == KS - 1) {
                 const int nt = wc % p.NT;
@@ -1778,7 +1812,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
                                     float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x0), 0xB1, 0xF, 0xF, true));
                                 const float y1 = __builtin_bit_cast(
                                     float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x1), 0xB1, 0xF, 0xF, true));
-                                const unsigned v = odd ? pack_bf16x2(y1, x1) : pack_bf16x2(x0, y0);
+                                const unsigned v = odd ? pack_lp2(y1, x1, p.h16) : pack_lp2(x0, y0, p.h16);
                                 const unsigned rd = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n2;
                                 __builtin_amdgcn_raw_buffer_store_b32(v, rsC, vbase + rd + j * 64u, 0, 0);
                             }
@@ -1809,6 +1843,7 @@ struct WinoWgradBfKP {
     const __bf16* Y;
     float* slab;
     int T, Cin, Cout, P, S, t_per_split, MT, NT, W, Wx, nb;
+    int h16;
 };
 
 __global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const WinoWgradBfKP p) {
@@ -1901,7 +1936,7 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const Wino
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
             }
             if (ks == KS - 1) {
                 const int nt = wc % p.NT;
@@ -1990,9 +2025,11 @@ __global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __rest
 }
 
 // --------------------------------------------------------------------------- host side
+inline bool is16(int dtype) { return dtype == MMH_BF16 || dtype == MMH_FP16; }
+
 int validate(const mmh_conv_desc* d) {
     MMH_REQUIRE(d != nullptr, "conv desc is NULL");
-    MMH_REQUIRE(d->dtype == MMH_F32 || d->dtype == MMH_BF16, "bad dtype=%d", d->dtype);
+    MMH_REQUIRE(d->dtype == MMH_F32 || is16(d->dtype), "bad dtype=%d", d->dtype);
     MMH_REQUIRE(d->Cin % 4 == 0 && d->Cout % 4 == 0, "Cin/Cout must be multiples of 4 (%d,%d)",
                 d->Cin, d->Cout);
     MMH_REQUIRE(d->x_cs % 4 == 0 && d->y_cs % 4 == 0 && d->x_cs >= d->Cin && d->y_cs >= d->Cout,
@@ -2140,7 +2177,8 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
     p.out_linear = 1; p.out_cs = (unsigned)d->y_cs;
     p.OH = d->Ho; p.OW = d->Wo; p.o_p = 1;
     p.act = act;
-    if (d->dtype == MMH_BF16) {
+    if (is16(d->dtype)) {
+        p.h16 = d->dtype == MMH_FP16;
         if (d->Cin % 64 == 0) {
             // w is the prepared bf16 tensor w_t [taps][Cout][Cin]
             p.wRows = d->Cout; p.wKper = d->Cin;
@@ -2206,13 +2244,14 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
             p.out_linear = s == 1;
             p.act = act;
             if (TH == 0 || TW == 0) p.nk = 0;  // no tap reaches this class: writes zeros
-            if (s == 2 && d->dtype != MMH_BF16 && g_dgrad_s2_multi) {   // collected, launched once below
+            if (s == 2 && !is16(d->dtype) && g_dgrad_s2_multi) {   // collected, launched once below
                 classes[ncls++] = p;
                 continue;
             }
             int rc;
-            if (d->dtype == MMH_BF16) {
-                // w is the prepared bf16 tensor [taps][Cin][Cout]
+            if (is16(d->dtype)) {
+                // w is the prepared 16-bit tensor [taps][Cin][Cout]
+                p.h16 = d->dtype == MMH_FP16;
                 p.wRows = d->Cin; p.wKper = d->Cout;
                 p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
                 MMH_REQUIRE(bf16_ok(p), "bf16 dgrad needs Cout %% 64 == 0 (Cout=%d)", d->Cout);
@@ -2284,7 +2323,7 @@ int g_border_bn64 = 1;  // border-only dgrad launches (Winograd path): 64-wide t
 int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
                       hipStream_t st, bool with_main = true, int phase = 3) {
     const int H = d->H, W = d->W, C = d->Cin;
-    const bool bf16 = d->dtype == MMH_BF16;
+    const bool bf16 = is16(d->dtype);
     float* rows = static_cast<float*>(ws);                       // [B][2][W][C]
     float* cols = rows + (size_t)d->B * 2 * W * C;               // [B][H][2][C]
     float* corners = cols + (size_t)d->B * H * 2 * C;            // [B][4][C]
@@ -2305,6 +2344,7 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
             g.chunk_major = 1;
             g.cw = chunks % 4 == 0 ? 4 : (chunks % 2 == 0 ? 2 : 1);
             p.nk = chunks * TH * TW;
+            p.h16 = d->dtype == MMH_FP16;
             p.wRows = d->Cin; p.wKper = d->Cout;
             p.w_bytes = (unsigned)((size_t)d->kh * d->kw * d->Cin * d->Cout * 2);
         } else {
@@ -2367,7 +2407,7 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
 }
 
 // Yhat[xi][tile][C] = A dY A^T for the 2x2 output-gradient tile (Winograd wgrad).
-template <bool BF>
+template <int BF>
 __global__ void wino_dy_kernel(const float* __restrict__ dy, void* __restrict__ Yh, int B, int H, int W,
                                int C4) {
     const int TH = H / 2, TW = W / 2;
@@ -2846,7 +2886,8 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
                 "wgrad workspace too small: %zu < %zu", ws_bytes,
                 (size_t)splits * p.Mrows * p.N * sizeof(float));
     p.slab = static_cast<float*>(ws);
-    const bool bf16 = d->dtype == MMH_BF16;
+    const bool bf16 = is16(d->dtype);
+    p.h16 = d->dtype == MMH_FP16;
     p.pix_per_split = (int)(mmh::cdiv(mmh::cdiv(p.P, splits), bf16 ? BKP : BK) * (bf16 ? BKP : BK));
     p.dbg = g_conv_dbg;
     p.nsplit = splits;
@@ -2927,7 +2968,7 @@ static long long wino_tiles(int B, int H, int W, int tile) {
     return (long long)B * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
 }
 
-static bool wino_dtype_ok(int dtype, int tile) { return dtype == MMH_F32 || (dtype == MMH_BF16 && tile == 2); }
+static bool wino_dtype_ok(int dtype, int tile) { return dtype == MMH_F32 || (is16(dtype) && tile == 2); }
 
 int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int tile, int dtype, void* U,
                      mmh_stream_t s) {
@@ -2940,20 +2981,28 @@ int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int t
     if (tile == 4)
         hipLaunchKernelGGL(wino4_weights_kernel, grid, dim3(256), 0, mmh::as_stream(s),
                            static_cast<const float*>(w), static_cast<float*>(U), Cin, Cout, flip_transpose);
+    else if (dtype == MMH_FP16)
+        hipLaunchKernelGGL(wino_weights_kernel<2>, grid, dim3(256), 0, mmh::as_stream(s),
+                           static_cast<const float*>(w), U, Cin, Cout, flip_transpose);
     else if (dtype == MMH_BF16)
-        hipLaunchKernelGGL(wino_weights_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+        hipLaunchKernelGGL(wino_weights_kernel<1>, grid, dim3(256), 0, mmh::as_stream(s),
                            static_cast<const float*>(w), U, Cin, Cout, flip_transpose);
     else
-        hipLaunchKernelGGL(wino_weights_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+        hipLaunchKernelGGL(wino_weights_kernel<0>, grid, dim3(256), 0, mmh::as_stream(s),
                            static_cast<const float*>(w), U, Cin, Cout, flip_transpose);
     return mmh::check_launch("wino_weights_kernel");
 }
 
+// Reflect-fold dgrad (padded-domain tiles, in-tile fold): both ring partners must share a tile.
+static bool wino_fold_ok(int H, int W) { return H >= 6 && W >= 6 && (H + 1) % 6 >= 2 && (W + 1) % 6 >= 2; }
+
 int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype, void* V,
                    mmh_stream_t s) {
     MMH_REQUIRE(x && V && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
-                    wino_dtype_ok(dtype, tile),
+                    wino_dtype_ok(dtype, tile) && reflect >= 0 && reflect <= 2,
                 "mmh_wino_input: bad arguments");
+    MMH_REQUIRE(reflect != 2 || (tile == 6 && dtype == MMH_F32 && wino_fold_ok(H, W)),
+                "mmh_wino_input: pad mode 2 (padded-domain dgrad) needs tile 6, fp32, (H+1) %% 6 >= 2, (W+1) %% 6 >= 2");
     const long long tiles = wino_tiles(B, H, W, tile);
     if (tile == 6)
         return mmh::wino6_input(static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C, reflect, g_wino_xcd,
@@ -2967,22 +3016,27 @@ int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int t
     } else {
         const long long total = tiles * (C / 4);
         const dim3 grid((unsigned)((total + 255) / 256));
-        if (dtype == MMH_BF16)
-            hipLaunchKernelGGL(wino_input_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+        if (dtype == MMH_FP16)
+            hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(x), V, B, H, W, C / 4, reflect);
+        else if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_input_kernel<1>, grid, dim3(256), 0, mmh::as_stream(s),
                                static_cast<const float*>(x), V, B, H, W, C / 4, reflect);
         else
-            hipLaunchKernelGGL(wino_input_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+            hipLaunchKernelGGL(wino_input_kernel<0>, grid, dim3(256), 0, mmh::as_stream(s),
                                static_cast<const float*>(x), V, B, H, W, C / 4, reflect);
     }
     return mmh::check_launch("wino_input_kernel");
 }
 
 int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* V, void* Yh,
-                      mmh_stream_t s) {
+                      int fold, mmh_stream_t s) {
     MMH_REQUIRE(dy && V && Yh && B > 0 && tile == 6 && dtype == MMH_F32 && wino_hw_ok(H, W, tile) && C % 4 == 0,
                 "mmh_wino_input_dy: needs tile 6, fp32");
+    MMH_REQUIRE(!fold || (wino_fold_ok(H, W) && (H + 7) / 6 == (H + 5) / 6 && (W + 7) / 6 == (W + 5) / 6),
+                "mmh_wino_input_dy: fold needs (H+1) %% 6 >= 2 and ceil((H+2)/6) == ceil(H/6) (W alike)");
     return mmh::wino6_input_dy(static_cast<const float*>(dy), static_cast<float*>(V), static_cast<float*>(Yh), B, H, W,
-                               C, g_wino_xcd, mmh::as_stream(s));
+                               C, g_wino_xcd, fold ? 1 : 0, mmh::as_stream(s));
 }
 
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh, mmh_stream_t s) {
@@ -2999,23 +3053,27 @@ int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype,
     } else {
         const long long total = tiles * (C / 4);
         const dim3 grid((unsigned)((total + 255) / 256));
-        if (dtype == MMH_BF16)
-            hipLaunchKernelGGL(wino_dy_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s),
+        if (dtype == MMH_FP16)
+            hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, mmh::as_stream(s),
+                               static_cast<const float*>(dy), Yh, B, H, W, C / 4);
+        else if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_dy_kernel<1>, grid, dim3(256), 0, mmh::as_stream(s),
                                static_cast<const float*>(dy), Yh, B, H, W, C / 4);
         else
-            hipLaunchKernelGGL(wino_dy_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s),
+            hipLaunchKernelGGL(wino_dy_kernel<0>, grid, dim3(256), 0, mmh::as_stream(s),
                                static_cast<const float*>(dy), Yh, B, H, W, C / 4);
     }
     return mmh::check_launch("wino_dy_kernel");
 }
 
-static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tiles, int K, int N, int nbatch,
+static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tiles, int K, int N, int nbatch, int h16,
                           hipStream_t st) {
     MMH_REQUIRE(K % BK16 == 0 && N % 32 == 0, "mmh_wino_gemm (bf16): needs K %% 64 == 0 and N %% 32 == 0");
     MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
     WinoGemmBfKP p{};
     p.A = static_cast<const __bf16*>(V); p.B = static_cast<const __bf16*>(U); p.C = static_cast<__bf16*>(Mo);
     p.M = (int)tiles; p.K = K; p.N = N; p.P = nbatch;
+    p.h16 = h16;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (N + 127) / 128;
     p.W = nbatch * p.MT * p.NT;
@@ -3041,23 +3099,25 @@ static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tile
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N, int nbatch, int dtype,
                   mmh_stream_t s) {
     MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0 && nbatch > 0 &&
-                    (dtype == MMH_F32 || dtype == MMH_BF16),
+                    (dtype == MMH_F32 || is16(dtype)),
                 "mmh_wino_gemm: bad arguments");
-    if (dtype == MMH_BF16) return wino_gemm_bf16(V, U, M, tiles, K, N, nbatch, mmh::as_stream(s));
+    if (is16(dtype)) return wino_gemm_bf16(V, U, M, tiles, K, N, nbatch, dtype == MMH_FP16, mmh::as_stream(s));
     return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
                      K, N, mmh::as_stream(s), nbatch);
 }
 
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,
-                    int dtype, void* stats, mmh_stream_t s) {
+                    int dtype, void* stats, int fold, mmh_stream_t s) {
     MMH_REQUIRE(M && y && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&
                     wino_dtype_ok(dtype, tile),
                 "mmh_wino_output: bad arguments");
     const long long tiles = wino_tiles(B, H, W, tile);
     MMH_REQUIRE(!stats || (tile == 6 && dtype == MMH_F32), "mmh_wino_output: statistics need tile 6, fp32");
+    MMH_REQUIRE(!fold || (tile == 6 && dtype == MMH_F32 && wino_fold_ok(H, W) && !bias && !stats && act == MMH_ACT_NONE),
+                "mmh_wino_output: fold needs tile 6, fp32, no bias / activation / statistics, (H+1) %% 6 >= 2");
     if (tile == 6)
         return mmh::wino6_output(static_cast<const float*>(M), static_cast<float*>(y), static_cast<const float*>(bias),
-                                 B, H, W, C, act, static_cast<float*>(stats), mmh::as_stream(s));
+                                 B, H, W, C, act, static_cast<float*>(stats), fold ? 1 : 0, mmh::as_stream(s));
     if (tile == 4) {
         const long long total = tiles * (C / 2);
         hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
@@ -3066,11 +3126,14 @@ int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int 
     } else {
         const long long total = tiles * (C / 4);
         const dim3 grid((unsigned)((total + 255) / 256));
-        if (dtype == MMH_BF16)
-            hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, mmh::as_stream(s), M,
+        if (dtype == MMH_FP16)
+            hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, mmh::as_stream(s), M,
+                               static_cast<float*>(y), static_cast<const float*>(bias), B, H, W, C / 4, act);
+        else if (dtype == MMH_BF16)
+            hipLaunchKernelGGL(wino_output_kernel<1>, grid, dim3(256), 0, mmh::as_stream(s), M,
                                static_cast<float*>(y), static_cast<const float*>(bias), B, H, W, C / 4, act);
         else
-            hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, mmh::as_stream(s), M,
+            hipLaunchKernelGGL(wino_output_kernel<0>, grid, dim3(256), 0, mmh::as_stream(s), M,
                                static_cast<float*>(y), static_cast<const float*>(bias), B, H, W, C / 4, act);
     }
     return mmh::check_launch("wino_output_kernel");
@@ -3094,16 +3157,17 @@ size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch
 int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout, int nbatch, int dtype,
                         void* ws, size_t ws_bytes, void* dU, mmh_stream_t s) {
     MMH_REQUIRE(V && Yh && ws && dU && tiles > 0 && Cin % 4 == 0 && Cout % 4 == 0 &&
-                    (dtype == MMH_F32 || dtype == MMH_BF16),
+                    (dtype == MMH_F32 || is16(dtype)),
                 "mmh_wino_wgrad_gemm: bad arguments");
     MMH_REQUIRE(ws_bytes >= mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, nbatch),
                 "mmh_wino_wgrad_gemm: workspace too small");
     MMH_REQUIRE(tiles * (long long)std::max(Cin, Cout) < (1ll << 30), "mmh_wino_wgrad_gemm: tensor too large");
     hipStream_t st = mmh::as_stream(s);
     const int splits = wino_wgrad_splits(Cin, Cout, tiles, nbatch);
-    if (dtype == MMH_BF16) {
+    if (is16(dtype)) {
         MMH_REQUIRE(Cin % BM == 0 && Cout % 128 == 0, "mmh_wino_wgrad_gemm (bf16): needs Cin, Cout %% 128 == 0");
         WinoWgradBfKP q{};
+        q.h16 = dtype == MMH_FP16;
         q.V = static_cast<const __bf16*>(V); q.Y = static_cast<const __bf16*>(Yh); q.slab = static_cast<float*>(ws);
         q.T = (int)tiles; q.Cin = Cin; q.Cout = Cout; q.P = nbatch;
         q.t_per_split = (int)(mmh::cdiv(mmh::cdiv(tiles, splits), BKP) * BKP);

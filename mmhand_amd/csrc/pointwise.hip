@@ -778,8 +778,10 @@ __global__ void decode_inputs_kernel(const uint8_t* __restrict__ img1, const uin
 }
 
 // ------------------------------------------------------------------ bf16 weight copies
+// T = __bf16 or _Float16
+template <typename T>
 __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, int taps, int R, int C,
-                                         __bf16* __restrict__ plain, __bf16* __restrict__ tr) {
+                                         T* __restrict__ plain, T* __restrict__ tr) {
     const int64_t total = (int64_t)taps * R * C;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -788,15 +790,16 @@ __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, int taps, 
         const int64_t t2 = i / C;
         const int r = (int)(t2 % R);
         const int t = (int)(t2 / R);
-        const __bf16 v = (__bf16)w[i];
+        const T v = (T)w[i];
         if (plain) plain[i] = v;
         if (tr) tr[((int64_t)t * C + c) * R + r] = v;
     }
 }
 
 // w [taps][R][C] fp32 -> flat [C][Kpad] bf16 with k = t*R + r (zero padded): fprop of small-Cin convs
+template <typename T>
 __global__ void prep_weights_bf16_flat_kernel(const float* __restrict__ w, int taps, int R, int C,
-                                              int Kpad, __bf16* __restrict__ out) {
+                                              int Kpad, T* __restrict__ out) {
     const int64_t total = (int64_t)C * Kpad;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -805,7 +808,7 @@ __global__ void prep_weights_bf16_flat_kernel(const float* __restrict__ w, int t
         const int n = (int)(i / Kpad);
         float v = 0.f;
         if (k < taps * R) v = w[(int64_t)k * C + n];      // [t][r][n] is flat in k = t*R + r
-        out[i] = (__bf16)v;
+        out[i] = (T)v;
     }
 }
 
@@ -1141,17 +1144,35 @@ int mmh_decode_inputs(const void* img1, const void* img2, const void* dep1, cons
 int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout, void* w_plain, void* w_t,
                           mmh_stream_t s) {
     MMH_REQUIRE(w && (w_plain || w_t) && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_bf16: bad arguments");
-    hipLaunchKernelGGL(prep_weights_bf16_kernel, dim3(grid_for((int64_t)taps * Cin * Cout)), dim3(TPB), 0,
+    hipLaunchKernelGGL(prep_weights_bf16_kernel<__bf16>, dim3(grid_for((int64_t)taps * Cin * Cout)), dim3(TPB), 0,
                        mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout,
                        static_cast<__bf16*>(w_plain), static_cast<__bf16*>(w_t));
     return mmh::check_launch("prep_weights_bf16");
+}
+
+int mmh_prep_weights_fp16(const void* w, int taps, int Cin, int Cout, void* w_plain, void* w_t,
+                          mmh_stream_t s) {
+    MMH_REQUIRE(w && (w_plain || w_t) && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_fp16: bad arguments");
+    hipLaunchKernelGGL(prep_weights_bf16_kernel<_Float16>, dim3(grid_for((int64_t)taps * Cin * Cout)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout,
+                       static_cast<_Float16*>(w_plain), static_cast<_Float16*>(w_t));
+    return mmh::check_launch("prep_weights_fp16");
+}
+
+int mmh_prep_weights_fp16_flat(const void* w, int taps, int Cin, int Cout, void* w_flat, mmh_stream_t s) {
+    MMH_REQUIRE(w && w_flat && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_fp16_flat: bad arguments");
+    const int Kpad = (taps * Cin + 63) / 64 * 64;
+    hipLaunchKernelGGL(prep_weights_bf16_flat_kernel<_Float16>, dim3(grid_for((int64_t)Cout * Kpad)), dim3(TPB), 0,
+                       mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout, Kpad,
+                       static_cast<_Float16*>(w_flat));
+    return mmh::check_launch("prep_weights_fp16_flat");
 }
 
 int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout, void* w_flat,
                                mmh_stream_t s) {
     MMH_REQUIRE(w && w_flat && taps > 0 && Cin > 0 && Cout > 0, "mmh_prep_weights_bf16_flat: bad arguments");
     const int Kpad = (taps * Cin + 63) / 64 * 64;
-    hipLaunchKernelGGL(prep_weights_bf16_flat_kernel, dim3(grid_for((int64_t)Cout * Kpad)), dim3(TPB), 0,
+    hipLaunchKernelGGL(prep_weights_bf16_flat_kernel<__bf16>, dim3(grid_for((int64_t)Cout * Kpad)), dim3(TPB), 0,
                        mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout, Kpad,
                        static_cast<__bf16*>(w_flat));
     return mmh::check_launch("prep_weights_bf16_flat");

@@ -129,7 +129,11 @@ __device__ __forceinline__ F2 act_of(F2 v, int act) { return F2{act6(v.x, act), 
 template <typename T>
 __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B,
                                                           int H, int W, int C2, int reflect, int xcd_remap) {
-    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    // reflect: 0 = zero padding 1, 1 = reflect padding 1 (tiles over the H x W outputs); 2 = zero
+    // padding 2 with tiles over the (H+2) x (W+2) outputs of the FULL correlation: the dgrad of a
+    // reflect-padded conv on its padded domain, folded back by wino6_output_kernel(fold)
+    const int org = reflect == 2 ? 2 : 1;
+    const int TH = (H + (reflect == 2 ? 7 : 5)) / 6, TW = (W + (reflect == 2 ? 7 : 5)) / 6;
     const long long tiles = (long long)B * TH * TW;
     // XCD-contiguous tile order: neighbouring 8x8 windows (2 shared rows / columns) meet in one L2
     unsigned blk = blockIdx.x;
@@ -143,9 +147,9 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     T d[8][8], colv[8], o8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        int hh = 6 * ty - 1 + r;
+        int hh = 6 * ty - org + r;
         bool okh;
-        if (reflect) {      // the padded image is rows -1 .. H; ragged tiles reach beyond it: zeros
+        if (reflect == 1) {      // the padded image is rows -1 .. H; ragged tiles reach beyond it: zeros
             okh = hh <= H;
             hh = hh < 0 ? -hh : hh;
             hh = hh >= H ? 2 * (H - 1) - hh : hh;
@@ -155,9 +159,9 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            int ww = 6 * tx - 1 + q;
+            int ww = 6 * tx - org + q;
             bool ok;
-            if (reflect) {
+            if (reflect == 1) {
                 ok = okh && ww <= W;
                 ww = ww < 0 ? -ww : ww;
                 ww = ww >= W ? 2 * (W - 1) - ww : ww;
@@ -196,8 +200,14 @@ __device__ __forceinline__ void stat_add(F2, float&, float&) {}
 template <typename T>
 __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restrict__ M, float* __restrict__ y,
                                                            const float* __restrict__ bias, int B, int H, int W,
-                                                           int C2, int act, float* __restrict__ stats) {
-    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+                                                           int C2, int act, float* __restrict__ stats, int fold) {
+    // fold: M holds the FULL correlation on the (H+2) x (W+2) padded domain (dgrad of a
+    // ReflectionPad2d(1) conv); tile (ty, tx) covers padded rows 6ty .. 6ty+5.  The transpose of the
+    // reflect padding adds ring row 0 onto padded row 2 and ring row H+1 onto padded row H-1 (columns
+    // alike, corners by composition) - with this tile origin both partners always sit in the SAME
+    // tile (host precondition (H+1) % 6 >= 2), so the fold happens in registers and y gets the
+    // folded gradient on the real H x W domain: no border GEMMs, no second pass.
+    const int TH = (H + (fold ? 7 : 5)) / 6, TW = (W + (fold ? 7 : 5)) / 6;
     const long long tiles = (long long)B * TH * TW;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tiles * C2) return;
@@ -218,6 +228,40 @@ __global__ void __launch_bounds__(256) wino6_output_kernel(const float* __restri
     const T bv = bias ? reinterpret_cast<const T*>(bias)[c] : zero_of(T{});
     T* yo = reinterpret_cast<T*>(y);
     T vals[6][6];
+    if (fold) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            w6_at(s6[r], o6);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) vals[r][q] = o6[q];
+        }
+        const int rb = H + 1 - 6 * ty, cb = W + 1 - 6 * tx;     // local index of the bottom / right ring
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {       // rows first (ring columns included), then columns: corners compose
+            if (ty == 0) vals[2][q] = vals[2][q] + vals[0][q];
+#pragma unroll
+            for (int r = 2; r < 6; ++r)
+                if (r == rb) vals[r - 2][q] = vals[r - 2][q] + vals[r][q];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if (tx == 0) vals[r][2] = vals[r][2] + vals[r][0];
+#pragma unroll
+            for (int q = 2; q < 6; ++q)
+                if (q == cb) vals[r][q - 2] = vals[r][q - 2] + vals[r][q];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int ph = 6 * ty + r;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int pw = 6 * tx + q;
+                if (ph >= 1 && ph <= H && pw >= 1 && pw <= W)
+                    yo[(((long long)b * H + ph - 1) * W + pw - 1) * C2 + c] = vals[r][q];
+            }
+        }
+        return;
+    }
     float n = 0.f, sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
@@ -289,7 +333,11 @@ __global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(256) wino6_input_dy_kernel(const float* __restrict__ dy, float* __restrict__ V,
                                                              float* __restrict__ Yh, int B, int H, int W, int C2,
-                                                             int xcd_remap) {
+                                                             int xcd_remap, int fold) {
+    // fold: the dgrad operand is taken on the padded domain (window origin -2, see
+    // wino6_output_kernel); the wgrad tile dy[6ty .. 6ty+5] then sits at rows / columns 2..7 of the
+    // window.  Host precondition: ceil((H+2)/6) == ceil(H/6), so both operands share one tile grid.
+    const int org = fold ? 2 : 1;
     const int TH = (H + 5) / 6, TW = (W + 5) / 6;
     const long long tiles = (long long)B * TH * TW;
     unsigned blk = blockIdx.x;
@@ -303,21 +351,21 @@ __global__ void __launch_bounds__(256) wino6_input_dy_kernel(const float* __rest
     T d[8][8], colv[8], o8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int hh = 6 * ty - 1 + r;
+        const int hh = 6 * ty - org + r;
         const bool okh = hh >= 0 && hh < H;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int ww = 6 * tx - 1 + q;
+            const int ww = 6 * tx - org + q;
             d[r][q] = (okh && ww >= 0 && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : zero_of(T{});
         }
     }
     const long long plane = tiles * C2;
-    {   // Yh from the inner 6x6 tile (rows / columns 1..6 of the window)
+    {   // Yh from the inner 6x6 tile (rows / columns org..org+5 of the window)
         T t[8][6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) colv[r] = d[r + 1][q + 1];
+            for (int r = 0; r < 6; ++r) colv[r] = fold ? d[r + 2][q + 2] : d[r + 1][q + 1];
             w6_a(colv, o8);
 #pragma unroll
             for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
@@ -387,7 +435,8 @@ int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpos
 int g_wino6_vec = 0x0;   // bit 0 / 1 / 2: input / output / dy transform works on 2 channels per thread
 
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st) {
-    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    const int ext = reflect == 2 ? 7 : 5;
+    const long long tiles = (long long)B * ((H + ext) / 6) * ((W + ext) / 6);
     const int cpt = (g_wino6_vec & 1) ? 2 : 1;
     const unsigned nblk = (unsigned)((tiles * (C / cpt) + 255) / 256);
     const int remap = (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0;
@@ -399,14 +448,15 @@ int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflec
 }
 
 int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, float* stats,
-                 hipStream_t st) {
-    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+                 int fold, hipStream_t st) {
+    const int ext = fold ? 7 : 5;
+    const long long tiles = (long long)B * ((H + ext) / 6) * ((W + ext) / 6);
     if ((g_wino6_vec & 2) && !stats)
         hipLaunchKernelGGL(wino6_output_kernel<F2>, dim3((unsigned)((tiles * (C / 2) + 255) / 256)), dim3(256), 0, st, M,
-                           y, bias, B, H, W, C / 2, act, nullptr);
+                           y, bias, B, H, W, C / 2, act, nullptr, fold);
     else
         hipLaunchKernelGGL(wino6_output_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, M, y,
-                           bias, B, H, W, C, act, stats);
+                           bias, B, H, W, C, act, stats, fold);
     return check_launch("wino6_output_kernel");
 }
 
@@ -421,11 +471,12 @@ int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t
     return check_launch("wino6_dy_kernel");
 }
 
-int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, hipStream_t st) {
+int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, int fold,
+                   hipStream_t st) {
     const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
     const unsigned nblk = (unsigned)((tiles * C + 255) / 256);
     hipLaunchKernelGGL(wino6_input_dy_kernel<float>, dim3(nblk), dim3(256), 0, st, dy, V, Yh, B, H, W, C,
-                       (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0);
+                       (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0, fold);
     return check_launch("wino6_input_dy_kernel");
 }
 

@@ -41,7 +41,7 @@ class InferenceGenerator:
     def __init__(self, net: Generator, use_graph=True, bf16=False):
         assert isinstance(net, Generator)
         self.net = net.eval()
-        self.bf16 = bool(bf16)        # bf16 MFMA compute for the channel-%64 convs (fp32 I/O)
+        self.bf16 = 2 if bf16 == 2 else bool(bf16)   # 16-bit MFMA compute (True bf16, 2 fp16) for the channel-%64 convs
         self.net.bf16 = self.bf16
         self.folded = net.norm == "batch"
         self.use_graph = use_graph

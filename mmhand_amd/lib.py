@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmmhand_hip.so")
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-F32, BF16 = 0, 1
+F32, BF16, FP16 = 0, 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -44,9 +44,9 @@ SIGNATURES = {
     "mmh_wino_weights": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mmh_wino_input": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "mmh_wino_dy": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "mmh_wino_input_dy": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mmh_wino_input_dy": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
-    "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mmh_norm_stats_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_wino_wgrad_gemm_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
@@ -66,6 +66,8 @@ SIGNATURES = {
     "mmh_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmh_prep_weights_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_prep_weights_bf16_flat": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mmh_prep_weights_fp16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mmh_prep_weights_fp16_flat": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmh_colsum_ws_bytes": (_sz, [_i64, _i]),
     "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _vp]),
     "mmh_norm_stats_ws_bytes": (_sz, [_i, _i64, _i]),

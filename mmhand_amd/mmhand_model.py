@@ -223,13 +223,17 @@ class MMHandModel(torch.nn.Module):
         #               master weights / accumulation / statistics AND apex's dynamic loss scaling
         #               (one scaler per loss, num_losses=3): scale -> backward -> overflow check on
         #               the scaled gradients -> unscale inside Adam -> skip / back off / grow
+        #   O1_FP16 / O2_FP16   the same with IEEE fp16 MFMA operands - apex's own numerics: the
+        #               dynamic loss scaler is then REQUIRED (fp16 gradients under- and overflow)
         #   BF16        the same bf16 compute without a loss scaler (bf16 has fp32's exponent range)
         level = str(getattr(opt, "opt_level", "O0")).upper()
-        if level not in ("O0", "O1", "O2", "BF16"):
-            raise ValueError("--opt_level %r: expected O0 | O1 | O2 | BF16 (apex's O3 = pure fp16 weights "
-                             "is 'not recommended' by the reference and not built)" % (opt.opt_level,))
-        self.bf16 = level in ("O1", "O2", "BF16")
-        self.loss_scaling = self.isTrain and level in ("O1", "O2")
+        if level not in ("O0", "O1", "O2", "O1_FP16", "O2_FP16", "BF16"):
+            raise ValueError("--opt_level %r: expected O0 | O1 | O2 | O1_FP16 | O2_FP16 | BF16 (apex's O3 = "
+                             "pure fp16 weights is 'not recommended' by the reference and not built)"
+                             % (opt.opt_level,))
+        # the networks' `bf16` attribute carries the operand type: False fp32, True bf16, 2 fp16
+        self.bf16 = 2 if level.endswith("_FP16") else level in ("O1", "O2", "BF16")
+        self.loss_scaling = self.isTrain and level != "O0" and level != "BF16"
         for n in nets:
             n.bf16 = self.bf16
 

@@ -98,22 +98,37 @@ def _cache_put(cache, key, w, value):
     return value
 
 
-def bf16_weights(w):
-    """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) bf16 copies of a physical fp32 weight; for
+def _lp(bf16):
+    """The `bf16` argument of every conv entry point below selects the MFMA operand type:
+    False / 0 = fp32, True / 1 = bf16, 2 = IEEE fp16 (apex O1's precision; needs loss scaling)."""
+    return 0 if not bf16 else (2 if bf16 == 2 else 1)
+
+
+def _dt(bf16):
+    return (L.F32, L.BF16, L.FP16)[_lp(bf16)]
+
+
+def _wd(bf16):
+    return (torch.float32, torch.bfloat16, torch.float16)[_lp(bf16)]
+
+
+def bf16_weights(w, bf16=True):
+    """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) 16-bit copies of a physical fp32 weight; for
     Cin % 64 != 0 the second entry is w_flat [Cout, Kpad] (flat (tap, ci) contraction index)."""
-    key = (w.data_ptr(), tuple(w.shape))
+    key = (w.data_ptr(), tuple(w.shape), _lp(bf16))
     ent = _cache_get(_bf16_cache, key, w)
     if ent is None:
         k, _, cin, cout = w.shape
-        wp = torch.empty((k, k, cin, cout), dtype=torch.bfloat16, device=w.device)
+        wd, fn = _wd(bf16), "mmh_prep_weights_" + ("fp16" if _lp(bf16) == 2 else "bf16")
+        wp = torch.empty((k, k, cin, cout), dtype=wd, device=w.device)
         if cin % 64 == 0:
-            wt = torch.empty((k, k, cout, cin), dtype=torch.bfloat16, device=w.device)
-            L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), _ptr(wt), _stream())
+            wt = torch.empty((k, k, cout, cin), dtype=wd, device=w.device)
+            L.call(fn, _ptr(w), k * k, cin, cout, _ptr(wp), _ptr(wt), _stream())
         else:
             kpad = (k * k * cin + 63) // 64 * 64
-            wt = torch.empty((cout, kpad), dtype=torch.bfloat16, device=w.device)
-            L.call("mmh_prep_weights_bf16", _ptr(w), k * k, cin, cout, _ptr(wp), None, _stream())
-            L.call("mmh_prep_weights_bf16_flat", _ptr(w), k * k, cin, cout, _ptr(wt), _stream())
+            wt = torch.empty((cout, kpad), dtype=wd, device=w.device)
+            L.call(fn, _ptr(w), k * k, cin, cout, _ptr(wp), None, _stream())
+            L.call(fn + "_flat", _ptr(w), k * k, cin, cout, _ptr(wt), _stream())
         ent = _cache_put(_bf16_cache, key, w, (wp, wt))
     return ent
 
@@ -179,18 +194,34 @@ def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
 def wino_weights(w, tile, flip_transpose=False, bf16=False):
     """Winograd-domain filter of a physical 3x3 weight (cached per weights epoch): fp32 U [P,K,N],
     bf16 U [P,N,K] (contraction index contiguous)."""
-    key = (w.data_ptr(), tuple(w.shape), tile, bool(flip_transpose), bool(bf16))
+    key = (w.data_ptr(), tuple(w.shape), tile, bool(flip_transpose), _lp(bf16))
     U = _cache_get(_wino_cache, key, w)
     if U is None:
         _, _, cin, cout = w.shape
         P = (tile + 2) ** 2
         kn = (cout, cin) if flip_transpose else (cin, cout)        # (K, N)
         U = torch.empty((P, kn[1], kn[0]) if bf16 else (P, kn[0], kn[1]),
-                        dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
-        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, L.BF16 if bf16 else L.F32,
+                        dtype=_wd(bf16), device=w.device)
+        L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, _dt(bf16),
                _ptr(U), _stream())
         _cache_put(_wino_cache, key, w, U)
     return U
+
+
+# Reflect-fold dgrad for F(6x6,3x3): the gradient of a ReflectionPad2d(1) conv is taken on the padded
+# (H+2) x (W+2) domain with the tile origin on the pad ring, where every ring pixel and the pixel it
+# folds onto share one 6x6 tile - the output transform adds them in registers.  Replaces the eight
+# border GEMMs + border_add per conv (16 ms of a 303 ms step).  MMH_WINO_FOLD=0: border-GEMM path.
+USE_WINO_FOLD = os.environ.get("MMH_WINO_FOLD", "1") != "0"
+
+
+def _fold_ok(H, W_):
+    return USE_WINO_FOLD and H >= 6 and W_ >= 6 and (H + 1) % 6 >= 2 and (W_ + 1) % 6 >= 2
+
+
+def _fold_same_grid(H, W_):
+    """fused backward transform: dgrad (padded-domain) and wgrad operands share one tile grid"""
+    return _fold_ok(H, W_) and -(-(H + 2) // 6) == -(-H // 6) and -(-(W_ + 2) // 6) == -(-W_ // 6)
 
 
 # Per-tile output statistics of the last Winograd F(6x6,3x3) conv outputs, keyed by the output's
@@ -199,15 +230,21 @@ FUSE_NORM_STATS = os.environ.get("MMH_FUSE_NORM_STATS", "1") != "0"
 _pending_stats = {}
 
 
-def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False):
+def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False,
+               fold=False):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
     keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor).
-    bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32."""
+    bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32.
+    fold (tile 6, fp32): x is dy of a reflect-padded conv; tiles cover the padded domain and the
+    output transform folds the pad ring back (reflect is ignored)."""
     B, H, W_, Cin = x.shape
     P = (tile + 2) ** 2
-    tiles = B * (-(-H // tile)) * (-(-W_ // tile))      # F(6x6,3x3) tiles are ragged
-    dt = L.BF16 if bf16 else L.F32
-    wd = torch.bfloat16 if bf16 else torch.float32
+    if fold:
+        tiles = B * (-(-(H + 2) // 6)) * (-(-(W_ + 2) // 6))
+    else:
+        tiles = B * (-(-H // tile)) * (-(-W_ // tile))      # F(6x6,3x3) tiles are ragged
+    dt = _dt(bf16)
+    wd = _wd(bf16)
     V = torch.empty((P, tiles, Cin), dtype=wd, device=x.device)
     M = torch.empty((P, tiles, Cout), dtype=wd, device=x.device)
     y = _empty((B, H, W_, Cout), x)
@@ -215,7 +252,7 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     if timed:       # HIP events on the launch stream (bench.py roofline): the GEMM launch alone, and
         e0, e1, o0, o1 = fprop_timer.bracket_op()       # the whole op (both transforms + GEMM)
         o0.record()
-    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, int(bool(reflect)), tile, dt, _ptr(V), _stream())
+    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, 2 if fold else int(bool(reflect)), tile, dt, _ptr(V), _stream())
     if timed:
         e0.record()
     L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
@@ -225,7 +262,8 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     stats = None
     if want_stats and FUSE_NORM_STATS and tile == 6 and not bf16 and act == L.ACT_NONE:
         stats = _empty((B, tiles // B, 3, Cout), x)
-    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _ptr(stats), _stream())
+    L.call("mmh_wino_output", _ptr(M), _ptr(y), _ptr(bias), B, H, W_, Cout, act, tile, dt, _ptr(stats),
+           int(bool(fold)), _stream())
     if timed:
         o1.record()
     if stats is not None:
@@ -250,13 +288,15 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
+    if reflect and tile == 6 and not bf16 and _fold_ok(H, W_):
+        return _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, fold=True)
     dx = _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, bf16=bf16)
     if reflect:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         wb = w
         if bf16 and Cout % 64 == 0:         # border GEMMs on the bf16 MFMA too
-            d.dtype = L.BF16
-            wb = bf16_weights(w)[0]
+            d.dtype = _dt(bf16)
+            wb = bf16_weights(w, bf16)[0]
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
         L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(wb), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
                _stream())
@@ -270,8 +310,8 @@ def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
     B, H, W_, Cout = dy.shape
     P = (tile + 2) ** 2
     tiles = B * (-(-H // tile)) * (-(-W_ // tile))      # F(6x6,3x3) tiles are ragged
-    dt = L.BF16 if bf16 else L.F32
-    wd = torch.bfloat16 if bf16 else torch.float32
+    dt = _dt(bf16)
+    wd = _wd(bf16)
     if V is None:
         _chk(x, "x")
         Cin = x.shape[3]
@@ -304,14 +344,17 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
     assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous() and V.dtype == torch.float32
     Vd = _empty((P, tiles, Cout), dy)
     Yh = _empty((P, tiles, Cout), dy)
-    L.call("mmh_wino_input_dy", _ptr(dy), B, H, W_, Cout, tile, L.F32, _ptr(Vd), _ptr(Yh), _stream())
-    # dgrad: correlation with the flipped filter, then the reflect-border terms
+    fold = bool(reflect) and _fold_same_grid(H, W_)
+    L.call("mmh_wino_input_dy", _ptr(dy), B, H, W_, Cout, tile, L.F32, _ptr(Vd), _ptr(Yh), int(fold), _stream())
+    # dgrad: correlation with the flipped filter; reflect padding: folded in the output transform
+    # (padded-domain tiles) or, where the size does not allow it, the eight border GEMMs
     M = _empty((P, tiles, Cin), dy)
     L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
     _count("mfma", 2.0 * 2 * P * tiles * Cin * Cout)       # this GEMM and the wgrad GEMM below
     dx = _empty((B, H, W_, Cin), dy)
-    L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, _stream())
-    if reflect:
+    L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, int(fold),
+           _stream())
+    if reflect and not fold:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
         L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
@@ -342,8 +385,8 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         _count_desc("valu", d)
         return y
     if bf16:
-        d.dtype = L.BF16
-        w = bf16_weights(w)[1]
+        d.dtype = _dt(bf16)
+        w = bf16_weights(w, bf16)[1]
     _count_desc("mfma", d)
     if fprop_timer is not None and fprop_timer.want(d):
         e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
@@ -383,8 +426,8 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
         return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if bf16 and Cout % 64 == 0:
-        d.dtype = L.BF16
-        w = bf16_weights(w)[0]
+        d.dtype = _dt(bf16)
+        w = bf16_weights(w, bf16)[0]
     dx = _empty((B, H, W_, Cin), dy)
     nbytes = L.load().mmh_conv2d_dgrad_folded_ws_bytes(C.byref(d))
     ws = _ws(nbytes, dy) if nbytes else None
@@ -411,7 +454,7 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
         _count_desc("valu", d)
         return dw
     if bf16:
-        d.dtype = L.BF16
+        d.dtype = _dt(bf16)
     assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
@@ -435,8 +478,8 @@ def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False):
     d = _convT_desc(x, w)
     y = _empty((d.B, d.H, d.W, d.Cin), x)
     if bf16 and d.Cout % 64 == 0:
-        d.dtype = L.BF16
-        w = bf16_weights(w)[0]
+        d.dtype = _dt(bf16)
+        w = bf16_weights(w, bf16)[0]
     L.call("mmh_convT2d_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), d.Cin, act,
            _stream())
     _count_desc("mfma", d)
@@ -449,8 +492,8 @@ def raw_convT_dgrad(dy, w, x_shape, bf16=False):
     d = conv_desc(B, 2 * h, 2 * w_, w.shape[2], CinT, 3, 2, 1, False)
     dx = _empty((B, h, w_, CinT), dy)
     if bf16 and d.Cin % 64 == 0:
-        d.dtype = L.BF16
-        w = bf16_weights(w)[1]
+        d.dtype = _dt(bf16)
+        w = bf16_weights(w, bf16)[1]
     L.call("mmh_convT2d_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _stream())
     _count_desc("mfma", d)
     return dx
@@ -462,7 +505,7 @@ def raw_convT_wgrad(x, dy, bf16=False):
     CoutT = dy.shape[3]
     d = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
     if bf16:
-        d.dtype = L.BF16
+        d.dtype = _dt(bf16)
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
     dw = _empty((3, 3, CoutT, CinT), x)

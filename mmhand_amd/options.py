@@ -9,7 +9,8 @@ Differences, all deliberate:
     initialises the 'nccl' backend, which is RCCL on ROCm;
   * --opt_level O0 = fp32; O1/O2 (apex AMP in the reference) = bf16 MFMA compute with fp32 master
     weights, accumulation and statistics plus apex's dynamic loss scaling (three device-resident
-    scalers, skip / back off / grow); BF16 = the same compute without a scaler;
+    scalers, skip / back off / grow); O1_FP16/O2_FP16 = the same with IEEE fp16 operands (apex's own
+    numerics); BF16 = the bf16 compute without a scaler;
   * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline) and
     --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
@@ -58,7 +59,8 @@ _BASE = [
     ("--distributed", dict(action="store_true", help="one process per GPU, RCCL all-reduce")),
     ("--seed", dict(type=int, default=49, help="manual seed for weight init")),
     ("--opt_level", dict(type=str, default="O0",
-                         help="O0 fp32 | O1/O2 bf16 MFMA compute + dynamic loss scaling | BF16 (no scaler)")),
+                         help="O0 fp32 | O1/O2 bf16 MFMA compute + dynamic loss scaling | O1_FP16/O2_FP16 the same in "
+                              "IEEE fp16 | BF16 (no scaler)")),
     ("--G_n_blocks", dict(type=int, default=9, help="PATBlocks in the generator")),
     ("--vgg_weights", dict(type=str, default=None, help="vgg19.features[0:4] state_dict file")),
     ("--vgg_random_init", dict(action="store_true",

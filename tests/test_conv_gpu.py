@@ -56,9 +56,13 @@ def test_conv2d_fprop_dgrad_wgrad(case, dev):
 
 # Winograd F(6x6,3x3) with ragged tiles: (B, H, W, Cin, Cout, reflect) — sizes that are / are not
 # multiples of 6, odd sizes, one tile per side
+# Reflect padding: sizes with (H+1) % 6 >= 2 and (W+1) % 6 >= 2 take the REFLECT-FOLD dgrad
+# (padded-domain tiles, ring folded inside the output transform: 16x16, 16x22, 19x13 - bottom ring
+# at local row 2, the edge of the rule -, 64x64, 25x16); the others the border-GEMM path.
 WINO6_CASES = [
     (2, 16, 16, 64, 128, True), (1, 12, 20, 256, 256, True), (2, 13, 17, 128, 128, True),
     (1, 24, 18, 128, 64, False), (2, 12, 12, 64, 64, False), (1, 37, 12, 32, 32, True),
+    (2, 16, 22, 64, 64, True), (1, 19, 13, 64, 32, True), (1, 64, 64, 32, 64, True), (2, 25, 16, 32, 32, True),
 ]
 
 
@@ -84,7 +88,15 @@ def test_conv_winograd_f6x6(case, dev, monkeypatch):
     assert R.rel_l1(dw, dwr) < TOL, ("wgrad", R.rel_l1(dw, dwr))
 
 
-@pytest.mark.parametrize("case", WINO6_CASES[:4])
+def test_reflect_fold_rule():
+    from mmhand_amd import ops
+    assert all(ops._fold_ok(h, h) and ops._fold_same_grid(h, h) for h in (16, 64, 128, 19, 25, 10))
+    assert not any(ops._fold_ok(h, 16) for h in (12, 17, 18, 23, 24, 48))
+    # whenever the fold applies, the padded domain needs no extra tile row
+    assert all(ops._fold_same_grid(h, w) for h in range(6, 200) for w in (16, 64) if ops._fold_ok(h, w))
+
+
+@pytest.mark.parametrize("case", WINO6_CASES[:4] + WINO6_CASES[6:])
 def test_conv_winograd_f6x6_fused_backward(case, dev, monkeypatch):
     """Conv2dFn backward through mmh_wino_input_dy (one read of dy for the dgrad and wgrad
     operands) equals the two separate F(6x6,3x3) passes bit for bit, and the fp64 oracle to 2e-5."""
@@ -232,12 +244,14 @@ BF16_CASES = [
 ]
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("case", BF16_CASES)
-def test_conv2d_bf16_mfma_path(case, wino, dev, monkeypatch):
-    """MMH_BF16: bf16 MFMA fprop/dgrad vs the fp64 oracle on bf16-rounded operands (tight) and on
-    the original fp32 operands (the stated bf16 tolerance).  wino: bf16 Winograd F(2x2,3x3) for
-    every pass of the eligible shapes (its per-pass size thresholds lifted), else the direct kernels."""
+def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
+    """MMH_BF16 / MMH_FP16: 16-bit MFMA fprop/dgrad/wgrad vs the fp64 oracle on operands rounded to
+    that type (tight) and on the original fp32 operands (the stated bf16 tolerance; fp16 has 3 more
+    significand bits).  wino: 16-bit Winograd F(2x2,3x3) for every pass of the eligible shapes (its
+    per-pass size thresholds lifted), else the direct kernels."""
     from mmhand_amd import ops
     B, H, W, Cin, Cout, k, s, p, refl = case
     monkeypatch.setattr(ops, "USE_WINOGRAD_BF16", wino)
@@ -248,11 +262,11 @@ def test_conv2d_bf16_mfma_path(case, wino, dev, monkeypatch):
     w = _mk((k, k, Cin, Cout), 2, dev) * 0.1
     bias = _mk((Cout,), 3, dev)
     ops.bump_weights_epoch()
-    y = ops.raw_conv_fprop(x, w, bias, s, p, refl, 0, bf16=True)
+    y = ops.raw_conv_fprop(x, w, bias, s, p, refl, 0, bf16=lp)
     dy = _mk(tuple(y.shape), 4, dev)
-    dx = ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl, bf16=True)
-    dw = ops.raw_conv_wgrad(x, dy, k, s, p, refl, bf16=True)
-    rb = lambda t: t.cpu().bfloat16().float()
+    dx = ops.raw_conv_dgrad(dy, w, x.shape, s, p, refl, bf16=lp)
+    dw = ops.raw_conv_wgrad(x, dy, k, s, p, refl, bf16=lp)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
     yr, dxr, dwr, _ = R.conv2d_grads(rb(x), rb(w), bias.cpu(), rb(dy), s, p, refl)
     yf, dxf, dwf, _ = R.conv2d_grads(x.cpu(), w.cpu(), bias.cpu(), dy.cpu(), s, p, refl)
     # dgrad with Cout not a multiple of 64 keeps the fp32 kernel; fprop runs in bf16 (flat
@@ -271,16 +285,17 @@ def test_conv2d_bf16_mfma_path(case, wino, dev, monkeypatch):
         R.rel_l1(y, yf), R.rel_l1(dx, dxf), R.rel_l1(dw, dwf))
 
 
-def test_convT_bf16_mfma_path(dev):
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_convT_bf16_mfma_path(lp, dev):
     from mmhand_amd import ops
     x = _mk((2, 8, 8, 128), 1, dev)
     w = _mk((3, 3, 64, 128), 2, dev) * 0.1
     ops.bump_weights_epoch()
-    y = ops.raw_convT_fprop(x, w, None, 0, bf16=True)
+    y = ops.raw_convT_fprop(x, w, None, 0, bf16=lp)
     dy = _mk(tuple(y.shape), 4, dev)
-    dx = ops.raw_convT_dgrad(dy, w, x.shape, bf16=True)
-    rb = lambda t: t.cpu().bfloat16().float()
-    dw = ops.raw_convT_wgrad(x, dy, bf16=True)
+    dx = ops.raw_convT_dgrad(dy, w, x.shape, bf16=lp)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    dw = ops.raw_convT_wgrad(x, dy, bf16=lp)
     yr, dxr, dwr, _ = R.convT2d_grads(rb(x), rb(w), None, rb(dy))
     assert R.rel_l1(y, yr) < 5e-5 and R.rel_l1(dx, dxr) < 5e-5 and R.rel_l1(dw, dwr) < 5e-5
 

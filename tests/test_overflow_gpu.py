@@ -193,3 +193,54 @@ def test_opt_level_O1_dynamic_loss_scaling(dev):
     assert m2._scaler.tolist() == model._scaler.tolist() and m2.skipped_steps == 3
     with pytest.raises(ValueError):
         MMHandModel(_small_opt("instance", opt_level="O3"))
+
+
+def test_opt_level_O1_FP16_natural_overflow_and_recovery(dev):
+    """--opt_level O1_FP16: IEEE fp16 MFMA operands, i.e. apex O1's own numerics.  (1) three
+    iterations track the fp32 run within the mixed-precision tolerance (2 %); (2) with a loss scale
+    far too large the scaled fp16 gradients overflow BY THEMSELVES (no injected inf): every step of
+    the iteration is skipped and each overflowing loss halves its scale - iterating drives the
+    scale down until steps land again, which is how apex finds its operating point."""
+    import numpy as np
+
+    from mmhand_amd.mmhand_model import MMHandModel
+    rows = {}
+    models = {}
+    for level in ("O0", "O1_FP16"):
+        random.seed(49)
+        m = MMHandModel(_small_opt("instance", opt_level=level, ngf=16, ndf=16))
+        if models:
+            for n in ("netG", "netD_PB", "netD_PP"):
+                getattr(m, n).load_state_dict(getattr(models["O0"], n).state_dict())
+        else:
+            init = {n: getattr(m, n).state_dict() for n in ("netG", "netD_PB", "netD_PP")}
+        models[level] = m
+    for n in ("netG", "netD_PB", "netD_PP"):
+        models["O0"].__getattr__(n).load_state_dict(init[n])
+        models["O1_FP16"].__getattr__(n).load_state_dict(init[n])
+    assert models["O1_FP16"].bf16 == 2 and models["O1_FP16"].loss_scaling
+    for level, m in models.items():
+        random.seed(49)
+        out = []
+        for it in range(3):
+            m.set_input(_batch(100 + it))
+            m.optimize_parameters()
+            out.append([float(v) for v in m.get_current_errors().values()])
+        rows[level] = np.array(out)
+    assert np.allclose(rows["O1_FP16"], rows["O0"], rtol=2e-2), (rows["O1_FP16"], rows["O0"])
+    assert not np.array_equal(rows["O1_FP16"], rows["O0"])
+    m = models["O1_FP16"]
+    m._settle_overflow(drain=True)
+    skipped0 = m.skipped_steps
+    m._scaler[:, 0] = 2.0 ** 40                      # scaled fp16 gradients overflow on their own
+    snap = m.netG.flat_param.clone()
+    m.set_input(_batch(200)); m.optimize_parameters()
+    assert torch.equal(m.netG.flat_param, snap) and torch.isfinite(m.netG.flat_param).all()
+    assert m._scaler[0, 0].item() == 2.0 ** 39
+    for it in range(40):                             # back off until the steps land again
+        m.set_input(_batch(201 + it)); m.optimize_parameters()
+        if not torch.equal(m.netG.flat_param, snap):
+            break
+    assert not torch.equal(m.netG.flat_param, snap) and torch.isfinite(m.netG.flat_param).all()
+    m._settle_overflow(drain=True)
+    assert m.skipped_steps > skipped0 and 2.0 ** 8 <= m.loss_scale(0) < 2.0 ** 40

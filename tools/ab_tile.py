@@ -28,7 +28,7 @@ for (H, Cin, Cout) in [(64, 512, 512), (64, 256, 256), (64, 512, 256)]:
         U = torch.randn(P, Cin, Cout, device=dev); y = torch.empty(B, H, H, Cout, device=dev)
         ti = timeit(lambda: lib.call("mmh_wino_input", x.data_ptr(), B, H, H, Cin, 1, t, lib.F32, V.data_ptr(), st()))
         tg = timeit(lambda: lib.call("mmh_wino_gemm", V.data_ptr(), U.data_ptr(), M.data_ptr(), tiles, Cin, Cout, P, lib.F32, st()))
-        to = timeit(lambda: lib.call("mmh_wino_output", M.data_ptr(), y.data_ptr(), None, B, H, H, Cout, 0, t, lib.F32, None, st()))
+        to = timeit(lambda: lib.call("mmh_wino_output", M.data_ptr(), y.data_ptr(), None, B, H, H, Cout, 0, t, lib.F32, None, 0, st()))
         gf = P * 2.0 * tiles * Cin * Cout / 1e9
         print(f"   tile {t}: input {ti*1e3:.0f} us ({(x.numel()+V.numel())*4/ti/1e9:.2f} TB/s) | gemm {tg*1e3:.0f} us ({gf/tg:.0f} TF) | "
               f"output {to*1e3:.0f} us ({(M.numel()+y.numel())*4/to/1e9:.2f} TB/s)", flush=True)

@@ -20,6 +20,6 @@ for (H, C) in [(64, 512), (64, 256)]:
     for v in (0, 7):
         lib.check(L.mmh_set_option(b"wino6_vec", v), "set")
         ti = timeit(lambda: lib.call("mmh_wino_input", x.data_ptr(), B, H, H, C, 1, t, lib.F32, V.data_ptr(), st()))
-        to = timeit(lambda: lib.call("mmh_wino_output", V.data_ptr(), y.data_ptr(), None, B, H, H, C, 0, t, lib.F32, None, st()))
+        to = timeit(lambda: lib.call("mmh_wino_output", V.data_ptr(), y.data_ptr(), None, B, H, H, C, 0, t, lib.F32, None, 0, st()))
         td = timeit(lambda: lib.call("mmh_wino_dy", x.data_ptr(), B, H, H, C, t, lib.F32, V.data_ptr(), st()))
         print(f"C={C} channels/thread={'2' if v else '1'}: input {ti*1e3:.0f} us | output {to*1e3:.0f} us | dy {td*1e3:.0f} us", flush=True)
