@@ -182,6 +182,24 @@ int mmh_prep_weights_fp16_flat(const void* w, int taps, int Cin, int Cout,
 int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout,
                                void* w_flat, mmh_stream_t s);
 
+/* ---- 16-bit direct 3x3 convolution, both operands 16-bit in HBM (conv_lp16.hip) ----------------
+ * The second-generation MFMA kernel of the --opt_level O1/O2 path for the 3x3 / stride 1 / pad 1
+ * stack (channels % 64 == 0, output channels % 256 == 0): 256x256x64 block tile, both operands
+ * global -> LDS by LDS-DMA with an XOR-swizzled image, two 64 KiB stages, one barrier per k-step.
+ *   x16   16-bit NHWC activations (the twin of the fp32 tensor: mmh_cvt_lp16, or written by the
+ *         producer), pixel stride d->x_cs (mode 0) / d->y_cs (mode 1) elements
+ *   w16   mode 0 (fprop): w_t [tap][Cout][Cin]; mode 1 (dgrad): w_plain [tap][Cin][Cout]
+ *         (mmh_prep_weights_bf16 / _fp16)
+ *   y     fp32 (y_is16 = 0) or 16-bit (y_is16 = 1) NHWC output, +bias, activation
+ *   zeros >= 128 zero bytes of device memory (what out-of-image taps read)
+ * mode 1 computes the zero-padded correlation with the flipped filter; for MMH_PAD_REFLECT the
+ * caller adds the border terms (mmh_conv2d_dgrad_border, phase 3) afterwards.                  */
+int mmh_cvt_lp16(const void* x, int64_t n, int dtype, void* out, mmh_stream_t s);
+int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d);
+int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
+                     const void* bias, void* y, int y_is16, int act, const void* zeros,
+                     mmh_stream_t s);
+
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,

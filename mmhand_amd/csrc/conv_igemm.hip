@@ -34,22 +34,26 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // The 16-bit MFMA kernels serve two element types with one body: bf16 (MMH_BF16) and IEEE fp16
 // (MMH_FP16, the reference's apex O1 precision).  Tiles are carried as 16-bit lanes typed bf16x*;
-// `h16` (a kernel argument, wave-uniform) picks the conversion and the MFMA opcode.
+// the kernel argument `h16` (wave-uniform) selects, by ONE branch at the top of each kernel, the
+// instantiation of the body with the matching conversion and MFMA opcode (a per-MFMA runtime select
+// costs 30-80 VGPRs: the compiler then keeps both accumulator paths alive).
 __device__ __forceinline__ bf16x4 to_bf16x4(float4 v) {
     bf16x4 r;
     r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
     return r;
 }
-__device__ __forceinline__ bf16x4 to_lp4(float4 v, int h16) {
-    if (h16) {
+template <bool H16>
+__device__ __forceinline__ bf16x4 to_lp4(float4 v) {
+    if (H16) {
         f16x4 r;
         r[0] = (_Float16)v.x; r[1] = (_Float16)v.y; r[2] = (_Float16)v.z; r[3] = (_Float16)v.w;
         return __builtin_bit_cast(bf16x4, r);
     }
     return to_bf16x4(v);
 }
-__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int h16) {
-    if (h16)
+template <bool H16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (H16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
                                                       0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -58,7 +62,7 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int h16) 
 // (8 bytes, RNE)
 template <int LP>
 __device__ __forceinline__ void wst4(void* base, long long idx4, float4 v) {
-    if (LP) reinterpret_cast<bf16x4*>(base)[idx4] = to_lp4(v, LP == 2);
+    if (LP) reinterpret_cast<bf16x4*>(base)[idx4] = to_lp4<LP == 2>(v);
     else reinterpret_cast<float4*>(base)[idx4] = v;
 }
 template <int LP>
@@ -894,7 +898,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, void* __restric
     if (i >= total) return;
     // thread -> (ci, co) with the output's fastest index fastest (coalesced plane stores): fp32 U is
     // [K][N] = [Cin][Cout] (or [Cout][Cin] flipped), bf16 U the transpose of that
-    const bool co_fast = (flip_transpose != 0) == BF;
+    const bool co_fast = (flip_transpose != 0) == (BF != 0);
     const int ci = co_fast ? i / Cout : i % Cin, co = co_fast ? i - (i / Cout) * Cout : i / Cin;
     float g[3][3];
 #pragma unroll
@@ -913,7 +917,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, void* __restric
         t[3][b] = g[2][b];
     }
     const size_t plane = (size_t)Cin * Cout;
-    const size_t o = (flip_transpose != 0) != BF ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
+    const size_t o = (flip_transpose != 0) != (BF != 0) ? (size_t)co * Cin + ci : (size_t)ci * Cout + co;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float u4[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]),
@@ -1033,9 +1037,9 @@ constexpr int BK16 = 64;     // contraction depth per k-step (bf16 kernel)
 constexpr int LDH = 72;      // LDS row pitch in bf16 elements (144 B: conflict-free ds_read_b128)
 
 
-template <int BN, int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int bx, const int by,
-                                                     const int gx, const int gy) {
+template <int BN, int WAVES_M, int WAVES_N, bool H16>
+__device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const int bx, const int by,
+                                                       const int gx, const int gy) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NBL = BN / 32;            // 16-byte weight loads per thread per k-step
@@ -1155,7 +1159,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_lp4(ra[i], p.h16);
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_lp4<H16>(ra[i]);
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
             *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + 32 * i) * LDH + bgrp * 8]) = rb[i];
@@ -1193,7 +1197,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = mfma16(af[i], bfr[jn], acc[i][jn], p.h16);
+                    acc[i][jn] = mfma16<H16>(af[i], bfr[jn], acc[i][jn]);
         }
         if (!(p.dbg & 2)) {
             __syncthreads();
@@ -1232,6 +1236,12 @@ __device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int 
     }
 }
 
+template <int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void conv_igemm_bf16_body(const ConvKP& p, const int bx, const int by,
+                                                     const int gx, const int gy) {
+    if (p.h16) conv_igemm_bf16_body_t<BN, WAVES_M, WAVES_N, true>(p, bx, by, gx, gy);
+    else conv_igemm_bf16_body_t<BN, WAVES_M, WAVES_N, false>(p, bx, by, gx, gy);
+}
 template <int BN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256, 2) conv_igemm_bf16_kernel(const ConvKP p) {
     conv_igemm_bf16_body<BN, WAVES_M, WAVES_N>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
@@ -1522,8 +1532,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p) {
+template <int BN, int WAVES_M, int WAVES_N, bool H16>
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WgradKP& p) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NBD = BN / 16;            // dy float4 loads per thread per k-step
@@ -1602,12 +1612,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
     auto store_tiles = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_lp4(ra[i], p.h16);
+            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_lp4<H16>(ra[i]);
 #pragma unroll
         for (int i = 0; i < NBD; ++i) {
             const int idx = tid + 256 * i;
             const int prow = idx / (BN / 4), c4 = idx - prow * (BN / 4);
-            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_lp4(rb[i], p.h16);
+            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_lp4<H16>(rb[i]);
         }
     };
 
@@ -1637,7 +1647,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
+                        acc[i][j] = mfma16<H16>(af[i], bfr[j], acc[i][j]);
             }
             __syncthreads();
             if (more) store_tiles();
@@ -1658,6 +1668,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p
                 if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
             }
         }
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p) {
+    if (p.h16) conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, true>(p);
+    else conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, false>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -1681,8 +1697,9 @@ struct WinoGemmBfKP {
     int h16;
 };
 
-__device__ __forceinline__ unsigned pack_lp2(float lo, float hi, int h16) {
-    if (h16) {
+template <bool H16>
+__device__ __forceinline__ unsigned pack_lp2(float lo, float hi) {
+    if (H16) {
         f16x2 v;
         v[0] = (_Float16)lo; v[1] = (_Float16)hi;
         return __builtin_bit_cast(unsigned, v);
@@ -1692,7 +1709,7 @@ __device__ __forceinline__ unsigned pack_lp2(float lo, float hi, int h16) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int BKS>
+template <int BKS, bool H16>
 __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBfKP p) {
     constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     constexpr int LDB = BKS + 8;          // row pitch (bf16): 144 B / 272 B, conflict-free ds_read_b128
@@ -1784,7 +1801,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
+                        acc[i][j] = mfma16<H16>(af[i], bfr[j], acc[i][j]);
             }
             if (ks == KS - 1) {
                 const int nt = wc % p.NT;
@@ -1812,7 +1829,7 @@ __global__ void __launch_bounds__(256, 2) wino_gemm_bf16_kernel(const WinoGemmBf
                                     float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x0), 0xB1, 0xF, 0xF, true));
                                 const float y1 = __builtin_bit_cast(
                                     float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x1), 0xB1, 0xF, 0xF, true));
-                                const unsigned v = odd ? pack_lp2(y1, x1, p.h16) : pack_lp2(x0, y0, p.h16);
+                                const unsigned v = odd ? pack_lp2<H16>(y1, x1) : pack_lp2<H16>(x0, y0);
                                 const unsigned rd = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * n2;
                                 __builtin_amdgcn_raw_buffer_store_b32(v, rsC, vbase + rd + j * 64u, 0, 0);
                             }
@@ -1846,6 +1863,7 @@ struct WinoWgradBfKP {
     int h16;
 };
 
+template <bool H16>
 __global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const WinoWgradBfKP p) {
     constexpr int BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1936,7 +1954,7 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const Wino
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = mfma16(af[i], bfr[j], acc[i][j], p.h16);
+                        acc[i][j] = mfma16<H16>(af[i], bfr[j], acc[i][j]);
             }
             if (ks == KS - 1) {
                 const int nt = wc % p.NT;
@@ -3082,16 +3100,18 @@ static int wino_gemm_bf16(const void* V, const void* U, void* Mo, long long tile
         p.nb = std::min(p.Wx, 32 * 2);
         constexpr size_t lds = (size_t)(2 * BM * (128 + 8)) * sizeof(__bf16);
         static int ready = -1;
-        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<128>, lds);
+        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<128, false>, lds) | allow_lds(wino_gemm_bf16_kernel<128, true>, lds);
         if (ready != 0) return ready;
-        hipLaunchKernelGGL(wino_gemm_bf16_kernel<128>, dim3(8 * p.nb), dim3(256), lds, st, p);
+        if (h16) hipLaunchKernelGGL((wino_gemm_bf16_kernel<128, true>), dim3(8 * p.nb), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((wino_gemm_bf16_kernel<128, false>), dim3(8 * p.nb), dim3(256), lds, st, p);
     } else {
         p.nb = std::min(p.Wx, 32 * g_wino_bf16_occ);
         constexpr size_t lds = (size_t)(2 * BM * (64 + 8)) * sizeof(__bf16);
         static int ready = -1;
-        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<64>, lds);
+        if (ready != 0) ready = allow_lds(wino_gemm_bf16_kernel<64, false>, lds) | allow_lds(wino_gemm_bf16_kernel<64, true>, lds);
         if (ready != 0) return ready;
-        hipLaunchKernelGGL(wino_gemm_bf16_kernel<64>, dim3(8 * p.nb), dim3(256), lds, st, p);
+        if (h16) hipLaunchKernelGGL((wino_gemm_bf16_kernel<64, true>), dim3(8 * p.nb), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((wino_gemm_bf16_kernel<64, false>), dim3(8 * p.nb), dim3(256), lds, st, p);
     }
     return mmh::check_launch("wino_gemm_bf16_kernel");
 }
@@ -3178,9 +3198,10 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
         q.nb = std::min(q.Wx, 32 * g_wino_bf16_occ);
         constexpr size_t lds = (size_t)(2 * BKP * LDT) * sizeof(__bf16);
         static int ready = -1;
-        if (ready != 0) ready = allow_lds(wino_wgrad_gemm_bf16_kernel, lds);
+        if (ready != 0) ready = allow_lds(wino_wgrad_gemm_bf16_kernel<false>, lds) | allow_lds(wino_wgrad_gemm_bf16_kernel<true>, lds);
         if (ready != 0) return ready;
-        hipLaunchKernelGGL(wino_wgrad_gemm_bf16_kernel, dim3(8 * q.nb), dim3(256), lds, st, q);
+        if (q.h16) hipLaunchKernelGGL(wino_wgrad_gemm_bf16_kernel<true>, dim3(8 * q.nb), dim3(256), lds, st, q);
+        else hipLaunchKernelGGL(wino_wgrad_gemm_bf16_kernel<false>, dim3(8 * q.nb), dim3(256), lds, st, q);
         if (int rc = mmh::check_launch("wino_wgrad_gemm_bf16_kernel")) return rc;
         const int64_t n4 = (int64_t)Cin * Cout / 4;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),

@@ -1,0 +1,299 @@
+// 16-bit (bf16 / fp16) implicit-GEMM convolution for the 3x3 stride-1 stack, gfx950, second generation.
+//
+// What differs from conv_igemm_bf16_body (conv_igemm.hip), which reads fp32 activations, converts
+// them in registers and stages 128x128x64 tiles through VGPRs with two barriers per k-step:
+//   * BOTH operands are 16-bit in HBM with the contraction index contiguous - activations
+//     [B][H][W][C] (a 16-bit twin written by the producer or by mmh_cvt_lp16), weights
+//     [tap][N][K] (mmh_prep_weights_bf16/_fp16) - so both go global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR staging, no ds_write);
+//   * 256 x 256 x 64 block tile, 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 =
+//     4 x 2 MFMA 32x32x16 tiles (128 accumulator VGPRs): 32 B/clk/CU of L2 traffic at the full
+//     MFMA rate (the 128^2 tile needs 64);
+//   * two LDS stages of 64 KiB (1 workgroup per CU, 2 waves per SIMD), ONE barrier per k-step:
+//     the DMA of k-step i+1 is in flight while the MFMAs of k-step i run;
+//   * LDS rows are 128 B (64 elements) with an XOR swizzle of the 16-byte chunk index by
+//     (row >> 1) & 7: every ds_read_b128 lane group touches 16 distinct (row parity, chunk) bank
+//     sets - conflict-free - and, as the DMA writes LDS linearly (lane i -> base + 16 i), the swizzle
+//     is applied to the per-lane GLOBAL source address (MI355X guide: swizzle both sides or neither).
+// The gather (zero / reflect padding, tap offsets) is folded into the per-lane source address of the
+// A-operand DMA; out-of-image taps and the M tail read a zero page.  k order: tap outer, 64-channel
+// chunk inner, so a lane recomputes its 4 source pixels once per tap.
+//
+// GEMM view: M = B*H*W output pixels, N output channels (rows of the weight operand), K = taps * C.
+// Requires C % 64 == 0, N % 256 == 0 (the 256 / 512-channel PATBlock and Discriminator trunks).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int TBM = 256, TBN = 256, TBK = 64;
+constexpr int ROWB = TBK * 2;                 // 128 bytes per LDS row
+constexpr int STAGE = (TBM + TBN) * ROWB;     // 64 KiB
+
+struct LpConvKP {
+    const char* x;          // 16-bit activations, pixel stride cs elements
+    const char* w;          // 16-bit weights [tap][N][K]
+    const char* zeros;      // >= 128 zero bytes
+    float* y;               // fp32 output [M][y_cs] (y16 == nullptr) ...
+    char* y16;              // ... or 16-bit output [M][y_cs]
+    const float* bias;
+    int B, H, W, C, cs;     // input geometry (same spatial size out: stride 1, 'same' padding)
+    int N, y_cs;
+    int tap_sign;           // source pixel of tap (kh, kw) = output pixel + tap_sign * (kh - 1, kw - 1):
+                            // +1 correlation (fprop), -1 flipped filter (dgrad)
+    int reflect;            // mirror the source pixel into the image (else zero outside)
+    int act, h16;
+    int MT, NT;             // row / column tiles
+};
+
+template <bool H16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (H16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == MMH_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MMH_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) conv_lp16_kernel(const LpConvKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;        // 2 x 4 waves: rows wr*128.., cols wc*64..
+
+    // XCD-aware tile order: the workgroups of one XCD (blockIdx % 8) walk consecutive tiles with
+    // the column tile fastest, so both column tiles of an A row panel - and neighbouring row panels,
+    // which share their halo rows - are served by one L2
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int m0 = mt * TBM, n0 = nt * TBN;
+    const int M = p.B * p.H * p.W;
+
+    // ---- DMA roles: wave w issues, per operand and k-step, 4 instructions of 8 rows x 128 B:
+    // rows (w*4 + j)*8 + lane/8, physical chunk lane%8 <- logical chunk (lane%8) ^ ((row>>1)&7)
+    int a_pix[4], a_hw[4];          // (b*H + oh)*W + ow, and oh << 16 | ow; a_pix < 0: row beyond M
+    unsigned b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        const int m = m0 + r;
+        const int b = m / (p.H * p.W);
+        const int rem = m - b * (p.H * p.W);
+        const int oh = rem / p.W, ow = rem - oh * p.W;
+        a_pix[j] = m < M ? m : -1;
+        a_hw[j] = (oh << 16) | ow;
+        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;      // + (tap*N*C + kc*64)*2 per k-step
+    }
+    const int KC = p.C / TBK;                 // channel chunks per tap
+    const int nk = 9 * KC;
+    unsigned a_off[4];                        // byte offset of this lane's 16 B inside x, or ~0u (zero page)
+    auto set_tap = [&](int t) {
+        const int kh = t / 3, kw = t - 3 * kh;
+        const int dh = p.tap_sign * (kh - 1), dw = p.tap_sign * (kw - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oh = a_hw[j] >> 16, ow = a_hw[j] & 0xffff;
+            int ih = oh + dh, iw = ow + dw;
+            bool ok = a_pix[j] >= 0;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+            const int src = a_pix[j] + (ih - oh) * p.W + (iw - ow);
+            a_off[j] = ok ? (unsigned)src * (unsigned)p.cs * 2u + q * 16u : 0xffffffffu;
+        }
+    };
+    auto issue = [&](int ks, int stage) {
+        const int t = ks / KC, kc = ks - t * KC;
+        if (kc == 0) set_tap(t);
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + TBM * ROWB;
+        const unsigned kb = (unsigned)kc * (TBK * 2);
+        const char* wbase = p.w + (size_t)t * p.N * p.C * 2 + kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* g = a_off[j] != 0xffffffffu ? p.x + a_off[j] + kb : p.zeros + (lane & 7) * 16;
+            __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: row R, logical chunk q = 2*s16 + h -> byte R*128 + ((q ^ ((R>>1)&7)) * 16).  Every
+    // row this lane reads (A: wr*128 + i*32 + l31, B: wc*64 + j*32 + l31) has the same key (l31>>1)&7,
+    // so the swizzled chunk offset is one register per s16 and the tile offsets are immediates
+    const unsigned key = (unsigned)((l31 >> 1) & 7);
+    const unsigned a_base = (unsigned)(wr * 128 + l31) * ROWB;
+    const unsigned b_base = (unsigned)(TBM + wc * 64 + l31) * ROWB;
+
+    issue(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        // this wave's DMAs of k-step ks have landed (vmcnt(0)), then everyone's (barrier); the barrier
+        // also means every wave has finished reading the other stage, which k-step ks+1 overwrites
+        __syncthreads();
+        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+        const char* st = smem + (ks & 1) * STAGE;
+        // fragments of k16-step s+1 are read while the MFMAs of step s run; the scheduling barriers keep
+        // the compiler from hoisting all four steps' reads (96 VGPRs) above the first MFMA
+        bf16x8 af[2][4], bfr[2][2];
+        auto load_frags = [&](int s16, int buf) {
+            const unsigned sw = ((unsigned)(2 * s16 + h) ^ key) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(st + a_base + sw + i * (32 * ROWB));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[buf][j] = *reinterpret_cast<const bf16x8*>(st + b_base + sw + j * (32 * ROWB));
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16) {
+            if (s16 < 3) load_frags(s16 + 1, (s16 + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = mfma16<H16>(af[s16 & 1][i], bfr[s16 & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wc * 64 + j * 32 + l31;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                v = act_apply(v, p.act);
+                if (p.y16) {
+                    if (H16) reinterpret_cast<_Float16*>(p.y16)[(size_t)m * p.y_cs + n] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(p.y16)[(size_t)m * p.y_cs + n] = (__bf16)v;
+                } else {
+                    p.y[(size_t)m * p.y_cs + n] = v;
+                }
+            }
+        }
+}
+
+// fp32 -> 16-bit copy (the activation twin), 8 elements per lane
+__global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ out, int64_t n8, int h16) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        if (h16) {
+            f16x8 r;
+            r[0] = (_Float16)a.x; r[1] = (_Float16)a.y; r[2] = (_Float16)a.z; r[3] = (_Float16)a.w;
+            r[4] = (_Float16)b.x; r[5] = (_Float16)b.y; r[6] = (_Float16)b.z; r[7] = (_Float16)b.w;
+            reinterpret_cast<f16x8*>(out)[i] = r;
+        } else {
+            bf16x8 r;
+            r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+            r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+            reinterpret_cast<bf16x8*>(out)[i] = r;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmh_cvt_lp16(const void* x, int64_t n, int dtype, void* out, mmh_stream_t s) {
+    MMH_REQUIRE(x && out && n > 0 && n % 8 == 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_cvt_lp16: bad arguments (n %% 8 == 0, dtype MMH_BF16 | MMH_FP16)");
+    const int64_t n8 = n / 8;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(mmh::cdiv(n8, 256), 8192));
+    hipLaunchKernelGGL(cvt_lp16_kernel, dim3(grid), dim3(256), 0, mmh::as_stream(s), static_cast<const float*>(x), out,
+                       n8, dtype == MMH_FP16 ? 1 : 0);
+    return mmh::check_launch("cvt_lp16_kernel");
+}
+
+int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d) {
+    return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
+           d->Ho == d->H && d->Wo == d->W && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16);
+}
+
+// mode 0: fprop  y[B,H,W,Cout] = conv(x16 [B,H,W,Cin], w16 = w_t [tap][Cout][Cin]) (+bias, act)
+// mode 1: dgrad  dx[B,H,W,Cin] = zero-padded correlation of dy16 [B,H,W,Cout] with the flipped filter,
+//                w16 = w_plain [tap][Cin][Cout]; for MMH_PAD_REFLECT this is the main term only
+//                (the caller adds the border terms: mmh_conv2d_dgrad_border)
+int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
+                     void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1),
+                "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
+    LpConvKP p{};
+    const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+    MMH_REQUIRE(N % TBN == 0, "mmh_conv3x3_lp16: output channels must be a multiple of 256 (got %d)", N);
+    p.x = static_cast<const char*>(x16);
+    p.w = static_cast<const char*>(w16);
+    p.zeros = static_cast<const char*>(zeros);
+    if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
+    p.bias = static_cast<const float*>(bias);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.C = K; p.cs = mode == 0 ? d->x_cs : d->y_cs;
+    p.N = N; p.y_cs = mode == 0 ? d->y_cs : d->x_cs;
+    p.tap_sign = mode == 0 ? 1 : -1;        // dgrad: dx[i] = sum_t w[t] dy[i + 1 - t]
+    p.reflect = (mode == 0 && d->pad_mode == MMH_PAD_REFLECT) ? 1 : 0;
+    p.act = act;
+    p.h16 = d->dtype == MMH_FP16;
+    const long long M = (long long)d->B * d->H * d->W;
+    MMH_REQUIRE(M * (long long)std::max(p.cs, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
+                "mmh_conv3x3_lp16: tensor too large");
+    p.MT = (int)((M + TBM - 1) / TBM);
+    p.NT = N / TBN;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    static int ready = -1;
+    if (ready != 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        ready = e == hipSuccess ? 0 : mmh::fail("conv_lp16_kernel: %s", hipGetErrorString(e));
+    }
+    if (ready != 0) return ready;
+    if (p.h16)
+        hipLaunchKernelGGL(conv_lp16_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
+    else
+        hipLaunchKernelGGL(conv_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
+    return mmh::check_launch("conv_lp16_kernel");
+}
+
+}  // extern "C"

@@ -465,6 +465,51 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     return dw
 
 
+# --------------------------------------------------------------------------- 16-bit direct 3x3 (v2)
+# Second-generation 16-bit kernel for the 3x3 / stride 1 / pad 1 stack (conv_lp16.hip): both operands
+# 16-bit in HBM, LDS-DMA, 256x256x64 tiles.  Takes a 16-bit twin of the activation (mmh_cvt_lp16).
+USE_LP16_V2 = os.environ.get("MMH_LP16_V2", "1") != "0"
+_zero_pages = {}
+
+
+def zero_page(dev):
+    z = _zero_pages.get(dev)
+    if z is None:
+        z = _zero_pages[dev] = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    return z
+
+
+def lp16_twin(x, bf16=True):
+    """16-bit copy (bf16 / fp16) of an fp32 NHWC tensor."""
+    _chk(x, "x")
+    out = torch.empty(x.shape, dtype=_wd(bf16), device=x.device)
+    L.call("mmh_cvt_lp16", _ptr(x), x.numel(), _dt(bf16), _ptr(out), _stream())
+    return out
+
+
+def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
+    """mode 0 fprop (N = Cout), 1 dgrad (N = Cin)"""
+    n = Cout if mode == 0 else Cin
+    return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 64 == 0 and Cout % 64 == 0 and n % 256 == 0
+
+
+def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
+    """mode 0: y = conv(x16, w) (+bias, act); mode 1: dx = zero-pad correlation of x16 (= dy) with the
+    flipped filter (the caller adds the reflect border terms).  w: the fp32 physical weight."""
+    B, H, W_, Cx = x16.shape
+    _, _, Cin, Cout = w.shape
+    assert x16.dtype == _wd(bf16) and x16.is_contiguous() and Cx == (Cin if mode == 0 else Cout)
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    d.dtype = _dt(bf16)
+    wp, wt = bf16_weights(w, bf16)
+    N = Cout if mode == 0 else Cin
+    y = torch.empty((B, H, W_, N), dtype=_wd(bf16) if out16 else torch.float32, device=x16.device)
+    L.call("mmh_conv3x3_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
+           int(out16), act, _ptr(zero_page(x16.device)), _stream())
+    _count_desc("mfma", d)
+    return y
+
+
 def _convT_desc(x, w):
     """ConvTranspose2d(k3,s2,p1,op1) seen as the dgrad of a stride-2 conv."""
     B, h, w_, CinT = x.shape
