@@ -193,8 +193,15 @@ int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout,
  *   y     fp32 (y_is16 = 0) or 16-bit (y_is16 = 1) NHWC output, +bias, activation
  *   zeros >= 128 zero bytes of device memory (what out-of-image taps read)
  * mode 1 computes the zero-padded correlation with the flipped filter; for MMH_PAD_REFLECT the
- * caller adds the border terms (mmh_conv2d_dgrad_border, phase 3) afterwards.                  */
+ * caller adds the border terms (mmh_conv2d_dgrad_border, phase 3) afterwards.
+ * mmh_wgrad3x3_lp16: dw [3][3][Cin][Cout] fp32 (+)= wgrad from the 16-bit x and dy (Cin, Cout
+ * % 256 == 0): [64 pixels][256 channels] tiles by LDS-DMA, both MFMA operands read transposed
+ * (ds_read_b64_tr_b16), split-K over pixel ranges with fp32 slabs in ws, fixed-order reduction.  */
 int mmh_cvt_lp16(const void* x, int64_t n, int dtype, void* out, mmh_stream_t s);
+size_t mmh_wgrad3x3_lp16_ws_bytes(const mmh_conv_desc* d);
+int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16, void* dw,
+                      void* ws, size_t ws_bytes, int accumulate, const void* zeros,
+                      mmh_stream_t s);
 int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d);
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
                      const void* bias, void* y, int y_is16, int act, const void* zeros,

@@ -212,6 +212,182 @@ __global__ void __launch_bounds__(512, 2) conv_lp16_kernel(const LpConvKP p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad: dw[tap][ci][co] = sum over pixels p of x16[src(p, tap)][ci] * dy16[p][co].
+// Per (tap, 256 ci, 256 co) output tile and pixel range (split-K) one workgroup; the contraction
+// index (pixel) is the SLOW index of both NHWC operands, so the tiles are staged [64 pixels][256
+// channels] (512-B rows, one LDS-DMA instruction = 2 rows) and both MFMA operands are read
+// TRANSPOSED with ds_read_b64_tr_b16.  A transposed 4x16 block touches 4 consecutive rows x 64 B:
+// with a 512-B pitch they would all sit on the same banks, so the 16-byte chunk index is XOR-ed
+// with (row & 3) << 2 (again on the DMA's source address and on the read address).  fp32 partial
+// slabs per split, summed in a fixed order by lp16_slab_reduce_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int WROWB = 512;                      // bytes per LDS row: 256 channels
+constexpr int WSTAGE = 2 * 64 * WROWB;          // x tile + dy tile, 64 pixels each: 64 KiB
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct LpWgradKP {
+    const char* x;          // 16-bit activations [B][H][W][Cin], pixel stride x_cs
+    const char* dy;         // 16-bit output gradients [B][H][W][Cout], pixel stride dy_cs
+    const char* zeros;
+    float* slab;            // [S][9][Cin][Cout]
+    int B, H, W, Cin, Cout, x_cs, dy_cs;
+    int reflect, h16;
+    int S, ksteps_per_split;    // pixel range of split s: [s*ksteps*64, (s+1)*ksteps*64)
+    int CT, NT;                 // ci / co tiles
+    int items;                  // S * CT * NT * 9
+};
+
+// operand fragment for lane: 8 consecutive rows (pixels) row0 + 8h .. of column col0 + (lane & 31)
+// from a [pixel][256 channels] image with the chunk swizzle above
+__device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int row0, int col0, int lane) {
+    const int h = lane >> 5, G1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p2 = lane & 3;
+    const int row = row0 + 8 * h + q;                       // row & 3 == q (row0 % 8 == 0)
+    const int col = col0 + 16 * G1 + 4 * p2;                // element index, 8-byte aligned
+    const unsigned chunk = (unsigned)(col >> 3) ^ ((unsigned)q << 2);
+    const char* a = tile + row * WROWB + (chunk << 4) + (col & 4) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * WROWB));
+    struct { s16x4 a, b; } both = {lo, hi};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) wgrad_lp16_kernel(const LpWgradKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    // XCD-contiguous work list, tap fastest: the nine taps of one (split, tile) read the same dy
+    // tile and neighbouring x pixels, back to back on one L2
+    const int per_xcd = (p.items + 7) / 8;
+    int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int tap = item % 9; item /= 9;
+    const int nt = item % p.NT; item /= p.NT;
+    const int ct = item % p.CT;
+    const int split = item / p.CT;
+    const int P = p.B * p.H * p.W;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int k0 = split * p.ksteps_per_split;
+    const int k1 = min((P + 63) / 64, k0 + p.ksteps_per_split);
+
+    // DMA roles: per k-step and operand 64 rows x 512 B = 32 KiB = 32 instructions of 2 rows; wave w
+    // issues 4 per operand: rows (w*4 + j)*2 + lane/32, physical chunk lane%32 <- logical ^ ((row&3)<<2)
+    unsigned x_coff[4], d_coff[4];
+    int pix[4], poh[4], pow_[4];        // this lane's 4 pixel rows of the current k-step: linear index, (oh, ow)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int prow = (wave * 4 + j) * 2 + (lane >> 5);
+        const unsigned c = (unsigned)(lane & 31) ^ ((unsigned)(prow & 3) << 2);
+        x_coff[j] = (unsigned)(ct * 256) * 2u + c * 16u;
+        d_coff[j] = (unsigned)(nt * 256) * 2u + c * 16u;
+        pix[j] = k0 * 64 + prow;
+        const int rem = pix[j] % (p.H * p.W);
+        poh[j] = rem / p.W;
+        pow_[j] = rem - poh[j] * p.W;
+    }
+    // k-steps are issued in order, each exactly once: the pixel coordinates advance by 64 per step
+    // (no division in the loop)
+    auto issue = [&](int stage) {
+        char* sX = smem + stage * WSTAGE;
+        char* sD = sX + 64 * WROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = pix[j] < P;
+            int ih = poh[j] + kh - 1, iw = pow_[j] + kw - 1;
+            bool okx = ok;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                okx = okx && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const int src = pix[j] + (ih - poh[j]) * p.W + (iw - pow_[j]);
+            const char* gx = okx ? p.x + (size_t)src * p.x_cs * 2 + x_coff[j] : p.zeros + (lane & 31) * 16;
+            const char* gd = ok ? p.dy + (size_t)pix[j] * p.dy_cs * 2 + d_coff[j] : p.zeros + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds(gx, (lds_vp)(sX + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gd, (lds_vp)(sD + (wave * 4 + j) * 1024), 16, 0, 0);
+            pix[j] += 64;
+            pow_[j] += 64;
+            while (pow_[j] >= p.W) {
+                pow_[j] -= p.W;
+                if (++poh[j] == p.H) poh[j] = 0;
+            }
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (k0 < k1) issue(0);
+    for (int ks = k0; ks < k1; ++ks) {
+        __syncthreads();
+        if (ks + 1 < k1) issue((ks + 1 - k0) & 1);
+        const char* sX = smem + ((ks - k0) & 1) * WSTAGE;
+        const char* sD = sX + 64 * WROWB;
+        bf16x8 af[2][4], bfr[2][2];
+        auto load_frags = [&](int s16, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[buf][i] = tr_frag_sw(sX, s16 * 16, wr * 128 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[buf][j] = tr_frag_sw(sD, s16 * 16, wc * 64 + j * 32, lane);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s16 = 0; s16 < 4; ++s16) {
+            if (s16 < 3) load_frags(s16 + 1, (s16 + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = mfma16<H16>(af[s16 & 1][i], bfr[s16 & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* slab = p.slab + ((size_t)split * 9 + tap) * p.Cin * p.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ct * 256 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = nt * 256 + wc * 64 + j * 32 + l31;
+                slab[(size_t)ci * p.Cout + co] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[i] (+)= sum over splits of slab[s][i], fixed order
+__global__ void lp16_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int S,
+                                        int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4*>(slab)[i];
+        for (int s = 1; s < S; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(slab)[(int64_t)s * n4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (accumulate) {
+            const float4 b = reinterpret_cast<const float4*>(dw)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = a;
+    }
+}
+
 // fp32 -> 16-bit copy (the activation twin), 8 elements per lane
 __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ out, int64_t n8, int h16) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,6 +470,62 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     else
         hipLaunchKernelGGL(conv_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
     return mmh::check_launch("conv_lp16_kernel");
+}
+
+static int lp16_wgrad_splits(const mmh_conv_desc* d) {
+    const int tiles = 9 * (d->Cin / 256) * (d->Cout / 256);
+    const long long ksteps = ((long long)d->B * d->H * d->W + 63) / 64;
+    int S = std::max(1, 256 / tiles);       // one workgroup per CU, never a mostly empty second round
+    S = (int)std::min<long long>(S, std::max<long long>(1, ksteps / 8));
+    return S;
+}
+
+size_t mmh_wgrad3x3_lp16_ws_bytes(const mmh_conv_desc* d) {
+    if (!d || d->Cin % 256 || d->Cout % 256) return 0;
+    return (size_t)lp16_wgrad_splits(d) * 9 * d->Cin * d->Cout * sizeof(float);
+}
+
+// dw [3][3][Cin][Cout] (fp32) (+)= wgrad of the 3x3 / stride 1 / pad 1 conv from 16-bit x and dy.
+int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16, void* dw, void* ws,
+                      size_t ws_bytes, int accumulate, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && dy16 && dw && ws && zeros && d->Cin % 256 == 0 &&
+                    d->Cout % 256 == 0,
+                "mmh_wgrad3x3_lp16: 3x3 / stride 1 / pad 1, Cin and Cout %% 256 == 0, 16-bit dtype");
+    MMH_REQUIRE(ws_bytes >= mmh_wgrad3x3_lp16_ws_bytes(d), "mmh_wgrad3x3_lp16: workspace too small");
+    LpWgradKP p{};
+    p.x = static_cast<const char*>(x16); p.dy = static_cast<const char*>(dy16);
+    p.zeros = static_cast<const char*>(zeros);
+    p.slab = static_cast<float*>(ws);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
+    p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.h16 = d->dtype == MMH_FP16;
+    const long long P = (long long)d->B * d->H * d->W;
+    MMH_REQUIRE(P * (long long)std::max(p.x_cs, p.dy_cs) < (1ll << 31), "mmh_wgrad3x3_lp16: tensor too large");
+    const int ksteps = (int)((P + 63) / 64);
+    p.S = lp16_wgrad_splits(d);
+    p.ksteps_per_split = (ksteps + p.S - 1) / p.S;
+    p.S = (ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;      // every split owns >= 1 k-step
+    p.CT = d->Cin / 256; p.NT = d->Cout / 256;
+    p.items = p.S * p.CT * p.NT * 9;
+    hipStream_t st = mmh::as_stream(s);
+    static int ready = -1;
+    if (ready != 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE);
+        ready = e == hipSuccess ? 0 : mmh::fail("wgrad_lp16_kernel: %s", hipGetErrorString(e));
+    }
+    if (ready != 0) return ready;
+    const int per_xcd = (p.items + 7) / 8;
+    if (p.h16) hipLaunchKernelGGL(wgrad_lp16_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
+    else hipLaunchKernelGGL(wgrad_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
+    if (int rc = mmh::check_launch("wgrad_lp16_kernel")) return rc;
+    const int64_t n4 = (int64_t)9 * d->Cin * d->Cout / 4;
+    hipLaunchKernelGGL(lp16_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4, 256), 4096)), dim3(256),
+                       0, st, p.slab, static_cast<float*>(dw), n4, p.S, accumulate);
+    return mmh::check_launch("lp16_slab_reduce_kernel");
 }
 
 }  // extern "C"

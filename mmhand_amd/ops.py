@@ -174,6 +174,10 @@ def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
     if not (USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cout % 32 == 0):
         return 0
     if bf16:
+        # fprop / dgrad of the 256- and 512-channel stack: the second-generation direct kernel
+        # (conv_lp16.hip, 870-1000 TFLOP/s) beats F(2x2,3x3) + its HBM-bound transforms
+        if op in ("fprop", "dgrad") and lp16_v2_ok(Cin, Cout, k, stride, pad, 0 if op == "fprop" else 1):
+            return 0
         # bf16 MFMA path: F(2x2,3x3) with bf16 Winograd-domain tensors (F(4x4,3x3) would amplify
         # the bf16 rounding ~8x: 2e-2 vs 4e-3 relative); the bf16 GEMM kernels need channels % 128
         ok = (USE_WINOGRAD_BF16 and H % 2 == 0 and W_ % 2 == 0 and H >= 4 and W_ >= 4
@@ -384,6 +388,16 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         L.call("mmh_conv7_thin_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
         _count_desc("valu", d)
         return y
+    if bf16 and lp16_v2_ok(Cin, Cout, k, stride, pad, 0):
+        timed = fprop_timer is not None and fprop_timer.want(d)
+        x16 = lp16_twin(x, bf16)
+        if timed:
+            e0, e1 = fprop_timer.bracket()
+            e0.record()
+        y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0)
+        if timed:
+            e1.record()
+        return y
     if bf16:
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[1]
@@ -412,9 +426,9 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     return dx
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0):
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None):
     """dx_channels > 0: only the first dx_channels input channels need a gradient (the caller
-    ignores the rest, which may come back as zeros)."""
+    ignores the rest, which may come back as zeros).  dy16: an existing 16-bit twin of dy."""
     _chk(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     k, _, _, Cout = w.shape
@@ -425,6 +439,16 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     if wt:
         return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if bf16 and lp16_v2_ok(Cin, Cout, k, stride, pad, 1):
+        # main term (zero-padded correlation with the flipped filter) on the v2 kernel; reflect padding
+        # adds the eight border terms (small 16-bit GEMMs + border_add) exactly as the other paths do
+        dx = raw_conv3x3_lp16(dy16 if dy16 is not None else lp16_twin(dy, bf16), w, None, False, L.ACT_NONE, bf16, 1)
+        if reflect:
+            d.dtype = _dt(bf16)
+            ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
+            L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(bf16_weights(w, bf16)[0]), _ptr(dx), _ptr(ws),
+                   ws.numel() * 4, 3, _stream())
+        return dx
     if bf16 and Cout % 64 == 0:
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[0]
@@ -441,6 +465,8 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     _chk(x, "x"); _chk(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
+    if bf16 and lp16_wgrad_ok(Cin, Cout, k, stride, pad):
+        return raw_wgrad3x3_lp16(lp16_twin(x, bf16), lp16_twin(dy, bf16), reflect, bf16)
     wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "wgrad")
     if wt:
         return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16)
@@ -508,6 +534,26 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
            int(out16), act, _ptr(zero_page(x16.device)), _stream())
     _count_desc("mfma", d)
     return y
+
+
+def lp16_wgrad_ok(Cin, Cout, k, stride, pad):
+    return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 256 == 0 and Cout % 256 == 0
+
+
+def raw_wgrad3x3_lp16(x16, dy16, reflect, bf16):
+    """dw [3,3,Cin,Cout] fp32 from the 16-bit twins of x and dy (conv_lp16.hip wgrad)."""
+    B, H, W_, Cin = x16.shape
+    Cout = dy16.shape[3]
+    assert x16.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and x16.is_contiguous() and dy16.is_contiguous()
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    d.dtype = _dt(bf16)
+    ws = torch.empty(max(int(L.load().mmh_wgrad3x3_lp16_ws_bytes(C.byref(d))), 16) // 4, dtype=torch.float32,
+                     device=x16.device)
+    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=x16.device)
+    L.call("mmh_wgrad3x3_lp16", C.byref(d), _ptr(x16), _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+           _ptr(zero_page(x16.device)), _stream())
+    _count_desc("mfma", d)
+    return dw
 
 
 def _convT_desc(x, w):
@@ -586,6 +632,22 @@ class Conv2dFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, reflect, act, bias is not None, bf16)
         ctx.x_shape = tuple(x.shape)
         ctx.wino_V = 0
+        ctx.lp16 = False
+        k = w.shape[0]
+        if bf16 and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0):
+            # 16-bit path of the 256 / 512-channel 3x3 stack: one 16-bit twin of x feeds the fprop and,
+            # kept instead of x, the wgrad of conv_lp16.hip
+            x16 = lp16_twin(x, bf16)
+            timed = fprop_timer is not None and fprop_timer.want(conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect))
+            if timed:
+                e0, e1 = fprop_timer.bracket()
+                e0.record()
+            y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0)
+            if timed:
+                e1.record()
+            ctx.lp16 = lp16_wgrad_ok(Cin, w.shape[3], k, stride, pad)
+            ctx.save_for_backward(x16 if ctx.lp16 else x, w, y if act != L.ACT_NONE else None)
+            return y
         if wt and KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
             # the wgrad pass contracts the same transformed input: keep it instead of x
             y, V = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, keep_V=True, bf16=bf16)
@@ -607,6 +669,15 @@ class Conv2dFn(torch.autograd.Function):
         if (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                 and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6):
             dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x)      # x is the saved V here
+            if has_bias and ctx.needs_input_grad[2]:
+                db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
+            return dx, dw, db, None, None, None, None, None, None
+        if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
+            g16 = lp16_twin(g, bf16)
+            if ctx.needs_input_grad[0]:
+                dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16)
+            if ctx.needs_input_grad[1]:
+                dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
             return dx, dw, db, None, None, None, None, None, None

@@ -58,8 +58,8 @@ def test_config3_inference_b64_full_shape(dev):
 
 def test_config5_generator_512_bf16_vs_oracle(dev):
     """configs[4] shapes on the bf16 path: ngf 64 at 512x512 -> PATBlocks at 128x128 with 256 / 512
-    channels (the bf16 Winograd F(2x2,3x3) GEMMs, the bf16 direct stems / strided / transposed
-    convs).  B=1, 2 PATBlocks (the oracle runs on the CPU): output within the stated bf16 tolerance
+    channels (the second-generation 16-bit direct kernels of conv_lp16.hip for the 3x3 stack, the
+    bf16 direct stems / strided / transposed convs).  B=1, 2 PATBlocks (the oracle runs on the CPU): output within the stated bf16 tolerance
     (1e-2 rel-L1) of the fp32 oracle; the backward runs on the bf16 dgrad / wgrad kernels and its
     weight gradients point the oracle's way (cosine > 0.97 on every conv weight; measured worst
     0.989 on the pose stem, whose input is sparse)."""
@@ -71,7 +71,7 @@ def test_config5_generator_512_bf16_vs_oracle(dev):
     net.to(dev).train()
     net.flatten_parameters()
     net.bf16 = True
-    assert ops._wino_tile(1, 128, 128, 512, 512, 3, 1, 1, True, "fprop") == 2
+    assert ops.lp16_v2_ok(512, 512, 3, 1, 1, 0) and ops._wino_tile(1, 128, 128, 512, 512, 3, 1, 1, True, "fprop") == 0
     b = O.synthetic_batch(1, 512, 512, seed=3)
     g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
     probe = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(3))
