@@ -326,10 +326,12 @@ def main():
                       f"[{tiles}x512].[512x512] (F({wtile}x{wtile},3x3)) of the 3x3 512->512 fprop @{hs}x{hs}")
         else:
             k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
-            k_name = (("conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
+            k_name = (("conv_lp16s_kernel<bf16> (16-bit operands by LDS-DMA, 256x256x64 tiles, MFMA 16x16x32)"
+                       if (a.dtype == "bf16" and ops.lp16_v2_ok(512, 512, 3, 1, 1, 0)) else
+                       "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
                        "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
-        tname = "r02_traffic_bf16.json" if a.dtype == "bf16" else "r01_traffic.json"
+        tname = "r02_traffic_bf16.json" if a.dtype == "bf16" else ("r02_traffic.json" if wino else "r01_traffic.json")
         tj = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tj) and a.batch == 32 and a.size == 256:
             tjd = json.load(open(tj))

@@ -32,6 +32,8 @@ int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, in
                    hipStream_t st);
 int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);
 extern int g_wino6_vec;
+extern int g_lp16_shape;
+extern int g_lp16_tap_inner;
 
 }  // namespace mmh
 

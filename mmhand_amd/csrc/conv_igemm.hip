@@ -2949,6 +2949,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino_xcd")) { g_wino_xcd = value; return 0; }
     if (!strcmp(key, "dgrad_s2_multi")) { g_dgrad_s2_multi = value; return 0; }
     if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
+    if (!strcmp(key, "lp16_shape")) { mmh::g_lp16_shape = value; return 0; }
+    if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_levels")) { g_wino_gemm_levels = value; return 0; }

@@ -285,6 +285,42 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
         R.rel_l1(y, yf), R.rel_l1(dx, dxf), R.rel_l1(dw, dwf))
 
 
+@pytest.mark.parametrize("shape", [16, 32])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 9, 11, 64, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
+                                  (1, 20, 12, 256, 256, True)])
+def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
+    """conv_lp16.hip through the C-ABI: fprop (both MFMA shapes), zero-pad dgrad and wgrad from 16-bit
+    twins against the fp64 oracle on operands rounded to the same type (accumulation is fp32)."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout, refl = case
+    lib.check(lib.load().mmh_set_option(b"lp16_shape", shape), "set")
+    try:
+        x = _mk((B, H, W, Cin), 1, dev)
+        w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+        bias = _mk((Cout,), 3, dev)
+        dy = _mk((B, H, W, Cout), 4, dev)
+        ops.bump_weights_epoch()
+        rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+        x16, dy16 = ops.lp16_twin(x, lp), ops.lp16_twin(dy, lp)
+        assert torch.equal(x16.float().cpu(), rb(x))
+        y = ops.raw_conv3x3_lp16(x16, w, bias, refl, 1, lp, 0)
+        yr = R.conv2d(rb(x), rb(w), bias.cpu(), 1, 1, refl, 1)
+        assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+        y16 = ops.raw_conv3x3_lp16(x16, w, bias, refl, 1, lp, 0, out16=True)       # 16-bit epilogue
+        assert R.rel_l1(y16.float(), yr) < (2e-3 if lp == 2 else 8e-3)
+        if Cin % 256 == 0:
+            dx = ops.raw_conv3x3_lp16(dy16, w, None, False, 0, lp, 1)
+            _, dxr, dwr, _ = R.conv2d_grads(rb(x), rb(w), None, rb(dy), 1, 1, False)
+            assert R.rel_l1(dx, dxr) < 5e-6, R.rel_l1(dx, dxr)
+            if Cout % 256 == 0:
+                dw = ops.raw_wgrad3x3_lp16(x16, dy16, refl, lp)
+                _, _, dwr, _ = R.conv2d_grads(rb(x), rb(w), None, rb(dy), 1, 1, refl)
+                assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
+    finally:
+        lib.check(lib.load().mmh_set_option(b"lp16_shape", 16), "set")
+
+
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 def test_convT_bf16_mfma_path(lp, dev):
     from mmhand_amd import ops
