@@ -248,12 +248,14 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count,
  * hash of (seed, element index) < keep threshold and scales by 1/(1-p);
  * if mask != NULL (uint8 per element, test hook) it is used instead.
  * keep_bits != NULL (uint8 per 4 channels): bit e = lane e survived ReLU / dropout -
- * all the backward needs of `out`, at 1/16 of its bytes.                    */
+ * all the backward needs of `out`, at 1/16 of its bytes.
+ * out_dtype: MMH_F32, or MMH_BF16 / MMH_FP16 = `out` is written as that 16-bit type
+ * (the input of a 16-bit convolution: no fp32 copy, no conversion pass).      */
 int mmh_scale_shift_act(const void* x, const void* scale, const void* shift,
                         const void* residual, void* out, int groups,
                         int64_t rows_per_group, int C, int relu, float drop_p,
                         uint64_t seed, const void* mask, void* keep_bits,
-                        mmh_stream_t s);
+                        int out_dtype, mmh_stream_t s);
 
 /* Backward of norm+relu+dropout.  dz = g * (relu||drop ? (out>0)/(1-p) : 1).
  * masked: 0 = no ReLU / dropout (`out` unused), 1 = `out` is the fp32 forward output,
@@ -279,10 +281,11 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
 
 /* ---- PATBlock gate + concat (models/Generator.py:115-130) -----------------
  * out = x1 + s1*sigmoid(s2)*sigmoid(s3);  x2n = cat(s3,out); x3n = cat(s2,out)
- * x1,s1,s2,s3,out: [rows][C];  x2n,x3n: [rows][2C] (NULL -> not produced).  */
+ * x1,s1,s2,s3,out: [rows][C];  x2n,x3n: [rows][2C] (NULL -> not produced).
+ * cat_dtype: element type of x2n / x3n (MMH_F32 | MMH_BF16 | MMH_FP16); `out` is always fp32. */
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2,
                           const void* s3, void* out, void* x2n, void* x3n,
-                          int64_t rows, int C, mmh_stream_t s);
+                          int64_t rows, int C, int cat_dtype, mmh_stream_t s);
 /* g_out/g_x2n/g_x3n may be NULL (treated as zero).                          */
 int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n,
                           const void* g_x3n, const void* s1, const void* s2,

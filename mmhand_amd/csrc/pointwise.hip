@@ -19,6 +19,22 @@ __device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) {
     reinterpret_cast<float4*>(p)[i4] = v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// store 4 values as fp32 (lp = 0), bf16 (1) or fp16 (2); i4 indexes groups of 4 elements
+typedef __bf16 pw_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pw_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_lp(void* p, int64_t i4, float4 v, int lp) {
+    if (lp == 1) {
+        pw_bf16x4 r;
+        r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+        reinterpret_cast<pw_bf16x4*>(p)[i4] = r;
+    } else if (lp == 2) {
+        pw_f16x4 r;
+        r[0] = (_Float16)v.x; r[1] = (_Float16)v.y; r[2] = (_Float16)v.z; r[3] = (_Float16)v.w;
+        reinterpret_cast<pw_f16x4*>(p)[i4] = r;
+    } else {
+        reinterpret_cast<float4*>(p)[i4] = v;
+    }
+}
 
 inline int grid_for(int64_t work_items, int cap = 4096) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(mmh::cdiv(work_items, TPB), cap));
@@ -187,10 +203,11 @@ __device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
 
 __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                        const float* __restrict__ shift,
-                                       const float* __restrict__ residual, float* __restrict__ out,
+                                       const float* __restrict__ residual, void* __restrict__ out,
                                        int64_t n4, int64_t rows_per_group, int C4, int relu,
                                        float drop_p, uint64_t seed,
-                                       const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits) {
+                                       const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits,
+                                       int out_lp) {
     const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -219,7 +236,7 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
             float4 q = ld4(residual, i);
             r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
         }
-        st4(out, i, make_float4(r[0], r[1], r[2], r[3]));
+        st4_lp(out, i, make_float4(r[0], r[1], r[2], r[3]), out_lp);
     }
 }
 
@@ -393,8 +410,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 // ------------------------------------------------------------------ PATBlock gate
 __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ s1,
                                 const float* __restrict__ s2, const float* __restrict__ s3,
-                                float* __restrict__ out, float* __restrict__ x2n,
-                                float* __restrict__ x3n, int64_t n4, int C4) {
+                                float* __restrict__ out, void* __restrict__ x2n,
+                                void* __restrict__ x3n, int64_t n4, int C4, int cat_lp) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
@@ -407,10 +424,10 @@ __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __res
         if (x2n) {
             int64_t row = i / C4;
             int c4 = (int)(i - row * C4);
-            st4(x2n, row * 2 * C4 + c4, d);        // cat(s3, out)
-            st4(x2n, row * 2 * C4 + C4 + c4, o);
-            st4(x3n, row * 2 * C4 + c4, c);        // cat(s2, out)
-            st4(x3n, row * 2 * C4 + C4 + c4, o);
+            st4_lp(x2n, row * 2 * C4 + c4, d, cat_lp);        // cat(s3, out)
+            st4_lp(x2n, row * 2 * C4 + C4 + c4, o, cat_lp);
+            st4_lp(x3n, row * 2 * C4 + c4, c, cat_lp);        // cat(s2, out)
+            st4_lp(x3n, row * 2 * C4 + C4 + c4, o, cat_lp);
         }
     }
 }
@@ -871,17 +888,19 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count, const void
 
 int mmh_scale_shift_act(const void* x, const void* scale, const void* shift, const void* residual,
                         void* out, int groups, int64_t rows, int C, int relu, float drop_p,
-                        uint64_t seed, const void* mask, void* keep_bits, mmh_stream_t s) {
+                        uint64_t seed, const void* mask, void* keep_bits, int out_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_scale_shift_act", C)) return rc;
     MMH_REQUIRE(x && scale && shift && out && groups > 0 && rows > 0, "mmh_scale_shift_act: bad arguments");
+    MMH_REQUIRE(out_dtype == MMH_F32 || out_dtype == MMH_BF16 || out_dtype == MMH_FP16,
+                "mmh_scale_shift_act: out_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu),
                 "mmh_scale_shift_act: dropout needs 0<=p<1 and a preceding ReLU");
     const int64_t n4 = (int64_t)groups * rows * (C / 4);
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
                        static_cast<const float*>(x), static_cast<const float*>(scale),
                        static_cast<const float*>(shift), static_cast<const float*>(residual),
-                       static_cast<float*>(out), n4, rows, C / 4, relu, drop_p, seed,
-                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits));
+                       out, n4, rows, C / 4, relu, drop_p, seed,
+                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits), out_dtype);
     return mmh::check_launch("scale_shift_act");
 }
 
@@ -963,16 +982,17 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act, mmh_
 }
 
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2, const void* s3, void* out,
-                          void* x2n, void* x3n, int64_t rows, int C, mmh_stream_t s) {
+                          void* x2n, void* x3n, int64_t rows, int C, int cat_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_patblock_gate_fwd", C)) return rc;
+    MMH_REQUIRE(cat_dtype == MMH_F32 || cat_dtype == MMH_BF16 || cat_dtype == MMH_FP16,
+                "mmh_patblock_gate_fwd: cat_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(x1 && s1 && s2 && s3 && out && rows > 0 && ((x2n == nullptr) == (x3n == nullptr)),
                 "mmh_patblock_gate_fwd: bad arguments");
     const int64_t n4 = rows * (C / 4);
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
                        static_cast<const float*>(x1), static_cast<const float*>(s1),
                        static_cast<const float*>(s2), static_cast<const float*>(s3),
-                       static_cast<float*>(out), static_cast<float*>(x2n), static_cast<float*>(x3n),
-                       n4, C / 4);
+                       static_cast<float*>(out), x2n, x3n, n4, C / 4, cat_dtype);
     return mmh::check_launch("gate_fwd");
 }
 

@@ -201,12 +201,24 @@ class _Net(nn.Module):
 
     # -- functional layers
     def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0):
-        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels)
+        """x: an fp32 NHWC tensor, or a (proxy, x16) pair from a producer that wrote it in 16 bits."""
+        x16 = None
+        if isinstance(x, tuple):
+            x, x16 = x
+        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16)
+
+    def _lp_edge(self, cp):
+        """16-bit hand-over to the 3x3 conv `cp` (training, 16-bit mode, conv on conv_lp16.hip for all
+        three passes): returns the operand type, else 0."""
+        if self.bf16 and self.training and ops.lp16_chain_ok(cp.weight.shape[2], cp.weight.shape[3], cp.k, 1, 1):
+            return self.bf16
+        return 0
 
     def convT(self, cp, x):
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16)
 
-    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None):
+    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0):
+        """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair."""
         drop_p = 0.5 if (drop and self.training) else 0.0
         mask = None
         seed = 0
@@ -217,13 +229,13 @@ class _Net(nn.Module):
                 seed = ops.next_dropout_seed()
         if self.norm == "instance":
             return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", relu,
-                                       drop_p, seed, mask, None)
+                                       drop_p, seed, mask, None, out_lp)
         np_ = bag[idx]
         if self.training:
             np_.num_batches_tracked += 1
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean,
                                        np_.running_var, "batch", relu, drop_p, seed, mask,
-                                       self.sync_group)
+                                       self.sync_group, out_lp)
         scale = np_.weight / torch.sqrt(np_.running_var + ops.EPS)
         shift = np_.bias - np_.running_mean * scale
         y = ops.AffineActFn.apply(x, scale, shift, relu)
@@ -233,7 +245,7 @@ class _Net(nn.Module):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets)."""
         i2 = 6 if self.use_dropout else 5
         y = self.conv(blk[1], x, 1, 1, True)
-        y = self.normact(blk, 2, y, True, self.use_dropout, site)
+        y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]))
         y = self.conv(blk[i2], y, 1, 1, True)
         if last_norm:
             y = self.normact(blk, i2 + 1, y, False, residual=residual)
@@ -303,7 +315,13 @@ class Generator(_Net):
             s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
             s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)
-            x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, b + 1 < self.n_blocks)
+            more = b + 1 < self.n_blocks
+            cat_lp = self._lp_edge(m["att"][b + 1]["conv_block_stream2"][1]) if more else 0
+            if cat_lp:      # the cats feed only the next block's 16-bit convs: written in 16 bits
+                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp)
+                x2, x3 = (p2, c2), (p3, c3)
+            else:
+                x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more)
         up = m["stream1_up"]
         y = x1
         for i in range(self.n_down):

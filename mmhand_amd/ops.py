@@ -536,6 +536,20 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
     return y
 
 
+def lp16_chain_ok(Cin, Cout, k, stride, pad):
+    """all three passes of this conv run on conv_lp16.hip: its producer may hand x over in 16 bits"""
+    return (lp16_v2_ok(Cin, Cout, k, stride, pad, 0) and lp16_v2_ok(Cin, Cout, k, stride, pad, 1)
+            and lp16_wgrad_ok(Cin, Cout, k, stride, pad))
+
+
+def lp_proxy(shape, device):
+    """fp32 tensor of the given logical shape over ONE element of storage (all strides 0): the autograd
+    edge of a tensor whose data travel in 16 bits beside it.  autograd casts a gradient to its input's
+    dtype, so a 16-bit tensor on the edge would add two conversion passes to the backward; the proxy
+    keeps the edge fp32 and costs 4 bytes."""
+    return torch.empty_strided(tuple(shape), (0,) * len(shape), dtype=torch.float32, device=device)
+
+
 def lp16_wgrad_ok(Cin, Cout, k, stride, pad):
     return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 256 == 0 and Cout % 256 == 0
 
@@ -625,7 +639,9 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0):
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None):
+        """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
+        the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read."""
         B, H, W_, Cin = x.shape
         ctx.dx_channels = dx_channels
         wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
@@ -634,10 +650,14 @@ class Conv2dFn(torch.autograd.Function):
         ctx.wino_V = 0
         ctx.lp16 = False
         k = w.shape[0]
+        if x16 is not None:
+            assert bf16 and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape) and lp16_chain_ok(
+                Cin, w.shape[3], k, stride, pad), "a 16-bit input needs the conv_lp16 path for all three passes"
         if bf16 and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0):
-            # 16-bit path of the 256 / 512-channel 3x3 stack: one 16-bit twin of x feeds the fprop and,
-            # kept instead of x, the wgrad of conv_lp16.hip
-            x16 = lp16_twin(x, bf16)
+            # 16-bit path of the 256 / 512-channel 3x3 stack: one 16-bit twin of x (or the producer's own
+            # 16-bit output) feeds the fprop and, kept instead of x, the wgrad
+            if x16 is None:
+                x16 = lp16_twin(x, bf16)
             timed = fprop_timer is not None and fprop_timer.want(conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect))
             if timed:
                 e0, e1 = fprop_timer.bracket()
@@ -671,7 +691,7 @@ class Conv2dFn(torch.autograd.Function):
             dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x)      # x is the saved V here
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
@@ -680,7 +700,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -690,7 +710,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
@@ -764,25 +784,36 @@ def raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var, m
     return scale, shift, invstd
 
 
-def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=False):
+def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=False, out_lp=0):
     """keep_bits: also return the uint8 [B,H,W,C/4] array of surviving-lane bits (4 per byte), the
-    only thing the norm backward needs of `out`."""
+    only thing the norm backward needs of `out`.  out_lp: 0 fp32 | True bf16 | 2 fp16 output."""
     B, H, W_, Cc = x.shape
     groups = scale.shape[0]
     rows = (B // groups) * H * W_
-    out = torch.empty_like(x)
+    out = torch.empty(x.shape, dtype=_wd(out_lp), device=x.device)
     kb = torch.empty((B, H, W_, Cc // 4), dtype=torch.uint8, device=x.device) if keep_bits else None
     L.call("mmh_scale_shift_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
-           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _stream())
+           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _dt(out_lp), _stream())
     return (out, kb) if keep_bits else out
 
 
 def _sync_stats(mean, m2, rows, group):
     """SyncBN: merge per-rank (mean, M2) with Chan's formula (replaces apex SyncBatchNorm,
-    models/MMHandModel.py:109-116).  One all_gather of [2C] floats per norm site."""
+    models/MMHandModel.py:109-116).  One all_gather of [3C] floats per norm site.  On the device the
+    gathered (count, mean, M2) triples of the ranks are exactly the partial layout
+    [groups=1][chunks=world][3][C] that mmh_norm_stats_merge reduces: one launch, no torch glue."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    packed = torch.cat([mean, m2], 0)          # [2, C]
+    collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
+    if mean.is_cuda:
+        packed = torch.cat([torch.full_like(mean, float(rows)), mean, m2], 0)          # [3, C]
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+        gmean = torch.empty_like(mean)
+        gm2 = torch.empty_like(m2)
+        L.call("mmh_norm_stats_merge", _ptr(gathered), 1, world, mean.shape[1], _ptr(gmean), _ptr(gm2), _stream())
+        return gmean, gm2, rows * world
+    packed = torch.cat([mean, m2], 0)          # [2, C]   (host-logic path of the CPU gloo test)
     gathered = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(gathered, packed, group=group)
     means = torch.stack([t[0] for t in gathered])      # [world, C]
@@ -790,6 +821,10 @@ def _sync_stats(mean, m2, rows, group):
     gmean = means.mean(0, keepdim=True)
     gm2 = m2s.sum(0, keepdim=True) + rows * ((means - gmean) ** 2).sum(0, keepdim=True)
     return gmean.contiguous(), gm2.contiguous(), rows * world
+
+
+# collectives issued by the norm layers (SyncBN), for tests / diagnostics: {"all_gather": n, "all_reduce": n}
+collective_counter = {}
 
 
 class NormActFn(torch.autograd.Function):
@@ -800,7 +835,9 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
-                seed, mask, sync_group):
+                seed, mask, sync_group, out_lp=0):
+        """out_lp (True bf16 | 2 fp16): the output is written in that 16-bit type only - it feeds a
+        16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass."""
         _chk(x, "x")
         if drop_p > 0 and not relu:
             # the keep bits are (out > 0): exact only behind a ReLU (the reference never drops without one)
@@ -815,16 +852,20 @@ class NormActFn(torch.autograd.Function):
                                                  running_var)
         masked = bool(relu or drop_p > 0)
         if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
-            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True)
+            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True,
+                                          out_lp=out_lp)
         else:
-            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask), None
+            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, out_lp=out_lp), None
         ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
                    residual is not None)
         ctx.save_for_backward(x, kb, mean, invstd, gamma)
+        if out_lp:
+            ctx.mark_non_differentiable(out)
+            return lp_proxy(x.shape, x.device), out
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g16=None):
         x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
         groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         if has_res and relu:
@@ -843,6 +884,7 @@ class NormActFn(torch.autograd.Function):
         if sync_group is not None:
             import torch.distributed as dist
             packed = torch.cat([s1, s2], 0)
+            collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
             dist.all_reduce(packed, group=sync_group)
             s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
         dx = torch.empty_like(x)
@@ -850,7 +892,7 @@ class NormActFn(torch.autograd.Function):
                _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
                _ptr(dx), _stream())
         dres = g if has_res else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class AffineActFn(torch.autograd.Function):
@@ -883,25 +925,30 @@ class GateFn(torch.autograd.Function):
     x2n = cat(s3, out), x3n = cat(s2, out) — the concat is written by the same kernel."""
 
     @staticmethod
-    def forward(ctx, x1, s1, s2, s3, want_cat):
+    def forward(ctx, x1, s1, s2, s3, want_cat, cat_lp=0):
+        """cat_lp (True bf16 | 2 fp16): cat(s3,out) / cat(s2,out) are written in that 16-bit type only
+        (they feed the next block's 16-bit convolutions and nothing else); `out` stays fp32."""
         for t in (x1, s1, s2, s3):
             _chk(t)
         B, H, W_, Cc = x1.shape
         out = torch.empty_like(x1)
         x2n = x3n = None
         if want_cat:
-            x2n = _empty((B, H, W_, 2 * Cc), x1)
-            x3n = _empty((B, H, W_, 2 * Cc), x1)
+            x2n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
+            x3n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
         L.call("mmh_patblock_gate_fwd", _ptr(x1), _ptr(s1), _ptr(s2), _ptr(s3), _ptr(out),
-               _ptr(x2n), _ptr(x3n), B * H * W_, Cc, _stream())
+               _ptr(x2n), _ptr(x3n), B * H * W_, Cc, _dt(cat_lp), _stream())
         ctx.save_for_backward(s1, s2, s3)
         ctx.want_cat = want_cat
+        if want_cat and cat_lp:
+            ctx.mark_non_differentiable(x2n, x3n)
+            return out, lp_proxy(x2n.shape, x1.device), lp_proxy(x3n.shape, x1.device), x2n, x3n
         if want_cat:
             return out, x2n, x3n
         return out, None, None
 
     @staticmethod
-    def backward(ctx, g_out, g_x2n, g_x3n):
+    def backward(ctx, g_out, g_x2n, g_x3n, _a=None, _b=None):
         s1, s2, s3 = ctx.saved_tensors
         B, H, W_, Cc = s1.shape
         g_out = None if g_out is None else g_out.contiguous()
@@ -911,7 +958,7 @@ class GateFn(torch.autograd.Function):
         gs2 = torch.empty_like(s1); gs3 = torch.empty_like(s1)
         L.call("mmh_patblock_gate_bwd", _ptr(g_out), _ptr(g_x2n), _ptr(g_x3n), _ptr(s1), _ptr(s2),
                _ptr(s3), _ptr(gx1), _ptr(gs1), _ptr(gs2), _ptr(gs3), B * H * W_, Cc, _stream())
-        return gx1, gs1, gs2, gs3, None
+        return gx1, gs1, gs2, gs3, None, None
 
 
 # --------------------------------------------------------------------------- losses
