@@ -322,7 +322,7 @@ def main():
         op_ms = timer.op_mean_ms()
         if wino:      # P x [tiles x 512] . [512 x 512]: the arithmetic this launch really does
             k_flop = planes * 2.0 * tiles * 512 * 512
-            k_name = (f"{'wino_gemm_bf16_kernel' if a.dtype == 'bf16' else 'wino_gemm_kernel<128>'}: the {planes} Winograd-domain GEMMs "
+            k_name = (f"{'wino_gemm_bf16_kernel' if a.dtype == 'bf16' else 'wino_gemm_kernel<128,2> (two-level accumulation)'}: the {planes} Winograd-domain GEMMs "
                       f"[{tiles}x512].[512x512] (F({wtile}x{wtile},3x3)) of the 3x3 512->512 fprop @{hs}x{hs}")
         else:
             k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9

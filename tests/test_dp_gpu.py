@@ -48,9 +48,9 @@ def _worker(rank, world, port, norm, tmp):
     full = O.synthetic_batch(4, 32, 32, seed=7)
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
     losses, sd = _run(norm, shard, True)
-    from mmhand_amd import mmhand_model
-    torch.save({"losses": losses, "sd": sd, "log": list(mmhand_model._LAST_BUCKET_LOG or [])},
-               os.path.join(tmp, f"rank{rank}.pt"))
+    from mmhand_amd import mmhand_model, ops
+    torch.save({"losses": losses, "sd": sd, "log": list(mmhand_model._LAST_BUCKET_LOG or []),
+                "syncbn": dict(ops.collective_counter)}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -66,6 +66,14 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_pat
     # replicas stay identical
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    # SyncBN collectives per iteration (--norm batch): one all_gather per norm site forward and one
+    # all_reduce per site backward.  G: 3 stems x 3 + n_blocks x 4 + 2 up = 19 sites here (47 at full
+    # size); D: 1 + 2 + 2 x n_layers_D = 7 per pass (9 at full size), 6 passes per iteration (2 in the
+    # G step, 2 per discriminator step) -> 61 + 61 here, 101 + 101 at full size.  --norm instance: none.
+    if norm == "batch":
+        assert r0["syncbn"] == {"all_gather": 2 * (19 + 6 * 7), "all_reduce": 2 * (19 + 6 * 7)}, r0["syncbn"]
+    else:
+        assert r0["syncbn"] == {}, r0["syncbn"]
     # gradient buckets (20 KB here) went out in reverse layer order DURING the backward pass: the
     # Generator's first bucket (its last layers) was issued before the gradients of its first
     # layers existed, and both ranks issued their collectives in the same order
