@@ -546,11 +546,11 @@ struct WinoGemmKP {
 // output transform (coefficients up to 32 per dimension) then amplifies it - that chain, not the
 // transforms, is 85 % of the F(6x6,3x3) error against fp64 (tools/wino_error_model.py).  With
 // LEVELS = 2 every k-step (32 channels: close to the optimal block sqrt(K)) starts a fresh chain in
-// `part` (C operand = 0) that is folded into `acc` by 64 vector adds: ~3x less accumulated rounding
-// for 64 more VGPRs (2 workgroups per CU instead of 3 at 128-wide tiles).
+// `part` (C operand = 0) that is folded into `acc` by 64 vector adds: ~3x less accumulated rounding.
+// The chains are run one tile ROW at a time, so `part` is 32 VGPRs and 3 workgroups per CU remain.
 constexpr int WINO_FOLD = 1;
 template <int BN, int LEVELS>
-__global__ void __launch_bounds__(256, (LEVELS == 2 && BN == 128) ? 2 : 3) wino_gemm_kernel(const WinoGemmKP p) {
+__global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmKP p) {
     constexpr int WTM = 64, WTN = BN / 2;
     constexpr int TM = 2, TN = WTN / 32;
     constexpr int NB = BN / 32;
@@ -619,7 +619,6 @@ __global__ void __launch_bounds__(256, (LEVELS == 2 && BN == 128) ? 2 : 3) wino_
     };
 
     f32x16 acc[TM][TN];
-    f32x16 part[LEVELS == 2 ? TM : 1][LEVELS == 2 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -640,40 +639,61 @@ __global__ void __launch_bounds__(256, (LEVELS == 2 && BN == 128) ? 2 : 3) wino_
                 if (more) setup_load(wc + p.nb);
             }
             if (more) issue_loads();
+            if constexpr (LEVELS == 2) {
+                // two-level summation, one tile ROW at a time: the k-step's chain of row i lives in
+                // part[TN] (C operand = 0 at its start) and is folded into acc[i] before row i+1 starts,
+                // so the second accumulator set costs TN*16 = 32 VGPRs, not 64 (3 workgroups per CU stay)
 #pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                float4 av[TM];
+                for (int i = 0; i < TM; ++i) {
+                    f32x16 part[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    av[i] = *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
-                float bsc[TN][4];
+                    for (int kg = 0; kg < 4; ++kg) {
+                        const float4 av =
+                            *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
+                        float bsc[TN][4];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
+                            for (int e = 0; e < 4; ++e)
+                                bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const float a = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+                            for (int j = 0; j < TN; ++j)
+                                part[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    a, bsc[j][e], (kg == 0 && e == 0) ? f32x16{} : part[j], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if constexpr (LEVELS == 2)
-                                part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    a, bsc[j][e], (kg == 0 && e == 0) ? f32x16{} : part[i][j], 0, 0, 0);
-                            else
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += part[j][r];
+                    __builtin_amdgcn_sched_barrier(0);      // row i+1's chains must not start before this fold
+                }
+            } else {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    float4 av[TM];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        av[i] = *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
+                    float bsc[TN][4];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const float a = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
                         }
                     }
                 }
-            }
-            if constexpr (LEVELS == 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += part[i][j][r];
             }
             if (ks == KS - 1) {
                 // tile done: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Rows past M
@@ -2776,8 +2796,7 @@ static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long til
     p.W = nbatch * p.MT * p.NT;
     p.Wx = (p.W + 7) / 8;
     const bool two = g_wino_gemm_levels == 2 && nbatch == 64 && K > WINO_FOLD * BK;   // nothing to fold below 2 blocks
-    // 32 CUs per XCD; the 128-wide two-level build needs 222 VGPRs: 2 workgroups per CU
-    p.nb = std::min(p.Wx, 32 * ((two && bn == 128) ? std::min(g_wino_gemm_occ, 2) : g_wino_gemm_occ));
+    p.nb = std::min(p.Wx, 32 * g_wino_gemm_occ);       // 32 CUs per XCD
     if (two) return bn == 128 ? launch_wino_gemm_t<128, 2>(p, st) : launch_wino_gemm_t<64, 2>(p, st);
     return bn == 128 ? launch_wino_gemm_t<128, 1>(p, st) : launch_wino_gemm_t<64, 1>(p, st);
 }
