@@ -807,7 +807,8 @@ def _sync_stats(mean, m2, rows, group):
     collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
     if mean.is_cuda:
         packed = torch.cat([torch.full_like(mean, float(rows)), mean, m2], 0)          # [3, C]
-        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        # flat [world*3, C]: the shape both RCCL and gloo accept for all_gather_into_tensor
+        gathered = torch.empty((world * 3, packed.shape[1]), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(gathered, packed, group=group)
         gmean = torch.empty_like(mean)
         gm2 = torch.empty_like(m2)
