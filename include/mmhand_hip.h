@@ -143,9 +143,10 @@ int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accum
                 mmh_stream_t s);
 size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d);
 /* phase 1 = the eight border GEMMs (dy, w -> ws; independent of dx, so the caller may run
- * them on a second stream beside the Winograd transforms), 2 = add ws into dx, 3 = both. */
+ * them on a second stream beside the Winograd transforms), 2 = add ws into dx, 3 = both.
+ * io16: bit 0 = dy, bit 1 = dx is a 16-bit tensor of d->dtype (gradients of a 16-bit convolution). */
 int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx,
-                            void* ws, size_t ws_bytes, int phase, mmh_stream_t s);
+                            void* ws, size_t ws_bytes, int phase, int io16, mmh_stream_t s);
 
 /* dw[kh][kw][Cin][Cout] (+)= sum over pixels.  Split-K partial slabs go to
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
@@ -212,21 +213,26 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,
                      int p, mmh_stream_t s);
 
-/* out[c] (+)= sum over rows of x[rows][C] (conv-bias gradient).           */
+/* out[c] (+)= sum over rows of x[rows][C] (conv-bias gradient).  x_dtype: element type of x
+ * (MMH_F32 | MMH_BF16 | MMH_FP16); sums are fp32.                          */
 size_t mmh_colsum_ws_bytes(int64_t rows, int C);
 int mmh_colsum(const void* x, int64_t rows, int C, int cs, void* out,
-               void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
+               void* ws, size_t ws_bytes, int accumulate, int x_dtype, mmh_stream_t s);
 
 /* ---- BatchNorm2d / InstanceNorm2d + ReLU + Dropout ------------------------
  * replaces norm_layer / nn.ReLU / nn.Dropout sites, models/Generator.py:66-77,
- * models/Discriminator.py:29-34, models/network_utils.py:74-84.             */
+ * models/Discriminator.py:29-34, models/network_utils.py:74-84.
+ * The *_dtype arguments name the element type of one activation / gradient tensor in HBM
+ * (MMH_F32 | MMH_BF16 | MMH_FP16).  Under --opt_level O1 the tensors that face a convolution
+ * (its output, its input, both gradients) are 16-bit, as under apex; statistics, scale / shift,
+ * sums and all arithmetic stay fp32.                                        */
 
 /* Per-(group,channel) mean and M2 = sum (x-mean)^2.  groups = B for instance
  * norm (rows_per_group = H*W), 1 for batch norm (rows_per_group = B*H*W).   */
 size_t mmh_norm_stats_ws_bytes(int groups, int64_t rows_per_group, int C);
 int mmh_norm_stats(const void* x, int groups, int64_t rows_per_group, int C,
                    int cs, void* mean, void* m2, void* ws, size_t ws_bytes,
-                   mmh_stream_t s);
+                   int x_dtype, mmh_stream_t s);
 
 /* Chan merge of `chunks` partial (count, mean, M2) triples per (group, channel), laid out
  * [groups][chunks][3][C] (what mmh_wino_output(stats) writes): the second stage of mmh_norm_stats. */
@@ -244,8 +250,8 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count,
                       float momentum, mmh_stream_t s);
 
 /* out = dropout(relu(x*scale[g][c] + shift[g][c])) (+ residual).  scale and
- * shift are [groups][C].  Dropout keeps an element when the counter-based
- * hash of (seed, element index) < keep threshold and scales by 1/(1-p);
+ * shift are [groups][C].  Dropout keeps an element when a counter-based hash
+ * of (seed, element position) clears the drop threshold and scales by 1/(1-p);
  * if mask != NULL (uint8 per element, test hook) it is used instead.
  * keep_bits != NULL (uint8 per 4 channels): bit e = lane e survived ReLU / dropout -
  * all the backward needs of `out`, at 1/16 of its bytes.
@@ -255,7 +261,7 @@ int mmh_scale_shift_act(const void* x, const void* scale, const void* shift,
                         const void* residual, void* out, int groups,
                         int64_t rows_per_group, int C, int relu, float drop_p,
                         uint64_t seed, const void* mask, void* keep_bits,
-                        int out_dtype, mmh_stream_t s);
+                        int x_dtype, int out_dtype, mmh_stream_t s);
 
 /* Backward of norm+relu+dropout.  dz = g * (relu||drop ? (out>0)/(1-p) : 1).
  * masked: 0 = no ReLU / dropout (`out` unused), 1 = `out` is the fp32 forward output,
@@ -267,13 +273,13 @@ int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x,
                         const void* mean, const void* invstd, int groups,
                         int64_t rows_per_group, int C, int masked,
                         float drop_p, void* s1, void* s2, void* ws,
-                        size_t ws_bytes, mmh_stream_t s);
+                        size_t ws_bytes, int g_dtype, int x_dtype, mmh_stream_t s);
 int mmh_norm_bwd_apply(const void* g, const void* out, const void* x,
                        const void* mean, const void* invstd,
                        const void* gamma, const void* s1, const void* s2,
                        double count, int groups, int64_t rows_per_group,
                        int C, int masked, float drop_p, void* dx,
-                       mmh_stream_t s);
+                       int g_dtype, int x_dtype, int dx_dtype, mmh_stream_t s);
 
 /* dx = g * act'(y): relu -> (y>0), tanh -> 1-y^2 (Generator.py:259 head).   */
 int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
@@ -282,15 +288,18 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
 /* ---- PATBlock gate + concat (models/Generator.py:115-130) -----------------
  * out = x1 + s1*sigmoid(s2)*sigmoid(s3);  x2n = cat(s3,out); x3n = cat(s2,out)
  * x1,s1,s2,s3,out: [rows][C];  x2n,x3n: [rows][2C] (NULL -> not produced).
- * cat_dtype: element type of x2n / x3n (MMH_F32 | MMH_BF16 | MMH_FP16); `out` is always fp32. */
+ * cat_dtype: element type of x2n / x3n, s23_dtype: of s2 / s3 (conv outputs)
+ * (MMH_F32 | MMH_BF16 | MMH_FP16); x1, s1 and `out` are always fp32.        */
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2,
                           const void* s3, void* out, void* x2n, void* x3n,
-                          int64_t rows, int C, int cat_dtype, mmh_stream_t s);
-/* g_out/g_x2n/g_x3n may be NULL (treated as zero).                          */
+                          int64_t rows, int C, int cat_dtype, int s23_dtype, mmh_stream_t s);
+/* g_out/g_x2n/g_x3n may be NULL (treated as zero).  gcat_dtype: element type of g_x2n / g_x3n
+ * (gradients from 16-bit convolutions), s23_dtype: of s2 / s3, gs23_dtype: of g_s2 / g_s3. */
 int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n,
                           const void* g_x3n, const void* s1, const void* s2,
                           const void* s3, void* g_x1, void* g_s1, void* g_s2,
-                          void* g_s3, int64_t rows, int C, mmh_stream_t s);
+                          void* g_s3, int64_t rows, int C, int gcat_dtype, int s23_dtype,
+                          int gs23_dtype, mmh_stream_t s);
 
 /* ---- losses ----------------------------------------------------------------
  * GANLoss = BCEWithLogits vs a constant target, mean (network_utils.py:129-163)

@@ -121,6 +121,7 @@ struct ConvKP {
     int xcd_remap;              // remap (blockIdx.y, blockIdx.x) so column tiles of a row tile share an XCD
     int accum;                  // epilogue adds into out instead of overwriting it
     int h16;                    // 16-bit kernels: 0 = bf16, 1 = fp16 operands
+    int src16;                  // 16-bit kernels: the gathered tensor is already 16-bit in HBM (chunk-major k order only)
 };
 
 struct KState { int th, tw, c4, j; };   // j: chunk index inside the current tap visit
@@ -154,6 +155,7 @@ __device__ __forceinline__ bool kstate_valid(const KState& s, const Gather& g) {
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;   // byte offset beyond any buffer: the load returns zeros
 
 // 16-byte buffer load: an out-of-range offset yields zeros, so padding, ragged tiles and the
@@ -1150,9 +1152,19 @@ __device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const in
 #pragma unroll
             for (int i = 0; i < 8; ++i) a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], s, a_ok[i]);
         }
-        const unsigned coff = (unsigned)(cc * 16 + grp) * 16u;      // bytes: 4 fp32 channels per group
+        if (p.src16) {      // 16-bit source: half the byte offsets, 8 bytes per group of 4 channels
+            const unsigned coff = (unsigned)(cc * 16 + grp) * 8u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ra[i] = bload4(rsA, a_off[i] != OOB ? a_off[i] + coff : OOB);
+            for (int i = 0; i < 8; ++i) {
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, a_off[i] != OOB ? (a_off[i] >> 1) + coff : OOB, 0, 0);
+                ra[i].x = __uint_as_float(r[0]);
+                ra[i].y = __uint_as_float(r[1]);
+            }
+        } else {
+            const unsigned coff = (unsigned)(cc * 16 + grp) * 16u;      // bytes: 4 fp32 channels per group
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra[i] = bload4(rsA, a_off[i] != OOB ? a_off[i] + coff : OOB);
+        }
         const int tap_true = (p.kh0 + p.tstep * th) * p.KW_true + p.kw0 + p.tstep * tw;
         const unsigned tap_off = ((unsigned)tap_true * (unsigned)p.wRows * (unsigned)p.wKper +
                                   (unsigned)(cc * 64 + bgrp * 8)) * 2u;
@@ -1178,8 +1190,13 @@ __device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const in
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_lp4<H16>(ra[i]);
+        for (int i = 0; i < 8; ++i) {
+            if (p.src16)
+                *reinterpret_cast<uint2*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) =
+                    make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+            else
+                *reinterpret_cast<bf16x4*>(&As[((tid >> 4) + 16 * i) * LDH + grp * 4]) = to_lp4<H16>(ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
             *reinterpret_cast<uint4*>(&Bs[((tid >> 3) + 32 * i) * LDH + bgrp * 8]) = rb[i];
@@ -1278,7 +1295,8 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_bf16_multi_kernel(const Mul
 // dx += the border terms produced by the multi-piece dgrad launch.  One thread per (target
 // pixel, 4 channels); every target sums its terms in a fixed order (deterministic).
 // scratch: rows [B][2][W][C], cols [B][H][2][C], corners [B][4][C].
-__global__ void border_add_kernel(float* __restrict__ dx, const float* __restrict__ rows,
+template <int LP>
+__global__ void border_add_kernel(void* __restrict__ dx, const float* __restrict__ rows,
                                   const float* __restrict__ cols, const float* __restrict__ corners,
                                   int B, int H, int W, int C4) {
     const int nr = (H - 2 == 1) ? 1 : 2, nc = (W - 2 == 1) ? 1 : 2;
@@ -1313,10 +1331,10 @@ __global__ void border_add_kernel(float* __restrict__ dx, const float* __restric
         if (i == 1 && j == W - 2) add(corners, ((int64_t)b * 4 + 1) * C4 + c);
         if (i == H - 2 && j == 1) add(corners, ((int64_t)b * 4 + 2) * C4 + c);
         if (i == H - 2 && j == W - 2) add(corners, ((int64_t)b * 4 + 3) * C4 + c);
-        float4* o = reinterpret_cast<float4*>(dx) + (((int64_t)b * H + i) * W + j) * C4 + c;
-        float4 v = *o;
+        const int64_t o = (((int64_t)b * H + i) * W + j) * C4 + c;
+        float4 v = wld4<LP>(dx, o);
         v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-        *o = v;
+        wst4<LP>(dx, o, v);
     }
 }
 
@@ -2359,7 +2377,7 @@ size_t reflect1_ws_bytes(const mmh_conv_desc* d) {
 int g_border_bn64 = 1;  // border-only dgrad launches (Winograd path): 64-wide tiles
 // phase: bit 0 = the GEMMs (border pieces into ws, main term into dx), bit 1 = border_add (ws -> dx)
 int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
-                      hipStream_t st, bool with_main = true, int phase = 3) {
+                      hipStream_t st, bool with_main = true, int phase = 3, bool dy16 = false, bool dx16 = false) {
     const int H = d->H, W = d->W, C = d->Cin;
     const bool bf16 = is16(d->dtype);
     float* rows = static_cast<float*>(ws);                       // [B][2][W][C]
@@ -2370,7 +2388,8 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
         ConvKP p{};
         Gather& g = p.g;
         g.src = static_cast<const float*>(dy);
-        g.src_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->y_cs * sizeof(float));
+        g.src_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->y_cs * (dy16 ? 2 : sizeof(float)));
+        p.src16 = dy16 ? 1 : 0;
         g.srcH = d->Ho; g.srcW = d->Wo; g.src_cs = (unsigned)d->y_cs;
         g.PH = PH; g.PW = PW; g.TH = TH; g.TW = TW;
         g.C4 = d->Cout / 4;
@@ -2439,8 +2458,12 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     const int nr = (H - 2 == 1) ? 1 : 2, nc = (W - 2 == 1) ? 1 : 2;
     const int64_t total = (int64_t)d->B * (nr * W + (H - nr) * nc) * (C / 4);
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
-    hipLaunchKernelGGL(border_add_kernel, dim3(blocks), dim3(256), 0, st, static_cast<float*>(dx), rows, cols,
-                       corners, d->B, H, W, C / 4);
+    if (dx16 && d->dtype == MMH_FP16)
+        hipLaunchKernelGGL(border_add_kernel<2>, dim3(blocks), dim3(256), 0, st, dx, rows, cols, corners, d->B, H, W, C / 4);
+    else if (dx16)
+        hipLaunchKernelGGL(border_add_kernel<1>, dim3(blocks), dim3(256), 0, st, dx, rows, cols, corners, d->B, H, W, C / 4);
+    else
+        hipLaunchKernelGGL(border_add_kernel<0>, dim3(blocks), dim3(256), 0, st, dx, rows, cols, corners, d->B, H, W, C / 4);
     return mmh::check_launch("border_add_kernel");
 }
 
@@ -2970,6 +2993,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
     if (!strcmp(key, "lp16_shape")) { mmh::g_lp16_shape = value; return 0; }
     if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
+    if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_levels")) { g_wino_gemm_levels = value; return 0; }
@@ -3312,7 +3336,7 @@ int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accum
 size_t mmh_conv2d_dgrad_border_ws_bytes(const mmh_conv_desc* d) { return d ? reflect1_ws_bytes(d) : 0; }
 
 int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws,
-                            size_t ws_bytes, int phase, mmh_stream_t s) {
+                            size_t ws_bytes, int phase, int io16, mmh_stream_t s) {
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == MMH_PAD_REFLECT &&
                     d->H >= 3 && d->W >= 3 && d->x_cs == d->Cin,
@@ -3320,7 +3344,8 @@ int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* 
     MMH_REQUIRE(phase >= 1 && phase <= 3, "mmh_conv2d_dgrad_border: phase must be 1 (GEMMs), 2 (add) or 3 (both)");
     MMH_REQUIRE(dy && w && (dx || !(phase & 2)) && ws && ws_bytes >= reflect1_ws_bytes(d),
                 "mmh_conv2d_dgrad_border: bad buffers");
-    return do_dgrad_reflect1(d, dy, w, dx, ws, mmh::as_stream(s), false, phase);
+    MMH_REQUIRE(!io16 || (is16(d->dtype) && d->y_cs == d->Cout), "mmh_conv2d_dgrad_border: io16 needs a 16-bit dtype and dense dy");
+    return do_dgrad_reflect1(d, dy, w, dx, ws, mmh::as_stream(s), false, phase, (io16 & 1) != 0, (io16 & 2) != 0);
 }
 
 size_t mmh_conv2d_dgrad_folded_ws_bytes(const mmh_conv_desc* d) {

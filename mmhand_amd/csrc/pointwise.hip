@@ -8,6 +8,8 @@
 #include <cmath>
 #include "common.h"
 
+namespace mmh { int g_pw_v2 = 1; }   // mmh_set_option("pw_v2"): 0 = first-generation pointwise kernels (A/B)
+
 namespace {
 
 constexpr int TPB = 256;
@@ -36,6 +38,18 @@ __device__ __forceinline__ void st4_lp(void* p, int64_t i4, float4 v, int lp) {
     }
 }
 
+// load 4 values stored as fp32 (lp = 0), bf16 (1) or fp16 (2); i4 indexes groups of 4 elements
+__device__ __forceinline__ float4 ld4_lp(const void* p, int64_t i4, int lp) {
+    if (lp == 1) {
+        const pw_bf16x4 r = reinterpret_cast<const pw_bf16x4*>(p)[i4];
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    } else if (lp == 2) {
+        const pw_f16x4 r = reinterpret_cast<const pw_f16x4*>(p)[i4];
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    return reinterpret_cast<const float4*>(p)[i4];
+}
+
 inline int grid_for(int64_t work_items, int cap = 4096) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(mmh::cdiv(work_items, TPB), cap));
 }
@@ -60,7 +74,7 @@ inline ColGeom col_geom(int groups, int64_t rows, int C) {
 
 // ------------------------------------------------------------------ norm statistics
 // partial layout: ws[((grp*chunks + chunk)*3 + {0:n,1:mean,2:M2})*C + c]
-__global__ void norm_stats_partial(const float* __restrict__ x, int64_t rows, int C, int cs,
+__global__ void norm_stats_partial(const void* __restrict__ x, int xlp, int64_t rows, int C, int cs,
                                    ColGeom cg, float* __restrict__ ws) {
     __shared__ float sh[3][TPB * 4];
     const int tid = threadIdx.x;
@@ -71,9 +85,10 @@ __global__ void norm_stats_partial(const float* __restrict__ x, int64_t rows, in
     float4 K = make_float4(0, 0, 0, 0), s = K, ss = K;
     float n = 0.f;
     if (rsub < cg.rpi) {
-        const float* base = x + (int64_t)grp * rows * cs + q * 4;
+        const int64_t base4 = ((int64_t)grp * rows * cs) / 4 + q;
+        const int cs4 = cs / 4;
         for (int64_t r = r0 + rsub; r < r1; r += cg.rpi) {
-            float4 v = *reinterpret_cast<const float4*>(base + r * cs);
+            float4 v = ld4_lp(x, base4 + r * cs4, xlp);
             if (n == 0.f) K = v;
             float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
             s.x += dx; s.y += dy; s.z += dz; s.w += dw;
@@ -201,7 +216,15 @@ __device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
     return (uint32_t)(z >> 32);
 }
 
-__global__ void scale_shift_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+// all 64 bits of the same finalizer: four 16-bit uniforms per hash (second-generation dropout)
+__device__ __forceinline__ uint64_t mix_u64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void scale_shift_act_kernel(const void* __restrict__ x, int in_lp, const float* __restrict__ scale,
                                        const float* __restrict__ shift,
                                        const float* __restrict__ residual, void* __restrict__ out,
                                        int64_t n4, int64_t rows_per_group, int C4, int relu,
@@ -216,7 +239,7 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
         int64_t row = i / C4;
         int c4 = (int)(i - row * C4);
         int64_t grp = row / rows_per_group;
-        float4 v = ld4(x, i);
+        float4 v = ld4_lp(x, i, in_lp);
         float4 sc = ld4(scale, grp * C4 + c4), sf = ld4(shift, grp * C4 + c4);
         float r[4] = {v.x * sc.x + sf.x, v.y * sc.y + sf.y, v.z * sc.z + sf.z, v.w * sc.w + sf.w};
         if (relu) {
@@ -240,13 +263,403 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
     }
 }
 
+// ------------------------------------------------------------------ second-generation row kernels
+// The first-generation kernels above keep one 16-byte (fp32) or 8-byte (16-bit) load per lane in
+// flight: ~16-32 KB per CU, against the ~50 KB per CU that 6 TB/s x the loaded HBM latency needs
+// (Little's law) - they measured 2.8-4.8 TB/s.  These handle 8 channels per lane (16 B of a 16-bit
+// tensor, 32 B of fp32) and issue the loads of UNR rows before using any of them; the thread's
+// column group is fixed (no per-element division, scale / shift / mean / invstd live in registers).
+// Geometry: block = 256 threads = (256 / C8) rows x C8 column groups, C8 = C / 8 a power of two <= 256;
+// grid = (row chunks, groups).
+constexpr int UNR = 4;
+struct f8 { float v[8]; };
+typedef __bf16 pw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pw_f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool W16>
+__device__ __forceinline__ f8 ld8(const void* p, int64_t i8, bool h16) {
+    f8 r;
+    if (W16) {
+        if (h16) {
+            const pw_f16x8 t = reinterpret_cast<const pw_f16x8*>(p)[i8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r.v[e] = (float)t[e];
+        } else {
+            const uint4 t = reinterpret_cast<const uint4*>(p)[i8];
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r.v[2 * e] = __uint_as_float(w[e] << 16);
+                r.v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+    } else {
+        const float4 a = reinterpret_cast<const float4*>(p)[2 * i8], b = reinterpret_cast<const float4*>(p)[2 * i8 + 1];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    }
+    return r;
+}
+template <bool W16>
+__device__ __forceinline__ void st8(void* p, int64_t i8, const f8& r, bool h16) {
+    if (W16) {
+        if (h16) {
+            pw_f16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (_Float16)r.v[e];
+            reinterpret_cast<pw_f16x8*>(p)[i8] = t;
+        } else {
+            pw_bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (__bf16)r.v[e];
+            reinterpret_cast<pw_bf16x8*>(p)[i8] = t;
+        }
+    } else {
+        reinterpret_cast<float4*>(p)[2 * i8] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        reinterpret_cast<float4*>(p)[2 * i8 + 1] = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    }
+}
+
+// a lane's 8 channels as loaded (16 or 32 bytes): kept packed until used, so that UNR rows in flight
+// cost 4 (16-bit) or 8 (fp32) registers each and the kernels keep 6-8 waves per SIMD
+template <bool W16> struct Raw8;
+template <> struct Raw8<true> { uint4 a; };
+template <> struct Raw8<false> { float4 a, b; };
+__device__ __forceinline__ void ldraw(Raw8<true>& r, const void* p, int64_t i8) {
+    r.a = reinterpret_cast<const uint4*>(p)[i8];
+}
+__device__ __forceinline__ void ldraw(Raw8<false>& r, const void* p, int64_t i8) {
+    r.a = reinterpret_cast<const float4*>(p)[2 * i8];
+    r.b = reinterpret_cast<const float4*>(p)[2 * i8 + 1];
+}
+__device__ __forceinline__ f8 widen(const Raw8<true>& t, bool h16) {
+    f8 r;
+    const unsigned w[4] = {t.a.x, t.a.y, t.a.z, t.a.w};
+    if (h16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const h2 v = __builtin_bit_cast(h2, w[e]);
+            r.v[2 * e] = (float)v[0];
+            r.v[2 * e + 1] = (float)v[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r.v[2 * e] = __uint_as_float(w[e] << 16);
+            r.v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        }
+    }
+    return r;
+}
+__device__ __forceinline__ f8 widen(const Raw8<false>& t, bool) {
+    f8 r;
+    r.v[0] = t.a.x; r.v[1] = t.a.y; r.v[2] = t.a.z; r.v[3] = t.a.w;
+    r.v[4] = t.b.x; r.v[5] = t.b.y; r.v[6] = t.b.z; r.v[7] = t.b.w;
+    return r;
+}
+
+struct RowGeom {
+    int c8, rpi, chunks;
+    int64_t rows_per_chunk;
+};
+inline bool row_geom_ok(int C) {
+    const int c8 = C / 8;
+    return C % 8 == 0 && c8 >= 1 && c8 <= TPB && (c8 & (c8 - 1)) == 0;
+}
+inline RowGeom row_geom(int groups, int64_t rows, int C) {
+    RowGeom g;
+    g.c8 = C / 8;
+    g.rpi = TPB / g.c8;
+    const int64_t step = (int64_t)g.rpi * UNR;                  // rows one block covers per iteration
+    const int64_t want = std::max<int64_t>(1, 4096 / std::max(groups, 1));
+    const int64_t maxc = std::max<int64_t>(1, rows / (2 * step));
+    g.chunks = (int)std::min(want, maxc);
+    g.rows_per_chunk = mmh::cdiv(mmh::cdiv(rows, g.chunks), step) * step;
+    g.chunks = (int)mmh::cdiv(rows, g.rows_per_chunk);
+    return g;
+}
+
+template <bool XW, bool OW, bool EXTRA>      // EXTRA: residual and / or the test mask present
+__global__ void __launch_bounds__(TPB) scale_shift_act_v2(
+        const void* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+        const float* __restrict__ residual, void* __restrict__ out, int64_t rows, RowGeom rg, int relu,
+        float drop_p, uint64_t seed, const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits,
+        bool xh16, bool oh16) {
+    const int q = threadIdx.x & (rg.c8 - 1), rsub = threadIdx.x / rg.c8;
+    const int grp = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rg.rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rg.rows_per_chunk);
+    const f8 sc = ld8<false>(scale, (int64_t)grp * rg.c8 + q, false);
+    const f8 sf = ld8<false>(shift, (int64_t)grp * rg.c8 + q, false);
+    // dropout: keep iff a 16-bit uniform >= thr16 (p = 0.5 exactly; other p to 1/65536); two hashes
+    // of (seed, group-of-8 index) give the eight uniforms of a lane's channels
+    const uint32_t thr16 = drop_p > 0.f ? (uint32_t)((double)drop_p * 65536.0) : 0u;
+    const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const int64_t gbase = (int64_t)grp * rows;
+    for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rg.rpi * UNR) {
+        Raw8<XW> xr[UNR];
+        Raw8<false> rv[EXTRA ? UNR : 1];
+        uint2 mk[EXTRA ? UNR : 1];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr < r1) {
+                const int64_t i8 = (gbase + rr) * rg.c8 + q;
+                ldraw(xr[u], x, i8);
+                if (EXTRA && residual) ldraw(rv[u], residual, i8);
+                if (EXTRA && mask) mk[u] = reinterpret_cast<const uint2*>(mask)[i8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr >= r1) continue;
+            const int64_t i8 = (gbase + rr) * rg.c8 + q;
+            const f8 xv = widen(xr[u], xh16);
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = xv.v[e] * sc.v[e] + sf.v[e];
+                if (relu) t = t > 0.f ? t : 0.f;
+                o.v[e] = t;
+            }
+            if (drop_p > 0.f) {
+                uint64_t h0 = 0, h1 = 0;
+                if (!(EXTRA && mask)) {
+                    h0 = mix_u64(seed, (uint64_t)i8 * 2);
+                    h1 = mix_u64(seed, (uint64_t)i8 * 2 + 1);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint2 m2 = mk[EXTRA ? u : 0];
+                    const unsigned mb = e < 4 ? (m2.x >> (8 * e)) & 0xffu : (m2.y >> (8 * (e - 4))) & 0xffu;
+                    const unsigned uf = (unsigned)((e < 4 ? h0 >> (16 * e) : h1 >> (16 * (e - 4))) & 0xffffu);
+                    const bool keep = (EXTRA && mask) ? (mb != 0) : (uf >= thr16);
+                    o.v[e] = keep ? o.v[e] * dsc : 0.f;
+                }
+            }
+            if (keep_bits) {
+                unsigned lo = 0, hi = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo |= (o.v[e] > 0.f ? 1u : 0u) << e;
+                    hi |= (o.v[4 + e] > 0.f ? 1u : 0u) << e;
+                }
+                reinterpret_cast<uint16_t*>(keep_bits)[i8] = (uint16_t)(lo | (hi << 8));
+            }
+            if (EXTRA && residual) {
+                const f8 q8 = widen(rv[EXTRA ? u : 0], false);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] += q8.v[e];
+            }
+            st8<OW>(out, i8, o, oh16);
+        }
+    }
+}
+
+// norm statistics, second generation: same chunks and partial layout as norm_stats_partial
+// (ws[((grp*chunks + chunk)*3 + {n,mean,M2})*C + c]); block = (256/C8 rows) x (C8 groups of 8 channels)
+template <bool XW>
+__global__ void __launch_bounds__(TPB) norm_stats_partial_v2(const void* __restrict__ x, bool xh16, int64_t rows,
+                                                             int C, int c8, int rpi, int chunks,
+                                                             int64_t rows_per_chunk, float* __restrict__ ws) {
+    __shared__ float sh[3][TPB * 8];
+    const int tid = threadIdx.x;
+    const int q = tid & (c8 - 1), rsub = tid / c8;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rows_per_chunk);
+    const int64_t gbase = (int64_t)grp * rows;
+    float K[8], sm[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { K[e] = 0.f; sm[e] = 0.f; ss[e] = 0.f; }
+    float n = 0.f;
+    for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rpi * UNR) {
+        Raw8<XW> xr[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rpi;
+            if (rr < r1) ldraw(xr[u], x, (gbase + rr) * c8 + q);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (r + (int64_t)u * rpi >= r1) continue;
+            const f8 xv = widen(xr[u], xh16);
+            if (n == 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) K[e] = xv.v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv.v[e] - K[e];
+                sm[e] += d;
+                ss[e] += d * d;
+            }
+            n += 1.f;
+        }
+    }
+    const float inv = n > 0.f ? 1.f / n : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float m2 = ss[e] - sm[e] * sm[e] * inv;
+        sh[0][tid * 8 + e] = n;
+        sh[1][tid * 8 + e] = K[e] + sm[e] * inv;
+        sh[2][tid * 8 + e] = m2 > 0.f ? m2 : 0.f;
+    }
+    __syncthreads();
+    // the first 8*c8 threads each finish one channel: Chan merge over the rpi row lanes, fixed order
+    for (int t = tid; t < 8 * c8; t += TPB) {
+        const int qq = t >> 3, e = t & 7;
+        float na = sh[0][qq * 8 + e], ma = sh[1][qq * 8 + e], qa = sh[2][qq * 8 + e];
+        for (int j = 1; j < rpi; ++j) {
+            const int o = (j * c8 + qq) * 8 + e;
+            const float nb = sh[0][o], mb = sh[1][o], qb = sh[2][o];
+            if (nb > 0.f) {
+                const float nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+        const int64_t o = ((int64_t)(grp * chunks + chunk) * 3) * C + qq * 8 + e;
+        ws[o] = na; ws[o + C] = ma; ws[o + 2 * C] = qa;
+    }
+}
+
+// column reductions, second generation (MODE as in col_reduce_partial below; same partial layout)
+template <int MODE, bool AW, bool XW>
+__global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
+        const void* __restrict__ a, bool ah16, const uint8_t* __restrict__ bits, const void* __restrict__ x,
+        bool xh16, const float* __restrict__ mean, const float* __restrict__ invstd, int64_t rows, int C, int c8,
+        int rpi, int chunks, int64_t rows_per_chunk, int masked, float dsc, float* __restrict__ ws) {
+    constexpr int NOUT = MODE == 0 ? 1 : 2;
+    __shared__ float sh[NOUT][TPB * 8];
+    const int tid = threadIdx.x;
+    const int q = tid & (c8 - 1), rsub = tid / c8;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rows_per_chunk);
+    const int64_t gbase = (int64_t)grp * rows;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    f8 mu, is;
+    if (MODE == 1) {
+        mu = ld8<false>(mean, (int64_t)grp * c8 + q, false);
+        is = ld8<false>(invstd, (int64_t)grp * c8 + q, false);
+    }
+    for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rpi * UNR) {
+        Raw8<AW> gr[UNR];
+        Raw8<XW> xr[MODE == 1 ? UNR : 1];
+        unsigned kb[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rpi;
+            if (rr < r1) {
+                const int64_t i8 = (gbase + rr) * c8 + q;
+                ldraw(gr[u], a, i8);
+                if (MODE == 1) {
+                    ldraw(xr[u], x, i8);
+                    if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (r + (int64_t)u * rpi >= r1) continue;
+            const f8 gv = widen(gr[u], ah16);
+            f8 xv;
+            if (MODE == 1) xv = widen(xr[MODE == 1 ? u : 0], xh16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = gv.v[e];
+                if (MODE == 1) {
+                    if (masked) gg = (kb[u] >> (e < 4 ? e : e + 4)) & 1u ? gg * dsc : 0.f;
+                    s2[e] += gg * ((xv.v[e] - mu.v[e]) * is.v[e]);
+                }
+                s1[e] += gg;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sh[0][tid * 8 + e] = s1[e];
+        if (NOUT == 2) sh[NOUT - 1][tid * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int t = tid; t < 8 * c8; t += TPB) {
+        const int qq = t >> 3, e = t & 7;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float acc = sh[o][qq * 8 + e];
+            for (int j = 1; j < rpi; ++j) acc += sh[o][(j * c8 + qq) * 8 + e];
+            ws[((int64_t)(grp * chunks + chunk) * NOUT + o) * C + qq * 8 + e] = acc;
+        }
+    }
+}
+
+template <bool GW, bool XW, bool DW>
+__global__ void __launch_bounds__(TPB) norm_bwd_apply_v2(
+        const void* __restrict__ g, bool gh16, const uint8_t* __restrict__ bits, const void* __restrict__ x,
+        bool xh16, const float* __restrict__ mean, const float* __restrict__ invstd,
+        const float* __restrict__ gamma, const float* __restrict__ s1, const float* __restrict__ s2,
+        float inv_count, int64_t rows, RowGeom rg, int masked, float dsc, void* __restrict__ dx, bool dh16) {
+    const int q = threadIdx.x & (rg.c8 - 1), rsub = threadIdx.x / rg.c8;
+    const int grp = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rg.rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rg.rows_per_chunk);
+    const int64_t gi = (int64_t)grp * rg.c8 + q;
+    const f8 mu = ld8<false>(mean, gi, false), is = ld8<false>(invstd, gi, false);
+    const f8 a1 = ld8<false>(s1, gi, false), a2 = ld8<false>(s2, gi, false);
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float gm = gamma ? gamma[q * 8 + e] : 1.f;
+        k0[e] = gm * is.v[e];
+        k1[e] = a1.v[e] * inv_count;
+        k2[e] = k0[e] * is.v[e] * (a2.v[e] * inv_count);
+    }
+    const int64_t gbase = (int64_t)grp * rows;
+    for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rg.rpi * UNR) {
+        Raw8<GW> gr[UNR];
+        Raw8<XW> xr[UNR];
+        unsigned kb[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr < r1) {
+                const int64_t i8 = (gbase + rr) * rg.c8 + q;
+                ldraw(gr[u], g, i8);
+                ldraw(xr[u], x, i8);
+                if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr >= r1) continue;
+            const f8 gv = widen(gr[u], gh16), xv = widen(xr[u], xh16);
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float gg = gv.v[e];
+                if (masked) gg = (kb[u] >> (e < 4 ? e : e + 4)) & 1u ? gg * dsc : 0.f;
+                // dx = k0*(dz - s1/count) - xhat*k0*s2/count, xhat = (x-mu)*invstd
+                o.v[e] = k0[e] * (gg - k1[e]) - (xv.v[e] - mu.v[e]) * k2[e];
+            }
+            st8<DW>(dx, (gbase + rr) * rg.c8 + q, o, dh16);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ column reductions
 // MODE 0: colsum(x)            -> 1 output  (conv-bias gradient)
 // MODE 1: norm backward sums   -> 2 outputs (s1 = sum dz, s2 = sum dz*xhat)
 // partial layout: ws[((grp*chunks + chunk)*NOUT + o)*C + c]
 template <int MODE>
-__global__ void col_reduce_partial(const float* __restrict__ a, const float* __restrict__ outv,
-                                   const float* __restrict__ x, const float* __restrict__ mean,
+__global__ void col_reduce_partial(const void* __restrict__ a, int alp, const float* __restrict__ outv,
+                                   const void* __restrict__ x, int xlp, const float* __restrict__ mean,
                                    const float* __restrict__ invstd, int64_t rows, int C, int cs,
                                    int masked, float dsc, ColGeom cg, float* __restrict__ ws) {
     constexpr int NOUT = MODE == 0 ? 1 : 2;
@@ -266,7 +679,7 @@ __global__ void col_reduce_partial(const float* __restrict__ a, const float* __r
         }
         for (int64_t r = r0 + rsub; r < r1; r += cg.rpi) {
             const int64_t off = (gbase + r) * cs + q * 4;
-            float4 g = *reinterpret_cast<const float4*>(a + off);
+            float4 g = ld4_lp(a, off >> 2, alp);
             float gv[4] = {g.x, g.y, g.z, g.w};
             if (MODE == 1) {
                 if (masked == 2) {      // 4 keep bits per float4 (mmh_scale_shift_act keep_bits)
@@ -280,7 +693,7 @@ __global__ void col_reduce_partial(const float* __restrict__ a, const float* __r
                     gv[2] = o.z > 0.f ? gv[2] * dsc : 0.f;
                     gv[3] = o.w > 0.f ? gv[3] * dsc : 0.f;
                 }
-                float4 xv = *reinterpret_cast<const float4*>(x + off);
+                float4 xv = ld4_lp(x, off >> 2, xlp);
                 float xh[4] = {(xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z,
                                (xv.w - mu.w) * is.w};
 #pragma unroll
@@ -353,20 +766,20 @@ __global__ void col_reduce_final(const float* __restrict__ ws, int groups, int C
     }
 }
 
-__global__ void norm_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ outv,
-                                      const float* __restrict__ x, const float* __restrict__ mean,
+__global__ void norm_bwd_apply_kernel(const void* __restrict__ g, int glp, const float* __restrict__ outv,
+                                      const void* __restrict__ x, int xlp, const float* __restrict__ mean,
                                       const float* __restrict__ invstd,
                                       const float* __restrict__ gamma, const float* __restrict__ s1,
                                       const float* __restrict__ s2, float inv_count, int64_t n4,
                                       int64_t rows_per_group, int C4, int masked, float dsc,
-                                      float* __restrict__ dx) {
+                                      void* __restrict__ dx, int dxlp) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         int64_t row = i / C4;
         int c4 = (int)(i - row * C4);
         int64_t gi = (row / rows_per_group) * C4 + c4;
-        float4 gv4 = ld4(g, i), xv = ld4(x, i), mu = ld4(mean, gi), is = ld4(invstd, gi);
+        float4 gv4 = ld4_lp(g, i, glp), xv = ld4_lp(x, i, xlp), mu = ld4(mean, gi), is = ld4(invstd, gi);
         float4 a1 = ld4(s1, gi), a2 = ld4(s2, gi);
         float4 gm = gamma ? ld4(gamma, c4) : make_float4(1.f, 1.f, 1.f, 1.f);
         float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
@@ -386,7 +799,7 @@ __global__ void norm_bwd_apply_kernel(const float* __restrict__ g, const float* 
         r.y = gm.y * is.y * (gv[1] - a1.y * inv_count - (xv.y - mu.y) * is.y * a2.y * inv_count);
         r.z = gm.z * is.z * (gv[2] - a1.z * inv_count - (xv.z - mu.z) * is.z * a2.z * inv_count);
         r.w = gm.w * is.w * (gv[3] - a1.w * inv_count - (xv.w - mu.w) * is.w * a2.w * inv_count);
-        st4(dx, i, r);
+        st4_lp(dx, i, r, dxlp);
     }
 }
 
@@ -409,13 +822,13 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
 
 // ------------------------------------------------------------------ PATBlock gate
 __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ s1,
-                                const float* __restrict__ s2, const float* __restrict__ s3,
+                                const void* __restrict__ s2, const void* __restrict__ s3,
                                 float* __restrict__ out, void* __restrict__ x2n,
-                                void* __restrict__ x3n, int64_t n4, int C4, int cat_lp) {
+                                void* __restrict__ x3n, int64_t n4, int C4, int cat_lp, int s_lp) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
-        float4 a = ld4(x1, i), b = ld4(s1, i), c = ld4(s2, i), d = ld4(s3, i), o;
+        float4 a = ld4(x1, i), b = ld4(s1, i), c = ld4_lp(s2, i, s_lp), d = ld4_lp(s3, i, s_lp), o;
         o.x = a.x + b.x * sigmoidf_(c.x) * sigmoidf_(d.x);
         o.y = a.y + b.y * sigmoidf_(c.y) * sigmoidf_(d.y);
         o.z = a.z + b.z * sigmoidf_(c.z) * sigmoidf_(d.z);
@@ -432,12 +845,12 @@ __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __res
     }
 }
 
-__global__ void gate_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ g_x2n,
-                                const float* __restrict__ g_x3n, const float* __restrict__ s1,
-                                const float* __restrict__ s2, const float* __restrict__ s3,
+__global__ void gate_bwd_kernel(const float* __restrict__ g_out, const void* __restrict__ g_x2n,
+                                const void* __restrict__ g_x3n, const float* __restrict__ s1,
+                                const void* __restrict__ s2, const void* __restrict__ s3,
                                 float* __restrict__ g_x1, float* __restrict__ g_s1,
-                                float* __restrict__ g_s2, float* __restrict__ g_s3, int64_t n4,
-                                int C4) {
+                                void* __restrict__ g_s2, void* __restrict__ g_s3, int64_t n4,
+                                int C4, int gcat_lp, int s_lp, int gs_lp) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4 z4 = make_float4(0, 0, 0, 0);
@@ -447,16 +860,16 @@ __global__ void gate_bwd_kernel(const float* __restrict__ g_out, const float* __
         float4 G = g_out ? ld4(g_out, i) : z4;
         float4 e2 = z4, e3 = z4;  // direct grads on s2 (via x3n) and s3 (via x2n)
         if (g_x2n) {
-            float4 t = ld4(g_x2n, row * 2 * C4 + C4 + c4);
+            float4 t = ld4_lp(g_x2n, row * 2 * C4 + C4 + c4, gcat_lp);
             G.x += t.x; G.y += t.y; G.z += t.z; G.w += t.w;
-            e3 = ld4(g_x2n, row * 2 * C4 + c4);
+            e3 = ld4_lp(g_x2n, row * 2 * C4 + c4, gcat_lp);
         }
         if (g_x3n) {
-            float4 t = ld4(g_x3n, row * 2 * C4 + C4 + c4);
+            float4 t = ld4_lp(g_x3n, row * 2 * C4 + C4 + c4, gcat_lp);
             G.x += t.x; G.y += t.y; G.z += t.z; G.w += t.w;
-            e2 = ld4(g_x3n, row * 2 * C4 + c4);
+            e2 = ld4_lp(g_x3n, row * 2 * C4 + c4, gcat_lp);
         }
-        float4 b = ld4(s1, i), c = ld4(s2, i), d = ld4(s3, i);
+        float4 b = ld4(s1, i), c = ld4_lp(s2, i, s_lp), d = ld4_lp(s3, i, s_lp);
         float Gv[4] = {G.x, G.y, G.z, G.w}, bv[4] = {b.x, b.y, b.z, b.w};
         float cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
         float e2v[4] = {e2.x, e2.y, e2.z, e2.w}, e3v[4] = {e3.x, e3.y, e3.z, e3.w};
@@ -470,8 +883,8 @@ __global__ void gate_bwd_kernel(const float* __restrict__ g_out, const float* __
         }
         st4(g_x1, i, G);
         st4(g_s1, i, make_float4(r1[0], r1[1], r1[2], r1[3]));
-        st4(g_s2, i, make_float4(r2[0], r2[1], r2[2], r2[3]));
-        st4(g_s3, i, make_float4(r3[0], r3[1], r3[2], r3[3]));
+        st4_lp(g_s2, i, make_float4(r2[0], r2[1], r2[2], r2[3]), gs_lp);
+        st4_lp(g_s3, i, make_float4(r3[0], r3[1], r3[2], r3[3]), gs_lp);
     }
 }
 
@@ -829,6 +1242,8 @@ __global__ void prep_weights_bf16_flat_kernel(const float* __restrict__ w, int t
     }
 }
 
+inline bool is_dtype(int d) { return d == MMH_F32 || d == MMH_BF16 || d == MMH_FP16; }
+
 int check_cols(const char* who, int C) {
     MMH_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024, "%s: C must be a multiple of 4 in (0,1024], got %d",
                 who, C);
@@ -846,15 +1261,26 @@ size_t mmh_norm_stats_ws_bytes(int groups, int64_t rows, int C) {
 }
 
 int mmh_norm_stats(const void* x, int groups, int64_t rows, int C, int cs, void* mean, void* m2,
-                   void* ws, size_t ws_bytes, mmh_stream_t s) {
+                   void* ws, size_t ws_bytes, int x_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_norm_stats", C)) return rc;
+    MMH_REQUIRE(is_dtype(x_dtype), "mmh_norm_stats: x_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(x && mean && m2 && ws && groups > 0 && rows > 0 && cs >= C && cs % 4 == 0,
                 "mmh_norm_stats: bad arguments");
     MMH_REQUIRE(ws_bytes >= mmh_norm_stats_ws_bytes(groups, rows, C), "mmh_norm_stats: workspace too small");
     ColGeom g = col_geom(groups, rows, C);
     hipStream_t st = mmh::as_stream(s);
+    if (mmh::g_pw_v2 && row_geom_ok(C) && cs == C) {
+        const int c8 = C / 8;
+        if (x_dtype != MMH_F32)
+            hipLaunchKernelGGL(norm_stats_partial_v2<true>, dim3(g.chunks, groups), dim3(TPB), 0, st, x,
+                               x_dtype == MMH_FP16, rows, C, c8, TPB / c8, g.chunks, g.rows_per_chunk,
+                               static_cast<float*>(ws));
+        else
+            hipLaunchKernelGGL(norm_stats_partial_v2<false>, dim3(g.chunks, groups), dim3(TPB), 0, st, x, false,
+                               rows, C, c8, TPB / c8, g.chunks, g.rows_per_chunk, static_cast<float*>(ws));
+    } else
     hipLaunchKernelGGL(norm_stats_partial, dim3(g.chunks, groups), dim3(TPB), 0, st,
-                       static_cast<const float*>(x), rows, C, cs, g, static_cast<float*>(ws));
+                       x, x_dtype, rows, C, cs, g, static_cast<float*>(ws));
     hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, st,
                        static_cast<const float*>(ws), groups, C, g.chunks, static_cast<float*>(mean),
                        static_cast<float*>(m2));
@@ -888,16 +1314,38 @@ int mmh_norm_finalize(const void* mean, const void* m2, double count, const void
 
 int mmh_scale_shift_act(const void* x, const void* scale, const void* shift, const void* residual,
                         void* out, int groups, int64_t rows, int C, int relu, float drop_p,
-                        uint64_t seed, const void* mask, void* keep_bits, int out_dtype, mmh_stream_t s) {
+                        uint64_t seed, const void* mask, void* keep_bits, int x_dtype, int out_dtype,
+                        mmh_stream_t s) {
     if (int rc = check_cols("mmh_scale_shift_act", C)) return rc;
     MMH_REQUIRE(x && scale && shift && out && groups > 0 && rows > 0, "mmh_scale_shift_act: bad arguments");
-    MMH_REQUIRE(out_dtype == MMH_F32 || out_dtype == MMH_BF16 || out_dtype == MMH_FP16,
-                "mmh_scale_shift_act: out_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
+    MMH_REQUIRE(is_dtype(x_dtype) && is_dtype(out_dtype),
+                "mmh_scale_shift_act: x_dtype / out_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || relu),
                 "mmh_scale_shift_act: dropout needs 0<=p<1 and a preceding ReLU");
+    if (mmh::g_pw_v2 && row_geom_ok(C)) {
+        const RowGeom rg = row_geom(groups, rows, C);
+        const dim3 grid(rg.chunks, groups);
+        const bool xw = x_dtype != MMH_F32, ow = out_dtype != MMH_F32;
+        const bool extra = residual != nullptr || mask != nullptr;
+#define MMH_SSA(XW, OW)                                                                                        \
+    if (extra) MMH_SSA2(XW, OW, true); else MMH_SSA2(XW, OW, false)
+#define MMH_SSA2(XW, OW, EX)                                                                                   \
+    hipLaunchKernelGGL((scale_shift_act_v2<XW, OW, EX>), grid, dim3(TPB), 0, mmh::as_stream(s), x,            \
+                       static_cast<const float*>(scale), static_cast<const float*>(shift),                    \
+                       static_cast<const float*>(residual), out, rows, rg, relu, drop_p, seed,                \
+                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits),                   \
+                       x_dtype == MMH_FP16, out_dtype == MMH_FP16)
+        if (xw && ow) { MMH_SSA(true, true); }
+        else if (xw) { MMH_SSA(true, false); }
+        else if (ow) { MMH_SSA(false, true); }
+        else { MMH_SSA(false, false); }
+#undef MMH_SSA
+#undef MMH_SSA2
+        return mmh::check_launch("scale_shift_act_v2");
+    }
     const int64_t n4 = (int64_t)groups * rows * (C / 4);
     hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
-                       static_cast<const float*>(x), static_cast<const float*>(scale),
+                       x, x_dtype, static_cast<const float*>(scale),
                        static_cast<const float*>(shift), static_cast<const float*>(residual),
                        out, n4, rows, C / 4, relu, drop_p, seed,
                        static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits), out_dtype);
@@ -913,17 +1361,32 @@ size_t mmh_norm_bwd_ws_bytes(int groups, int64_t rows, int C) {
 int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x, const void* mean,
                         const void* invstd, int groups, int64_t rows, int C, int masked,
                         float drop_p, void* s1, void* s2, void* ws, size_t ws_bytes,
-                        mmh_stream_t s) {
+                        int g_dtype, int x_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_norm_bwd_reduce", C)) return rc;
+    MMH_REQUIRE(is_dtype(g_dtype) && is_dtype(x_dtype), "mmh_norm_bwd_reduce: bad g_dtype / x_dtype");
     MMH_REQUIRE(g && x && mean && invstd && s1 && s2 && ws && (!masked || out),
                 "mmh_norm_bwd_reduce: NULL buffer");
     MMH_REQUIRE(ws_bytes >= mmh_norm_bwd_ws_bytes(groups, rows, C), "mmh_norm_bwd_reduce: workspace too small");
     ColGeom cg = col_geom(groups, rows, C);
     hipStream_t st = mmh::as_stream(s);
     const float dsc = 1.f / (1.f - drop_p);
+    if (mmh::g_pw_v2 && row_geom_ok(C) && masked != 1) {
+        const int c8 = C / 8;
+        const bool gw = g_dtype != MMH_F32, xw = x_dtype != MMH_F32;
+#define MMH_CR(AW, XW)                                                                                        \
+    hipLaunchKernelGGL((col_reduce_partial_v2<1, AW, XW>), dim3(cg.chunks, groups), dim3(TPB), 0, st, g,      \
+                       g_dtype == MMH_FP16, static_cast<const uint8_t*>(out), x, x_dtype == MMH_FP16,         \
+                       static_cast<const float*>(mean), static_cast<const float*>(invstd), rows, C, c8,       \
+                       TPB / c8, cg.chunks, cg.rows_per_chunk, masked, dsc, static_cast<float*>(ws))
+        if (gw && xw) MMH_CR(true, true);
+        else if (gw) MMH_CR(true, false);
+        else if (xw) MMH_CR(false, true);
+        else MMH_CR(false, false);
+#undef MMH_CR
+    } else
     hipLaunchKernelGGL((col_reduce_partial<1>), dim3(cg.chunks, groups), dim3(TPB), 0, st,
-                       static_cast<const float*>(g), static_cast<const float*>(out),
-                       static_cast<const float*>(x), static_cast<const float*>(mean),
+                       g, g_dtype, static_cast<const float*>(out),
+                       x, x_dtype, static_cast<const float*>(mean),
                        static_cast<const float*>(invstd), rows, C, C, masked, dsc, cg,
                        static_cast<float*>(ws));
     hipLaunchKernelGGL(col_reduce_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, st,
@@ -935,18 +1398,43 @@ int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x, const voi
 int mmh_norm_bwd_apply(const void* g, const void* out, const void* x, const void* mean,
                        const void* invstd, const void* gamma, const void* s1, const void* s2,
                        double count, int groups, int64_t rows, int C, int masked, float drop_p,
-                       void* dx, mmh_stream_t s) {
+                       void* dx, int g_dtype, int x_dtype, int dx_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_norm_bwd_apply", C)) return rc;
+    MMH_REQUIRE(is_dtype(g_dtype) && is_dtype(x_dtype) && is_dtype(dx_dtype),
+                "mmh_norm_bwd_apply: bad g_dtype / x_dtype / dx_dtype");
     MMH_REQUIRE(g && x && mean && invstd && s1 && s2 && dx && (!masked || out) && count > 0,
                 "mmh_norm_bwd_apply: bad arguments");
+    if (mmh::g_pw_v2 && row_geom_ok(C) && masked != 1) {
+        const RowGeom rg = row_geom(groups, rows, C);
+        const int sel = (g_dtype != MMH_F32 ? 4 : 0) | (x_dtype != MMH_F32 ? 2 : 0) | (dx_dtype != MMH_F32 ? 1 : 0);
+#define MMH_BA(GW, XW, DW)                                                                                     \
+    hipLaunchKernelGGL((norm_bwd_apply_v2<GW, XW, DW>), dim3(rg.chunks, groups), dim3(TPB), 0,                \
+                       mmh::as_stream(s), g, g_dtype == MMH_FP16, static_cast<const uint8_t*>(out), x,        \
+                       x_dtype == MMH_FP16, static_cast<const float*>(mean), static_cast<const float*>(invstd), \
+                       static_cast<const float*>(gamma), static_cast<const float*>(s1),                       \
+                       static_cast<const float*>(s2), (float)(1.0 / count), rows, rg, masked,                 \
+                       1.f / (1.f - drop_p), dx, dx_dtype == MMH_FP16)
+        switch (sel) {
+            case 0: MMH_BA(false, false, false); break;
+            case 1: MMH_BA(false, false, true); break;
+            case 2: MMH_BA(false, true, false); break;
+            case 3: MMH_BA(false, true, true); break;
+            case 4: MMH_BA(true, false, false); break;
+            case 5: MMH_BA(true, false, true); break;
+            case 6: MMH_BA(true, true, false); break;
+            default: MMH_BA(true, true, true); break;
+        }
+#undef MMH_BA
+        return mmh::check_launch("norm_bwd_apply_v2");
+    }
     const int64_t n4 = (int64_t)groups * rows * (C / 4);
     hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
-                       static_cast<const float*>(g), static_cast<const float*>(out),
-                       static_cast<const float*>(x), static_cast<const float*>(mean),
+                       g, g_dtype, static_cast<const float*>(out),
+                       x, x_dtype, static_cast<const float*>(mean),
                        static_cast<const float*>(invstd), static_cast<const float*>(gamma),
                        static_cast<const float*>(s1), static_cast<const float*>(s2),
                        (float)(1.0 / count), n4, rows, C / 4, masked, 1.f / (1.f - drop_p),
-                       static_cast<float*>(dx));
+                       dx, dx_dtype);
     return mmh::check_launch("norm_bwd_apply");
 }
 
@@ -957,14 +1445,26 @@ size_t mmh_colsum_ws_bytes(int64_t rows, int C) {
 }
 
 int mmh_colsum(const void* x, int64_t rows, int C, int cs, void* out, void* ws, size_t ws_bytes,
-               int accumulate, mmh_stream_t s) {
+               int accumulate, int x_dtype, mmh_stream_t s) {
     if (int rc = check_cols("mmh_colsum", C)) return rc;
+    MMH_REQUIRE(is_dtype(x_dtype), "mmh_colsum: x_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(x && out && ws && rows > 0 && cs >= C && cs % 4 == 0, "mmh_colsum: bad arguments");
     MMH_REQUIRE(ws_bytes >= mmh_colsum_ws_bytes(rows, C), "mmh_colsum: workspace too small");
     ColGeom cg = col_geom(1, rows, C);
     hipStream_t st = mmh::as_stream(s);
+    if (mmh::g_pw_v2 && row_geom_ok(C) && cs == C) {
+        const int c8 = C / 8;
+        if (x_dtype != MMH_F32)
+            hipLaunchKernelGGL((col_reduce_partial_v2<0, true, false>), dim3(cg.chunks, 1), dim3(TPB), 0, st, x,
+                               x_dtype == MMH_FP16, nullptr, nullptr, false, nullptr, nullptr, rows, C, c8,
+                               TPB / c8, cg.chunks, cg.rows_per_chunk, 0, 1.f, static_cast<float*>(ws));
+        else
+            hipLaunchKernelGGL((col_reduce_partial_v2<0, false, false>), dim3(cg.chunks, 1), dim3(TPB), 0, st, x,
+                               false, nullptr, nullptr, false, nullptr, nullptr, rows, C, c8, TPB / c8,
+                               cg.chunks, cg.rows_per_chunk, 0, 1.f, static_cast<float*>(ws));
+    } else
     hipLaunchKernelGGL((col_reduce_partial<0>), dim3(cg.chunks, 1), dim3(TPB), 0, st,
-                       static_cast<const float*>(x), nullptr, nullptr, nullptr, nullptr, rows, C, cs,
+                       x, x_dtype, nullptr, nullptr, 0, nullptr, nullptr, rows, C, cs,
                        0, 1.f, cg, static_cast<float*>(ws));
     hipLaunchKernelGGL(col_reduce_final, dim3((C + 31) / 32), dim3(TPB), 0, st,
                        static_cast<const float*>(ws), 1, C, cg.chunks, 1, static_cast<float*>(out),
@@ -982,33 +1482,34 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act, mmh_
 }
 
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2, const void* s3, void* out,
-                          void* x2n, void* x3n, int64_t rows, int C, int cat_dtype, mmh_stream_t s) {
+                          void* x2n, void* x3n, int64_t rows, int C, int cat_dtype, int s23_dtype,
+                          mmh_stream_t s) {
     if (int rc = check_cols("mmh_patblock_gate_fwd", C)) return rc;
-    MMH_REQUIRE(cat_dtype == MMH_F32 || cat_dtype == MMH_BF16 || cat_dtype == MMH_FP16,
-                "mmh_patblock_gate_fwd: cat_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
+    MMH_REQUIRE(is_dtype(cat_dtype) && is_dtype(s23_dtype),
+                "mmh_patblock_gate_fwd: cat_dtype / s23_dtype must be MMH_F32 | MMH_BF16 | MMH_FP16");
     MMH_REQUIRE(x1 && s1 && s2 && s3 && out && rows > 0 && ((x2n == nullptr) == (x3n == nullptr)),
                 "mmh_patblock_gate_fwd: bad arguments");
     const int64_t n4 = rows * (C / 4);
     hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
-                       static_cast<const float*>(x1), static_cast<const float*>(s1),
-                       static_cast<const float*>(s2), static_cast<const float*>(s3),
-                       static_cast<float*>(out), x2n, x3n, n4, C / 4, cat_dtype);
+                       static_cast<const float*>(x1), static_cast<const float*>(s1), s2, s3,
+                       static_cast<float*>(out), x2n, x3n, n4, C / 4, cat_dtype, s23_dtype);
     return mmh::check_launch("gate_fwd");
 }
 
 int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n, const void* g_x3n, const void* s1,
                           const void* s2, const void* s3, void* g_x1, void* g_s1, void* g_s2,
-                          void* g_s3, int64_t rows, int C, mmh_stream_t s) {
+                          void* g_s3, int64_t rows, int C, int gcat_dtype, int s23_dtype, int gs23_dtype,
+                          mmh_stream_t s) {
     if (int rc = check_cols("mmh_patblock_gate_bwd", C)) return rc;
+    MMH_REQUIRE(is_dtype(gcat_dtype) && is_dtype(s23_dtype) && is_dtype(gs23_dtype),
+                "mmh_patblock_gate_bwd: bad gcat_dtype / s23_dtype / gs23_dtype");
     MMH_REQUIRE(s1 && s2 && s3 && g_x1 && g_s1 && g_s2 && g_s3 && rows > 0,
                 "mmh_patblock_gate_bwd: bad arguments");
     const int64_t n4 = rows * (C / 4);
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n4)), dim3(TPB), 0, mmh::as_stream(s),
-                       static_cast<const float*>(g_out), static_cast<const float*>(g_x2n),
-                       static_cast<const float*>(g_x3n), static_cast<const float*>(s1),
-                       static_cast<const float*>(s2), static_cast<const float*>(s3),
-                       static_cast<float*>(g_x1), static_cast<float*>(g_s1),
-                       static_cast<float*>(g_s2), static_cast<float*>(g_s3), n4, C / 4);
+                       static_cast<const float*>(g_out), g_x2n, g_x3n, static_cast<const float*>(s1),
+                       s2, s3, static_cast<float*>(g_x1), static_cast<float*>(g_s1), g_s2, g_s3, n4,
+                       C / 4, gcat_dtype, s23_dtype, gs23_dtype);
     return mmh::check_launch("gate_bwd");
 }
 

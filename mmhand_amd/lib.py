@@ -52,7 +52,7 @@ SIGNATURES = {
     "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "mmh_wino_dw": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mmh_conv2d_dgrad_border_ws_bytes": (_sz, [_DP]),
-    "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_conv7_thin_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv7_thin_dgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv7_thin_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -74,17 +74,17 @@ SIGNATURES = {
     "mmh_wgrad3x3_lp16": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "mmh_conv3x3_lp16": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_colsum_ws_bytes": (_sz, [_i64, _i]),
-    "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_norm_stats_ws_bytes": (_sz, [_i, _i64, _i]),
-    "mmh_norm_stats": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_norm_stats": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_norm_finalize": (_i, [_vp, _vp, _d, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
-    "mmh_scale_shift_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _vp]),
+    "mmh_scale_shift_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _i, _vp]),
     "mmh_norm_bwd_ws_bytes": (_sz, [_i, _i64, _i]),
-    "mmh_norm_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
-    "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _vp]),
+    "mmh_norm_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp]),
     "mmh_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
-    "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
-    "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_reduce_ws_bytes": (_sz, [_i64]),
     "mmh_bce_logits_fwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_bce_logits_bwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _vp]),

@@ -501,6 +501,7 @@ class MMHandModel(torch.nn.Module):
         """models/MMHandModel.py:310-330: one G step, DG_ratio D_PP steps, DG_ratio D_PB steps, each
         optimizer step skipped once a gradient of the iteration was not finite."""
         self._settle_overflow()
+        ops.lp_grads_reset()
         if self.dp:
             self._optimize_parameters_dp()
         else:

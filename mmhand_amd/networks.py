@@ -200,11 +200,16 @@ class _Net(nn.Module):
         return self
 
     # -- functional layers
-    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0):
-        """x: an fp32 NHWC tensor, or a (proxy, x16) pair from a producer that wrote it in 16 bits."""
+    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False):
+        """x: an fp32 NHWC tensor, or a (proxy, x16) pair from a producer that wrote it in 16 bits.
+        y_lp (see _lp_edge): the consumer (normact / the PATBlock gate) takes the output in 16 bits ->
+        returns a (proxy, y16) pair."""
         x16 = None
         if isinstance(x, tuple):
             x, x16 = x
+        if y_lp:
+            p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True)
+            return p, y16
         return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16)
 
     def _lp_edge(self, cp):
@@ -214,11 +219,19 @@ class _Net(nn.Module):
             return self.bf16
         return 0
 
+    def _lp_out(self, cp):
+        """the 3x3 conv `cp` hands its output (and takes its gradient) in 16 bits"""
+        return bool(ops.USE_LP16_EDGES and self._lp_edge(cp))
+
     def convT(self, cp, x):
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16)
 
     def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0):
-        """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair."""
+        """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
+        x may itself be a (proxy, x16) pair from a 16-bit convolution (conv(y_lp=True))."""
+        x16 = None
+        if isinstance(x, tuple):
+            x, x16 = x
         drop_p = 0.5 if (drop and self.training) else 0.0
         mask = None
         seed = 0
@@ -229,13 +242,13 @@ class _Net(nn.Module):
                 seed = ops.next_dropout_seed()
         if self.norm == "instance":
             return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", relu,
-                                       drop_p, seed, mask, None, out_lp)
+                                       drop_p, seed, mask, None, out_lp, x16)
         np_ = bag[idx]
         if self.training:
             np_.num_batches_tracked += 1
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean,
                                        np_.running_var, "batch", relu, drop_p, seed, mask,
-                                       self.sync_group, out_lp)
+                                       self.sync_group, out_lp, x16)
         scale = np_.weight / torch.sqrt(np_.running_var + ops.EPS)
         shift = np_.bias - np_.running_mean * scale
         y = ops.AffineActFn.apply(x, scale, shift, relu)
@@ -244,9 +257,12 @@ class _Net(nn.Module):
     def two_conv_block(self, blk, x, site, last_norm, residual=None):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets)."""
         i2 = 6 if self.use_dropout else 5
-        y = self.conv(blk[1], x, 1, 1, True)
+        # 16-bit mode: every tensor that faces one of these convolutions (input, output, both gradients)
+        # lives in HBM in 16 bits only, as under apex O1; without a last norm the caller (the PATBlock
+        # gate) receives the (proxy, y16) pair
+        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]))
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]))
-        y = self.conv(blk[i2], y, 1, 1, True)
+        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]))
         if last_norm:
             y = self.normact(blk, i2 + 1, y, False, residual=residual)
         return y
@@ -317,11 +333,15 @@ class Generator(_Net):
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)
             more = b + 1 < self.n_blocks
             cat_lp = self._lp_edge(m["att"][b + 1]["conv_block_stream2"][1]) if more else 0
+            s16 = (None, None)
+            if isinstance(s2, tuple):       # stream 2 / 3 end in a 16-bit convolution
+                (s2, a), (s3, b_) = s2, s3
+                s16 = (a, b_)
             if cat_lp:      # the cats feed only the next block's 16-bit convs: written in 16 bits
-                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp)
+                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp, *s16)
                 x2, x3 = (p2, c2), (p3, c3)
             else:
-                x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more)
+                x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more, 0, *s16)
         up = m["stream1_up"]
         y = x1
         for i in range(self.n_down):

@@ -303,7 +303,7 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
             wb = bf16_weights(w, bf16)[0]
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
         L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(wb), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
-               _stream())
+               0, _stream())
     return dx
 
 
@@ -362,7 +362,7 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
         L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
-               _stream())
+               0, _stream())
     # wgrad
     ws = _ws(L.load().mmh_wino_wgrad_gemm_ws_bytes(tiles, Cin, Cout, P), dy)
     dU = _empty((P, Cin, Cout), dy)
@@ -426,11 +426,16 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     return dx
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None):
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None, out16=False):
     """dx_channels > 0: only the first dx_channels input channels need a gradient (the caller
-    ignores the rest, which may come back as zeros).  dy16: an existing 16-bit twin of dy."""
-    _chk(dy, "dy"); _chk(w, "w")
+    ignores the rest, which may come back as zeros).  dy16: an existing 16-bit twin of dy (dy itself
+    may then be None); out16: return dx in 16 bits (conv_lp16 path only)."""
+    _chk(w, "w")
     B, H, W_, Cin = x_shape
+    if dy is None or out16:
+        assert bf16 and lp16_v2_ok(Cin, w.shape[3], w.shape[0], stride, pad, 1) and (dy16 is not None or dy is not None)
+    if dy is not None:
+        _chk(dy, "dy")
     k, _, _, Cout = w.shape
     if (USE_THIN and 0 < dx_channels <= 4 and k == 7 and stride == 1 and pad == 3 and Cout % 4 == 0
             and Cin >= 4):
@@ -442,12 +447,16 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     if bf16 and lp16_v2_ok(Cin, Cout, k, stride, pad, 1):
         # main term (zero-padded correlation with the flipped filter) on the v2 kernel; reflect padding
         # adds the eight border terms (small 16-bit GEMMs + border_add) exactly as the other paths do
-        dx = raw_conv3x3_lp16(dy16 if dy16 is not None else lp16_twin(dy, bf16), w, None, False, L.ACT_NONE, bf16, 1)
+        if dy16 is None:
+            dy16 = lp16_twin(dy, bf16)
+        dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16)
         if reflect:
             d.dtype = _dt(bf16)
-            ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
-            L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(bf16_weights(w, bf16)[0]), _ptr(dx), _ptr(ws),
-                   ws.numel() * 4, 3, _stream())
+            ws = torch.empty(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)) // 4 + 4, dtype=torch.float32,
+                             device=dx.device)
+            # border GEMMs read the 16-bit dy; io16 bit 0 = dy is 16-bit, bit 1 = dx is 16-bit
+            L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy16), _ptr(bf16_weights(w, bf16)[0]), _ptr(dx), _ptr(ws),
+                   ws.numel() * 4, 3, 1 | (2 if out16 else 0), _stream())
         return dx
     if bf16 and Cout % 64 == 0:
         d.dtype = _dt(bf16)
@@ -495,6 +504,9 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
 # Second-generation 16-bit kernel for the 3x3 / stride 1 / pad 1 stack (conv_lp16.hip): both operands
 # 16-bit in HBM, LDS-DMA, 256x256x64 tiles.  Takes a 16-bit twin of the activation (mmh_cvt_lp16).
 USE_LP16_V2 = os.environ.get("MMH_LP16_V2", "1") != "0"
+# 16-bit mode: the tensors between a conv_lp16 convolution and its norm / gate neighbours (conv outputs,
+# and the gradients on both sides) live in HBM in 16 bits only, as apex O1's fp16 conv outputs do.
+USE_LP16_EDGES = os.environ.get("MMH_LP16_EDGES", "1") != "0"
 _zero_pages = {}
 
 
@@ -540,6 +552,37 @@ def lp16_chain_ok(Cin, Cout, k, stride, pad):
     """all three passes of this conv run on conv_lp16.hip: its producer may hand x over in 16 bits"""
     return (lp16_v2_ok(Cin, Cout, k, stride, pad, 0) and lp16_v2_ok(Cin, Cout, k, stride, pad, 1)
             and lp16_wgrad_ok(Cin, Cout, k, stride, pad))
+
+
+def _tdt(t):
+    """mmh dtype code of a tensor's element type"""
+    return {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.FP16}[t.dtype]
+
+
+# Gradients of 16-bit edges.  autograd validates a gradient against the fp32 proxy on the edge, so the
+# producer of a 16-bit gradient returns a fresh proxy and parks the real tensor here under the proxy's
+# address; the consumer (the backward of the node on the other side of the edge) takes it out.  An edge
+# with two consumers would make autograd add the proxies - the lookup then fails loudly.
+_lp_grads = {}
+
+
+def lp_grad_out(t16):
+    p = lp_proxy(t16.shape, t16.device)
+    _lp_grads[p.data_ptr()] = (p, t16)        # p is held so that its address stays unique
+    return p
+
+
+def lp_grad_in(g, what):
+    ent = _lp_grads.pop(g.data_ptr(), None) if g is not None else None
+    if ent is None or tuple(ent[1].shape) != tuple(g.shape):
+        raise RuntimeError(f"{what}: the gradient of a 16-bit edge did not arrive through the 16-bit channel "
+                           "(an edge with more than one consumer, or a foreign backward node)")
+    return ent[1]
+
+
+def lp_grads_reset():
+    """drop gradients parked by a backward pass that did not finish"""
+    _lp_grads.clear()
 
 
 def lp_proxy(shape, device):
@@ -621,9 +664,10 @@ def raw_convT_wgrad(x, dy, bf16=False):
 
 
 def raw_colsum(x2d_rows, Ccols, x):
-    ws = _ws(L.load().mmh_colsum_ws_bytes(x2d_rows, Ccols), x)
-    out = _empty((Ccols,), x)
-    L.call("mmh_colsum", _ptr(x), x2d_rows, Ccols, Ccols, _ptr(out), _ptr(ws), ws.numel() * 4, 0,
+    """x: fp32 or 16-bit; the sums are fp32"""
+    ws = torch.empty(L.load().mmh_colsum_ws_bytes(x2d_rows, Ccols) // 4 + 4, dtype=torch.float32, device=x.device)
+    out = torch.empty((Ccols,), dtype=torch.float32, device=x.device)
+    L.call("mmh_colsum", _ptr(x), x2d_rows, Ccols, Ccols, _ptr(out), _ptr(ws), ws.numel() * 4, 0, _tdt(x),
            _stream())
     return out
 
@@ -639,9 +683,11 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None):
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False):
         """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
-        the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read."""
+        the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
+        y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
+        GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
         B, H, W_, Cin = x.shape
         ctx.dx_channels = dx_channels
         wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
@@ -649,10 +695,15 @@ class Conv2dFn(torch.autograd.Function):
         ctx.x_shape = tuple(x.shape)
         ctx.wino_V = 0
         ctx.lp16 = False
+        ctx.x_lp = x16 is not None
+        ctx.y_lp = bool(y_lp)
         k = w.shape[0]
         if x16 is not None:
             assert bf16 and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape) and lp16_chain_ok(
                 Cin, w.shape[3], k, stride, pad), "a 16-bit input needs the conv_lp16 path for all three passes"
+        if y_lp:
+            assert bf16 and act == L.ACT_NONE and lp16_chain_ok(Cin, w.shape[3], k, stride, pad), \
+                "a 16-bit output needs the conv_lp16 path for all three passes and no activation"
         if bf16 and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0):
             # 16-bit path of the 256 / 512-channel 3x3 stack: one 16-bit twin of x (or the producer's own
             # 16-bit output) feeds the fprop and, kept instead of x, the wgrad
@@ -662,11 +713,14 @@ class Conv2dFn(torch.autograd.Function):
             if timed:
                 e0, e1 = fprop_timer.bracket()
                 e0.record()
-            y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0)
+            y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp))
             if timed:
                 e1.record()
             ctx.lp16 = lp16_wgrad_ok(Cin, w.shape[3], k, stride, pad)
             ctx.save_for_backward(x16 if ctx.lp16 else x, w, y if act != L.ACT_NONE else None)
+            if y_lp:
+                ctx.mark_non_differentiable(y)
+                return lp_proxy(y.shape, y.device), y
             return y
         if wt and KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
             # the wgrad pass contracts the same transformed input: keep it instead of x
@@ -679,28 +733,43 @@ class Conv2dFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g16=None):
         x, w, y = ctx.saved_tensors
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
+        dx = dw = db = None
+        if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
+            g16 = lp_grad_in(g, "Conv2dFn")
+            if ctx.needs_input_grad[0]:
+                dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16,
+                                    out16=ctx.x_lp)
+                if ctx.x_lp:
+                    dx = lp_grad_out(dx)
+            if ctx.needs_input_grad[1]:
+                dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16)
+            return dx, dw, db, None, None, None, None, None, None, None, None
         g = g.contiguous()
         if act != L.ACT_NONE:
             g = raw_act_bwd(g, y, act)
-        dx = dw = db = None
         if (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                 and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6):
             dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x)      # x is the saved V here
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
-                dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16)
+                dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16,
+                                    out16=ctx.x_lp)
+                if ctx.x_lp:
+                    dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
                 dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -710,7 +779,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
         if has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
@@ -767,11 +836,11 @@ def raw_norm_stats(x, groups):
         m2 = _empty((groups, Cc), x)
         L.call("mmh_norm_stats_merge", _ptr(stats), groups, stats.shape[1], Cc, _ptr(mean), _ptr(m2), _stream())
         return mean, m2, rows
-    ws = _ws(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc), x)
-    mean = _empty((groups, Cc), x)
-    m2 = _empty((groups, Cc), x)
+    ws = torch.empty(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc) // 4 + 4, dtype=torch.float32, device=x.device)
+    mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+    m2 = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
     L.call("mmh_norm_stats", _ptr(x), groups, rows, Cc, Cc, _ptr(mean), _ptr(m2), _ptr(ws),
-           ws.numel() * 4, _stream())
+           ws.numel() * 4, _tdt(x), _stream())
     return mean, m2, rows
 
 
@@ -793,7 +862,7 @@ def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, kee
     out = torch.empty(x.shape, dtype=_wd(out_lp), device=x.device)
     kb = torch.empty((B, H, W_, Cc // 4), dtype=torch.uint8, device=x.device) if keep_bits else None
     L.call("mmh_scale_shift_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
-           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _dt(out_lp), _stream())
+           groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _tdt(x), _dt(out_lp), _stream())
     return (out, kb) if keep_bits else out
 
 
@@ -836,10 +905,19 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
-                seed, mask, sync_group, out_lp=0):
+                seed, mask, sync_group, out_lp=0, x16=None):
         """out_lp (True bf16 | 2 fp16): the output is written in that 16-bit type only - it feeds a
-        16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass."""
-        _chk(x, "x")
+        16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass.
+        x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
+        the autograd edge.  Statistics and all arithmetic are fp32 either way (apex O1 keeps
+        batch_norm in fp32 on fp16 conv outputs)."""
+        ctx.in_lp = x16 is not None
+        ctx.out_lp = bool(out_lp)
+        if x16 is not None:
+            assert tuple(x16.shape) == tuple(x.shape) and x16.is_contiguous()
+            x = x16
+        else:
+            _chk(x, "x")
         if drop_p > 0 and not relu:
             # the keep bits are (out > 0): exact only behind a ReLU (the reference never drops without one)
             raise RuntimeError("NormActFn: dropout without a preceding ReLU is not supported")
@@ -861,6 +939,8 @@ class NormActFn(torch.autograd.Function):
                    residual is not None)
         ctx.save_for_backward(x, kb, mean, invstd, gamma)
         if out_lp:
+            if residual is not None:
+                raise RuntimeError("NormActFn: a 16-bit output together with a residual is not supported")
             ctx.mark_non_differentiable(out)
             return lp_proxy(x.shape, x.device), out
         return out
@@ -871,13 +951,14 @@ class NormActFn(torch.autograd.Function):
         groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         if has_res and relu:
             raise RuntimeError("NormActFn: residual together with ReLU is not on the reference path")
-        g = g.contiguous()
+        # a 16-bit edge on the output: its gradient comes from a 16-bit convolution's dgrad, in 16 bits
+        g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
         Cc = x.shape[3]
         masked = 2 if (relu or drop_p > 0) else 0
         ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
         s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
         L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
-               rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
+               rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _tdt(g), _tdt(x), _stream())
         dgamma = dbeta = None
         if gamma is not None:
             dgamma = s2.sum(0) if groups > 1 else s2.reshape(-1).clone()
@@ -888,12 +969,14 @@ class NormActFn(torch.autograd.Function):
             collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
             dist.all_reduce(packed, group=sync_group)
             s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x)        # a 16-bit x came from a 16-bit convolution: its gradient goes back in 16 bits
         L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
                _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
-               _ptr(dx), _stream())
+               _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
         dres = g if has_res else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        if ctx.in_lp:
+            dx = lp_grad_out(dx)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class AffineActFn(torch.autograd.Function):
@@ -926,10 +1009,17 @@ class GateFn(torch.autograd.Function):
     x2n = cat(s3, out), x3n = cat(s2, out) — the concat is written by the same kernel."""
 
     @staticmethod
-    def forward(ctx, x1, s1, s2, s3, want_cat, cat_lp=0):
+    def forward(ctx, x1, s1, s2, s3, want_cat, cat_lp=0, s2_16=None, s3_16=None):
         """cat_lp (True bf16 | 2 fp16): cat(s3,out) / cat(s2,out) are written in that 16-bit type only
-        (they feed the next block's 16-bit convolutions and nothing else); `out` stays fp32."""
-        for t in (x1, s1, s2, s3):
+        (they feed the next block's 16-bit convolutions and nothing else); `out` stays fp32.
+        s2_16 / s3_16: s2 and s3 were written in 16 bits only by their convolutions (Conv2dFn y_lp);
+        s2 / s3 are then the proxies on the autograd edges and the gradients go back in 16 bits."""
+        ctx.s_lp = s2_16 is not None
+        ctx.cat_lp = bool(want_cat and cat_lp)
+        if ctx.s_lp:
+            assert s3_16 is not None and s2_16.dtype == s3_16.dtype and s2_16.is_contiguous() and s3_16.is_contiguous()
+            s2, s3 = s2_16, s3_16
+        for t in (x1, s1) + (() if ctx.s_lp else (s2, s3)):
             _chk(t)
         B, H, W_, Cc = x1.shape
         out = torch.empty_like(x1)
@@ -938,7 +1028,7 @@ class GateFn(torch.autograd.Function):
             x2n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
             x3n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
         L.call("mmh_patblock_gate_fwd", _ptr(x1), _ptr(s1), _ptr(s2), _ptr(s3), _ptr(out),
-               _ptr(x2n), _ptr(x3n), B * H * W_, Cc, _dt(cat_lp), _stream())
+               _ptr(x2n), _ptr(x3n), B * H * W_, Cc, _dt(cat_lp), _tdt(s2), _stream())
         ctx.save_for_backward(s1, s2, s3)
         ctx.want_cat = want_cat
         if want_cat and cat_lp:
@@ -953,13 +1043,20 @@ class GateFn(torch.autograd.Function):
         s1, s2, s3 = ctx.saved_tensors
         B, H, W_, Cc = s1.shape
         g_out = None if g_out is None else g_out.contiguous()
-        g_x2n = None if g_x2n is None else g_x2n.contiguous()
-        g_x3n = None if g_x3n is None else g_x3n.contiguous()
+        if ctx.cat_lp:      # the cats fed 16-bit convolutions: their gradients come back in 16 bits
+            g_x2n = lp_grad_in(g_x2n, "GateFn (cat(s3,out))")
+            g_x3n = lp_grad_in(g_x3n, "GateFn (cat(s2,out))")
+        else:
+            g_x2n = None if g_x2n is None else g_x2n.contiguous()
+            g_x3n = None if g_x3n is None else g_x3n.contiguous()
         gx1 = torch.empty_like(s1); gs1 = torch.empty_like(s1)
-        gs2 = torch.empty_like(s1); gs3 = torch.empty_like(s1)
+        gs2 = torch.empty_like(s2); gs3 = torch.empty_like(s3)
         L.call("mmh_patblock_gate_bwd", _ptr(g_out), _ptr(g_x2n), _ptr(g_x3n), _ptr(s1), _ptr(s2),
-               _ptr(s3), _ptr(gx1), _ptr(gs1), _ptr(gs2), _ptr(gs3), B * H * W_, Cc, _stream())
-        return gx1, gs1, gs2, gs3, None, None
+               _ptr(s3), _ptr(gx1), _ptr(gs1), _ptr(gs2), _ptr(gs3), B * H * W_, Cc,
+               L.F32 if g_x2n is None else _tdt(g_x2n), _tdt(s2), _tdt(gs2), _stream())
+        if ctx.s_lp:
+            gs2, gs3 = lp_grad_out(gs2), lp_grad_out(gs3)
+        return gx1, gs1, gs2, gs3, None, None, None, None
 
 
 # --------------------------------------------------------------------------- losses
