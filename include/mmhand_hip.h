@@ -152,9 +152,10 @@ int mmh_conv2d_dgrad_border(const mmh_conv_desc* d, const void* dy, const void* 
  * `ws` (mmh_conv2d_wgrad_ws_bytes); the fixed-order second stage makes the
  * result deterministic.  accumulate!=0 adds into dw.                       */
 size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d);
+/* io16 (16-bit dtypes): 0 = x and dy are fp32 (converted on load), 3 = both are already 16-bit in HBM. */
 int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
                      void* dw, void* ws, size_t ws_bytes, int accumulate,
-                     mmh_stream_t s);
+                     int io16, mmh_stream_t s);
 
 /* ConvTranspose2d(k3,s2,p1,op1) (models/Generator.py:240-253).  `d` is the
  * stride-2 Conv2d of which this is the dgrad: d->{H,W,Cin} describe the
@@ -166,7 +167,7 @@ int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
                       void* dx, mmh_stream_t s);
 int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy,
                       void* dw, void* ws, size_t ws_bytes, int accumulate,
-                      mmh_stream_t s);
+                     int io16, mmh_stream_t s);
 
 /* fp32 weights [taps][Cin][Cout] -> bf16 copies for the MMH_BF16 conv path:
  * w_plain [taps][Cin][Cout] (contraction = Cout, used by dgrad) and
@@ -207,6 +208,16 @@ int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d);
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
                      const void* bias, void* y, int y_is16, int act, const void* zeros,
                      mmh_stream_t s);
+
+/* The same machine for the other 3x3 / pad 1 convolutions of the step (stride 2 down-sampling,
+ * ConvTranspose2d, 64 / 128 output channels): mode 0 fprop, mode 1 dgrad (stride 2: the four
+ * output-parity classes in one launch; ConvTranspose2d(k3,s2,p1,op1).forward is mode 1 of the
+ * stride-2 conv it is the adjoint of).  Needs Cin, Cout % 64 == 0, even H and W for stride 2.
+ * Operands as for mmh_conv3x3_lp16.  models/Generator.py:165-223,240-253, Discriminator.py:86-99. */
+int mmh_conv_lp16_supported(const mmh_conv_desc* d, int mode);
+int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
+                  const void* bias, void* y, int y_is16, int act, const void* zeros,
+                  mmh_stream_t s);
 
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */

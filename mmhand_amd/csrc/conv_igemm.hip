@@ -1356,6 +1356,7 @@ struct WgradKP {
     int dbg;                // timing-only ablation bits (results wrong)
     int nsplit;             // splits per batch: blockIdx.z = batch * nsplit + split
     long long src_bs, dy_bs;   // element strides between batches (Winograd: 16 planes)
+    int x16, dy16;             // 16-bit kernels: the gathered tensor / dy is already 16-bit in HBM
     int xcd_remap;          // grid size % 8 == 0: XCD x works on a contiguous range of (z, y, x) ids
     int h16;                    // 16-bit kernel: 0 = bf16, 1 = fp16 operands
 };
@@ -1570,7 +1571,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col0
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool H16>
+template <int BN, int WAVES_M, int WAVES_N, bool H16, bool IO16>     // IO16: x and dy are 16-bit in HBM
 __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradKP& p) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -1631,9 +1632,16 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradKP& p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pix = pbase + (tid >> 5) + 8 * i;
-            ra[i] = bload4(rsA, gather_off(g, (unsigned)px_b[i] * (unsigned)(g.srcH * g.srcW),
-                                           px_h[i] * g.ap_h + g.a0_h, px_w[i] * g.ap_w + g.a0_w, kt,
-                                           g_ok && pix < pend));
+            const unsigned goff = gather_off(g, (unsigned)px_b[i] * (unsigned)(g.srcH * g.srcW),
+                                             px_h[i] * g.ap_h + g.a0_h, px_w[i] * g.ap_w + g.a0_w, kt,
+                                             g_ok && pix < pend);
+            if (IO16) {        // 16-bit source: half the byte offset, 8 bytes per group of 4 channels
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsA, goff != OOB ? goff >> 1 : OOB, 0, 0);
+                ra[i].x = __uint_as_float(r[0]);
+                ra[i].y = __uint_as_float(r[1]);
+            } else {
+                ra[i] = bload4(rsA, goff);
+            }
             px_w[i] += BKP;
             while (px_w[i] >= g.PW) {
                 px_w[i] -= g.PW;
@@ -1644,18 +1652,30 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradKP& p) {
         for (int i = 0; i < NBD; ++i) {
             const int pix = pbase + d_prow[i];
             const unsigned off = (unsigned)pix * p.dy_cs * 4u + d_col[i];
-            rb[i] = bload4(rsD, (pix < pend && d_col[i] != OOB) ? off : OOB);
+            const bool ok = pix < pend && d_col[i] != OOB;
+            if (IO16) {
+                const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsD, ok ? off >> 1 : OOB, 0, 0);
+                rb[i].x = __uint_as_float(r[0]);
+                rb[i].y = __uint_as_float(r[1]);
+            } else {
+                rb[i] = bload4(rsD, ok ? off : OOB);
+            }
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<bf16x4*>(&As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4]) = to_lp4<H16>(ra[i]);
+        for (int i = 0; i < 8; ++i) {
+            __bf16* dst = &As[((tid >> 5) + 8 * i) * LDT + (tid & 31) * 4];
+            if (IO16) *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+            else *reinterpret_cast<bf16x4*>(dst) = to_lp4<H16>(ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NBD; ++i) {
             const int idx = tid + 256 * i;
             const int prow = idx / (BN / 4), c4 = idx - prow * (BN / 4);
-            *reinterpret_cast<bf16x4*>(&Bs[prow * LDT + c4 * 4]) = to_lp4<H16>(rb[i]);
+            __bf16* dst = &Bs[prow * LDT + c4 * 4];
+            if (IO16) *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+            else *reinterpret_cast<bf16x4*>(dst) = to_lp4<H16>(rb[i]);
         }
     };
 
@@ -1708,10 +1728,10 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradKP& p) {
         }
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool IO16>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_bf16_kernel(const WgradKP p) {
-    if (p.h16) conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, true>(p);
-    else conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, false>(p);
+    if (p.h16) conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, true, IO16>(p);
+    else conv_wgrad_bf16_body<BN, WAVES_M, WAVES_N, false, IO16>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -2906,11 +2926,18 @@ int launch_wgrad_t(const WgradKP& p, int splits, hipStream_t st) {
 template <int BN, int WM, int WN>
 int launch_wgrad_bf16_t(const WgradKP& p, int splits, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * BKP * LDT * 2;
-    static int ready = -1;
-    if (ready != 0) ready = allow_lds(conv_wgrad_bf16_kernel<BN, WM, WN>, lds);
-    if (ready != 0) return ready;
     dim3 grid((p.N + BN - 1) / BN, (p.Mrows + BM - 1) / BM, splits);
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BN, WM, WN>), grid, dim3(256), lds, st, p);
+    if (p.x16) {
+        static int ready16 = -1;
+        if (ready16 != 0) ready16 = allow_lds(conv_wgrad_bf16_kernel<BN, WM, WN, true>, lds);
+        if (ready16 != 0) return ready16;
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BN, WM, WN, true>), grid, dim3(256), lds, st, p);
+        return mmh::check_launch("conv_wgrad_bf16_kernel");
+    }
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_wgrad_bf16_kernel<BN, WM, WN, false>, lds);
+    if (ready != 0) return ready;
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<BN, WM, WN, false>), grid, dim3(256), lds, st, p);
     return mmh::check_launch("conv_wgrad_bf16_kernel");
 }
 
@@ -2931,12 +2958,17 @@ size_t wgrad_ws(const mmh_conv_desc* d) {
 }
 
 int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
-             size_t ws_bytes, int accumulate, hipStream_t st) {
+             size_t ws_bytes, int accumulate, hipStream_t st, bool x16 = false, bool dy16 = false) {
+    MMH_REQUIRE(!(x16 || dy16) || is16(d->dtype), "wgrad: 16-bit operands need a 16-bit dtype");
+    MMH_REQUIRE(x16 == dy16, "wgrad: io16 must be 0 (both tensors fp32) or 3 (both 16-bit)");
     WgradKP p{};
     p.g = fwd_gather(d, x);
     p.g.chunk_major = 0;
+    p.x16 = x16 ? 1 : 0;
+    p.dy16 = dy16 ? 1 : 0;
+    if (x16) p.g.src_bytes /= 2;
     p.dy = static_cast<const float*>(dy);
-    p.dy_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->y_cs * sizeof(float));
+    p.dy_bytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->y_cs * (dy16 ? 2 : sizeof(float)));
     p.dy_cs = (unsigned)d->y_cs;
     p.Mrows = d->kh * d->kw * d->Cin;
     p.N = d->Cout;
@@ -3373,10 +3405,10 @@ int mmh_conv2d_dgrad_folded(const mmh_conv_desc* d, const void* dy, const void* 
 size_t mmh_conv2d_wgrad_ws_bytes(const mmh_conv_desc* d) { return d ? wgrad_ws(d) : 0; }
 
 int mmh_conv2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
-                     size_t ws_bytes, int accumulate, mmh_stream_t s) {
+                     size_t ws_bytes, int accumulate, int io16, mmh_stream_t s) {
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(x && dy && dw && ws, "mmh_conv2d_wgrad: NULL buffer");
-    return do_wgrad(d, x, dy, dw, ws, ws_bytes, accumulate, mmh::as_stream(s));
+    return do_wgrad(d, x, dy, dw, ws, ws_bytes, accumulate, mmh::as_stream(s), (io16 & 1) != 0, (io16 & 2) != 0);
 }
 
 // ConvTranspose2d == dgrad of the stride-2 conv `d`; its input plays dy, its output plays dx.
@@ -3397,12 +3429,12 @@ int mmh_convT2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, voi
 }
 
 int mmh_convT2d_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
-                      size_t ws_bytes, int accumulate, mmh_stream_t s) {
+                      size_t ws_bytes, int accumulate, int io16, mmh_stream_t s) {
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(x && dy && dw && ws, "mmh_convT2d_wgrad: NULL buffer");
     // dw[tap][Cout_T][Cin_T]: the transposed conv's output-gradient is gathered like the
     // stride-2 conv's input, its input is the per-pixel operand.
-    return do_wgrad(d, dy, x, dw, ws, ws_bytes, accumulate, mmh::as_stream(s));
+    return do_wgrad(d, dy, x, dw, ws, ws_bytes, accumulate, mmh::as_stream(s), (io16 & 2) != 0, (io16 & 1) != 0);
 }
 
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C, int p,

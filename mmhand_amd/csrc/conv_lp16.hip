@@ -213,6 +213,212 @@ __global__ void __launch_bounds__(512, 2) conv_lp16s_kernel(const LpConvKP p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same machine for the other 3x3 convolutions of the step: stride 2 (the down-sampling convs),
+// their dgrad and ConvTranspose2d (per output-parity class), and 64 / 128 output channels.
+//   M-space  m -> (b, mh, mw), mh < MH, mw < MW
+//   source   pixel (mh*ss + dh, mw*ss + dw) of the [B][SH][SW][cs] tensor, dh = (ah + sgn*kh) >> dsh for
+//            tap kh = kh0 + tstep*th (th < nth); outside the image: zero page (or mirrored, ss == 1)
+//   output   pixel (mh*os + oh0, mw*os + ow0) of [B][OH][OW][y_cs]
+//   fprop stride s:         MH x MW = Ho x Wo, ss = s, dh = kh - pad, os = 1
+//   dgrad stride 1:         dh = pad - kh
+//   dgrad stride 2, class (ph, pw) = blockIdx.y: M-space = input pixels (2 mh + ph, 2 mw + pw), taps with
+//            kh = (ph + pad) & 1 (mod 2), source (dy) pixel mh + (ph + pad - kh) / 2, os = 2, oh0 = ph
+// Tile 256 x TBN x 64, TBN = 256 | 128 | 64 (template): 8 waves as 2 (M) x 4 (N), wave tile 128 x TBN/4.
+struct LpGConvKP {
+    const char* x;
+    const char* w;          // [tap = kh*KW + kw][N][C] 16-bit
+    const char* zeros;
+    float* y;
+    char* y16;
+    const float* bias;
+    int B, MH, MW;
+    int SH, SW, C, cs, ss;
+    int ah, aw, sgn, dsh;
+    int kh0, kw0, tstep, nth, ntw, KW;
+    int classes;            // 1, or 4: stride-2 dgrad, class = blockIdx.y overrides kh0/kw0/nth/ntw/ah/aw/oh0/ow0
+    int pad, KH;
+    int reflect;
+    int OH, OW, os, oh0, ow0, y_cs, N;
+    int act, MT, NT;
+};
+
+template <bool H16, int BNT>
+__device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
+    constexpr int NB = BNT / 64;               // B-operand DMA instructions per wave and k-step
+    constexpr int NJ = BNT / 64;               // 16-column MFMA tiles per wave (wave tile 128 x TBN/4)
+    constexpr int GSTAGE = (TBM + BNT) * ROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int m0 = mt * TBM, n0 = nt * BNT;
+    const int M = p.B * p.MH * p.MW;
+    int kh0 = p.kh0, kw0 = p.kw0, nth = p.nth, ntw = p.ntw, ah = p.ah, aw = p.aw, oh0 = p.oh0, ow0 = p.ow0;
+    if (p.classes == 4) {
+        const int ph = blockIdx.y >> 1, pw = blockIdx.y & 1;
+        kh0 = (ph + p.pad) & 1; kw0 = (pw + p.pad) & 1;
+        nth = (p.KH - kh0 + 1) / 2; ntw = (p.KW - kw0 + 1) / 2;
+        ah = ph + p.pad; aw = pw + p.pad;
+        oh0 = ph; ow0 = pw;
+    }
+    int a_img[4], a_hw[4];          // image base b*SH*SW (or -1: row beyond M) and (mh*ss) << 16 | (mw*ss)
+    unsigned b_off[NB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int m = m0 + r;
+        const int b = m / (p.MH * p.MW);
+        const int rem = m - b * (p.MH * p.MW);
+        const int mh = rem / p.MW, mw = rem - mh * p.MW;
+        a_img[j] = m < M ? b * p.SH * p.SW : -1;
+        a_hw[j] = ((mh * p.ss) << 16) | (mw * p.ss);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int r = (wave * NB + j) * 8 + (lane >> 3);
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;
+    }
+    const int KC = p.C / TBK;
+    const int nk = nth * ntw * KC;
+    unsigned a_off[4];
+    int wtap = 0;
+    auto set_tap = [&](int t) {
+        const int th = t / ntw, tw = t - th * ntw;
+        const int kh = kh0 + p.tstep * th, kw = kw0 + p.tstep * tw;
+        const int dh = (ah + p.sgn * kh) >> p.dsh, dw = (aw + p.sgn * kw) >> p.dsh;
+        wtap = kh * p.KW + kw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ih = (a_hw[j] >> 16) + dh, iw = (a_hw[j] & 0xffff) + dw;
+            bool ok = a_img[j] >= 0;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.SH ? 2 * (p.SH - 1) - ih : ih;
+                iw = iw >= p.SW ? 2 * (p.SW - 1) - iw : iw;
+            } else {
+                ok = ok && ih >= 0 && ih < p.SH && iw >= 0 && iw < p.SW;
+            }
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+            const int src = a_img[j] + ih * p.SW + iw;
+            a_off[j] = ok ? (unsigned)src * (unsigned)p.cs * 2u + q * 16u : 0xffffffffu;
+        }
+    };
+    auto issue = [&](int ks, int stage) {
+        const int t = ks / KC, kc = ks - t * KC;
+        if (kc == 0) set_tap(t);
+        char* sA = smem + stage * GSTAGE;
+        char* sB = sA + TBM * ROWB;
+        const unsigned kb = (unsigned)kc * (TBK * 2);
+        const char* wbase = p.w + (size_t)wtap * p.N * p.C * 2 + kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* g = a_off[j] != 0xffffffffu ? p.x + a_off[j] + kb : p.zeros + (lane & 7) * 16;
+            __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * NB + j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned key = (unsigned)(l15 >> 1);
+    const unsigned a_base = (unsigned)(wr * 128 + l15) * ROWB;
+    const unsigned b_base = (unsigned)(TBM + wc * (BNT / 4) + l15) * ROWB;
+
+    if (nk > 0) issue(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        __syncthreads();
+        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+        const char* st = smem + (ks & 1) * GSTAGE;
+#pragma unroll
+        for (int s32 = 0; s32 < 2; ++s32) {
+            const unsigned sw = ((unsigned)(4 * s32 + g4) ^ key) << 4;
+            bf16x8 af[8], bfr[NJ];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + sw + i * (16 * ROWB));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_base + sw + j * (16 * ROWB));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16s<H16>(af[i], bfr[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 128 + i * 16 + 4 * g4 + r;
+            if (m >= M) continue;
+            const int b = m / (p.MH * p.MW);
+            const int rem = m - b * (p.MH * p.MW);
+            const int mh = rem / p.MW, mw = rem - mh * p.MW;
+            const size_t opix = ((size_t)b * p.OH + (mh * p.os + oh0)) * p.OW + (mw * p.os + ow0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wc * (BNT / 4) + j * 16 + l15;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                v = act_apply(v, p.act);
+                if (p.y16) {
+                    if (H16) reinterpret_cast<_Float16*>(p.y16)[opix * p.y_cs + n] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(p.y16)[opix * p.y_cs + n] = (__bf16)v;
+                } else {
+                    p.y[opix * p.y_cs + n] = v;
+                }
+            }
+        }
+}
+
+// one kernel per tile width over the common body (a __global__ template on the tile width made this
+// clang drop the host stubs without a diagnostic)
+#define MMH_LPG_KERNEL(TBNV)                                                                                    \
+    template <bool H16>                                                                                         \
+    __global__ void __launch_bounds__(512, 2) conv_lp16g##TBNV##_kernel(const LpGConvKP p) {                    \
+        conv_lp16g_body<H16, TBNV>(p);                                                                          \
+    }                                                                                                           \
+    int launch_lp16g_##TBNV(const LpGConvKP& p, bool h16, dim3 grid, hipStream_t st) {                          \
+        constexpr int lds = 2 * (TBM + TBNV) * ROWB;                                                            \
+        static int ready = -1;                                                                                  \
+        if (ready != 0) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16g##TBNV##_kernel<false>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);               \
+            if (e == hipSuccess)                                                                                \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16g##TBNV##_kernel<true>),        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+            ready = e == hipSuccess ? 0 : mmh::fail("conv_lp16g_kernel: %s", hipGetErrorString(e));            \
+        }                                                                                                       \
+        if (ready != 0) return ready;                                                                           \
+        if (h16) hipLaunchKernelGGL(conv_lp16g##TBNV##_kernel<true>, grid, dim3(512), lds, st, p);             \
+        else hipLaunchKernelGGL(conv_lp16g##TBNV##_kernel<false>, grid, dim3(512), lds, st, p);                \
+        return 0;                                                                                               \
+    }
+MMH_LPG_KERNEL(256)
+MMH_LPG_KERNEL(128)
+MMH_LPG_KERNEL(64)
+#undef MMH_LPG_KERNEL
+
 template <bool H16>
 __global__ void __launch_bounds__(512, 2) conv_lp16_kernel(const LpConvKP p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -655,6 +861,71 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     else
         hipLaunchKernelGGL(conv_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
     return mmh::check_launch("conv_lp16_kernel");
+}
+
+
+// General 16-bit 3x3 convolution on conv_lp16g_kernel: pad 1, stride 1 | 2, 64 | 128 | 256-wide column
+// tiles.  mode 0: fprop y = conv(x16, w16 = w_t [tap][Cout][Cin]) (+bias, act);
+// mode 1: dgrad dx = conv^T(dy16, w16 = w_plain [tap][Cin][Cout]) on the zero-padded problem (for
+// MMH_PAD_REFLECT the caller adds the border terms); ConvTranspose2d(k3,s2,p1,op1) is mode 1 of the
+// stride-2 conv it is the adjoint of.  y / dx: fp32 or 16-bit (y_is16).
+int mmh_conv_lp16_supported(const mmh_conv_desc* d, int mode) {
+    if (!d || d->kh != 3 || d->kw != 3 || d->pad != 1 || (d->stride != 1 && d->stride != 2)) return 0;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return 0;
+    const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+    if (K % 64 || N % 64) return 0;
+    if (d->stride == 2 && (d->H % 2 || d->W % 2 || d->Ho != d->H / 2 || d->Wo != d->W / 2)) return 0;
+    if (d->stride == 2 && d->pad_mode == MMH_PAD_REFLECT) return 0;
+    if (d->stride == 1 && (d->Ho != d->H || d->Wo != d->W)) return 0;
+    return 1;
+}
+
+int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
+                  void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE((mode == 0 || mode == 1) && mmh_conv_lp16_supported(d, mode) && x16 && w16 && y && zeros,
+                "mmh_conv_lp16: 3x3 / pad 1 / stride 1|2 (even H, W; zero padding for stride 2), channels %% 64 == 0, "
+                "16-bit dtype");
+    LpGConvKP p{};
+    const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
+    p.x = static_cast<const char*>(x16);
+    p.w = static_cast<const char*>(w16);
+    p.zeros = static_cast<const char*>(zeros);
+    if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
+    p.bias = static_cast<const float*>(bias);
+    p.B = d->B; p.C = K; p.N = N;
+    p.KW = 3; p.KH = 3; p.pad = 1; p.tstep = 1; p.nth = 3; p.ntw = 3; p.classes = 1; p.os = 1;
+    p.act = act;
+    if (mode == 0) {            // fprop: M-space = output pixels, source = x
+        p.MH = d->Ho; p.MW = d->Wo; p.SH = d->H; p.SW = d->W; p.cs = d->x_cs; p.ss = d->stride;
+        p.ah = p.aw = -1; p.sgn = 1; p.dsh = 0;
+        p.OH = d->Ho; p.OW = d->Wo; p.y_cs = d->y_cs;
+        p.reflect = (d->pad_mode == MMH_PAD_REFLECT) ? 1 : 0;
+    } else if (d->stride == 1) {
+        p.MH = d->H; p.MW = d->W; p.SH = d->Ho; p.SW = d->Wo; p.cs = d->y_cs; p.ss = 1;
+        p.ah = p.aw = 1; p.sgn = -1; p.dsh = 0;
+        p.OH = d->H; p.OW = d->W; p.y_cs = d->x_cs;
+    } else {                    // stride-2 dgrad: four output-parity classes in grid.y
+        p.MH = d->H / 2; p.MW = d->W / 2; p.SH = d->Ho; p.SW = d->Wo; p.cs = d->y_cs; p.ss = 1;
+        p.sgn = -1; p.dsh = 1; p.tstep = 2; p.classes = 4; p.os = 2;
+        p.OH = d->H; p.OW = d->W; p.y_cs = d->x_cs;
+    }
+    const long long M = (long long)p.B * p.MH * p.MW;
+    MMH_REQUIRE((long long)p.B * p.SH * p.SW * p.cs < (1ll << 31) && (long long)p.B * p.OH * p.OW < (1ll << 31) &&
+                    p.SH < 16384 && p.SW < 32768,
+                "mmh_conv_lp16: tensor too large");
+    p.MT = (int)((M + TBM - 1) / TBM);
+    const int tbn = N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : 64);
+    p.NT = N / tbn;
+    const bool h16 = d->dtype == MMH_FP16;
+    hipStream_t st = mmh::as_stream(s);
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const dim3 grid(8 * per_xcd, p.classes);
+    int rc;
+    if (tbn == 256) rc = launch_lp16g_256(p, h16, grid, st);
+    else if (tbn == 128) rc = launch_lp16g_128(p, h16, grid, st);
+    else rc = launch_lp16g_64(p, h16, grid, st);
+    if (rc) return rc;
+    return mmh::check_launch("conv_lp16g_kernel");
 }
 
 static int lp16_wgrad_splits(const mmh_conv_desc* d) {

@@ -59,16 +59,18 @@ SIGNATURES = {
     "mmh_conv7_thin_wgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv7_thin_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),
-    "mmh_conv2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_conv2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_convT2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mmh_convT2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp]),
-    "mmh_convT2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_convT2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_reflect_fold": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "mmh_prep_weights_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_prep_weights_bf16_flat": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmh_prep_weights_fp16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_prep_weights_fp16_flat": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmh_cvt_lp16": (_i, [_vp, _i64, _i, _vp, _vp]),
+    "mmh_conv_lp16_supported": (_i, [_DP, _i]),
+    "mmh_conv_lp16": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_conv3x3_lp16_supported": (_i, [_DP]),
     "mmh_wgrad3x3_lp16_ws_bytes": (_sz, [_DP]),
     "mmh_wgrad3x3_lp16": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),

@@ -212,19 +212,30 @@ class _Net(nn.Module):
             return p, y16
         return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16)
 
-    def _lp_edge(self, cp):
-        """16-bit hand-over to the 3x3 conv `cp` (training, 16-bit mode, conv on conv_lp16.hip for all
-        three passes): returns the operand type, else 0."""
-        if self.bf16 and self.training and ops.lp16_chain_ok(cp.weight.shape[2], cp.weight.shape[3], cp.k, 1, 1):
-            return self.bf16
-        return 0
+    def _lp_edge(self, cp, stride=1, reflect=True):
+        """16-bit hand-over to the 3x3 / pad 1 conv (or ConvTranspose2d) `cp` (training, 16-bit mode, all
+        three passes of the conv on kernels that read and write 16-bit tensors): returns the operand
+        type, else 0."""
+        if not (self.bf16 and self.training and cp is not None and cp.k == 3):
+            return 0
+        ws = cp.weight.shape        # physical: conv [k,k,Cin,Cout]; transposed conv [k,k,CoutT,CinT]
+        if cp.transposed:
+            return self.bf16 if ops.convT_lp16_ok(ws[3], ws[2], self.bf16) else 0
+        return self.bf16 if ops.lp16_chain_ok(ws[2], ws[3], 3, stride, 1, reflect, self.bf16) else 0
 
-    def _lp_out(self, cp):
-        """the 3x3 conv `cp` hands its output (and takes its gradient) in 16 bits"""
-        return bool(ops.USE_LP16_EDGES and self._lp_edge(cp))
+    def _lp_out(self, cp, stride=1, reflect=True):
+        """the conv `cp` hands its output (and takes its gradient) in 16 bits"""
+        return bool(ops.USE_LP16_EDGES and self._lp_edge(cp, stride, reflect))
 
-    def convT(self, cp, x):
-        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16)
+    def convT(self, cp, x, y_lp=False):
+        """x: fp32 NHWC or a (proxy, x16) pair; y_lp: returns a (proxy, y16) pair"""
+        x16 = None
+        if isinstance(x, tuple):
+            x, x16 = x
+        if y_lp:
+            p, y16 = ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, True)
+            return p, y16
+        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16)
 
     def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0):
         """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
@@ -317,11 +328,22 @@ class Generator(_Net):
         """x1,x2,x3: NHWC (channels zero-padded to 4) -> NHWC [B,H,W,pad4(output_nc)]."""
         m = self.model
         xs = []
+        # 16-bit mode: the tensors between the 3x3 convs and their norms travel in 16 bits (see two_conv_block);
+        # the 7x7 stems read fp32 inputs and write fp32
         for s, x in zip((1, 2, 3), (x1, x2, x3)):
             d = m[f"stream{s}_down"]
-            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True), True)
+            first = d[4] if self.n_down > 0 else None
+            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True), True, out_lp=self._lp_edge(first, 2, False))
             for i in range(self.n_down):
-                x = self.normact(d, 5 + 3 * i, self.conv(d[4 + 3 * i], x, 2, 1, False), True)
+                cp = d[4 + 3 * i]
+                if i + 1 < self.n_down:
+                    out_lp = self._lp_edge(d[4 + 3 * (i + 1)], 2, False)
+                elif s != 1 and self.n_blocks > 0:      # streams 2 / 3 feed only block 0's first conv
+                    out_lp = self._lp_edge(m["att"][0][f"conv_block_stream{s}"][1])
+                else:
+                    out_lp = 0
+                x = self.normact(d, 5 + 3 * i, self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False)), True,
+                                 out_lp=out_lp)
             xs.append(x)
         x1, x2, x3 = xs
         for b in range(self.n_blocks):
@@ -345,7 +367,9 @@ class Generator(_Net):
         up = m["stream1_up"]
         y = x1
         for i in range(self.n_down):
-            y = self.normact(up, 3 * i + 1, self.convT(up[3 * i], y), True)
+            nxt = up[3 * (i + 1)] if i + 1 < self.n_down else None      # the 7x7 head reads fp32
+            y = self.normact(up, 3 * i + 1, self.convT(up[3 * i], y, y_lp=self._lp_out(up[3 * i])), True,
+                             out_lp=self._lp_edge(nxt))
         return self.conv(up[3 * self.n_down + 1], y, 1, 3, True, L.ACT_TANH)
 
     def forward(self, input):
@@ -395,9 +419,14 @@ class Discriminator(_Net):
         """dx_channels > 0: the caller needs the gradient of only the first dx_channels input
         channels (the generated image inside cat(fake, P2) / cat(fake, H1))."""
         m = self.model
-        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels), True)
+        first = m[4] if self.n_down > 0 else None
+        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels), True,
+                         out_lp=self._lp_edge(first, 2, False))
         for i in range(self.n_down):
-            y = self.normact(m, 5 + 3 * i, self.conv(m[4 + 3 * i], y, 2, 1, False), True)
+            cp = m[4 + 3 * i]
+            out_lp = self._lp_edge(m[4 + 3 * (i + 1)], 2, False) if i + 1 < self.n_down else 0
+            y = self.normact(m, 5 + 3 * i, self.conv(cp, y, 2, 1, False, y_lp=self._lp_out(cp, 2, False)), True,
+                             out_lp=out_lp)
         base = 4 + 3 * self.n_down
         for b in range(self.n_blocks):
             y = self.two_conv_block(m[base + b]["conv_block"], y, f"model.{base + b}.conv_block",

@@ -39,6 +39,14 @@ def _chk(t, name="tensor"):
     return t
 
 
+def _chk16(t, name="tensor"):
+    """fp32 or 16-bit contiguous device tensor"""
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16, torch.float16) and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous fp32 / 16-bit CUDA tensor, got "
+                           f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return t
+
+
 def pad4(c):
     return (c + 3) // 4 * 4
 
@@ -398,6 +406,8 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         if timed:
             e1.record()
         return y
+    if bf16 and lp16g_ok(d, 0, bf16):
+        return raw_conv_lp16g(d, 0, lp16_twin(x, bf16), w, bias, act, bf16)
     if bf16:
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[1]
@@ -433,7 +443,9 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     _chk(w, "w")
     B, H, W_, Cin = x_shape
     if dy is None or out16:
-        assert bf16 and lp16_v2_ok(Cin, w.shape[3], w.shape[0], stride, pad, 1) and (dy16 is not None or dy is not None)
+        assert bf16 and (dy16 is not None or dy is not None) and (
+            lp16_v2_ok(Cin, w.shape[3], w.shape[0], stride, pad, 1)
+            or (not reflect and lp16g_ok(conv_desc(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, reflect), 1, bf16)))
     if dy is not None:
         _chk(dy, "dy")
     k, _, _, Cout = w.shape
@@ -458,6 +470,9 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
             L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy16), _ptr(bf16_weights(w, bf16)[0]), _ptr(dx), _ptr(ws),
                    ws.numel() * 4, 3, 1 | (2 if out16 else 0), _stream())
         return dx
+    if bf16 and not reflect and lp16g_ok(d, 1, bf16):
+        return raw_conv_lp16g(d, 1, dy16 if dy16 is not None else lp16_twin(dy, bf16), w, None, L.ACT_NONE, bf16,
+                              out16=out16)
     if bf16 and Cout % 64 == 0:
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[0]
@@ -471,11 +486,27 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
 
 
 def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
-    _chk(x, "x"); _chk(dy, "dy")
+    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits."""
+    _chk16(x, "x"); _chk16(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
+    lp_in = x.dtype != torch.float32 or dy.dtype != torch.float32
+    assert bf16 or not lp_in
     if bf16 and lp16_wgrad_ok(Cin, Cout, k, stride, pad):
-        return raw_wgrad3x3_lp16(lp16_twin(x, bf16), lp16_twin(dy, bf16), reflect, bf16)
+        return raw_wgrad3x3_lp16(x if x.dtype != torch.float32 else lp16_twin(x, bf16),
+                                 dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16), reflect, bf16)
+    if lp_in:       # first-generation 16-bit wgrad kernel reading the 16-bit tensors directly (both or neither)
+        x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
+        dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
+        d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+        d.dtype = _dt(bf16)
+        assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
+        ws = _ws(L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d)), x)
+        dw = _empty((k, k, Cin, Cout), x)
+        L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+               (1 if x.dtype != torch.float32 else 0) | (2 if dy.dtype != torch.float32 else 0), _stream())
+        _count_desc("mfma", d)
+        return dw
     wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "wgrad")
     if wt:
         return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16)
@@ -495,7 +526,7 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     ws = _ws(nbytes, x)
     dw = _empty((k, k, Cin, Cout), x)
     L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
-           ws.numel() * 4, 0, _stream())
+           ws.numel() * 4, 0, 0, _stream())
     _count_desc("mfma", d)
     return dw
 
@@ -548,10 +579,54 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
     return y
 
 
-def lp16_chain_ok(Cin, Cout, k, stride, pad):
-    """all three passes of this conv run on conv_lp16.hip: its producer may hand x over in 16 bits"""
-    return (lp16_v2_ok(Cin, Cout, k, stride, pad, 0) and lp16_v2_ok(Cin, Cout, k, stride, pad, 1)
-            and lp16_wgrad_ok(Cin, Cout, k, stride, pad))
+# the same kernel family for the other 3x3 / pad 1 convs (stride 2, ConvTranspose2d, 64 / 128 columns)
+USE_LP16_G = os.environ.get("MMH_LP16_G", "1") != "0"
+
+
+def lp16g_ok(d, mode, bf16):
+    """conv_lp16g_kernel takes pass `mode` (0 fprop | 1 dgrad) of the conv described by d"""
+    if not (bf16 and USE_LP16_V2 and USE_LP16_G):
+        return False
+    old = d.dtype
+    d.dtype = _dt(bf16)
+    ok = bool(L.load().mmh_conv_lp16_supported(C.byref(d), mode))
+    d.dtype = old
+    return ok
+
+
+def raw_conv_lp16g(d, mode, x16, w, bias, act, bf16, out16=False):
+    """pass `mode` of conv d on the general 16-bit kernel; x16: the 16-bit input (mode 0) / output
+    gradient (mode 1); w: the fp32 physical weight [3,3,Cin,Cout]."""
+    assert x16.dtype == _wd(bf16) and x16.is_contiguous()
+    d.dtype = _dt(bf16)
+    wp, wt = bf16_weights(w, bf16)
+    shape = (d.B, d.Ho, d.Wo, d.Cout) if mode == 0 else (d.B, d.H, d.W, d.Cin)
+    y = torch.empty(shape, dtype=_wd(bf16) if out16 else torch.float32, device=x16.device)
+    L.call("mmh_conv_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
+           int(out16), act, _ptr(zero_page(x16.device)), _stream())
+    _count_desc("mfma", d)
+    return y
+
+
+def lp16_chain_ok(Cin, Cout, k, stride, pad, reflect=True, bf16=True):
+    """All three passes of this conv read and write 16-bit tensors directly (fprop and dgrad on
+    conv_lp16.hip, wgrad there or on the first-generation kernel with 16-bit sources): its neighbours may
+    hand x over, and take y, in 16 bits.  reflect: the padding mode (decides the dgrad kernel)."""
+    if not (USE_LP16_V2 and k == 3 and pad == 1):
+        return False
+    if (lp16_v2_ok(Cin, Cout, k, stride, pad, 0) and lp16_v2_ok(Cin, Cout, k, stride, pad, 1)
+            and lp16_wgrad_ok(Cin, Cout, k, stride, pad)):
+        return True
+    d = conv_desc(1, 8, 8, Cin, Cout, k, stride, pad, reflect)
+    fprop = lp16_v2_ok(Cin, Cout, k, stride, pad, 0) or lp16g_ok(d, 0, bf16)
+    dgrad = lp16_v2_ok(Cin, Cout, k, stride, pad, 1) or (not reflect and lp16g_ok(d, 1, bf16))
+    return fprop and dgrad and Cin % 4 == 0 and Cout % 4 == 0
+
+
+def convT_lp16_ok(CinT, CoutT, bf16=True):
+    """ConvTranspose2d(k3,s2,p1,op1) with 16-bit tensors on all three passes"""
+    d = conv_desc(1, 8, 8, CoutT, CinT, 3, 2, 1, False)
+    return USE_LP16_V2 and lp16g_ok(d, 0, bf16) and lp16g_ok(d, 1, bf16)
 
 
 def _tdt(t):
@@ -621,9 +696,14 @@ def _convT_desc(x, w):
     return conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
 
 
-def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False):
-    _chk(x, "x"); _chk(w, "w")
+def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False, out16=False):
+    """x: fp32 or (16-bit mode) 16-bit; out16: 16-bit output (conv_lp16 path only)"""
+    _chk16(x, "x"); _chk(w, "w")
     d = _convT_desc(x, w)
+    if bf16 and lp16g_ok(d, 1, bf16):       # the adjoint of a stride-2 conv = its dgrad
+        return raw_conv_lp16g(d, 1, x if x.dtype != torch.float32 else lp16_twin(x, bf16), w, bias, act, bf16,
+                              out16=out16)
+    assert x.dtype == torch.float32 and not out16
     y = _empty((d.B, d.H, d.W, d.Cin), x)
     if bf16 and d.Cout % 64 == 0:
         d.dtype = _dt(bf16)
@@ -634,10 +714,14 @@ def raw_convT_fprop(x, w, bias, act=L.ACT_NONE, bf16=False):
     return y
 
 
-def raw_convT_dgrad(dy, w, x_shape, bf16=False):
-    _chk(dy, "dy")
+def raw_convT_dgrad(dy, w, x_shape, bf16=False, out16=False):
+    _chk16(dy, "dy")
     B, h, w_, CinT = x_shape
     d = conv_desc(B, 2 * h, 2 * w_, w.shape[2], CinT, 3, 2, 1, False)
+    if bf16 and lp16g_ok(d, 0, bf16):
+        return raw_conv_lp16g(d, 0, dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16), w, None, L.ACT_NONE,
+                              bf16, out16=out16)
+    assert dy.dtype == torch.float32 and not out16
     dx = _empty((B, h, w_, CinT), dy)
     if bf16 and d.Cin % 64 == 0:
         d.dtype = _dt(bf16)
@@ -648,17 +732,23 @@ def raw_convT_dgrad(dy, w, x_shape, bf16=False):
 
 
 def raw_convT_wgrad(x, dy, bf16=False):
-    _chk(x, "x"); _chk(dy, "dy")
+    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits."""
+    _chk16(x, "x"); _chk16(dy, "dy")
+    assert bf16 or (x.dtype == torch.float32 and dy.dtype == torch.float32)
     B, h, w_, CinT = x.shape
     CoutT = dy.shape[3]
     d = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
     if bf16:
         d.dtype = _dt(bf16)
+    if x.dtype != dy.dtype:         # the kernel takes both tensors in 16 bits or neither
+        x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
+        dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
     dw = _empty((3, 3, CoutT, CinT), x)
     L.call("mmh_convT2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
-           ws.numel() * 4, 0, _stream())
+           ws.numel() * 4, 0, (1 if x.dtype != torch.float32 else 0) | (2 if dy.dtype != torch.float32 else 0),
+           _stream())
     _count_desc("mfma", d)
     return dw
 
@@ -698,25 +788,31 @@ class Conv2dFn(torch.autograd.Function):
         ctx.x_lp = x16 is not None
         ctx.y_lp = bool(y_lp)
         k = w.shape[0]
+        chain = bool(bf16) and lp16_chain_ok(Cin, w.shape[3], k, stride, pad, reflect, bf16)
         if x16 is not None:
-            assert bf16 and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape) and lp16_chain_ok(
-                Cin, w.shape[3], k, stride, pad), "a 16-bit input needs the conv_lp16 path for all three passes"
+            assert chain and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape), \
+                "a 16-bit input needs 16-bit kernels for all three passes"
         if y_lp:
-            assert bf16 and act == L.ACT_NONE and lp16_chain_ok(Cin, w.shape[3], k, stride, pad), \
-                "a 16-bit output needs the conv_lp16 path for all three passes and no activation"
-        if bf16 and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0):
-            # 16-bit path of the 256 / 512-channel 3x3 stack: one 16-bit twin of x (or the producer's own
-            # 16-bit output) feeds the fprop and, kept instead of x, the wgrad
+            assert chain and act == L.ACT_NONE, "a 16-bit output needs 16-bit kernels for all three passes and no activation"
+        v2 = bool(bf16) and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0)
+        if v2 or chain:
+            # 16-bit path: one 16-bit twin of x (or the producer's own 16-bit output) feeds the fprop and,
+            # kept instead of x, the wgrad.  256 / 512-channel stride-1 stack: conv_lp16s_kernel, the other
+            # 3x3 convs (stride 2, 64 / 128 columns): conv_lp16g_kernel
             if x16 is None:
                 x16 = lp16_twin(x, bf16)
-            timed = fprop_timer is not None and fprop_timer.want(conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect))
+            d = conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect)
+            timed = fprop_timer is not None and fprop_timer.want(d)
             if timed:
                 e0, e1 = fprop_timer.bracket()
                 e0.record()
-            y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp))
+            if v2:
+                y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp))
+            else:
+                y = raw_conv_lp16g(d, 0, x16, w, bias, act, bf16, out16=bool(y_lp))
             if timed:
                 e1.record()
-            ctx.lp16 = lp16_wgrad_ok(Cin, w.shape[3], k, stride, pad)
+            ctx.lp16 = chain or lp16_wgrad_ok(Cin, w.shape[3], k, stride, pad)
             ctx.save_for_backward(x16 if ctx.lp16 else x, w, y if act != L.ACT_NONE else None)
             if y_lp:
                 ctx.mark_non_differentiable(y)
@@ -745,7 +841,7 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.x_lp:
                     dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
-                dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
+                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16)
             return dx, dw, db, None, None, None, None, None, None, None, None
@@ -766,7 +862,7 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.x_lp:
                     dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
-                dw = raw_wgrad3x3_lp16(x, g16, reflect, bf16)
+                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
             if has_bias and ctx.needs_input_grad[2]:
                 db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
             return dx, dw, db, None, None, None, None, None, None, None, None
@@ -786,25 +882,50 @@ class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d(k3,s2,p1,op1): fprop = stride-2 dgrad kernel, dgrad = stride-2 fprop."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, bf16=False):
-        y = raw_convT_fprop(x, w, bias, L.ACT_NONE, bf16)
+    def forward(ctx, x, w, bias, bf16=False, x16=None, y_lp=False):
+        """x16 / y_lp: 16-bit edges as in Conv2dFn (convT_lp16_ok)."""
         ctx.has_bias = bias is not None
         ctx.bf16 = bf16
+        ctx.x_lp = x16 is not None
+        ctx.y_lp = bool(y_lp)
+        ctx.x_shape = tuple(x.shape)
+        chain = bool(bf16) and convT_lp16_ok(x.shape[3], w.shape[2], bf16)
+        if x16 is not None or y_lp:
+            assert chain, "16-bit edges of a ConvTranspose2d need 16-bit kernels for all three passes"
+        if chain:
+            if x16 is None:
+                x16 = lp16_twin(x, bf16)
+            y = raw_convT_fprop(x16, w, bias, L.ACT_NONE, bf16, out16=bool(y_lp))
+            ctx.lp16 = True
+            ctx.save_for_backward(x16, w)
+            if y_lp:
+                ctx.mark_non_differentiable(y)
+                return lp_proxy(y.shape, y.device), y
+            return y
+        ctx.lp16 = False
+        y = raw_convT_fprop(x, w, bias, L.ACT_NONE, bf16)
         ctx.save_for_backward(x, w)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g16=None):
         x, w = ctx.saved_tensors
-        g = g.contiguous()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = raw_convT_dgrad(g, w, x.shape, ctx.bf16)
+        if ctx.lp16:
+            g = lp_grad_in(g, "ConvT2dFn") if ctx.y_lp else lp16_twin(g.contiguous(), ctx.bf16)
+            if ctx.needs_input_grad[0]:
+                dx = raw_convT_dgrad(g, w, ctx.x_shape, ctx.bf16, out16=ctx.x_lp)
+                if ctx.x_lp:
+                    dx = lp_grad_out(dx)
+        else:
+            g = g.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = raw_convT_dgrad(g, w, ctx.x_shape, ctx.bf16)
         if ctx.needs_input_grad[1]:
             dw = raw_convT_wgrad(x, g, ctx.bf16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None
+        return dx, dw, db, None, None, None
 
 
 # --------------------------------------------------------------------------- norm

@@ -322,6 +322,42 @@ def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 2, False), (1, 32, 20, 128, 256, 2, False),
+                                  (3, 10, 14, 64, 64, 1, False), (2, 11, 9, 64, 128, 1, True),
+                                  (1, 8, 8, 256, 64, 2, False), (2, 6, 6, 128, 128, 2, False)])
+def test_conv_lp16g_kernels(case, lp, dev):
+    """conv_lp16g_kernel through the C-ABI: fprop and dgrad of 3x3 / pad 1 convs at stride 1 | 2 with
+    64 / 128 / 256-wide column tiles (stride-2 dgrad: the four parity classes in one launch), fp32 and
+    16-bit epilogues, against the fp64 oracle on operands rounded to the same type."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, stride, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    ops.bump_weights_epoch()
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    d = ops.conv_desc(B, H, W, Cin, Cout, 3, stride, 1, refl)
+    dy = _mk((B, d.Ho, d.Wo, Cout), 4, dev)
+    assert ops.lp16g_ok(d, 0, lp)
+    x16, dy16 = ops.lp16_twin(x, lp), ops.lp16_twin(dy, lp)
+    y = ops.raw_conv_lp16g(d, 0, x16, w, bias, 1, lp)
+    yr = R.conv2d(rb(x), rb(w), bias.cpu(), stride, 1, refl, 1)
+    assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+    y16 = ops.raw_conv_lp16g(d, 0, x16, w, bias, 1, lp, out16=True)
+    assert R.rel_l1(y16.float(), yr) < (2e-3 if lp == 2 else 8e-3)
+    if not refl:
+        assert ops.lp16g_ok(d, 1, lp)
+        dx = ops.raw_conv_lp16g(d, 1, dy16, w, None, 0, lp)
+        _, dxr, _, _ = R.conv2d_grads(rb(x), rb(w), None, rb(dy), stride, 1, False)
+        assert R.rel_l1(dx, dxr) < 5e-6, R.rel_l1(dx, dxr)
+        dx16 = ops.raw_conv_lp16g(d, 1, dy16, w, None, 0, lp, out16=True)
+        assert R.rel_l1(dx16.float(), dxr) < (2e-3 if lp == 2 else 8e-3)
+        # and through the routing of the raw ops
+        assert R.rel_l1(ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), stride, 1, False, lp), dxr) < 5e-6
+    assert R.rel_l1(ops.raw_conv_fprop(x, w, bias, stride, 1, refl, 1, lp), yr) < 5e-6
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 def test_convT_bf16_mfma_path(lp, dev):
     from mmhand_amd import ops
     x = _mk((2, 8, 8, 128), 1, dev)
