@@ -219,6 +219,18 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
                   const void* bias, void* y, int y_is16, int act, const void* zeros,
                   mmh_stream_t s);
 
+/* Flat-K 16-bit fprop for the 7x7 stems (Cin = 3..42: models/Generator.py:158-164,
+ * models/Discriminator.py:79-84): contraction index k = tap * C8 + c over the channels padded to C8
+ * (a multiple of 8, <= 64).  x16p = mmh_lp16_pad_cvt(x) [B][H][W][C8]; w_flat =
+ * mmh_prep_weights_lp16_flat8(w) [Cout][roundup(kh*kw*C8, 64)]; stride 1, 'same' zero / reflect padding. */
+int mmh_lp16_pad_cvt(const void* x, int64_t rows, int C, int C8, int dtype, void* out, mmh_stream_t s);
+int mmh_prep_weights_lp16_flat8(const void* w, int taps, int Cin, int Cout, int C8, int dtype,
+                                void* out, mmh_stream_t s);
+int mmh_conv_lp16_flat_supported(const mmh_conv_desc* d, int C8);
+int mmh_conv_lp16_flat(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_flat,
+                       const void* bias, void* y, int y_is16, int act, const void* zeros,
+                       mmh_stream_t s);
+
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,

@@ -391,6 +391,186 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Flat-K variant for the 7x7 stems (Cin = 3 .. 42): the contraction index runs over (tap, channel)
+// flattened, k = tap * C8 + c with the channels padded to C8 (a multiple of 8: one 16-byte chunk is
+// 8 channels of one tap), so a 64-deep k-step spans 64 / C8 taps (C8 = 8: eight taps) and every lane
+// of the A-operand DMA carries its own tap.  Tile 256 pixels x 64 channels x 64, 8 waves stacked along
+// M (wave tile 32 x 64: 2 A and 4 B fragments per 8 MFMAs), two 40 KiB stages.
+//   x16p  [B][H][W][C8] 16-bit (mmh_lp16_pad_cvt)      w  [N][Kpad] 16-bit, Kpad = roundup(KH*KW*C8, 64)
+struct LpFlatKP {
+    const char* x;
+    const char* w;
+    const char* zeros;
+    float* y;
+    char* y16;
+    const float* bias;
+    int B, H, W, C8, KH, KW, pad, reflect;
+    int cpt, q8, r8;        // chunks per tap = C8 / 8; 8 / cpt and 8 % cpt (a lane's chunk index advances by 8 per k-step)
+    int Kpad, nk;
+    int N, y_cs, act, MT, NT;
+};
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) conv_lp16f_kernel(const LpFlatKP p) {
+    constexpr int FSTAGE = (TBM + 64) * ROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int m0 = mt * TBM, n0 = nt * 64;
+    const int M = p.B * p.H * p.W;
+    const int taps = p.KH * p.KW;
+    // A DMA: 4 rows per lane; per row the lane's logical chunk q (of 8) and its running (tap, chunk-in-tap)
+    int a_pix[4], a_hw[4], a_tap[4], a_cc[4], a_kh[4], a_kw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const int b = m / (p.H * p.W);
+        const int rem = m - b * (p.H * p.W);
+        const int oh = rem / p.W, ow = rem - oh * p.W;
+        a_pix[j] = m < M ? b * p.H * p.W : -1;
+        a_hw[j] = (oh << 16) | ow;
+        a_tap[j] = q / p.cpt;
+        a_cc[j] = q - a_tap[j] * p.cpt;
+        a_kh[j] = a_tap[j] / p.KW;
+        a_kw[j] = a_tap[j] - a_kh[j] * p.KW;
+    }
+    const int br = wave * 8 + (lane >> 3);                              // B DMA: one row per lane
+    const unsigned b_off = (unsigned)(n0 + br) * (unsigned)p.Kpad * 2u + (unsigned)((lane & 7) ^ ((br >> 1) & 7)) * 16u;
+
+    auto issue = [&](int ks, int stage) {
+        char* sA = smem + stage * FSTAGE;
+        char* sB = sA + TBM * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ih = (a_hw[j] >> 16) + a_kh[j] - p.pad, iw = (a_hw[j] & 0xffff) + a_kw[j] - p.pad;
+            bool ok = a_pix[j] >= 0 && a_tap[j] < taps;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const unsigned off = (unsigned)(a_pix[j] + ih * p.W + iw) * (unsigned)p.C8 * 2u + (unsigned)a_cc[j] * 16u;
+            const char* g = ok ? p.x + off : p.zeros + (lane & 7) * 16;
+            __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+            // next k-step: this lane's flat chunk index advances by 8
+            int dt = p.q8;
+            a_cc[j] += p.r8;
+            if (a_cc[j] >= p.cpt) { a_cc[j] -= p.cpt; ++dt; }
+            a_tap[j] += dt;
+            a_kw[j] += dt;
+            while (a_kw[j] >= p.KW) { a_kw[j] -= p.KW; ++a_kh[j]; }
+        }
+        __builtin_amdgcn_global_load_lds(p.w + b_off + (unsigned)ks * (TBK * 2), (lds_vp)(sB + wave * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned key = (unsigned)(l15 >> 1);
+    const unsigned a_base = (unsigned)(wave * 32 + l15) * ROWB;
+    const unsigned b_base = (unsigned)(TBM + l15) * ROWB;
+
+    if (p.nk > 0) issue(0, 0);
+    for (int ks = 0; ks < p.nk; ++ks) {
+        __syncthreads();
+        if (ks + 1 < p.nk) issue(ks + 1, (ks + 1) & 1);
+        const char* st = smem + (ks & 1) * FSTAGE;
+#pragma unroll
+        for (int s32 = 0; s32 < 2; ++s32) {
+            const unsigned sw = ((unsigned)(4 * s32 + g4) ^ key) << 4;
+            bf16x8 af[2], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + sw + i * (16 * ROWB));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_base + sw + j * (16 * ROWB));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], bfr[j], acc[i][j]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wave * 32 + i * 16 + 4 * g4 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j * 16 + l15;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                v = act_apply(v, p.act);
+                if (p.y16) {
+                    if (H16) reinterpret_cast<_Float16*>(p.y16)[(size_t)m * p.y_cs + n] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(p.y16)[(size_t)m * p.y_cs + n] = (__bf16)v;
+                } else {
+                    p.y[(size_t)m * p.y_cs + n] = v;
+                }
+            }
+        }
+}
+
+// x fp32 [rows][C] -> 16-bit [rows][C8], channels zero-padded (the stems' input for conv_lp16f_kernel)
+__global__ void lp16_pad_cvt_kernel(const float* __restrict__ x, int64_t rows, int C, int C8, int h16,
+                                    void* __restrict__ out) {
+    const int64_t total = rows * (C8 / 8);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int c8n = C8 / 8;
+    for (; i < total; i += stride) {
+        const int64_t row = i / c8n;
+        const int c0 = (int)(i - row * c8n) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? x[row * C + c0 + e] : 0.f;
+        if (h16) {
+            f16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (_Float16)v[e];
+            reinterpret_cast<f16x8*>(out)[i] = r;
+        } else {
+            bf16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+            reinterpret_cast<bf16x8*>(out)[i] = r;
+        }
+    }
+}
+
+// w fp32 [taps][Cin][Cout] -> 16-bit [Cout][Kpad], k = tap * C8 + c (zero padded)
+__global__ void prep_weights_flat8_kernel(const float* __restrict__ w, int taps, int Cin, int Cout, int C8, int Kpad,
+                                          int h16, void* __restrict__ out) {
+    const int64_t total = (int64_t)Cout * Kpad;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+        const int t = k / C8, c = k - t * C8;
+        const float v = (t < taps && c < Cin) ? w[((int64_t)t * Cin + c) * Cout + n] : 0.f;
+        if (h16) reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
+        else reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+    }
+}
+
 // one kernel per tile width over the common body (a __global__ template on the tile width made this
 // clang drop the host stubs without a diagnostic)
 #define MMH_LPG_KERNEL(TBNV)                                                                                    \
@@ -926,6 +1106,77 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
     else rc = launch_lp16g_64(p, h16, grid, st);
     if (rc) return rc;
     return mmh::check_launch("conv_lp16g_kernel");
+}
+
+
+// ---- flat-K 16-bit fprop for the 7x7 stems (models/Generator.py:158-164, Discriminator.py:79-84) ----
+int mmh_lp16_pad_cvt(const void* x, int64_t rows, int C, int C8, int dtype, void* out, mmh_stream_t s) {
+    MMH_REQUIRE(x && out && rows > 0 && C > 0 && C8 >= C && C8 % 8 == 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_lp16_pad_cvt: bad arguments (C8 %% 8 == 0, C8 >= C, 16-bit dtype)");
+    const int64_t total = rows * (C8 / 8);
+    hipLaunchKernelGGL(lp16_pad_cvt_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(total, 256), 8192)), dim3(256), 0,
+                       mmh::as_stream(s), static_cast<const float*>(x), rows, C, C8, dtype == MMH_FP16 ? 1 : 0, out);
+    return mmh::check_launch("lp16_pad_cvt_kernel");
+}
+
+int mmh_prep_weights_lp16_flat8(const void* w, int taps, int Cin, int Cout, int C8, int dtype, void* out,
+                                mmh_stream_t s) {
+    MMH_REQUIRE(w && out && taps > 0 && Cin > 0 && Cout > 0 && C8 >= Cin && C8 % 8 == 0 &&
+                    (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_prep_weights_lp16_flat8: bad arguments");
+    const int Kpad = (taps * C8 + 63) / 64 * 64;
+    const int64_t total = (int64_t)Cout * Kpad;
+    hipLaunchKernelGGL(prep_weights_flat8_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(total, 256), 4096)), dim3(256),
+                       0, mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout, C8, Kpad,
+                       dtype == MMH_FP16 ? 1 : 0, out);
+    return mmh::check_launch("prep_weights_flat8_kernel");
+}
+
+int mmh_conv_lp16_flat_supported(const mmh_conv_desc* d, int C8) {
+    return d && d->kh == d->kw && d->kh * d->kw * (C8 / 8) >= 8 && d->stride == 1 && d->pad == d->kh / 2 && d->kh % 2 == 1 &&
+           d->Cout % 64 == 0 && C8 % 8 == 0 && C8 >= d->Cin && C8 <= 64 && d->Ho == d->H && d->Wo == d->W &&
+           (d->dtype == MMH_BF16 || d->dtype == MMH_FP16);
+}
+
+// y[B,H,W,Cout] = conv(x16p [B,H,W,C8], w_flat [Cout][Kpad]) (+bias, act); stride 1, 'same' padding
+int mmh_conv_lp16_flat(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_flat, const void* bias,
+                       void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(mmh_conv_lp16_flat_supported(d, C8) && x16p && w_flat && y && zeros,
+                "mmh_conv_lp16_flat: odd square kernel, stride 1, same padding, Cout %% 64 == 0, C8 %% 8 == 0 <= 64");
+    LpFlatKP p{};
+    p.x = static_cast<const char*>(x16p);
+    p.w = static_cast<const char*>(w_flat);
+    p.zeros = static_cast<const char*>(zeros);
+    if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
+    p.bias = static_cast<const float*>(bias);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.KH = d->kh; p.KW = d->kw; p.pad = d->pad;
+    p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.cpt = C8 / 8; p.q8 = 8 / p.cpt; p.r8 = 8 % p.cpt;
+    p.Kpad = (d->kh * d->kw * C8 + 63) / 64 * 64;
+    p.nk = p.Kpad / 64;
+    p.N = d->Cout; p.y_cs = d->y_cs; p.act = act;
+    const long long M = (long long)d->B * d->H * d->W;
+    MMH_REQUIRE(M * (long long)std::max(C8, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
+                "mmh_conv_lp16_flat: tensor too large");
+    p.MT = (int)((M + TBM - 1) / TBM);
+    p.NT = d->Cout / 64;
+    constexpr int lds = 2 * (TBM + 64) * ROWB;
+    static int ready = -1;
+    if (ready != 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16f_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16f_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        ready = e == hipSuccess ? 0 : mmh::fail("conv_lp16f_kernel: %s", hipGetErrorString(e));
+    }
+    if (ready != 0) return ready;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    if (d->dtype == MMH_FP16)
+        hipLaunchKernelGGL(conv_lp16f_kernel<true>, dim3(8 * per_xcd), dim3(512), lds, mmh::as_stream(s), p);
+    else
+        hipLaunchKernelGGL(conv_lp16f_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, mmh::as_stream(s), p);
+    return mmh::check_launch("conv_lp16f_kernel");
 }
 
 static int lp16_wgrad_splits(const mmh_conv_desc* d) {

@@ -91,6 +91,7 @@ def bump_weights_epoch():
     tensor that happens to land on a freed tensor's address never hits a stale entry."""
     _weights_epoch[0] += 1
     _bf16_cache.clear()
+    _flat8_cache.clear()
     _wino_cache.clear()
 
 
@@ -408,6 +409,15 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         return y
     if bf16 and lp16g_ok(d, 0, bf16):
         return raw_conv_lp16g(d, 0, lp16_twin(x, bf16), w, bias, act, bf16)
+    if bf16 and lp16_flat_ok(d, bf16):
+        timed = fprop_timer is not None and fprop_timer.want(d)
+        if timed:
+            e0, e1 = fprop_timer.bracket()
+            e0.record()
+        y = raw_conv_lp16_flat(d, x, w, bias, act, bf16)
+        if timed:
+            e1.record()
+        return y
     if bf16:
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[1]
@@ -608,6 +618,49 @@ def raw_conv_lp16g(d, mode, x16, w, bias, act, bf16, out16=False):
     return y
 
 
+# flat-K 16-bit fprop for the 7x7 stems (conv_lp16f_kernel)
+USE_LP16_FLAT = os.environ.get("MMH_LP16_FLAT", "1") != "0"
+_flat8_cache = {}
+
+
+def lp16_flat_ok(d, bf16):
+    if not (bf16 and USE_LP16_V2 and USE_LP16_FLAT) or d.Cin > 64 or d.kh < 5:
+        return False
+    old = d.dtype
+    d.dtype = _dt(bf16)
+    ok = bool(L.load().mmh_conv_lp16_flat_supported(C.byref(d), (d.Cin + 7) // 8 * 8))
+    d.dtype = old
+    return ok
+
+
+def flat8_weights(w, bf16):
+    """16-bit [Cout][roundup(k*k*C8, 64)] copy of a physical fp32 weight [k,k,Cin,Cout], k = tap*C8 + c"""
+    key = (w.data_ptr(), tuple(w.shape), _lp(bf16))
+    ent = _cache_get(_flat8_cache, key, w)
+    if ent is None:
+        k, _, cin, cout = w.shape
+        c8 = (cin + 7) // 8 * 8
+        kpad = (k * k * c8 + 63) // 64 * 64
+        out = torch.empty((cout, kpad), dtype=_wd(bf16), device=w.device)
+        L.call("mmh_prep_weights_lp16_flat8", _ptr(w), k * k, cin, cout, c8, _dt(bf16), _ptr(out), _stream())
+        ent = _cache_put(_flat8_cache, key, w, out)
+    return ent
+
+
+def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False):
+    """fprop of a small-Cin 'same' conv on the flat-K 16-bit kernel; x: fp32 NHWC [B,H,W,Cin]"""
+    _chk(x, "x")
+    c8 = (d.Cin + 7) // 8 * 8
+    x16p = torch.empty((d.B, d.H, d.W, c8), dtype=_wd(bf16), device=x.device)
+    L.call("mmh_lp16_pad_cvt", _ptr(x), d.B * d.H * d.W, d.Cin, c8, _dt(bf16), _ptr(x16p), _stream())
+    d.dtype = _dt(bf16)
+    y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x.device)
+    L.call("mmh_conv_lp16_flat", C.byref(d), _ptr(x16p), c8, _ptr(flat8_weights(w, bf16)), _ptr(bias), _ptr(y),
+           int(out16), act, _ptr(zero_page(x.device)), _stream())
+    _count_desc("mfma", d)
+    return y
+
+
 def lp16_chain_ok(Cin, Cout, k, stride, pad, reflect=True, bf16=True):
     """All three passes of this conv read and write 16-bit tensors directly (fprop and dgrad on
     conv_lp16.hip, wgrad there or on the first-generation kernel with 16-bit sources): its neighbours may
@@ -778,6 +831,7 @@ class Conv2dFn(torch.autograd.Function):
         the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
         GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
+        ctx.set_materialize_grads(False)    # no full-size zero "gradient" for the non-differentiable 16-bit output
         B, H, W_, Cin = x.shape
         ctx.dx_channels = dx_channels
         wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
@@ -833,6 +887,8 @@ class Conv2dFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
+        if g is None:
+            return (None,) * 11
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:
@@ -884,6 +940,7 @@ class ConvT2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, bf16=False, x16=None, y_lp=False):
         """x16 / y_lp: 16-bit edges as in Conv2dFn (convT_lp16_ok)."""
+        ctx.set_materialize_grads(False)
         ctx.has_bias = bias is not None
         ctx.bf16 = bf16
         ctx.x_lp = x16 is not None
@@ -911,6 +968,8 @@ class ConvT2dFn(torch.autograd.Function):
     def backward(ctx, g, _g16=None):
         x, w = ctx.saved_tensors
         dx = dw = db = None
+        if g is None:
+            return (None,) * 6
         if ctx.lp16:
             g = lp_grad_in(g, "ConvT2dFn") if ctx.y_lp else lp16_twin(g.contiguous(), ctx.bf16)
             if ctx.needs_input_grad[0]:
@@ -1032,6 +1091,7 @@ class NormActFn(torch.autograd.Function):
         x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
         the autograd edge.  Statistics and all arithmetic are fp32 either way (apex O1 keeps
         batch_norm in fp32 on fp16 conv outputs)."""
+        ctx.set_materialize_grads(False)
         ctx.in_lp = x16 is not None
         ctx.out_lp = bool(out_lp)
         if x16 is not None:
@@ -1068,6 +1128,8 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g16=None):
+        if g is None:
+            return (None,) * 14
         x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
         groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         if has_res and relu:
@@ -1135,6 +1197,7 @@ class GateFn(torch.autograd.Function):
         (they feed the next block's 16-bit convolutions and nothing else); `out` stays fp32.
         s2_16 / s3_16: s2 and s3 were written in 16 bits only by their convolutions (Conv2dFn y_lp);
         s2 / s3 are then the proxies on the autograd edges and the gradients go back in 16 bits."""
+        ctx.set_materialize_grads(False)
         ctx.s_lp = s2_16 is not None
         ctx.cat_lp = bool(want_cat and cat_lp)
         if ctx.s_lp:

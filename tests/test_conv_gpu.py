@@ -358,6 +358,31 @@ def test_conv_lp16g_kernels(case, lp, dev):
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 20, 24, 4, 64, 7, True), (1, 16, 16, 44, 64, 7, True), (2, 12, 13, 8, 64, 7, True),
+                                  (1, 18, 14, 24, 128, 7, False), (2, 10, 10, 4, 64, 3, False), (1, 9, 9, 12, 64, 5, True)])
+def test_conv_lp16_flat_stems(case, lp, dev):
+    """conv_lp16f_kernel (flat (tap, channel) contraction, channels padded to 8) through the C-ABI:
+    the 7x7 stems' fprop against the fp64 oracle on operands rounded to the same type."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, k, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((k, k, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    ops.bump_weights_epoch()
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    d = ops.conv_desc(B, H, W, Cin, Cout, k, 1, k // 2, refl)
+    yr = R.conv2d(rb(x), rb(w), bias.cpu(), 1, k // 2, refl, 1)
+    y = ops.raw_conv_lp16_flat(d, x, w, bias, 1, lp)
+    assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+    y16 = ops.raw_conv_lp16_flat(d, x, w, bias, 1, lp, out16=True)
+    assert R.rel_l1(y16.float(), yr) < (2e-3 if lp == 2 else 8e-3)
+    if k == 7:      # the route the stems take
+        d2 = ops.conv_desc(B, H, W, Cin, Cout, k, 1, k // 2, refl)
+        assert ops.lp16_flat_ok(d2, lp)
+        assert R.rel_l1(ops.raw_conv_fprop(x, w, bias, 1, k // 2, refl, 1, lp), yr) < 5e-6
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 def test_convT_bf16_mfma_path(lp, dev):
     from mmhand_amd import ops
     x = _mk((2, 8, 8, 128), 1, dev)
