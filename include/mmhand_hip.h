@@ -360,12 +360,13 @@ int mmh_mse_bwd(const void* a, const void* b, int64_t n, float weight,
  * fprop: d->Cout == 4, d->Cin % 4 == 0, 7x7 / stride 1 / pad 3 (reflect or zero), fp32;
  *        w [7][7][Cin][4]; same result as mmh_conv2d_fprop.
  * dgrad: writes channels [0,4) of dx (pixel stride d->x_cs) and leaves the others alone;
- *        w is the conv's full weight [7][7][d->Cin][d->Cout]; ws from the _ws_bytes query. */
+ *        w is the conv's full weight [7][7][d->Cin][d->Cout]; ws from the _ws_bytes query;
+ *        dy_dtype: element type of dy (MMH_F32 | MMH_BF16 | MMH_FP16), arithmetic fp32. */
 int mmh_conv7_thin_fprop(const mmh_conv_desc* d, const void* x, const void* w,
                          const void* bias, void* y, int act, mmh_stream_t s);
 size_t mmh_conv7_thin_dgrad_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w,
-                         void* dx, void* ws, size_t ws_bytes, mmh_stream_t s);
+                         void* dx, void* ws, size_t ws_bytes, int dy_dtype, mmh_stream_t s);
 /* wgrad of the head (d->Cout == 4, d->Cin % 64 == 0): dw [7][7][Cin][4] (+)= sum over pixels;
  * per-workgroup partial sums in ws, added in a fixed order (deterministic).              */
 size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d);

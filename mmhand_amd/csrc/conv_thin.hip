@@ -39,6 +39,7 @@ struct ThinKP {
     int Ho, Wo, y_cs;           // output NHWC; channels [0, 4) written
     int pad, reflect, act;
     int tiles_x, tiles_y;
+    int x_lp;                   // element type of x: 0 fp32, 1 bf16, 2 fp16 (x_bytes in that type)
 };
 
 __device__ __forceinline__ float thin_act(float v, int act) {
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) thin_conv7_kernel(const ThinKP p) {
         } else {
             ok = ok && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
         }
-        soff[i] = ok ? (unsigned)(((b * p.H + ih) * p.W + iw) * p.x_cs) * 4u : OOBT;
+        soff[i] = ok ? (unsigned)(((b * p.H + ih) * p.W + iw) * p.x_cs) * (p.x_lp ? 2u : 4u) : OOBT;
     }
 
     f2 acc[4][2];
@@ -88,8 +89,21 @@ __global__ void __launch_bounds__(256) thin_conv7_kernel(const ThinKP p) {
         float4 st[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[i] == OOBT ? OOBT : soff[i] + c0 * 4u, 0, 0);
-            st[i] = __builtin_bit_cast(float4, v);
+            if (p.x_lp) {       // 4 channels = 8 bytes of a 16-bit tensor
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, soff[i] == OOBT ? OOBT : soff[i] + c0 * 2u, 0, 0);
+                if (p.x_lp == 1) {
+                    st[i] = make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
+                                        __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
+                } else {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 a = __builtin_bit_cast(h2, v[0]), c = __builtin_bit_cast(h2, v[1]);
+                    st[i] = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
+                }
+            } else {
+                const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[i] == OOBT ? OOBT : soff[i] + c0 * 4u, 0, 0);
+                st[i] = __builtin_bit_cast(float4, v);
+            }
         }
         __syncthreads();        // the previous chunk's readers are done
 #pragma unroll
@@ -356,14 +370,15 @@ size_t mmh_conv7_thin_dgrad_ws_bytes(const mmh_conv_desc* d) {
 }
 
 int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, void* ws, size_t ws_bytes,
-                         mmh_stream_t s) {
+                         int dy_dtype, mmh_stream_t s) {
+    MMH_REQUIRE(dy_dtype == MMH_F32 || dy_dtype == MMH_BF16 || dy_dtype == MMH_FP16, "mmh_conv7_thin_dgrad: bad dy_dtype");
     MMH_REQUIRE(thin_shape_ok(d), "mmh_conv7_thin_dgrad: needs a 7x7 / stride 1 / pad 3 fp32 conv");
     MMH_REQUIRE(d->Cout % 4 == 0 && d->Cout > 0 && d->Cin >= 1 && d->x_cs >= 4 && d->x_cs % 4 == 0 &&
                     d->y_cs >= d->Cout && d->y_cs % 4 == 0,
                 "mmh_conv7_thin_dgrad: needs Cout %% 4 == 0 and an input pixel stride of at least 4 channels");
     MMH_REQUIRE(dy && w && dx && ws && ws_bytes >= mmh_conv7_thin_dgrad_ws_bytes(d), "mmh_conv7_thin_dgrad: bad buffers");
     hipStream_t st = mmh::as_stream(s);
-    const long long yb = (long long)d->B * d->Ho * d->Wo * d->y_cs * 4;
+    const long long yb = (long long)d->B * d->Ho * d->Wo * d->y_cs * (dy_dtype == MMH_F32 ? 4 : 2);
     MMH_REQUIRE(yb < (1ll << 32) - 64, "mmh_conv7_thin_dgrad: dy too large for 32-bit offsets");
     float* wq = static_cast<float*>(ws);
     const int nq = 49 * d->Cout * 4;
@@ -376,6 +391,7 @@ int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, 
     p.x = static_cast<const float*>(dy); p.x_bytes = (unsigned)yb;
     p.B = d->B; p.H = d->Ho; p.W = d->Wo; p.Cin = d->Cout; p.x_cs = d->y_cs;
     p.w = wq; p.bias = nullptr; p.act = MMH_ACT_NONE; p.reflect = 0;
+    p.x_lp = dy_dtype;
     if (refl) {     // padded domain (H+6)x(W+6): full correlation, then the reflect fold
         p.pad = 6; p.Ho = d->H + 6; p.Wo = d->W + 6; p.y = dxp; p.y_cs = 4;
     } else {        // zero padding: dx is the 'same' correlation with the flipped filter

@@ -55,7 +55,7 @@ SIGNATURES = {
     "mmh_conv2d_dgrad_border": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_conv7_thin_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv7_thin_dgrad_ws_bytes": (_sz, [_DP]),
-    "mmh_conv7_thin_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_conv7_thin_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv7_thin_wgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv7_thin_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),

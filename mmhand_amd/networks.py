@@ -227,6 +227,15 @@ class _Net(nn.Module):
         """the conv `cp` hands its output (and takes its gradient) in 16 bits"""
         return bool(ops.USE_LP16_EDGES and self._lp_edge(cp, stride, reflect))
 
+    def _lp_out_stem(self, cp, B, H, W, input_grad, dx_channels=0):
+        """the 7x7 stem `cp` hands its output over in 16 bits (flat-K fprop; an input gradient, if any,
+        only for the first <= 4 channels)"""
+        if not (self.bf16 and self.training and ops.USE_LP16_EDGES) or (input_grad and not 0 < dx_channels <= 4):
+            return False
+        ws = cp.weight.shape
+        d = ops.conv_desc(B, H, W, ws[2], ws[3], cp.k, 1, cp.k // 2, True)
+        return ops.stem_lp16_ok(d, self.bf16, dx_channels)
+
     def convT(self, cp, x, y_lp=False):
         """x: fp32 NHWC or a (proxy, x16) pair; y_lp: returns a (proxy, y16) pair"""
         x16 = None
@@ -333,7 +342,9 @@ class Generator(_Net):
         for s, x in zip((1, 2, 3), (x1, x2, x3)):
             d = m[f"stream{s}_down"]
             first = d[4] if self.n_down > 0 else None
-            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True), True, out_lp=self._lp_edge(first, 2, False))
+            Bx, Hx, Wx, _ = x.shape
+            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True, y_lp=self._lp_out_stem(d[1], Bx, Hx, Wx, x.requires_grad)),
+                             True, out_lp=self._lp_edge(first, 2, False))
             for i in range(self.n_down):
                 cp = d[4 + 3 * i]
                 if i + 1 < self.n_down:
@@ -420,7 +431,9 @@ class Discriminator(_Net):
         channels (the generated image inside cat(fake, P2) / cat(fake, H1))."""
         m = self.model
         first = m[4] if self.n_down > 0 else None
-        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels), True,
+        Bx, Hx, Wx, _ = x.shape
+        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels,
+                                         y_lp=self._lp_out_stem(m[1], Bx, Hx, Wx, x.requires_grad, dx_channels)), True,
                          out_lp=self._lp_edge(first, 2, False))
         for i in range(self.n_down):
             cp = m[4 + 3 * i]

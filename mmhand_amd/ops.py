@@ -434,14 +434,15 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
 
 def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     """dgrad of a 7x7 / stride 1 / pad 3 conv for the first 4 input channels only (the others are
-    returned as zeros): the Discriminator stems seen from the generated image."""
-    _chk(dy, "dy"); _chk(w, "w")
+    returned as zeros): the Discriminator stems seen from the generated image.  dy: fp32 or 16-bit."""
+    _chk16(dy, "dy"); _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
     d = conv_desc(B, H, W_, Cin, Cout, 7, 1, 3, reflect)
     dx = torch.zeros((B, H, W_, Cin), dtype=torch.float32, device=dy.device)
     ws = _ws(L.load().mmh_conv7_thin_dgrad_ws_bytes(C.byref(d)), dy)
-    L.call("mmh_conv7_thin_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, _stream())
+    L.call("mmh_conv7_thin_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, _tdt(dy),
+           _stream())
     _count("valu", 2.0 * B * H * W_ * 4 * Cout * 49)
     return dx
 
@@ -661,6 +662,13 @@ def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False):
     return y
 
 
+def stem_lp16_ok(d, bf16, dx_channels):
+    """a 7x7 stem may hand its output over in 16 bits: flat-K fprop, and its input gradient is either
+    not needed or only that of the first <= 4 channels (thin dgrad)"""
+    return (lp16_flat_ok(d, bf16) and d.kh == 7 and d.stride == 1 and d.pad == 3 and USE_THIN
+            and 0 <= dx_channels <= 4 and d.Cout % 4 == 0)
+
+
 def lp16_chain_ok(Cin, Cout, k, stride, pad, reflect=True, bf16=True):
     """All three passes of this conv read and write 16-bit tensors directly (fprop and dgrad on
     conv_lp16.hip, wgrad there or on the first-generation kernel with 16-bit sources): its neighbours may
@@ -846,8 +854,20 @@ class Conv2dFn(torch.autograd.Function):
         if x16 is not None:
             assert chain and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape), \
                 "a 16-bit input needs 16-bit kernels for all three passes"
+        ctx.stem16 = False
+        if y_lp and not chain:
+            # a 7x7 stem handing its output over in 16 bits: flat-K fprop with a 16-bit epilogue; the
+            # backward takes the 16-bit gradient into the thin dgrad, the wgrad and the bias sum
+            d = conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect)
+            assert bf16 and act == L.ACT_NONE and x16 is None and stem_lp16_ok(d, bf16, dx_channels), \
+                "a 16-bit output needs 16-bit kernels for all passes and no activation"
+            y = raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=True)
+            ctx.stem16 = True
+            ctx.save_for_backward(x, w, None)
+            ctx.mark_non_differentiable(y)
+            return lp_proxy(y.shape, y.device), y
         if y_lp:
-            assert chain and act == L.ACT_NONE, "a 16-bit output needs 16-bit kernels for all three passes and no activation"
+            assert act == L.ACT_NONE, "a 16-bit output needs no activation"
         v2 = bool(bf16) and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0)
         if v2 or chain:
             # 16-bit path: one 16-bit twin of x (or the producer's own 16-bit output) feeds the fprop and,
@@ -889,6 +909,15 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if g is None:
             return (None,) * 11
+        if ctx.stem16:
+            g16 = lp_grad_in(g, "Conv2dFn (stem)")
+            if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)
+                dx = raw_conv_dgrad_thin(g16, w, ctx.x_shape, reflect)
+            if ctx.needs_input_grad[1]:
+                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16)
+            return dx, dw, db, None, None, None, None, None, None, None, None
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:

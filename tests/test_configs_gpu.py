@@ -56,13 +56,16 @@ def test_config3_inference_b64_full_shape(dev):
     assert R.rel_l1(out[:1], ref) < 1e-3, R.rel_l1(out[:1], ref)
 
 
-def test_config5_generator_512_bf16_vs_oracle(dev):
-    """configs[4] shapes on the bf16 path: ngf 64 at 512x512 -> PATBlocks at 128x128 with 256 / 512
-    channels (the second-generation 16-bit direct kernels of conv_lp16.hip for the 3x3 stack, the
-    bf16 direct stems / strided / transposed convs).  B=1, 2 PATBlocks (the oracle runs on the CPU): output within the stated bf16 tolerance
-    (1e-2 rel-L1) of the fp32 oracle; the backward runs on the bf16 dgrad / wgrad kernels and its
-    weight gradients point the oracle's way (cosine > 0.97 on every conv weight; measured worst
-    0.989 on the pose stem, whose input is sparse)."""
+@pytest.mark.parametrize("lp,tol", [(True, 1.5e-2), (2, 2.5e-3)], ids=["bf16", "fp16"])
+def test_config5_generator_512_bf16_vs_oracle(lp, tol, dev):
+    """configs[4] shapes on the 16-bit path: ngf 64 at 512x512 -> PATBlocks at 128x128 with 256 / 512
+    channels (conv_lp16.hip for every 3x3 conv and the stems' fprop).  B=1, 2 PATBlocks (the oracle runs
+    on the CPU).  Every tensor that faces a convolution is stored in 16 bits, as under apex O1, so each
+    conv output carries one rounding to the storage type on top of the 16-bit operands: the output
+    stays within 1.5e-2 rel-L1 of the fp64 oracle in bf16 (8 significand bits; measured 1.04e-2, and
+    8e-3 with fp32 storage between the convs) and within 2.5e-3 in fp16 (11 bits - apex's own type).  The
+    backward runs on the 16-bit dgrad / wgrad kernels and its weight gradients point the oracle's way
+    (cosine > 0.97 on every conv weight; worst on the pose stem, whose input is sparse)."""
     from mmhand_amd import ops
     from mmhand_amd.networks import Generator
     NB = 2
@@ -70,7 +73,7 @@ def test_config5_generator_512_bf16_vs_oracle(dev):
     sd = net.state_dict()
     net.to(dev).train()
     net.flatten_parameters()
-    net.bf16 = True
+    net.bf16 = lp
     assert ops.lp16_v2_ok(512, 512, 3, 1, 1, 0) and ops._wino_tile(1, 128, 128, 512, 512, 3, 1, 1, True, "fprop") == 0
     b = O.synthetic_batch(1, 512, 512, seed=3)
     g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
@@ -81,7 +84,7 @@ def test_config5_generator_512_bf16_vs_oracle(dev):
     ref = O.generator_forward(onet, g_in, NB)
     (ref * probe).sum().backward()
     err = R.rel_l1(out, ref.detach())
-    assert 1e-6 < err < 1e-2, err                     # > 1e-6: the bf16 kernels really ran
+    assert 1e-6 < err < tol, err                      # > 1e-6: the 16-bit kernels really ran
     from tests.test_model_gpu import logical_grads
     og = dict((k, t.grad) for k, t in onet.named_parameters())
     worst = 1.0
@@ -90,7 +93,7 @@ def test_config5_generator_512_bf16_vs_oracle(dev):
             c = torch.nn.functional.cosine_similarity(g.flatten().double(), og[k].flatten().double(), dim=0).item()
             worst = min(worst, c)
             assert c > 0.97, (k, c)
-    print(f"\n512x512 bf16 generator: out rel-L1 {err:.2e}, worst weight-gradient cosine {worst:.4f}")
+    print(f"\n512x512 {'fp16' if lp == 2 else 'bf16'} generator: out rel-L1 {err:.2e}, worst weight-gradient cosine {worst:.4f}")
 
 
 CFG5 = [
