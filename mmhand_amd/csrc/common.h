@@ -34,6 +34,7 @@ int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipS
 extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;
+extern int g_lp16_dbg;
 extern int g_pw_v2;
 
 }  // namespace mmh

@@ -49,6 +49,7 @@ struct LpConvKP {
     int act, h16;
     int MT, NT;             // row / column tiles
     int tap_inner;          // k order: 1 = (channel chunk, tap), 0 = (tap, channel chunk)
+    int dbg;                // timing-only ablation bits (mmh_set_option "lp16_dbg"): results wrong
 };
 
 template <bool H16>
@@ -170,8 +171,9 @@ __global__ void __launch_bounds__(512, 2) conv_lp16s_kernel(const LpConvKP p) {
 
     issue(0, 0);
     for (int ks = 0; ks < nk; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
         __syncthreads();
-        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+        if (ks + 1 < nk && !(p.dbg & 1)) issue(ks + 1, (ks + 1) & 1);      // dbg 1: no DMA after the first stage
         const char* st = smem + (ks & 1) * STAGE;
 #pragma unroll
         for (int s32 = 0; s32 < 2; ++s32) {
@@ -180,8 +182,10 @@ __global__ void __launch_bounds__(512, 2) conv_lp16s_kernel(const LpConvKP p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + sw + i * (16 * ROWB));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_base + sw + j * (16 * ROWB));
+            for (int j = 0; j < 4; ++j)      // dbg 2: B fragments not read from LDS
+                bfr[j] = (p.dbg & 2) ? af[j] : *reinterpret_cast<const bf16x8*>(st + b_base + sw + j * (16 * ROWB));
             __builtin_amdgcn_s_setprio(1);
+            if (!(p.dbg & 4))               // dbg 4: no MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -213,6 +217,379 @@ __global__ void __launch_bounds__(512, 2) conv_lp16s_kernel(const LpConvKP p) {
         }
 }
 
+
+// conv_lp16s_kernel with the LDS fragment reads software-pipelined INTO the MFMA stream: an ablation
+// (tools/ablate_lp16.py, 512->512: 628 us = 452 us without the DMA = 201 us of fragment reads + 247 us
+// of MFMAs) showed the two phases running back to back - both waves of a SIMD leave the barrier in
+// lockstep, read, wait, then multiply.  Here a wave's 32-deep step is: 4 MFMAs on A fragment i, then the
+// ds_read that refills fragment i for the NEXT 32-deep step (rolling reuse, no extra A registers; the B
+// fragments alternate between two sets), so the reads hide under the MFMAs of the same wave.  The one
+// barrier per k-step moves to the middle of the step: by then stage ks is fully read (the DMA of k-step
+// ks+2 may overwrite it) and stage ks+1 has had a whole k-step to land.
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) conv_lp16p_kernel(const LpConvKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int m0 = mt * TBM, n0 = nt * TBN;
+    const int M = p.B * p.H * p.W;
+    int a_pix[4], a_hw[4];
+    unsigned b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        const int m = m0 + r;
+        const int b = m / (p.H * p.W);
+        const int rem = m - b * (p.H * p.W);
+        const int oh = rem / p.W, ow = rem - oh * p.W;
+        a_pix[j] = m < M ? m : -1;
+        a_hw[j] = (oh << 16) | ow;
+        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;
+    }
+    const int KC = p.C / TBK;
+    const int nk = 9 * KC;
+    unsigned a_off[4];
+    auto set_tap = [&](int t) {
+        const int kh = t / 3, kw = t - 3 * kh;
+        const int dh = p.tap_sign * (kh - 1), dw = p.tap_sign * (kw - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oh = a_hw[j] >> 16, ow = a_hw[j] & 0xffff;
+            int ih = oh + dh, iw = ow + dw;
+            bool ok = a_pix[j] >= 0;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+            const int src = a_pix[j] + (ih - oh) * p.W + (iw - ow);
+            a_off[j] = ok ? (unsigned)src * (unsigned)p.cs * 2u + q * 16u : 0xffffffffu;
+        }
+    };
+    // k order (mmh_set_option "lp16_tap_inner"): tap outer / 64-channel chunk inner by default - a lane
+    // recomputes its 4 source pixels once per tap.  Chunk-outer order keeps the nine taps of a chunk in
+    // L2 (FETCH_SIZE is 9.2x the input with tap-outer order: each tap streams 8 MiB per XCD through a
+    // 4 MiB L2 and is served by the Infinity Cache) but pays the source-pixel arithmetic every k-step:
+    // measured 7 % SLOWER (A/B in one process, tools/ab_lp16_shape.py) - the kernel is not fetch-bound.
+    auto issue = [&](int ks, int stage) {
+        int kc, t;
+        if (p.tap_inner) { kc = ks / 9; t = ks - kc * 9; set_tap(t); }
+        else { t = ks / KC; kc = ks - t * KC; if (kc == 0) set_tap(t); }
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + TBM * ROWB;
+        const unsigned kb = (unsigned)kc * (TBK * 2);
+        const char* wbase = p.w + (size_t)t * p.N * p.C * 2 + kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* g = a_off[j] != 0xffffffffu ? p.x + a_off[j] + kb : p.zeros + (lane & 7) * 16;
+            __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (wave * 4 + j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // rows read by this lane: A wr*128 + i*16 + l15, B wc*64 + j*16 + l15: key (row >> 1) & 7 = (l15 >> 1)
+    const unsigned key = (unsigned)(l15 >> 1);
+    const unsigned a_base = (unsigned)(wr * 128 + l15) * ROWB;
+    const unsigned b_base = (unsigned)(TBM + wc * 64 + l15) * ROWB;
+
+    // byte offsets of this lane's fragments inside a stage for the two 32-deep halves of a k-step
+    const unsigned sw0 = ((unsigned)g4 ^ key) << 4, sw1 = ((unsigned)(4 + g4) ^ key) << 4;
+    bf16x8 af[8], b0[4], b1[4];
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();                    // (waits for both: the first step has no MFMAs to hide under)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8*>(smem + b_base + sw0 + j * (16 * ROWB));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_base + sw0 + i * (16 * ROWB));
+    for (int ks = 0; ks < nk; ++ks) {
+        const char* st = smem + (ks & 1) * STAGE;
+        const char* sn = smem + ((ks + 1) & 1) * STAGE;
+        // ---- half 0: multiply (ks, 0) out of af / b0 while the fragments of (ks, 1) stream in
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const bf16x8*>(st + b_base + sw1 + j * (16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b0[j], acc[i][j]);
+            af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + sw1 + i * (16 * ROWB));
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+        }
+        // stage ks is read, stage ks+1 has landed.  The wait is explicit: the compiler does not count the
+        // LDS-DMA of an earlier loop iteration against this barrier (seen in the ISA, and as a race)
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+        __syncthreads();
+        if (ks + 2 < nk) issue(ks + 2, ks & 1);
+        // ---- half 1: multiply (ks, 1) out of af / b1 while the fragments of (ks+1, 0) stream in
+        const bool more = ks + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8*>(sn + b_base + sw0 + j * (16 * ROWB));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b1[j], acc[i][j]);
+            if (more) af[i] = *reinterpret_cast<const bf16x8*>(sn + a_base + sw0 + i * (16 * ROWB));
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 128 + i * 16 + 4 * g4 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + l15;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                v = act_apply(v, p.act);
+                if (p.y16) {
+                    if (H16) reinterpret_cast<_Float16*>(p.y16)[(size_t)m * p.y_cs + n] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(p.y16)[(size_t)m * p.y_cs + n] = (__bf16)v;
+                } else {
+                    p.y[(size_t)m * p.y_cs + n] = v;
+                }
+            }
+        }
+}
+
+
+
+
+// ---------------------------------------------------------------------------------------------
+// conv_lp16h_kernel: the stride-1 3x3 kernel with the activation tile held in LDS ONCE for all nine
+// taps.  The M tile is a 16 x 16 pixel block of one image; per 64-channel chunk its 18 x 18 halo
+// (324 pixel rows x 128 B = 40.5 KiB) is brought in by LDS-DMA one whole chunk (nine k-steps) ahead and
+// the nine taps read it at shifted rows - the A operand crosses L2 -> LDS once instead of nine times
+// (conv_lp16p_kernel: FETCH_SIZE 9.2x the input, and inside the training step, where the input does
+// not come from a warm cache, it is the DMA that the k-step waits for).  Only the weights stream per
+// k-step (32 KiB, L2 resident).  LDS: 2 halo stages + 2 weight stages = 145 KiB.
+//   k order: 64-channel chunk outer, tap inner.  Halo row of output pixel (py, px), tap offset (dh, dw) in
+//   {0,1,2}^2: (py + dh) * 18 + px + dw; fprop (dh, dw) = (kh, kw), dgrad (2 - kh, 2 - kw).
+//   Rows keep the (row >> 1) & 7 chunk swizzle: a fragment's 16 lanes read 16 consecutive halo rows, which
+//   from any starting row pair up as (even, odd) rows with equal keys - conflict-free as before.
+// The fragment reads are pipelined into the MFMA stream as in conv_lp16p_kernel.
+constexpr int HT = 16;                      // tile edge (output pixels)
+constexpr int HW_ = HT + 2;                 // halo edge
+constexpr int HROWS = HW_ * HW_;            // 324 halo pixel rows
+constexpr int HSTAGE_A = ((HROWS * ROWB + 1023) / 1024) * 1024;     // 41984
+constexpr int HSTAGE_B = TBN * ROWB;                                 // 32768
+constexpr int HROUNDS = (HROWS + 63) / 64;                           // 6 DMA instructions per wave and chunk
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const sAh = smem;                         // [2][HSTAGE_A]
+    char* const sBh = smem + 2 * HSTAGE_A;          // [2][HSTAGE_B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int n0 = nt * TBN;
+    const int TX = (p.W + HT - 1) / HT, TY = (p.H + HT - 1) / HT;
+    const int b = mt / (TX * TY);
+    const int trem = mt - b * (TX * TY);
+    const int ty = trem / TX, tx = trem - ty * TX;
+    const int oh0 = ty * HT, ow0 = tx * HT;
+
+    // halo DMA roles: round rd covers halo rows rd*64 .. +63; wave w rows rd*64 + w*8 + lane/8
+    unsigned a_off[HROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < HROUNDS; ++rd) {
+        const int r = rd * 64 + wave * 8 + (lane >> 3);
+        const int hy = r / HW_, hx = r - hy * HW_;
+        int ih = oh0 + hy - 1, iw = ow0 + hx - 1;
+        bool ok = r < HROWS;
+        if (p.reflect) {
+            ih = ih < 0 ? -ih : ih;
+            iw = iw < 0 ? -iw : iw;
+            ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+            iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+        }
+        ok = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        a_off[rd] = ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + q * 16u
+                       : (r < HROWS ? 0xfffffffeu : 0xffffffffu);        // ...fe: zero page, ...ff: no row
+    }
+    unsigned b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;
+    }
+    const int KC = p.C / TBK;
+    const int nk = 9 * KC;
+    auto issue_halo = [&](int kc) {
+        char* sA = sAh + (kc & 1) * HSTAGE_A;
+        const unsigned kb = (unsigned)kc * (TBK * 2);
+#pragma unroll
+        for (int rd = 0; rd < HROUNDS; ++rd) {
+            if (a_off[rd] != 0xffffffffu) {
+                const char* g = a_off[rd] != 0xfffffffeu ? p.x + a_off[rd] + kb : p.zeros + (lane & 7) * 16;
+                __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (rd * 8 + wave) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int ks) {
+        const int kc = ks / 9, t = ks - kc * 9;
+        char* sB = sBh + (ks & 1) * HSTAGE_B;
+        const char* wbase = p.w + ((size_t)t * p.N * p.C + (size_t)kc * TBK) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // B fragments: rows wc*64 + j*16 + l15 of the weight stage (key (row >> 1) & 7 = l15 >> 1)
+    const unsigned bkey = (unsigned)(l15 >> 1);
+    const unsigned b_base = (unsigned)(wc * 64 + l15) * ROWB;
+    const unsigned bsw0 = ((unsigned)g4 ^ bkey) << 4, bsw1 = ((unsigned)(4 + g4) ^ bkey) << 4;
+    // A fragment i of this lane for tap offset (dh, dw): halo row (wr*8 + i + dh) * 18 + l15 + dw
+    auto a_addr = [&](const char* sA, int dh, int dw, int i, int half) -> const char* {
+        const unsigned hr = (unsigned)((wr * 8 + i + dh) * HW_ + l15 + dw);
+        return sA + hr * ROWB + ((((unsigned)(4 * half + g4)) ^ ((hr >> 1) & 7u)) << 4);
+    };
+    auto tap_dh = [&](int t) { const int kh = t / 3; return p.tap_sign > 0 ? kh : 2 - kh; };
+    auto tap_dw = [&](int t) { const int kw = t - 3 * (t / 3); return p.tap_sign > 0 ? kw : 2 - kw; };
+
+    bf16x8 af[8], b0[4], b1[4];
+    issue_halo(0);
+    issue_w(0);
+    if (nk > 1) issue_w(1);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    {
+        const int dh = tap_dh(0), dw = tap_dw(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8*>(sBh + b_base + bsw0 + j * (16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_addr(sAh, dh, dw, i, 0));
+    }
+    int kc = 0, t = 0;                  // (chunk, tap) of k-step ks
+    for (int ks = 0; ks < nk; ++ks) {
+        const char* sA = sAh + (kc & 1) * HSTAGE_A;
+        const char* sB = sBh + (ks & 1) * HSTAGE_B;
+        const int dh = tap_dh(t), dw = tap_dw(t);
+        // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = *reinterpret_cast<const bf16x8*>(sB + b_base + bsw1 + j * (16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b0[j], acc[i][j]);
+            af[i] = *reinterpret_cast<const bf16x8*>(a_addr(sA, dh, dw, i, 1));
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- middle of the k-step: the weight stage ks is read; stage ks+1 (issued one k-step ago) must have
+        // landed.  The halo of the next chunk, issued right after the weights at t == 0, may stay in
+        // flight across the barrier of t == 1 (it is needed nine k-steps after its issue): the wait then
+        // leaves the newest HROUNDS - 1 loads outstanding (vmcnt counts in issue order; every wave issues
+        // HROUNDS - 1 or HROUNDS of them)
+        if (t == 1 && kc + 1 < KC) __builtin_amdgcn_s_waitcnt(0x0070 | (HROUNDS - 1));      // vmcnt(5) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                             // vmcnt(0) lgkmcnt(0)
+        __syncthreads();
+        if (ks + 2 < nk) issue_w(ks + 2);
+        if (t == 0 && kc + 1 < KC) issue_halo(kc + 1);
+        // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
+        int kc2 = kc, t2 = t + 1;
+        if (t2 == 9) { t2 = 0; ++kc2; }
+        const bool more = ks + 1 < nk;
+        if (more) {
+            const char* sBn = sBh + ((ks + 1) & 1) * HSTAGE_B;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const bf16x8*>(sBn + b_base + bsw0 + j * (16 * ROWB));
+        }
+        {
+            const char* sAn = sAh + (kc2 & 1) * HSTAGE_A;
+            const int dh2 = tap_dh(t2), dw2 = tap_dw(t2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b1[j], acc[i][j]);
+                if (more) af[i] = *reinterpret_cast<const bf16x8*>(a_addr(sAn, dh2, dw2, i, 0));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        kc = kc2; t = t2;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oh = oh0 + wr * 8 + i, ow = ow0 + 4 * g4 + r;
+            if (oh >= p.H || ow >= p.W) continue;
+            const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wc * 64 + j * 16 + l15;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                v = act_apply(v, p.act);
+                if (p.y16) {
+                    if (H16) reinterpret_cast<_Float16*>(p.y16)[m * p.y_cs + n] = (_Float16)v;
+                    else reinterpret_cast<__bf16*>(p.y16)[m * p.y_cs + n] = (__bf16)v;
+                } else {
+                    p.y[m * p.y_cs + n] = v;
+                }
+            }
+        }
+}
 
 // ---------------------------------------------------------------------------------------------
 // The same machine for the other 3x3 convolutions of the step: stride 2 (the down-sampling convs),
@@ -344,6 +721,7 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
 
     if (nk > 0) issue(0, 0);
     for (int ks = 0; ks < nk; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
         __syncthreads();
         if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
         const char* st = smem + (ks & 1) * GSTAGE;
@@ -489,6 +867,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16f_kernel(const LpFlatKP p) {
 
     if (p.nk > 0) issue(0, 0);
     for (int ks = 0; ks < p.nk; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
         __syncthreads();
         if (ks + 1 < p.nk) issue(ks + 1, (ks + 1) & 1);
         const char* st = smem + (ks & 1) * FSTAGE;
@@ -700,6 +1079,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16_kernel(const LpConvKP p) {
     for (int ks = 0; ks < nk; ++ks) {
         // this wave's DMAs of k-step ks have landed (vmcnt(0)), then everyone's (barrier); the barrier
         // also means every wave has finished reading the other stage, which k-step ks+1 overwrites
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
         __syncthreads();
         if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
         const char* st = smem + (ks & 1) * STAGE;
@@ -879,6 +1259,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16_kernel(const LpWgradKP p) {
 
     if (k0 < k1) issue(0);
     for (int ks = k0; ks < k1; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
         __syncthreads();
         if (ks + 1 < k1) issue((ks + 1 - k0) & 1);
         const char* sX = smem + ((ks - k0) & 1) * WSTAGE;
@@ -958,9 +1339,10 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 
 }  // namespace
 
-// MFMA shape of the fprop / dgrad kernel: 16 (16x16x32; measured 6-9 % faster: 990-1060 TFLOP/s on the
-// PATBlock shapes) | 32 (32x32x16); mmh_set_option "lp16_shape"
-namespace mmh { int g_lp16_shape = 16; int g_lp16_tap_inner = 0; }
+// fprop / dgrad kernel (mmh_set_option "lp16_shape"): 17 = MFMA 16x16x32 with the LDS fragment reads
+// pipelined into the MFMA stream (default; 1030-1140 TFLOP/s on the PATBlock shapes), 16 = the same
+// without the pipelining (6-13 % slower), 32 = MFMA 32x32x16 (a further 6-9 % slower)
+namespace mmh { int g_lp16_shape = 17; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; }
 using mmh::g_lp16_shape;
 
 extern "C" {
@@ -1003,6 +1385,7 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     p.act = act;
     p.h16 = d->dtype == MMH_FP16;
     p.tap_inner = mmh::g_lp16_tap_inner;
+    p.dbg = mmh::g_lp16_dbg;
     const long long M = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(M * (long long)std::max(p.cs, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
                 "mmh_conv3x3_lp16: tensor too large");
@@ -1019,6 +1402,42 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
         ready = e == hipSuccess ? 0 : mmh::fail("conv_lp16_kernel: %s", hipGetErrorString(e));
     }
     if (ready != 0) return ready;
+    if (g_lp16_shape == 18 && d->H >= HT && d->W >= HT) {       // activation tile (halo) resident in LDS for all nine taps
+        constexpr int lds = 2 * HSTAGE_A + 2 * HSTAGE_B;
+        static int ready18 = -1;
+        if (ready18 != 0) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16h_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16h_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            ready18 = e == hipSuccess ? 0 : mmh::fail("conv_lp16h_kernel: %s", hipGetErrorString(e));
+        }
+        if (ready18 != 0) return ready18;
+        LpConvKP ph = p;
+        ph.MT = d->B * ((d->H + HT - 1) / HT) * ((d->W + HT - 1) / HT);
+        const int pxh = (ph.MT * ph.NT + 7) / 8;
+        if (p.h16) hipLaunchKernelGGL(conv_lp16h_kernel<true>, dim3(8 * pxh), dim3(512), lds, mmh::as_stream(s), ph);
+        else hipLaunchKernelGGL(conv_lp16h_kernel<false>, dim3(8 * pxh), dim3(512), lds, mmh::as_stream(s), ph);
+        return mmh::check_launch("conv_lp16h_kernel");
+    }
+    if (g_lp16_shape == 17 || g_lp16_shape == 18) {       // 16x16x32 with the fragment reads pipelined into the MFMA stream
+        static int ready17 = -1;
+        if (ready17 != 0) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16p_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16p_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+            ready17 = e == hipSuccess ? 0 : mmh::fail("conv_lp16p_kernel: %s", hipGetErrorString(e));
+        }
+        if (ready17 != 0) return ready17;
+        if (p.h16)
+            hipLaunchKernelGGL(conv_lp16p_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
+        else
+            hipLaunchKernelGGL(conv_lp16p_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
+        return mmh::check_launch("conv_lp16p_kernel");
+    }
     if (g_lp16_shape == 16) {
         static int ready16 = -1;
         if (ready16 != 0) {
