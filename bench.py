@@ -326,7 +326,8 @@ def main():
                       f"[{tiles}x512].[512x512] (F({wtile}x{wtile},3x3)) of the 3x3 512->512 fprop @{hs}x{hs}")
         else:
             k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
-            k_name = (("conv_lp16s_kernel<bf16> (16-bit operands by LDS-DMA, 256x256x64 tiles, MFMA 16x16x32)"
+            k_name = (("conv_lp16h_kernel<bf16> (16-bit operands by LDS-DMA, 16x16-pixel tile x 256 channels with its halo "
+                       "resident in LDS for all nine taps, MFMA 16x16x32, fragment reads pipelined into the MFMA stream)"
                        if (a.dtype == "bf16" and ops.lp16_v2_ok(512, 512, 3, 1, 1, 0)) else
                        "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
                        "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")

@@ -1339,10 +1339,12 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 
 }  // namespace
 
-// fprop / dgrad kernel (mmh_set_option "lp16_shape"): 17 = MFMA 16x16x32 with the LDS fragment reads
-// pipelined into the MFMA stream (default; 1030-1140 TFLOP/s on the PATBlock shapes), 16 = the same
-// without the pipelining (6-13 % slower), 32 = MFMA 32x32x16 (a further 6-9 % slower)
-namespace mmh { int g_lp16_shape = 17; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; }
+// fprop / dgrad kernel (mmh_set_option "lp16_shape"): 18 = conv_lp16h_kernel (default: MFMA 16x16x32,
+// fragment reads pipelined into the MFMA stream, activation halo of a 16x16 pixel tile resident in LDS for
+// all nine taps; 1040-1170 TFLOP/s on the PATBlock shapes), 17 = conv_lp16p_kernel (the same pipelining
+// on 256-pixel row tiles, the activation tile re-fetched per tap; also what images smaller than 16x16
+// take), 16 = without the pipelining (6-13 % slower), 32 = MFMA 32x32x16 (a further 6-9 % slower)
+namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; }
 using mmh::g_lp16_shape;
 
 extern "C" {

@@ -285,13 +285,14 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
         R.rel_l1(y, yf), R.rel_l1(dx, dxf), R.rel_l1(dw, dwf))
 
 
-@pytest.mark.parametrize("shape", [16, 17, 32])
+@pytest.mark.parametrize("shape", [16, 17, 18, 32])
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 9, 11, 64, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
-                                  (1, 20, 12, 256, 256, True)])
+                                  (1, 20, 12, 256, 256, True), (2, 17, 33, 256, 256, True), (1, 32, 48, 64, 256, False)])
 def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
-    """conv_lp16.hip through the C-ABI: fprop (MFMA 16x16x32, the same with the fragment reads pipelined
-    into the MFMA stream (17, the default), 32x32x16), zero-pad dgrad and wgrad from 16-bit
+    """conv_lp16.hip through the C-ABI: fprop (MFMA 16x16x32 (16), the same with the fragment reads
+    pipelined into the MFMA stream (17), with the activation halo resident in LDS for all nine taps on
+    16x16 pixel tiles (18, the default; images smaller than a tile take 17), 32x32x16), zero-pad dgrad and wgrad from 16-bit
     twins against the fp64 oracle on operands rounded to the same type (accumulation is fp32)."""
     from mmhand_amd import lib, ops
     B, H, W, Cin, Cout, refl = case
@@ -319,7 +320,7 @@ def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
                 _, _, dwr, _ = R.conv2d_grads(rb(x), rb(w), None, rb(dy), 1, 1, refl)
                 assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
     finally:
-        lib.check(lib.load().mmh_set_option(b"lp16_shape", 17), "set")
+        lib.check(lib.load().mmh_set_option(b"lp16_shape", 18), "set")
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])

@@ -29,14 +29,14 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
             if len(c) >= 5:
                 print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
 if "wino_gemm" in pat:
-    print("wino_gemm_kernel is persistent: every launch has 8 XCDs x 64 (two-level build, 2 per CU) or 96 workgroups, whatever the GEMM shape, so\n"
+    print("wino_gemm_kernel is persistent: every launch has 8 XCDs x 96 workgroups (3 per CU), whatever the GEMM shape, so\n"
           "shapes are told apart by duration.  The slowest cluster is the Winograd-domain GEMM set of a 3x3\n"
           "512->512 conv at 64x64, B=32 (fprop and dgrad launches are the same GEMM): F(6x6,3x3) = 64 x\n"
           "[3872x512].[512x512] = 129.9 GFLOP per launch (F(4x4,3x3), MMH_WINOGRAD_TILE=4: 36 x [8192x512].[512x512]\n"
           "= 154.6 GFLOP); bench.py's roofline.achieved = that FLOP count / its HIP-event mean over the fprop\n"
           "launches.  The other clusters: 512->256 / 256->512 and 256->256 convs (1/2 and 1/4 of the FLOPs).")
 elif "lp16" in pat:
-    print("conv_lp16s_kernel: workgroups = 8 x ceil(row tiles x column tiles / 8) with 256x256 tiles; (1024,1,1) = 512 row\n"
+    print("conv_lp16h_kernel / conv_lp16p_kernel: workgroups = 8 x ceil(row tiles x column tiles / 8) with 256x256 tiles; (1024,1,1) = 512 row\n"
           "tiles x 2 column tiles = the 3x3 512->512 convs at 64x64, B=32 (fprop and dgrad main term, 618.5 GFLOP per\n"
           "launch) and the 512->256 / 256->512 dgrads; (512,1,1) = the 256-column convs.  bench.py --dtype bf16 times\n"
           "the 512->512 fprop launches with HIP events.")
