@@ -506,18 +506,24 @@ class MMHandModel(torch.nn.Module):
             self._optimize_parameters_dp()
         else:
             r = self.opt.DG_ratio
-            self.forward()
-            self.optimizer_G.zero_grad()
-            self.backward_G()
-            self._guarded_step(self.optimizer_G, 0, 0)
-            for i in range(r):
-                self.optimizer_D_PP.zero_grad()
-                self.backward_D_PP()
-                self._guarded_step(self.optimizer_D_PP, 1 + i, 2)
-            for i in range(r):
-                self.optimizer_D_PB.zero_grad()
-                self.backward_D_PB()
-                self._guarded_step(self.optimizer_D_PB, 1 + r + i, 1)
+            # single process: the wgrad kernels add straight into the parameters' .grad views of the flat
+            # gradient buffer (no AccumulateGrad add kernels; ops.ACCUM_PARAM_GRADS)
+            prev, ops.ACCUM_PARAM_GRADS = ops.ACCUM_PARAM_GRADS, True
+            try:
+                self.forward()
+                self.optimizer_G.zero_grad()
+                self.backward_G()
+                self._guarded_step(self.optimizer_G, 0, 0)
+                for i in range(r):
+                    self.optimizer_D_PP.zero_grad()
+                    self.backward_D_PP()
+                    self._guarded_step(self.optimizer_D_PP, 1 + i, 2)
+                for i in range(r):
+                    self.optimizer_D_PB.zero_grad()
+                    self.backward_D_PB()
+                    self._guarded_step(self.optimizer_D_PB, 1 + r + i, 1)
+            finally:
+                ops.ACCUM_PARAM_GRADS = prev
         host = self._flags_free.pop()
         host.copy_(self._flags, non_blocking=True)
         ev = torch.cuda.Event()

@@ -200,17 +200,20 @@ class _Net(nn.Module):
         return self
 
     # -- functional layers
-    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False):
+    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False, to_norm=False):
         """x: an fp32 NHWC tensor, or a (proxy, x16) pair from a producer that wrote it in 16 bits.
         y_lp (see _lp_edge): the consumer (normact / the PATBlock gate) takes the output in 16 bits ->
         returns a (proxy, y16) pair."""
         x16 = None
         if isinstance(x, tuple):
             x, x16 = x
+        # to_norm: the output goes straight into this net's norm layer; under InstanceNorm the conv bias then
+        # has an identically zero gradient (ops.EXACT_NULL_BIAS_GRAD)
+        nb = bool(to_norm and self.norm == "instance" and self.training)
         if y_lp:
-            p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True)
+            p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True, nb)
             return p, y16
-        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16)
+        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, False, nb)
 
     def _lp_edge(self, cp, stride=1, reflect=True):
         """16-bit hand-over to the 3x3 / pad 1 conv (or ConvTranspose2d) `cp` (training, 16-bit mode, all
@@ -236,15 +239,16 @@ class _Net(nn.Module):
         d = ops.conv_desc(B, H, W, ws[2], ws[3], cp.k, 1, cp.k // 2, True)
         return ops.stem_lp16_ok(d, self.bf16, dx_channels)
 
-    def convT(self, cp, x, y_lp=False):
-        """x: fp32 NHWC or a (proxy, x16) pair; y_lp: returns a (proxy, y16) pair"""
+    def convT(self, cp, x, y_lp=False, to_norm=False):
+        """x: fp32 NHWC or a (proxy, x16) pair; y_lp: returns a (proxy, y16) pair; to_norm as in conv()"""
         x16 = None
         if isinstance(x, tuple):
             x, x16 = x
+        nb = bool(to_norm and self.norm == "instance" and self.training)
         if y_lp:
-            p, y16 = ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, True)
+            p, y16 = ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, True, nb)
             return p, y16
-        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16)
+        return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, False, nb)
 
     def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0):
         """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
@@ -280,9 +284,9 @@ class _Net(nn.Module):
         # 16-bit mode: every tensor that faces one of these convolutions (input, output, both gradients)
         # lives in HBM in 16 bits only, as under apex O1; without a last norm the caller (the PATBlock
         # gate) receives the (proxy, y16) pair
-        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]))
+        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True)
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]))
-        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]))
+        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm)
         if last_norm:
             y = self.normact(blk, i2 + 1, y, False, residual=residual)
         return y
@@ -343,7 +347,7 @@ class Generator(_Net):
             d = m[f"stream{s}_down"]
             first = d[4] if self.n_down > 0 else None
             Bx, Hx, Wx, _ = x.shape
-            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True, y_lp=self._lp_out_stem(d[1], Bx, Hx, Wx, x.requires_grad)),
+            x = self.normact(d, 2, self.conv(d[1], x, 1, 3, True, y_lp=self._lp_out_stem(d[1], Bx, Hx, Wx, x.requires_grad), to_norm=True),
                              True, out_lp=self._lp_edge(first, 2, False))
             for i in range(self.n_down):
                 cp = d[4 + 3 * i]
@@ -353,7 +357,7 @@ class Generator(_Net):
                     out_lp = self._lp_edge(m["att"][0][f"conv_block_stream{s}"][1])
                 else:
                     out_lp = 0
-                x = self.normact(d, 5 + 3 * i, self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False)), True,
+                x = self.normact(d, 5 + 3 * i, self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True), True,
                                  out_lp=out_lp)
             xs.append(x)
         x1, x2, x3 = xs
@@ -379,7 +383,7 @@ class Generator(_Net):
         y = x1
         for i in range(self.n_down):
             nxt = up[3 * (i + 1)] if i + 1 < self.n_down else None      # the 7x7 head reads fp32
-            y = self.normact(up, 3 * i + 1, self.convT(up[3 * i], y, y_lp=self._lp_out(up[3 * i])), True,
+            y = self.normact(up, 3 * i + 1, self.convT(up[3 * i], y, y_lp=self._lp_out(up[3 * i]), to_norm=True), True,
                              out_lp=self._lp_edge(nxt))
         return self.conv(up[3 * self.n_down + 1], y, 1, 3, True, L.ACT_TANH)
 
@@ -432,13 +436,13 @@ class Discriminator(_Net):
         m = self.model
         first = m[4] if self.n_down > 0 else None
         Bx, Hx, Wx, _ = x.shape
-        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels,
+        y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels, to_norm=True,
                                          y_lp=self._lp_out_stem(m[1], Bx, Hx, Wx, x.requires_grad, dx_channels)), True,
                          out_lp=self._lp_edge(first, 2, False))
         for i in range(self.n_down):
             cp = m[4 + 3 * i]
             out_lp = self._lp_edge(m[4 + 3 * (i + 1)], 2, False) if i + 1 < self.n_down else 0
-            y = self.normact(m, 5 + 3 * i, self.conv(cp, y, 2, 1, False, y_lp=self._lp_out(cp, 2, False)), True,
+            y = self.normact(m, 5 + 3 * i, self.conv(cp, y, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True), True,
                              out_lp=out_lp)
         base = 4 + 3 * self.n_down
         for b in range(self.n_blocks):

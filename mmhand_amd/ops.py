@@ -316,7 +316,7 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
     return dx
 
 
-def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
+def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False, out=None):
     """fp32 3x3 / stride 1 / pad 1 wgrad by Winograd: dw = G^T [sum_tiles (B^T d B).(A dY A^T)] G.
     V = the transformed input kept by the forward pass (x is then unused and may be None)."""
     _chk(dy, "dy")
@@ -340,12 +340,12 @@ def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False):
     L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, dt, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
     _count("mfma", 2.0 * P * tiles * Cin * Cout)
-    dw = _empty((3, 3, Cin, Cout), dy)
-    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
+    dw = out if out is not None else _empty((3, 3, Cin, Cout), dy)
+    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), int(out is not None), _stream())
     return dw
 
 
-def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
+def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None):
     """dgrad and wgrad of a 3x3 / stride 1 / pad 1 conv by Winograd F(6x6,3x3) with ONE pass over
     dy for both of its transforms (mmh_wino_input_dy).  V = the forward pass's transformed input.
     Returns (dx, dw)."""
@@ -377,8 +377,8 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V):
     dU = _empty((P, Cin, Cout), dy)
     L.call("mmh_wino_wgrad_gemm", _ptr(V), _ptr(Yh), tiles, Cin, Cout, P, L.F32, _ptr(ws), ws.numel() * 4, _ptr(dU),
            _stream())
-    dw = _empty((3, 3, Cin, Cout), dy)
-    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), 0, _stream())
+    dw = dw_out if dw_out is not None else _empty((3, 3, Cin, Cout), dy)
+    L.call("mmh_wino_dw", _ptr(dU), Cin, Cout, tile, _ptr(dw), int(dw_out is not None), _stream())
     return dx, dw
 
 
@@ -496,8 +496,8 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     return dx
 
 
-def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
-    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits."""
+def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False, out=None):
+    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits.  out: add dw into this tensor."""
     _chk16(x, "x"); _chk16(dy, "dy")
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
@@ -505,7 +505,7 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     assert bf16 or not lp_in
     if bf16 and lp16_wgrad_ok(Cin, Cout, k, stride, pad):
         return raw_wgrad3x3_lp16(x if x.dtype != torch.float32 else lp16_twin(x, bf16),
-                                 dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16), reflect, bf16)
+                                 dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16), reflect, bf16, out=out)
     if lp_in:       # first-generation 16-bit wgrad kernel reading the 16-bit tensors directly (both or neither)
         x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
         dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
@@ -513,21 +513,21 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
         d.dtype = _dt(bf16)
         assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
         ws = _ws(L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d)), x)
-        dw = _empty((k, k, Cin, Cout), x)
-        L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
+        dw = out if out is not None else _empty((k, k, Cin, Cout), x)
+        L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, int(out is not None),
                (1 if x.dtype != torch.float32 else 0) | (2 if dy.dtype != torch.float32 else 0), _stream())
         _count_desc("mfma", d)
         return dw
     wt = _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "wgrad")
     if wt:
-        return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16)
+        return raw_conv_wgrad_wino(x, dy, reflect, wt, bf16=bf16, out=out)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 64 == 0:
         # the Generator head: 4 output columns; fp32 vector-ALU kernel (also under --opt_level O1/O2)
         ws = _ws(L.load().mmh_conv7_thin_wgrad_ws_bytes(C.byref(d)), x)
-        dw = _empty((k, k, Cin, Cout), x)
-        L.call("mmh_conv7_thin_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
-               _stream())
+        dw = out if out is not None else _empty((k, k, Cin, Cout), x)
+        L.call("mmh_conv7_thin_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
+               int(out is not None), _stream())
         _count_desc("valu", d)
         return dw
     if bf16:
@@ -535,9 +535,9 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False):
     assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
-    dw = _empty((k, k, Cin, Cout), x)
+    dw = out if out is not None else _empty((k, k, Cin, Cout), x)
     L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
-           ws.numel() * 4, 0, 0, _stream())
+           ws.numel() * 4, int(out is not None), 0, _stream())
     _count_desc("mfma", d)
     return dw
 
@@ -721,6 +721,31 @@ def lp_grads_reset():
     _lp_grads.clear()
 
 
+# Weight / bias gradients written straight into the parameter's .grad view of the flat gradient buffer
+# (the wgrad kernels' own accumulate path) instead of returning a temporary that autograd's AccumulateGrad
+# adds in a separate kernel (239 add launches per step).  Off by default: MMHandModel turns it on for
+# single-process training; under data parallelism the bucket hooks hang on AccumulateGrad.
+ACCUM_PARAM_GRADS = False
+# Conv biases that feed an InstanceNorm have an identically zero gradient (the norm removes the channel
+# mean): autograd - the reference's and ours - produces rounding noise for them, which Adam turns into
+# +-lr steps no output can see.  1: return the exact zero without the reduction pass (62 colsum launches);
+# MMH_NULL_BIAS_GRAD=compute restores the literal behaviour.
+EXACT_NULL_BIAS_GRAD = os.environ.get("MMH_NULL_BIAS_GRAD", "exact") != "compute"
+
+
+def _grad_target(p):
+    """p.grad when gradients are to be accumulated in place (see ACCUM_PARAM_GRADS), else None"""
+    if ACCUM_PARAM_GRADS and p is not None and p.requires_grad and p.grad is not None and p.grad.is_contiguous() \
+            and p.grad.dtype == torch.float32 and p.grad.shape == p.shape:
+        return p.grad
+    return None
+
+
+def _finish_param_grad(g, target):
+    """what a backward returns for a parameter whose gradient was added into `target` in place"""
+    return None if target is not None else g
+
+
 def lp_proxy(shape, device):
     """fp32 tensor of the given logical shape over ONE element of storage (all strides 0): the autograd
     edge of a tensor whose data travel in 16 bits beside it.  autograd casts a gradient to its input's
@@ -733,8 +758,9 @@ def lp16_wgrad_ok(Cin, Cout, k, stride, pad):
     return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 256 == 0 and Cout % 256 == 0
 
 
-def raw_wgrad3x3_lp16(x16, dy16, reflect, bf16):
-    """dw [3,3,Cin,Cout] fp32 from the 16-bit twins of x and dy (conv_lp16.hip wgrad)."""
+def raw_wgrad3x3_lp16(x16, dy16, reflect, bf16, out=None):
+    """dw [3,3,Cin,Cout] fp32 from the 16-bit twins of x and dy (conv_lp16.hip wgrad).  out: add into
+    this tensor instead of returning a new one."""
     B, H, W_, Cin = x16.shape
     Cout = dy16.shape[3]
     assert x16.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and x16.is_contiguous() and dy16.is_contiguous()
@@ -742,9 +768,9 @@ def raw_wgrad3x3_lp16(x16, dy16, reflect, bf16):
     d.dtype = _dt(bf16)
     ws = torch.empty(max(int(L.load().mmh_wgrad3x3_lp16_ws_bytes(C.byref(d))), 16) // 4, dtype=torch.float32,
                      device=x16.device)
-    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=x16.device)
-    L.call("mmh_wgrad3x3_lp16", C.byref(d), _ptr(x16), _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4, 0,
-           _ptr(zero_page(x16.device)), _stream())
+    dw = out if out is not None else torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=x16.device)
+    L.call("mmh_wgrad3x3_lp16", C.byref(d), _ptr(x16), _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4,
+           int(out is not None), _ptr(zero_page(x16.device)), _stream())
     _count_desc("mfma", d)
     return dw
 
@@ -792,8 +818,8 @@ def raw_convT_dgrad(dy, w, x_shape, bf16=False, out16=False):
     return dx
 
 
-def raw_convT_wgrad(x, dy, bf16=False):
-    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits."""
+def raw_convT_wgrad(x, dy, bf16=False, out=None):
+    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits.  out: add dw into this tensor."""
     _chk16(x, "x"); _chk16(dy, "dy")
     assert bf16 or (x.dtype == torch.float32 and dy.dtype == torch.float32)
     B, h, w_, CinT = x.shape
@@ -806,19 +832,21 @@ def raw_convT_wgrad(x, dy, bf16=False):
         dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
     nbytes = L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d))
     ws = _ws(nbytes, x)
-    dw = _empty((3, 3, CoutT, CinT), x)
+    dw = out if out is not None else _empty((3, 3, CoutT, CinT), x)
     L.call("mmh_convT2d_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
-           ws.numel() * 4, 0, (1 if x.dtype != torch.float32 else 0) | (2 if dy.dtype != torch.float32 else 0),
-           _stream())
+           ws.numel() * 4, int(out is not None),
+           (1 if x.dtype != torch.float32 else 0) | (2 if dy.dtype != torch.float32 else 0), _stream())
     _count_desc("mfma", d)
     return dw
 
 
-def raw_colsum(x2d_rows, Ccols, x):
-    """x: fp32 or 16-bit; the sums are fp32"""
+def raw_colsum(x2d_rows, Ccols, x, out=None):
+    """x: fp32 or 16-bit; the sums are fp32.  out: add into this tensor."""
     ws = torch.empty(L.load().mmh_colsum_ws_bytes(x2d_rows, Ccols) // 4 + 4, dtype=torch.float32, device=x.device)
-    out = torch.empty((Ccols,), dtype=torch.float32, device=x.device)
-    L.call("mmh_colsum", _ptr(x), x2d_rows, Ccols, Ccols, _ptr(out), _ptr(ws), ws.numel() * 4, 0, _tdt(x),
+    acc = out is not None
+    if out is None:
+        out = torch.empty((Ccols,), dtype=torch.float32, device=x.device)
+    L.call("mmh_colsum", _ptr(x), x2d_rows, Ccols, Ccols, _ptr(out), _ptr(ws), ws.numel() * 4, int(acc), _tdt(x),
            _stream())
     return out
 
@@ -834,12 +862,16 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False):
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False,
+                null_bias_grad=False):
         """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
         the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
         GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
         ctx.set_materialize_grads(False)    # no full-size zero "gradient" for the non-differentiable 16-bit output
+        # null_bias_grad: the output feeds an InstanceNorm directly - the bias gradient is identically zero
+        ctx.skip_db = bool(null_bias_grad and EXACT_NULL_BIAS_GRAD)
+        ctx.bias_p = bias
         B, H, W_, Cin = x.shape
         ctx.dx_channels = dx_channels
         wt = _wino_tile(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, bf16)
@@ -908,16 +940,21 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
         if g is None:
-            return (None,) * 11
+            return (None,) * 12
+        wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
+        bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
+        want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
+        if has_bias and ctx.needs_input_grad[2] and ctx.skip_db and ctx.bias_p.grad is None:
+            db = torch.zeros_like(ctx.bias_p)       # exact zero; with a preassigned .grad nothing needs adding
         if ctx.stem16:
             g16 = lp_grad_in(g, "Conv2dFn (stem)")
             if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)
                 dx = raw_conv_dgrad_thin(g16, w, ctx.x_shape, reflect)
             if ctx.needs_input_grad[1]:
-                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
-            if has_bias and ctx.needs_input_grad[2]:
-                db = raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16)
-            return dx, dw, db, None, None, None, None, None, None, None, None
+                dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:
@@ -926,19 +963,20 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.x_lp:
                     dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
-                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
-            if has_bias and ctx.needs_input_grad[2]:
-                db = raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16)
-            return dx, dw, db, None, None, None, None, None, None, None, None
+                dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         g = g.contiguous()
         if act != L.ACT_NONE:
             g = raw_act_bwd(g, y, act)
         if (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                 and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6):
-            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x)      # x is the saved V here
-            if has_bias and ctx.needs_input_grad[2]:
-                db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None, None, None
+            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x, dw_out=wt_)      # x is the saved V here
+            dw = _finish_param_grad(dw, wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
@@ -947,29 +985,31 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.x_lp:
                     dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
-                dw = raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16)
-            if has_bias and ctx.needs_input_grad[2]:
-                db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-            return dx, dw, db, None, None, None, None, None, None, None, None
+                dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
+            return dx, dw, db, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
             if ctx.wino_V:
-                dw = raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x, bf16=bf16)
+                dw = _finish_param_grad(raw_conv_wgrad_wino(None, g, reflect, ctx.wino_V, V=x, bf16=bf16, out=wt_), wt_)
             else:
-                dw = raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None, None, None, None, None, None
+                dw = _finish_param_grad(raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
+        if want_db:
+            db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d(k3,s2,p1,op1): fprop = stride-2 dgrad kernel, dgrad = stride-2 fprop."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, bf16=False, x16=None, y_lp=False):
-        """x16 / y_lp: 16-bit edges as in Conv2dFn (convT_lp16_ok)."""
+    def forward(ctx, x, w, bias, bf16=False, x16=None, y_lp=False, null_bias_grad=False):
+        """x16 / y_lp: 16-bit edges as in Conv2dFn (convT_lp16_ok); null_bias_grad as there."""
         ctx.set_materialize_grads(False)
+        ctx.skip_db = bool(null_bias_grad and EXACT_NULL_BIAS_GRAD)
+        ctx.bias_p = bias
         ctx.has_bias = bias is not None
         ctx.bf16 = bf16
         ctx.x_lp = x16 is not None
@@ -998,7 +1038,11 @@ class ConvT2dFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         if g is None:
-            return (None,) * 6
+            return (None,) * 7
+        wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None
+        bt_ = _grad_target(ctx.bias_p) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.skip_db and ctx.bias_p.grad is None:
+            db = torch.zeros_like(ctx.bias_p)
         if ctx.lp16:
             g = lp_grad_in(g, "ConvT2dFn") if ctx.y_lp else lp16_twin(g.contiguous(), ctx.bf16)
             if ctx.needs_input_grad[0]:
@@ -1010,10 +1054,10 @@ class ConvT2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = raw_convT_dgrad(g, w, ctx.x_shape, ctx.bf16)
         if ctx.needs_input_grad[1]:
-            dw = raw_convT_wgrad(x, g, ctx.bf16)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = raw_colsum(g.numel() // g.shape[3], g.shape[3], g)
-        return dx, dw, db, None, None, None
+            dw = _finish_param_grad(raw_convT_wgrad(x, g, ctx.bf16, out=wt_), wt_)
+        if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.skip_db:
+            db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
+        return dx, dw, db, None, None, None, None
 
 
 # --------------------------------------------------------------------------- norm
