@@ -35,6 +35,7 @@ extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;
 extern int g_lp16_dbg;
+extern int g_lp16_wgrad_ring;
 extern int g_pw_v2;
 
 }  // namespace mmh

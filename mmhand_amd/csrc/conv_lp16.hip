@@ -1155,6 +1155,7 @@ struct LpWgradKP {
     int S, ksteps_per_split;    // pixel range of split s: [s*ksteps*64, (s+1)*ksteps*64)
     int CT, NT;                 // ci / co tiles
     int items;                  // S * CT * NT * 9
+    int dbg;                    // timing-only ablation bits (results wrong): 1 no DMA, 2 no fragment reads, 4 no MFMA
 };
 
 // Operand fragment for lane: 8 consecutive rows (pixels) row0 + 8h .. of column col0 + (lane & 31) from a
@@ -1257,31 +1258,51 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16_kernel(const LpWgradKP p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) b_tr[j] = tr_off(wc * 64 + j * 32, lane);
 
-    if (k0 < k1) issue(0);
-    for (int ks = k0; ks < k1; ++ks) {
-        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
-        __syncthreads();
-        if (ks + 1 < k1) issue((ks + 1 - k0) & 1);
-        const char* sX = smem + ((ks - k0) & 1) * WSTAGE;
+    // One barrier per k-step, in its MIDDLE (as conv_lp16p_kernel): the fragments of the first k16-step of
+    // k-step ks+1 are read while the last k16-step of k-step ks multiplies, so no wave starts a k-step
+    // waiting on LDS.  At the barrier stage ks is fully read (the DMA of ks+2 may overwrite it) and stage
+    // ks+1, issued one k-step earlier, has landed.
+    bf16x8 af[2][4], bfr[2][2];
+    auto load_frags = [&](const char* sX, int s16, int buf) {
+        if (p.dbg & 2) return;
         const char* sD = sX + 64 * WROWB;
-        bf16x8 af[2][4], bfr[2][2];
-        auto load_frags = [&](int s16, int buf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[buf][i] = tr_frag_at(sX + a_tr[i] + s16 * (16 * WROWB));
+        for (int i = 0; i < 4; ++i) af[buf][i] = tr_frag_at(sX + a_tr[i] + s16 * (16 * WROWB));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[buf][j] = tr_frag_at(sD + b_tr[j] + s16 * (16 * WROWB));
-        };
-        load_frags(0, 0);
+        for (int j = 0; j < 2; ++j) bfr[buf][j] = tr_frag_at(sD + b_tr[j] + s16 * (16 * WROWB));
+    };
+    auto mult = [&](int buf) {
+        if (p.dbg & 4) return;
 #pragma unroll
-        for (int s16 = 0; s16 < 4; ++s16) {
-            if (s16 < 3) load_frags(s16 + 1, (s16 + 1) & 1);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = mfma16<H16>(af[s16 & 1][i], bfr[s16 & 1][j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<H16>(af[buf][i], bfr[buf][j], acc[i][j]);
+    };
+    if (k0 < k1) {
+        issue(0);
+        if (k0 + 1 < k1) issue(1);
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+        __syncthreads();
+        load_frags(smem, 0, 0);
+    }
+    for (int ks = k0; ks < k1; ++ks) {
+        const char* sX = smem + ((ks - k0) & 1) * WSTAGE;
+        const char* sN = smem + ((ks + 1 - k0) & 1) * WSTAGE;
+        load_frags(sX, 1, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(sX, 2, 0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(sX, 3, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);     // stage ks is read (lgkmcnt), stage ks+1 has landed (vmcnt)
+        __syncthreads();
+        if (ks + 2 < k1 && !(p.dbg & 1)) issue((ks - k0) & 1);
+        if (ks + 1 < k1) load_frags(sN, 0, 0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     float* slab = p.slab + ((size_t)split * 9 + tap) * p.Cin * p.Cout;
@@ -1297,6 +1318,158 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16_kernel(const LpWgradKP p) {
             }
         }
 }
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) wgrad_lp16r_kernel(const LpWgradKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    // XCD-contiguous work list, tap fastest: the nine taps of one (split, tile) read the same dy
+    // tile and neighbouring x pixels, back to back on one L2
+    const int per_xcd = (p.items + 7) / 8;
+    int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int tap = item % 9; item /= 9;
+    const int nt = item % p.NT; item /= p.NT;
+    const int ct = item % p.CT;
+    const int split = item / p.CT;
+    const int P = p.B * p.H * p.W;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int k0 = split * p.ksteps_per_split;
+    const int k1 = min((P + 63) / 64, k0 + p.ksteps_per_split);
+
+    // DMA in HALF k-steps of 32 pixels (16 KiB per operand) into a ring of five 32-KiB slots: the k-step that
+    // is being multiplied holds two, three are in flight - 96 KiB instead of the 64 KiB of a two-stage
+    // pipeline.  Why: with the reads and the MFMAs ablated the DMA stream alone takes 493 us of the
+    // kernel's 769 (512->512; tools/ablate_lp16.py): 64 KiB in flight per CU over a ~1.5 us L2 / Infinity
+    // Cache round trip is all the bandwidth a CU gets.  Per half and operand 32 rows x 512 B = 16
+    // instructions of 2 rows; wave w issues 2 per operand: rows (w*2 + j)*2 + lane/32, physical chunk
+    // lane%32 <- logical ^ ((row&3)<<2).  Halves are issued in order, each exactly once, also beyond the
+    // split's range (zero page; never multiplied), so every wave has the same number of loads in flight
+    // and the waits can name it: vmcnt(4) = "all but the newest half".  (32-pixel steps with four halves in
+    // flight: 20 % slower - twice the barriers, no fragment prefetch across them.)
+    constexpr int RH = 5;                           // ring slots
+    constexpr int HBYTES = 64 * WROWB;              // 32 rows x 512 B x 2 operands
+    const int pend = min(P, k1 * 64);
+    unsigned x_coff[2], d_coff[2];
+    int pix[2], poh[2], pow_[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int prow = (wave * 2 + j) * 2 + (lane >> 5);
+        const unsigned c = (unsigned)(lane & 31) ^ ((unsigned)(prow & 3) << 2);
+        x_coff[j] = (unsigned)(ct * 256) * 2u + c * 16u;
+        d_coff[j] = (unsigned)(nt * 256) * 2u + c * 16u;
+        pix[j] = k0 * 64 + prow;
+        const int rem = pix[j] % (p.H * p.W);
+        poh[j] = rem / p.W;
+        pow_[j] = rem - poh[j] * p.W;
+    }
+    int slot_next = 0;
+    auto issue_half = [&]() {
+        char* sX = smem + slot_next * HBYTES;
+        char* sD = sX + 32 * WROWB;
+        slot_next = slot_next + 1 == RH ? 0 : slot_next + 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = pix[j] < pend;
+            int ih = poh[j] + kh - 1, iw = pow_[j] + kw - 1;
+            bool okx = ok;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                okx = okx && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const int src = pix[j] + (ih - poh[j]) * p.W + (iw - pow_[j]);
+            const char* gx = okx ? p.x + (size_t)src * p.x_cs * 2 + x_coff[j] : p.zeros + (lane & 31) * 16;
+            const char* gd = ok ? p.dy + (size_t)pix[j] * p.dy_cs * 2 + d_coff[j] : p.zeros + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds(gx, (lds_vp)(sX + (wave * 2 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gd, (lds_vp)(sD + (wave * 2 + j) * 1024), 16, 0, 0);
+            pix[j] += 32;
+            pow_[j] += 32;
+            while (pow_[j] >= p.W) {
+                pow_[j] -= p.W;
+                if (++poh[j] == p.H) poh[j] = 0;
+            }
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    unsigned a_tr[4], b_tr[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_tr[i] = tr_off(wr * 128 + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_tr[j] = tr_off(wc * 64 + j * 32, lane);
+
+    bf16x8 af[2][4], bfr[2][2];
+    auto load_frags = [&](const char* sH, int s1, int buf) {       // s1: k16-step inside the half (0 | 1)
+        const char* sD = sH + 32 * WROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[buf][i] = tr_frag_at(sH + a_tr[i] + s1 * (16 * WROWB));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[buf][j] = tr_frag_at(sD + b_tr[j] + s1 * (16 * WROWB));
+    };
+    auto mult = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<H16>(af[buf][i], bfr[buf][j], acc[i][j]);
+    };
+    if (k0 < k1) {
+        issue_half(); issue_half(); issue_half();           // halves 0, 1, 2
+    }
+    int slot = 0;                                           // ring slot of the first half of k-step ks
+    for (int ks = k0; ks < k1; ++ks) {
+        // halves 2t and 2t+1 of this k-step have landed when at most the newest half (2t+2: 4 loads per
+        // wave) is still in flight; the barrier also says every wave is done with k-step ks-1, whose
+        // two slots the halves 2t+3 and 2t+4 now take
+        __builtin_amdgcn_s_waitcnt(0x0070 | 4);             // vmcnt(4) lgkmcnt(0)
+        __syncthreads();
+        issue_half(); issue_half();
+        const char* hA = smem + slot * HBYTES;
+        const int slotB = slot + 1 == RH ? 0 : slot + 1;
+        const char* hB = smem + slotB * HBYTES;
+        slot = slotB + 1 == RH ? 0 : slotB + 1;
+        load_frags(hA, 0, 0);
+        load_frags(hA, 1, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(hB, 0, 0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(hB, 1, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);     // drain the halves issued past the range before the LDS is released
+
+    float* slab = p.slab + ((size_t)split * 9 + tap) * p.Cin * p.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ct * 256 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = nt * 256 + wc * 64 + j * 32 + l31;
+                slab[(size_t)ci * p.Cout + co] = acc[i][j][r];
+            }
+        }
+}
+
 
 // dw[i] (+)= sum over splits of slab[s][i], fixed order
 __global__ void lp16_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int S,
@@ -1344,7 +1517,7 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 // all nine taps; 1040-1170 TFLOP/s on the PATBlock shapes), 17 = conv_lp16p_kernel (the same pipelining
 // on 256-pixel row tiles, the activation tile re-fetched per tap; also what images smaller than 16x16
 // take), 16 = without the pipelining (6-13 % slower), 32 = MFMA 32x32x16 (a further 6-9 % slower)
-namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; }
+namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 1; }
 using mmh::g_lp16_shape;
 
 extern "C" {
@@ -1627,6 +1800,7 @@ int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16,
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
     p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
     p.h16 = d->dtype == MMH_FP16;
+    p.dbg = mmh::g_lp16_dbg;
     const long long P = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(P * (long long)std::max(p.x_cs, p.dy_cs) < (1ll << 31), "mmh_wgrad3x3_lp16: tensor too large");
     const int ksteps = (int)((P + 63) / 64);
@@ -1647,8 +1821,23 @@ int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16,
     }
     if (ready != 0) return ready;
     const int per_xcd = (p.items + 7) / 8;
-    if (p.h16) hipLaunchKernelGGL(wgrad_lp16_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
-    else hipLaunchKernelGGL(wgrad_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
+    static int ring_ok = -1;        // 160 KiB of LDS for one workgroup: the whole CU
+    if (ring_ok < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16r_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 64 * WROWB);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16r_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 64 * WROWB);
+        ring_ok = e == hipSuccess ? 1 : 0;
+        if (!ring_ok) (void)hipGetLastError();
+    }
+    if (ring_ok && mmh::g_lp16_wgrad_ring) {
+        if (p.h16) hipLaunchKernelGGL(wgrad_lp16r_kernel<true>, dim3(8 * per_xcd), dim3(512), 5 * 64 * WROWB, st, p);
+        else hipLaunchKernelGGL(wgrad_lp16r_kernel<false>, dim3(8 * per_xcd), dim3(512), 5 * 64 * WROWB, st, p);
+    } else {
+        if (p.h16) hipLaunchKernelGGL(wgrad_lp16_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
+        else hipLaunchKernelGGL(wgrad_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * WSTAGE, st, p);
+    }
     if (int rc = mmh::check_launch("wgrad_lp16_kernel")) return rc;
     const int64_t n4 = (int64_t)9 * d->Cin * d->Cout / 4;
     hipLaunchKernelGGL(lp16_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4, 256), 4096)), dim3(256),

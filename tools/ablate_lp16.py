@@ -28,3 +28,15 @@ for (Cin, Cout) in ((512, 512), (256, 256)):
         t = timeit(lambda: ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0))
         print(f"{Cin}->{Cout} dbg={bits} (noDMA={bits&1} noread={(bits>>1)&1} noMFMA={(bits>>2)&1}): {t*1e3:8.1f} us  {flop/t*1e-9:7.0f} TF-equiv", flush=True)
     L.mmh_set_option(b"lp16_dbg", 0)
+
+print("wgrad_lp16_kernel:")
+for (Cin, Cout) in ((512, 512), (256, 256)):
+    B, H = 32, 64
+    x = torch.randn(B, H, H, Cin, device=dev); dy = torch.randn(B, H, H, Cout, device=dev)
+    xb = ops.lp16_twin(x, True); dyb = ops.lp16_twin(dy, True)
+    flop = 2.0 * B * H * H * Cin * Cout * 9
+    for bits in (0, 1, 2, 4, 3, 5, 6, 7):
+        L.mmh_set_option(b"lp16_dbg", bits)
+        t = timeit(lambda: ops.raw_wgrad3x3_lp16(xb, dyb, True, True))
+        print(f"wgrad {Cin}->{Cout} dbg={bits} (noDMA={bits&1} noread={(bits>>1)&1} noMFMA={(bits>>2)&1}): {t*1e3:8.1f} us  {flop/t*1e-9:7.0f} TF-equiv", flush=True)
+    L.mmh_set_option(b"lp16_dbg", 0)
