@@ -944,8 +944,10 @@ class Conv2dFn(torch.autograd.Function):
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
         bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
         want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
-        if has_bias and ctx.needs_input_grad[2] and ctx.skip_db and ctx.bias_p.grad is None:
-            db = torch.zeros_like(ctx.bias_p)       # exact zero; with a preassigned .grad nothing needs adding
+        if has_bias and ctx.needs_input_grad[2] and ctx.skip_db and (ctx.bias_p.grad is None or not ACCUM_PARAM_GRADS):
+            # exact zero.  Returned as a tensor unless gradients are accumulated in place (then there is
+            # nothing to add): under data parallelism the bucket hooks count one AccumulateGrad per parameter
+            db = torch.zeros_like(ctx.bias_p)
         if ctx.stem16:
             g16 = lp_grad_in(g, "Conv2dFn (stem)")
             if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)
@@ -1041,7 +1043,7 @@ class ConvT2dFn(torch.autograd.Function):
             return (None,) * 7
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None
         bt_ = _grad_target(ctx.bias_p) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.skip_db and ctx.bias_p.grad is None:
+        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.skip_db and (ctx.bias_p.grad is None or not ACCUM_PARAM_GRADS):
             db = torch.zeros_like(ctx.bias_p)
         if ctx.lp16:
             g = lp_grad_in(g, "ConvT2dFn") if ctx.y_lp else lp16_twin(g.contiguous(), ctx.bf16)
