@@ -323,6 +323,42 @@ def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
         lib.check(lib.load().mmh_set_option(b"lp16_shape", 18), "set")
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["fprop", "dgrad"])
+@pytest.mark.parametrize("case", [(32, 64, 64, 256, 512), (32, 64, 64, 512, 256), (4, 128, 128, 256, 256)])
+def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
+    """The builds of the 16-bit 3x3 kernel on the training shapes (too large for the CPU oracle): the
+    pipelined (17) and halo (18) kernels against the plain one (16), three runs each - a missing wait on
+    the LDS-DMA showed up exactly here, as run-to-run differences on two-column-tile shapes - and the two
+    wgrad kernels (two stages / ring of half stages) bit-identical."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout = case
+    L_ = lib.load()
+    x = _mk((B, H, W, Cin if mode == 0 else Cout), 1, dev)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.05
+    ops.bump_weights_epoch()
+    xb = ops.lp16_twin(x, True)
+    try:
+        lib.check(L_.mmh_set_option(b"lp16_shape", 16), "set")
+        ref = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
+        scale = float(ref.abs().max())
+        for shape in (17, 18):
+            lib.check(L_.mmh_set_option(b"lp16_shape", shape), "set")
+            for _ in range(3):
+                y = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
+                assert float((y - ref).abs().max()) < 2e-5 * scale, (shape, float((y - ref).abs().max()), scale)
+        if mode == 0:
+            dy = _mk((B, H, W, Cout), 3, dev)
+            dyb = ops.lp16_twin(dy, True)
+            outs = []
+            for ring in (0, 1, 1):
+                lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", ring), "set")
+                outs.append(ops.raw_wgrad3x3_lp16(xb, dyb, True, True))
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    finally:
+        lib.check(L_.mmh_set_option(b"lp16_shape", 18), "set")
+        lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 1), "set")
+
+
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, 2, False), (1, 32, 20, 128, 256, 2, False),
                                   (3, 10, 14, 64, 64, 1, False), (2, 11, 9, 64, 128, 1, True),
