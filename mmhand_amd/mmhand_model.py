@@ -332,8 +332,24 @@ class MMHandModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ input
     def set_input(self, input):
+        """models/MMHandModel.py:200-221.  Host tensors travel on a copy stream of their own: the host
+        runs an iteration ahead of the GPU, so the H2D copies of batch i+1 (453 MB at B=32, 256^2) overlap
+        the kernels of iteration i instead of queueing behind them; the compute stream only waits for
+        the copies' event.  (Pinned source tensors make the copies asynchronous; the caller must not
+        overwrite them before the next set_input, as with any non_blocking copy.)"""
         dev = self.device
-        t = {k: input[k].to(dev, non_blocking=True).float() for k in ("H1", "P1", "D1", "H2", "P2", "D2")}
+        keys = ("H1", "P1", "D1", "H2", "P2", "D2")
+        if dev.type == "cuda" and any(not input[k].is_cuda for k in keys):
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(self._copy_stream):
+                t = {k: input[k].to(dev, non_blocking=True).float() for k in keys}
+            cur.wait_stream(self._copy_stream)
+            for v in t.values():
+                v.record_stream(cur)
+        else:
+            t = {k: input[k].to(dev, non_blocking=True).float() for k in keys}
         self.input_H1, self.input_P1, self.input_D1 = t["H1"], t["P1"], t["D1"]
         self.input_H2, self.input_P2, self.input_D2 = t["H2"], t["P2"], t["D2"]
         o = self.opt
