@@ -231,6 +231,17 @@ int mmh_conv_lp16_flat(const mmh_conv_desc* d, const void* x16p, int C8, const v
                        const void* bias, void* y, int y_is16, int act, const void* zeros,
                        mmh_stream_t s);
 
+/* 16-bit wgrad with flat (tap, channel) rows - the stems, the stride-2 convs and ConvTranspose2d under
+ * apex O1 (models/Generator.py:158-223,240-253, models/Discriminator.py:79-99): dw [kh][kw][Cin][Cout]
+ * fp32 (+)= from x16 [B][H][W][x_cs] (C8 channels per tap read: C8 = Cin, or the padded width of
+ * mmh_lp16_pad_cvt) and dy16 [B][Ho][Wo][y_cs].  ConvTranspose2d: x16 := its output gradient, dy16 :=
+ * its input, d = the stride-2 conv it is the adjoint of (as mmh_convT2d_wgrad).              */
+int mmh_wgrad_lp16_flat_supported(const mmh_conv_desc* d, int C8);
+size_t mmh_wgrad_lp16_flat_ws_bytes(const mmh_conv_desc* d, int C8);
+int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_cs, const void* dy16,
+                        void* dw, void* ws, size_t ws_bytes, int accumulate, const void* zeros,
+                        mmh_stream_t s);
+
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,

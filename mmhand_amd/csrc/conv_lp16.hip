@@ -1471,6 +1471,206 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16r_kernel(const LpWgradKP p) 
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// wgrad with flat (tap, channel) rows: the weight gradient of the stems (7x7, Cin 3..42), of the
+// stride-2 3x3 convs and of ConvTranspose2d.  dw[(tap, ci)][co] = sum over output pixels of
+// x[pixel*stride + tap - pad][ci] * dy[pixel][co]: GEMM rows are the flat index f = tap * C8 + ci (C8 =
+// channels per tap, a multiple of 8 = one 16-byte chunk), tiled by 256; columns are co, tiled by
+// NTW = 64 | 128 | 256; the contraction runs over output pixels in the ring of half k-steps of
+// wgrad_lp16r_kernel.  Every DMA lane of the x tile carries its own tap (its 16-byte chunk is 8 channels
+// of one tap), as in conv_lp16f_kernel.  Waves: WM x WN = 8x1 (NTW 64), 4x2 (128), 2x4 (256), wave tile
+// (256/WM) x (NTW/WN) in 32x32x16 MFMAs from transposed reads.
+struct LpWgradFKP {
+    const char* x;          // 16-bit gathered tensor [B][H][W][x_cs], C8 channels used per tap
+    const char* dy;         // 16-bit per-pixel tensor [B][Ho][Wo][dy_cs]
+    const char* zeros;
+    float* slab;            // [S][MT*256][Cout]
+    int B, H, W, C8, x_cs;
+    int Ho, Wo, Cout, dy_cs;
+    int KH, KW, stride, pad, reflect;
+    int Mflat;              // KH*KW*C8
+    int S, ksteps_per_split, MT, NT, items;
+};
+
+template <bool H16, int WM, int WN, int NTW>
+__device__ __forceinline__ void wgrad_lp16f_body(const LpWgradFKP& p) {
+    constexpr int TM = 256 / WM / 32, TN = NTW / WN / 32;
+    constexpr int RH = 5;
+    constexpr int HBYTES = 64 * WROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int per_xcd = (p.items + 7) / 8;
+    int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int mt = item % p.MT; item /= p.MT;       // row tiles fastest: they share the dy tile and the x pixels
+    const int nt = item % p.NT;
+    const int split = item / p.NT;
+    const int P = p.B * p.Ho * p.Wo;
+    const int k0 = split * p.ksteps_per_split;
+    const int k1 = min((P + 63) / 64, k0 + p.ksteps_per_split);
+    const int pend = min(P, k1 * 64);
+
+    // per DMA instruction j of a half (rows (wave*2 + j)*2 + lane/32): this lane's logical chunk, its tap
+    unsigned x_coff[2], d_coff[2];
+    int a_kh[2], a_kw[2];
+    bool a_ok[2], d_ok[2];
+    int pix[2], pimg[2], poh[2], pow_[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int prow = (wave * 2 + j) * 2 + (lane >> 5);
+        const unsigned c = (unsigned)(lane & 31) ^ ((unsigned)(prow & 3) << 2);
+        const int f = mt * 256 + (int)c * 8;
+        const int tap = f / p.C8;
+        a_kh[j] = tap / p.KW;
+        a_kw[j] = tap - a_kh[j] * p.KW;
+        a_ok[j] = f < p.Mflat;
+        x_coff[j] = (unsigned)(f - tap * p.C8) * 2u;
+        d_ok[j] = (int)c * 8 < NTW;
+        d_coff[j] = (unsigned)(nt * NTW + (int)c * 8) * 2u;
+        pix[j] = k0 * 64 + prow;
+        pimg[j] = pix[j] / (p.Ho * p.Wo);
+        const int rem = pix[j] - pimg[j] * (p.Ho * p.Wo);
+        poh[j] = rem / p.Wo;
+        pow_[j] = rem - poh[j] * p.Wo;
+    }
+    int slot_next = 0;
+    auto issue_half = [&]() {
+        char* sX = smem + slot_next * HBYTES;
+        char* sD = sX + 32 * WROWB;
+        slot_next = slot_next + 1 == RH ? 0 : slot_next + 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = pix[j] < pend;
+            int ih = poh[j] * p.stride + a_kh[j] - p.pad, iw = pow_[j] * p.stride + a_kw[j] - p.pad;
+            bool okx = ok && a_ok[j];
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            } else {
+                okx = okx && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            const size_t src = ((size_t)pimg[j] * p.H + ih) * p.W + iw;
+            const char* gx = okx ? p.x + src * p.x_cs * 2 + x_coff[j] : p.zeros + (lane & 31) * 16;
+            const char* gd = (ok && d_ok[j]) ? p.dy + (size_t)pix[j] * p.dy_cs * 2 + d_coff[j] : p.zeros + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds(gx, (lds_vp)(sX + (wave * 2 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gd, (lds_vp)(sD + (wave * 2 + j) * 1024), 16, 0, 0);
+            pix[j] += 32;
+            pow_[j] += 32;
+            while (pow_[j] >= p.Wo) {
+                pow_[j] -= p.Wo;
+                if (++poh[j] == p.Ho) { poh[j] = 0; ++pimg[j]; }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    unsigned a_tr[TM], b_tr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_tr[i] = tr_off(wm * (256 / WM) + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_tr[j] = tr_off(wn * (NTW / WN) + j * 32, lane);
+
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto load_frags = [&](const char* sH, int s1, int buf) {
+        const char* sD = sH + 32 * WROWB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[buf][i] = tr_frag_at(sH + a_tr[i] + s1 * (16 * WROWB));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[buf][j] = tr_frag_at(sD + b_tr[j] + s1 * (16 * WROWB));
+    };
+    auto mult = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<H16>(af[buf][i], bfr[buf][j], acc[i][j]);
+    };
+    if (k0 < k1) { issue_half(); issue_half(); issue_half(); }
+    int slot = 0;
+    for (int ks = k0; ks < k1; ++ks) {
+        __builtin_amdgcn_s_waitcnt(0x0070 | 4);             // vmcnt(4): all but the newest half; lgkmcnt(0)
+        __syncthreads();
+        issue_half(); issue_half();
+        const char* hA = smem + slot * HBYTES;
+        const int slotB = slot + 1 == RH ? 0 : slot + 1;
+        const char* hB = smem + slotB * HBYTES;
+        slot = slotB + 1 == RH ? 0 : slotB + 1;
+        load_frags(hA, 0, 0);
+        load_frags(hA, 1, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(hB, 0, 0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(hB, 1, 1);
+        mult(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+
+    float* slab = p.slab + (size_t)split * ((size_t)p.MT * 256) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = mt * 256 + wm * (256 / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = nt * NTW + wn * (NTW / WN) + j * 32 + l31;
+                slab[(size_t)f * p.Cout + co] = acc[i][j][r];
+            }
+        }
+}
+
+#define MMH_WGF_KERNEL(NAME, WM, WN, NTW)                                                          \
+    template <bool H16>                                                                            \
+    __global__ void __launch_bounds__(512, 2) NAME(const LpWgradFKP p) {                           \
+        wgrad_lp16f_body<H16, WM, WN, NTW>(p);                                                     \
+    }
+MMH_WGF_KERNEL(wgrad_lp16f64_kernel, 8, 1, 64)
+MMH_WGF_KERNEL(wgrad_lp16f128_kernel, 4, 2, 128)
+MMH_WGF_KERNEL(wgrad_lp16f256_kernel, 2, 4, 256)
+#undef MMH_WGF_KERNEL
+
+// dw[tap][ci][co] (+)= sum over splits of slab[s][tap*C8 + ci][co], ci < Cin; fixed order
+__global__ void lp16f_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int taps, int Cin,
+                                         int C8, int Cout, int S, size_t slab_stride, int accumulate) {
+    const int64_t n4 = (int64_t)taps * Cin * Cout / 4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int co4 = Cout / 4;
+    for (; i < n4; i += stride) {
+        const int64_t row = i / co4;
+        const int c4 = (int)(i - row * co4);
+        const int tap = (int)(row / Cin), ci = (int)(row - (int64_t)tap * Cin);
+        const size_t src = ((size_t)tap * C8 + ci) * Cout + (size_t)c4 * 4;
+        float4 a = *reinterpret_cast<const float4*>(slab + src);
+        for (int s = 1; s < S; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * slab_stride + src);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (accumulate) {
+            const float4 b = reinterpret_cast<const float4*>(dw)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = a;
+    }
+}
+
 // dw[i] (+)= sum over splits of slab[s][i], fixed order
 __global__ void lp16_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int S,
                                         int accumulate) {
@@ -1771,6 +1971,85 @@ int mmh_conv_lp16_flat(const mmh_conv_desc* d, const void* x16p, int C8, const v
     else
         hipLaunchKernelGGL(conv_lp16f_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, mmh::as_stream(s), p);
     return mmh::check_launch("conv_lp16f_kernel");
+}
+
+
+// ---- flat (tap, channel)-row 16-bit wgrad: stems, stride-2 convs, ConvTranspose2d ----
+static void lp16f_geometry(const mmh_conv_desc* d, int C8, int& ntw, int& MT, int& NT, int& S, int& ksteps) {
+    ntw = d->Cout % 256 == 0 ? 256 : (d->Cout % 128 == 0 ? 128 : 64);
+    MT = (d->kh * d->kw * C8 + 255) / 256;
+    NT = d->Cout / ntw;
+    const long long P = (long long)d->B * d->Ho * d->Wo;
+    ksteps = (int)((P + 63) / 64);
+    S = std::max(1, 256 / (MT * NT));
+    S = (int)std::min<long long>(S, std::max<long long>(1, ksteps / 8));
+}
+
+int mmh_wgrad_lp16_flat_supported(const mmh_conv_desc* d, int C8) {
+    return d && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16) && C8 % 8 == 0 && C8 >= d->Cin && d->Cout % 64 == 0 &&
+           d->Cout % 4 == 0 && d->Cin % 4 == 0 && d->kh == d->kw && (d->stride == 1 || d->stride == 2) &&
+           (d->pad_mode != MMH_PAD_REFLECT || d->stride == 1);
+}
+
+size_t mmh_wgrad_lp16_flat_ws_bytes(const mmh_conv_desc* d, int C8) {
+    if (!mmh_wgrad_lp16_flat_supported(d, C8)) return 0;
+    int ntw, MT, NT, S, ksteps;
+    lp16f_geometry(d, C8, ntw, MT, NT, S, ksteps);
+    return (size_t)S * MT * 256 * d->Cout * sizeof(float);
+}
+
+// dw [kh][kw][Cin][Cout] (fp32) (+)= wgrad of conv d from the 16-bit x16 [B][H][W][x_cs] (C8 channels per
+// tap are read: C8 = Cin, or the padded width of mmh_lp16_pad_cvt for the stems, then x_cs = C8) and dy16.
+int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_cs, const void* dy16, void* dw,
+                        void* ws, size_t ws_bytes, int accumulate, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(mmh_wgrad_lp16_flat_supported(d, C8) && x16 && dy16 && dw && ws && zeros && x_cs >= C8 && x_cs % 8 == 0,
+                "mmh_wgrad_lp16_flat: square kernel, stride 1|2, Cout %% 64 == 0, C8 %% 8 == 0 >= Cin, 16-bit dtype");
+    MMH_REQUIRE(ws_bytes >= mmh_wgrad_lp16_flat_ws_bytes(d, C8), "mmh_wgrad_lp16_flat: workspace too small");
+    LpWgradFKP p{};
+    p.x = static_cast<const char*>(x16); p.dy = static_cast<const char*>(dy16);
+    p.zeros = static_cast<const char*>(zeros);
+    p.slab = static_cast<float*>(ws);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.x_cs = x_cs;
+    p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.dy_cs = d->y_cs;
+    p.KH = d->kh; p.KW = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.Mflat = d->kh * d->kw * C8;
+    int ntw, ksteps;
+    lp16f_geometry(d, C8, ntw, p.MT, p.NT, p.S, ksteps);
+    p.ksteps_per_split = (ksteps + p.S - 1) / p.S;
+    p.S = (ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    p.items = p.S * p.MT * p.NT;
+    MMH_REQUIRE((long long)d->B * d->H * d->W * x_cs < (1ll << 31) && (long long)d->B * d->Ho * d->Wo * d->y_cs < (1ll << 31),
+                "mmh_wgrad_lp16_flat: tensor too large");
+    hipStream_t st = mmh::as_stream(s);
+    const bool h16 = d->dtype == MMH_FP16;
+    constexpr int lds = 5 * 64 * WROWB;
+    const int per_xcd = (p.items + 7) / 8;
+#define MMH_WGF_LAUNCH(NAME)                                                                                      \
+    do {                                                                                                          \
+        static int ready = -1;                                                                                    \
+        if (ready != 0) {                                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(NAME<false>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                  \
+            if (e == hipSuccess)                                                                                  \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(NAME<true>),                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
+            ready = e == hipSuccess ? 0 : mmh::fail(#NAME ": %s", hipGetErrorString(e));                          \
+        }                                                                                                         \
+        if (ready != 0) return ready;                                                                             \
+        if (h16) hipLaunchKernelGGL(NAME<true>, dim3(8 * per_xcd), dim3(512), lds, st, p);                        \
+        else hipLaunchKernelGGL(NAME<false>, dim3(8 * per_xcd), dim3(512), lds, st, p);                           \
+    } while (0)
+    if (ntw == 256) MMH_WGF_LAUNCH(wgrad_lp16f256_kernel);
+    else if (ntw == 128) MMH_WGF_LAUNCH(wgrad_lp16f128_kernel);
+    else MMH_WGF_LAUNCH(wgrad_lp16f64_kernel);
+#undef MMH_WGF_LAUNCH
+    if (int rc = mmh::check_launch("wgrad_lp16f_kernel")) return rc;
+    const int64_t n4 = (int64_t)d->kh * d->kw * d->Cin * d->Cout / 4;
+    hipLaunchKernelGGL(lp16f_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4, 256), 4096)), dim3(256), 0,
+                       st, p.slab, static_cast<float*>(dw), d->kh * d->kw, d->Cin, C8, d->Cout, p.S,
+                       (size_t)p.MT * 256 * d->Cout, accumulate);
+    return mmh::check_launch("lp16f_slab_reduce_kernel");
 }
 
 static int lp16_wgrad_splits(const mmh_conv_desc* d) {

@@ -506,10 +506,20 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False, out=None):
     if bf16 and lp16_wgrad_ok(Cin, Cout, k, stride, pad):
         return raw_wgrad3x3_lp16(x if x.dtype != torch.float32 else lp16_twin(x, bf16),
                                  dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16), reflect, bf16, out=out)
-    if lp_in:       # first-generation 16-bit wgrad kernel reading the 16-bit tensors directly (both or neither)
+    if lp_in:
+        d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+        c8 = (Cin + 7) // 8 * 8
+        if lp16_flat_wgrad_ok(d, c8, bf16):     # flat (tap, channel)-row second-generation kernel
+            if x.dtype == torch.float32:
+                x = lp16_pad8(x, bf16)
+            elif x.shape[3] < c8:
+                x = lp16_pad8(x.float(), bf16)
+            dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
+            dd = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+            return raw_wgrad_lp16_flat(dd, x, c8, dy, bf16, out=out)
+        # first-generation 16-bit wgrad kernel reading the 16-bit tensors directly (both or neither)
         x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
         dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
-        d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
         d.dtype = _dt(bf16)
         assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
         ws = _ws(L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d)), x)
@@ -648,16 +658,71 @@ def flat8_weights(w, bf16):
     return ent
 
 
-def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False):
-    """fprop of a small-Cin 'same' conv on the flat-K 16-bit kernel; x: fp32 NHWC [B,H,W,Cin]"""
+def lp16_pad8(x, bf16):
+    """fp32 NHWC [B,H,W,C] -> 16-bit [B,H,W,C8], channels zero-padded to a multiple of 8"""
     _chk(x, "x")
-    c8 = (d.Cin + 7) // 8 * 8
-    x16p = torch.empty((d.B, d.H, d.W, c8), dtype=_wd(bf16), device=x.device)
-    L.call("mmh_lp16_pad_cvt", _ptr(x), d.B * d.H * d.W, d.Cin, c8, _dt(bf16), _ptr(x16p), _stream())
+    B, H, W_, Cc = x.shape
+    c8 = (Cc + 7) // 8 * 8
+    x16p = torch.empty((B, H, W_, c8), dtype=_wd(bf16), device=x.device)
+    L.call("mmh_lp16_pad_cvt", _ptr(x), B * H * W_, Cc, c8, _dt(bf16), _ptr(x16p), _stream())
+    return x16p
+
+
+# flat (tap, channel)-row 16-bit wgrad (wgrad_lp16f_kernel): stems, stride-2 convs, ConvTranspose2d
+USE_LP16_FLAT_WGRAD = os.environ.get("MMH_LP16_FLAT_WGRAD", "1") != "0"
+
+
+def lp16_flat_wgrad_ok(d, c8, bf16, any_cin=False):
+    """the flat-row second-generation wgrad kernel takes conv d - and pays: with fewer than 64 channels per
+    tap (the 7x7 stems, 64 output columns) its DMA moves the im2col matrix for a quarter of the MFMA work
+    per byte and the first-generation kernel is 15-40 % faster (any_cin: ask for support only)"""
+    if not (bf16 and USE_LP16_V2 and USE_LP16_FLAT_WGRAD) or (d.Cin < 64 and not any_cin):
+        return False
+    old = d.dtype
     d.dtype = _dt(bf16)
-    y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x.device)
+    ok = bool(L.load().mmh_wgrad_lp16_flat_supported(C.byref(d), c8))
+    d.dtype = old
+    return ok
+
+
+def raw_wgrad_lp16_flat(d, x16, c8, dy16, bf16, out=None):
+    """dw [k,k,d.Cin,d.Cout] fp32 of conv d from the 16-bit gathered tensor x16 [B,H,W,>=c8] (c8 channels per tap)
+    and the 16-bit per-pixel tensor dy16 [B,Ho,Wo,Cout]; out: add into this tensor."""
+    assert x16.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and x16.is_contiguous() and dy16.is_contiguous()
+    d.dtype = _dt(bf16)
+    ws = torch.empty(max(int(L.load().mmh_wgrad_lp16_flat_ws_bytes(C.byref(d), c8)), 16) // 4, dtype=torch.float32,
+                     device=x16.device)
+    dw = out if out is not None else torch.empty((d.kh, d.kw, d.Cin, d.Cout), dtype=torch.float32, device=x16.device)
+    L.call("mmh_wgrad_lp16_flat", C.byref(d), _ptr(x16), c8, x16.shape[3], _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4,
+           int(out is not None), _ptr(zero_page(x16.device)), _stream())
+    _count_desc("mfma", d)
+    return dw
+
+
+def raw_conv_wgrad_lp16_gen1(x16, dy16, Cin, k, stride, pad, reflect, bf16, out=None):
+    """first-generation 16-bit wgrad kernel on 16-bit tensors; x16 [B,H,W,x_cs >= Cin] (a stem's padded input)"""
+    B, H, W_, xcs = x16.shape
+    Cout = dy16.shape[3]
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect, x_cs=xcs)
+    d.dtype = _dt(bf16)
+    ws = _ws(L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(d)), x16)
+    dw = out if out is not None else torch.empty((k, k, Cin, Cout), dtype=torch.float32, device=x16.device)
+    L.call("mmh_conv2d_wgrad", C.byref(d), _ptr(x16), _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4, int(out is not None),
+           3, _stream())
+    _count_desc("mfma", d)
+    return dw
+
+
+def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None):
+    """fprop of a small-Cin 'same' conv on the flat-K 16-bit kernel; x: fp32 NHWC [B,H,W,Cin] (or its padded
+    16-bit copy x16p = lp16_pad8(x))"""
+    c8 = (d.Cin + 7) // 8 * 8
+    if x16p is None:
+        x16p = lp16_pad8(x, bf16)
+    d.dtype = _dt(bf16)
+    y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x16p.device)
     L.call("mmh_conv_lp16_flat", C.byref(d), _ptr(x16p), c8, _ptr(flat8_weights(w, bf16)), _ptr(bias), _ptr(y),
-           int(out16), act, _ptr(zero_page(x.device)), _stream())
+           int(out16), act, _ptr(zero_page(x16p.device)), _stream())
     _count_desc("mfma", d)
     return y
 
@@ -827,6 +892,12 @@ def raw_convT_wgrad(x, dy, bf16=False, out=None):
     d = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
     if bf16:
         d.dtype = _dt(bf16)
+    if bf16 and (x.dtype != torch.float32 or dy.dtype != torch.float32) and lp16_flat_wgrad_ok(d, CoutT, bf16):
+        # flat-row second-generation kernel: the output gradient is the gathered tensor, x the per-pixel one
+        x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
+        dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
+        dd = conv_desc(B, 2 * h, 2 * w_, CoutT, CinT, 3, 2, 1, False)
+        return raw_wgrad_lp16_flat(dd, dy, CoutT, x, bf16, out=out)
     if x.dtype != dy.dtype:         # the kernel takes both tensors in 16 bits or neither
         x = x if x.dtype != torch.float32 else lp16_twin(x, bf16)
         dy = dy if dy.dtype != torch.float32 else lp16_twin(dy, bf16)
@@ -893,9 +964,10 @@ class Conv2dFn(torch.autograd.Function):
             d = conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect)
             assert bf16 and act == L.ACT_NONE and x16 is None and stem_lp16_ok(d, bf16, dx_channels), \
                 "a 16-bit output needs 16-bit kernels for all passes and no activation"
-            y = raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=True)
+            x16p = lp16_pad8(x, bf16)
+            y = raw_conv_lp16_flat(d, None, w, bias, act, bf16, out16=True, x16p=x16p)
             ctx.stem16 = True
-            ctx.save_for_backward(x, w, None)
+            ctx.save_for_backward(x16p, w, None)        # the padded 16-bit input serves the wgrad too
             ctx.mark_non_differentiable(y)
             return lp_proxy(y.shape, y.device), y
         if y_lp:
@@ -948,12 +1020,18 @@ class Conv2dFn(torch.autograd.Function):
             # exact zero.  Returned as a tensor unless gradients are accumulated in place (then there is
             # nothing to add): under data parallelism the bucket hooks count one AccumulateGrad per parameter
             db = torch.zeros_like(ctx.bias_p)
-        if ctx.stem16:
+        if ctx.stem16:      # x is the stem's padded 16-bit input [B,H,W,C8] saved by the forward pass
             g16 = lp_grad_in(g, "Conv2dFn (stem)")
             if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)
                 dx = raw_conv_dgrad_thin(g16, w, ctx.x_shape, reflect)
             if ctx.needs_input_grad[1]:
-                dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
+                Bx, Hx, Wx, Cx = ctx.x_shape
+                dd = conv_desc(Bx, Hx, Wx, Cx, w.shape[3], w.shape[0], stride, pad, reflect)
+                if lp16_flat_wgrad_ok(dd, x.shape[3], bf16):
+                    dw = _finish_param_grad(raw_wgrad_lp16_flat(dd, x, x.shape[3], g16, bf16, out=wt_), wt_)
+                else:       # small Cin: the first-generation kernel, reading the padded 16-bit input in place
+                    dw = _finish_param_grad(raw_conv_wgrad_lp16_gen1(x, g16, Cx, w.shape[0], stride, pad, reflect, bf16,
+                                                                     out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
             return dx, dw, db, None, None, None, None, None, None, None, None, None

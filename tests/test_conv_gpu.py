@@ -421,6 +421,39 @@ def test_conv_lp16_flat_stems(case, lp, dev):
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 20, 24, 4, 64, 7, 1, True), (1, 16, 16, 44, 64, 7, 1, True), (2, 12, 13, 8, 64, 7, 1, True),
+                                  (1, 18, 14, 24, 128, 7, 1, False), (2, 16, 16, 64, 128, 3, 2, False),
+                                  (1, 32, 20, 128, 256, 3, 2, False), (3, 10, 14, 64, 64, 3, 1, False),
+                                  (2, 8, 8, 256, 64, 3, 2, False)])
+def test_wgrad_lp16_flat(case, lp, dev):
+    """wgrad_lp16f_kernel (flat (tap, channel) rows, ring of half k-steps) through the C-ABI: the wgrad of the
+    7x7 stems (channels padded to 8), of the stride-2 convs and of 64 / 128-column convs, against the fp64
+    oracle on operands rounded to the storage type; with and without accumulation into dw."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, k, stride, refl = case
+    pad = k // 2
+    x = _mk((B, H, W, Cin), 1, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    d = ops.conv_desc(B, H, W, Cin, Cout, k, stride, pad, refl)
+    dy = _mk((B, d.Ho, d.Wo, Cout), 4, dev)
+    c8 = (Cin + 7) // 8 * 8
+    assert ops.lp16_flat_wgrad_ok(d, c8, lp, any_cin=True)
+    x16p, dy16 = ops.lp16_pad8(x, lp), ops.lp16_twin(dy, lp)
+    dw = ops.raw_wgrad_lp16_flat(ops.conv_desc(B, H, W, Cin, Cout, k, stride, pad, refl), x16p, c8, dy16, lp)
+    _, _, dwr, _ = R.conv2d_grads(rb(x), torch.zeros(k, k, Cin, Cout), None, rb(dy), stride, pad, refl)
+    assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
+    acc = torch.ones_like(dw)
+    ops.raw_wgrad_lp16_flat(ops.conv_desc(B, H, W, Cin, Cout, k, stride, pad, refl), x16p, c8, dy16, lp, out=acc)
+    assert R.rel_l1(acc - 1.0, dwr) < 1e-4
+    # the route raw_conv_wgrad takes for 16-bit operands
+    dw2 = ops.raw_conv_wgrad(x16p if Cin == c8 else x, dy16, k, stride, pad, refl, lp)
+    assert R.rel_l1(dw2, dwr) < 5e-6
+    # a stem's backward: the first-generation kernel on the padded 16-bit input (small Cin)
+    dw3 = ops.raw_conv_wgrad_lp16_gen1(x16p, dy16, Cin, k, stride, pad, refl, lp)
+    assert R.rel_l1(dw3, dwr) < 5e-5
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 def test_convT_bf16_mfma_path(lp, dev):
     from mmhand_amd import ops
     x = _mk((2, 8, 8, 128), 1, dev)
