@@ -15,6 +15,7 @@ python tools/step_breakdown.py --dtype bf16 > $O/breakdown_bf16.txt 2>&1
 python tools/step_breakdown.py --dtype f32 > $O/breakdown_f32.txt 2>&1
 python tools/bench_pointwise.py --lp 1 > $O/pointwise_bf16.txt 2>&1
 python tools/ab_lp16_pipe.py > $O/ab_lp16_kernels.txt 2>&1
+python tools/ab_lp16_wgrad.py > $O/ab_lp16_wgrad.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_f32_line.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_bf16_line.log 2>&1
