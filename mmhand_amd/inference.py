@@ -82,7 +82,64 @@ class InferenceGenerator:
             self._graph = None
             ops.bump_weights_epoch()
 
+    def _lp_chain_ok(self):
+        """16-bit mode: every conv of the folded forward on the conv_lp16 kernels, activations handed from
+        epilogue to loader in 16 bits (no twin conversions, no fp32 intermediate except the residual stream)"""
+        n = self.net
+        if not self.bf16 or n.n_down != 2 or n.n_blocks < 1:
+            return False
+        dim = n.ngf * 4
+        d1 = ops.conv_desc(1, 16, 16, n.ngf, 2 * n.ngf, 3, 2, 1, False)
+        d2 = ops.conv_desc(1, 8, 8, 2 * n.ngf, dim, 3, 2, 1, False)
+        st = ops.conv_desc(1, 16, 16, 4, n.ngf, 7, 1, 3, True)
+        return (ops.lp16_v2_ok(dim, dim, 3, 1, 1, 0) and ops.lp16_v2_ok(2 * dim, 2 * dim, 3, 1, 1, 0)
+                and ops.lp16_v2_ok(2 * dim, dim, 3, 1, 1, 0) and ops.lp16g_ok(d1, 0, self.bf16) and ops.lp16g_ok(d2, 0, self.bf16)
+                and ops.lp16_flat_ok(st, self.bf16) and ops.convT_lp16_ok(dim, 2 * n.ngf, self.bf16)
+                and ops.convT_lp16_ok(2 * n.ngf, n.ngf, self.bf16))
+
+    def _forward_folded_lp16(self, x1, x2, x3):
+        """The folded forward with 16-bit activations between the kernels (BatchNorm folded, ReLU in the conv
+        epilogues): stems on the flat-K kernel, stride-2 / transposed convs on conv_lp16g, the PATBlock convs
+        on the halo kernel; the gate reads its two gates in 16 bits and writes the next block's concats in 16
+        bits.  fp32 only: the residual stream x1 (its conv reads a twin), the gate's s1, the head's input."""
+        n, f, lp = self.net, self.f, self.bf16
+        xs = []
+        for s, x in zip((1, 2, 3), (x1, x2, x3)):
+            w, b = f[("down", s, 0)]
+            B, H, W_, Cc = x.shape
+            x = ops.raw_conv_lp16_flat(ops.conv_desc(B, H, W_, Cc, w.shape[3], 7, 1, 3, True), x, w, b, L.ACT_RELU, lp, out16=True)
+            for i in range(n.n_down):
+                w, b = f[("down", s, 1 + i)]
+                B, H, W_, Cc = x.shape
+                last = i + 1 == n.n_down
+                x = ops.raw_conv_lp16g(ops.conv_desc(B, H, W_, Cc, w.shape[3], 3, 2, 1, False), 0, x, w, b, L.ACT_RELU, lp,
+                                       out16=not (last and s == 1))        # stream 1 enters the fp32 residual stream
+            xs.append(x)
+        x1, x2, x3 = xs                     # x1 fp32, x2 / x3 16-bit
+        for blk in range(n.n_blocks):
+            ss = []
+            for s, x in zip((1, 2, 3), (x1, x2, x3)):
+                x16 = ops.lp16_twin(x, lp) if x.dtype == torch.float32 else x
+                w, b = f[("att", blk, s, 0)]
+                y = ops.raw_conv3x3_lp16(x16, w, b, True, L.ACT_RELU, lp, 0, out16=True)
+                w, b = f[("att", blk, s, 1)]
+                ss.append(ops.raw_conv3x3_lp16(y, w, b, True, L.ACT_NONE, lp, 0, out16=s != 1))
+            more = blk + 1 < n.n_blocks
+            px = ops.lp_proxy(ss[1].shape, ss[1].device)
+            res = ops.GateFn.apply(x1, ss[0], px, px, more, lp if more else 0, ss[1], ss[2])
+            x1 = res[0]
+            if more:
+                x2, x3 = res[3], res[4]
+        y = x1
+        for i in range(n.n_down):
+            w, b = f[("up", i)]
+            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU, lp, out16=i + 1 < n.n_down)
+        w, b = f[("head",)]
+        return ops.raw_conv_fprop(y, w, b, 1, 3, True, L.ACT_TANH, lp)
+
     def _forward_folded(self, x1, x2, x3):
+        if self._lp_chain_ok():
+            return self._forward_folded_lp16(x1, x2, x3)
         n, f = self.net, self.f
         xs = []
         for s, x in zip((1, 2, 3), (x1, x2, x3)):

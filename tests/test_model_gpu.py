@@ -315,3 +315,34 @@ def test_inference_generator_bf16(dev):
     ref = O.generator_forward(onet, g_in, 2)
     err = R.rel_l1(out, ref)
     assert 1e-6 < err < 2e-2, err
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_inference_generator_16bit_chain_full_width(lp, dev):
+    """ngf 64 (256 / 512 channels in the PATBlocks): the folded forward runs entirely on the conv_lp16
+    kernels with 16-bit activations handed from epilogue to loader (InferenceGenerator._forward_folded_lp16).
+    Against the eval-mode fp64 oracle it must be as good as the same 16-bit kernels with fp32 tensors between
+    them (the recipe weights make this net sensitive to 16-bit operands: 6e-2 in bf16, 9e-3 in fp16 either
+    way; fp32: 5e-5) - the 16-bit hand-over adds at most a tenth to that - and replay must be deterministic."""
+    from mmhand_amd.inference import InferenceGenerator
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, 64, "batch", True, 2)
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.to(dev)
+    b = O.synthetic_batch(2, 64, 64, seed=5)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    onet = O._Net(sd, "batch", True); onet.training = False
+    ref = O.generator_forward(onet, g_in, 2)
+    plain = InferenceGenerator(net, use_graph=False, bf16=lp)
+    plain._lp_chain_ok = lambda: False                      # 16-bit kernels, fp32 tensors between them
+    e_plain = R.rel_l1(plain([t.to(dev) for t in g_in]), ref)
+    gen = InferenceGenerator(net, use_graph=True, bf16=lp)
+    assert gen._lp_chain_ok()
+    out = gen([t.to(dev) for t in g_in])
+    e_chain = R.rel_l1(out, ref)
+    assert 1e-6 < e_chain < 1.1 * e_plain + 1e-4, (e_chain, e_plain)
+    assert e_chain < (8e-2 if lp is True else 1.2e-2), e_chain
+    out2 = gen([t.to(dev) for t in g_in])                   # graph replay
+    assert torch.equal(out, out2)
+    net.bf16 = False
