@@ -934,11 +934,18 @@ __global__ void loss_partial_kernel(const float* __restrict__ a, const float* __
 
 __global__ void loss_final_kernel(const float* __restrict__ partial, int nparts, double scale,
                                   float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double acc = 0;
-        for (int i = 0; i < nparts; ++i) acc += partial[i];
-        out[0] = (float)(acc * scale);
+    // 256 lanes sum their strided partials in double (i ascending), then a fixed-order tree: deterministic,
+    // and not one thread walking 4096 values (that serial loop was 50 us per loss)
+    __shared__ double sh[TPB];
+    double acc = 0;
+    for (int i = threadIdx.x; i < nparts; i += TPB) acc += partial[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = TPB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[0] = (float)(sh[0] * scale);
 }
 
 __global__ void bce_bwd_kernel(const float* __restrict__ x, int64_t n4, float target, float k,
@@ -1513,12 +1520,12 @@ int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n, const void* g_x3
     return mmh::check_launch("gate_bwd");
 }
 
-size_t mmh_reduce_ws_bytes(int64_t n) { return (size_t)grid_for(n / 4, 1024) * sizeof(float); }
+size_t mmh_reduce_ws_bytes(int64_t n) { return (size_t)grid_for(n / 4, 4096) * sizeof(float); }
 
 static int loss_fwd(int mode, const void* a, const void* b, int64_t n, float target, float weight,
                     double denom, void* out, void* ws, size_t ws_bytes, mmh_stream_t s) {
     MMH_REQUIRE(a && out && ws && n > 0 && n % 4 == 0 && denom > 0, "loss_fwd: bad arguments");
-    const int blocks = grid_for(n / 4, 1024);
+    const int blocks = grid_for(n / 4, 4096);
     MMH_REQUIRE(ws_bytes >= blocks * sizeof(float), "loss_fwd: workspace too small");
     hipStream_t st = mmh::as_stream(s);
     if (mode == 0)
@@ -1532,7 +1539,7 @@ static int loss_fwd(int mode, const void* a, const void* b, int64_t n, float tar
         hipLaunchKernelGGL((loss_partial_kernel<2>), dim3(blocks), dim3(TPB), 0, st,
                            static_cast<const float*>(a), static_cast<const float*>(b), n, 0.f,
                            static_cast<float*>(ws));
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, static_cast<const float*>(ws),
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(TPB), 0, st, static_cast<const float*>(ws),
                        blocks, (double)weight / denom, static_cast<float*>(out));
     return mmh::check_launch("loss_fwd");
 }
