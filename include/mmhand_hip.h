@@ -315,6 +315,48 @@ int mmh_norm_bwd_apply(const void* g, const void* out, const void* x,
                        int C, int masked, float drop_p, void* dx,
                        int g_dtype, int x_dtype, int dx_dtype, mmh_stream_t s);
 
+/* ---- norm-apply fused into the consuming convolution (fp32, Winograd F(6x6,3x3) stack) ----
+ * The reference runs conv -> Norm -> ReLU -> Dropout -> ReflectionPad -> conv as separate modules
+ * (models/Generator.py:66-77, models/Discriminator.py:29-34).  Here the apply pass of the norm between
+ * two 3x3 convs runs inside the second conv's input transform (mmh_wino_input_normact), and the apply
+ * pass of its backward inside the first conv's backward transform (mmh_wino_input_dy_normbwd): the
+ * activation between norm and conv, and the gradient between conv and norm, never reach HBM.  No
+ * keep bits are stored either: the backward decides again from fma(x, scale, shift) > 0 - the
+ * expression the forward evaluated - and the dropout bit array of the site.
+ *
+ * mmh_dropout_bits: bit e of byte i of `bits` [n/8] = element 8 i + e is kept (hash of (seed,
+ * position) against p, or mask != NULL: uint8 per element, test hook).
+ * *_rc: mmh_norm_bwd_reduce / _apply (fp32 tensors) with the keep decision taken again instead of
+ * read; dbits NULL iff drop_p == 0.  C / 8 must be a power of two <= 256.                      */
+int mmh_dropout_bits(int64_t n, float drop_p, uint64_t seed, const void* mask, void* bits,
+                     mmh_stream_t s);
+/* the same decisions as row words for the two transforms below, which walk one channel along image rows:
+ * rows (uint32) [image_rows = B*H][ceil(W/32)][C], bit k of word j = element (row, 32 j + k, c)      */
+int mmh_dropout_bits_rows(const void* bits, int64_t image_rows, int W, int C, void* rows,
+                          mmh_stream_t s);
+int mmh_norm_bwd_reduce_rc(const void* g, const void* x, const void* mean, const void* invstd,
+                           const void* scale, const void* shift, const void* dbits, int groups,
+                           int64_t rows_per_group, int C, int relu, float drop_p, void* s1,
+                           void* s2, void* ws, size_t ws_bytes, mmh_stream_t s);
+int mmh_norm_bwd_apply_rc(const void* g, const void* x, const void* mean, const void* invstd,
+                          const void* gamma, const void* s1, const void* s2, const void* scale,
+                          const void* shift, const void* dbits, double count, int groups,
+                          int64_t rows_per_group, int C, int relu, float drop_p, void* dx,
+                          mmh_stream_t s);
+/* V = mmh_wino_input(dropout(relu(x*scale + shift)))   (tile 6, fp32; reflect 0 | 1; groups 1 | B;
+ * drows = mmh_dropout_bits_rows, NULL iff drop_p == 0)                                           */
+int mmh_wino_input_normact(const void* x, int B, int H, int W, int C, int reflect, void* V,
+                           const void* scale, const void* shift, int groups, int relu,
+                           float drop_p, const void* drows, mmh_stream_t s);
+/* (V, Yh) = mmh_wino_input_dy(dx), dx = the result of mmh_norm_bwd_apply_rc(g, x, ...) computed per
+ * element inside the transform (x = the norm's input = the forward output of the conv whose
+ * backward this is).                                                                            */
+int mmh_wino_input_dy_normbwd(const void* g, const void* x, int B, int H, int W, int C, void* V,
+                              void* Yh, int fold, const void* mean, const void* invstd,
+                              const void* gamma, const void* s1, const void* s2, double count,
+                              const void* scale, const void* shift, const void* drows, int groups,
+                              int relu, float drop_p, mmh_stream_t s);
+
 /* dx = g * act'(y): relu -> (y>0), tanh -> 1-y^2 (Generator.py:259 head).   */
 int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
                 mmh_stream_t s);

@@ -22,12 +22,36 @@ inline hipStream_t as_stream(mmh_stream_t s) { return reinterpret_cast<hipStream
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// One element of the norm backward, dx = k0*(dz - k1) - (x - mu)*k2 with dz = keep ? g/(1-p) : 0, as a
+// PINNED sequence of operations (the empty asm statements stop the compiler from contracting it with
+// its neighbours): norm_bwd_apply_v2 (pointwise.hip) and the backward transform that computes dx on
+// the fly (wino6.hip) must round identically.
+__device__ __forceinline__ float norm_bwd_elem(float g, bool keep, float dsc, float xv, float mu, float k0, float k1,
+                                               float k2) {
+    float dz = keep ? g * dsc : 0.f;
+    asm volatile("" : "+v"(dz));
+    float a = dz - k1;
+    asm volatile("" : "+v"(a));
+    float t = (xv - mu) * k2;
+    asm volatile("" : "+v"(t));
+    float o = __builtin_fmaf(k0, a, -t);
+    asm volatile("" : "+v"(o));
+    return o;
+}
+
 // Winograd F(6x6,3x3) transforms (wino6.hip); tiles = B * ceil(H/6) * ceil(W/6), 64 planes
 int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st);
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st);
 int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, float* stats,
                  int fold, hipStream_t st);
 int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t st);
+int wino6_input_normact(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd,
+                        const float* scale, const float* shift, int groups, int relu, float drop_p,
+                        const uint32_t* drows, hipStream_t st);
+int wino6_input_dy_normbwd(const float* g, const float* x, float* V, float* Yh, int B, int H, int W, int C, int xcd,
+                           int fold, const float* mean, const float* invstd, const float* gamma, const float* s1,
+                           const float* s2, double count, const float* scale, const float* shift,
+                           const uint32_t* drows, int groups, int relu, float drop_p, hipStream_t st);
 int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, int fold,
                    hipStream_t st);
 int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);

@@ -221,17 +221,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // barrier per k-step (2 workgroups/CU) instead of one buffer and two barriers
 // (3 workgroups/CU; measured 5-6 % faster on the 512-channel shapes).
 // ---------------------------------------------------------------------------
-template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF>
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF, int BMT = 128>   // BMT: rows per workgroup
 __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, const int by,
                                                 const int gx, const int gy) {
-    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int WTM = BMT / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int RA = BMT / 32;    // A rows per thread
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NB = BN / 32;  // float4 B loads per thread per k-step
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
     constexpr int NBUF = DBUF ? 2 : 1;
     constexpr bool IL = B_NMAJOR;   // dgrad: loads interleaved with the MFMA groups (+1-2 % measured)
-    constexpr int ASZ = BM * LDA;
+    constexpr int ASZ = BMT * LDA;
     constexpr int BSZ = B_NMAJOR ? BN * LDA : BK * BN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As_base = smem;
@@ -256,19 +257,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             mt = x * band + i / gx;
         }
     }
-    const int m0 = mt * BM;
+    const int m0 = mt * BMT;
     const int n0 = nt * BN;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src, g.src_bytes);
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.w, p.w_bytes);
 
-    // --- per-thread A rows: 4 rows, one k-group (tid&7) ---
+    // --- per-thread A rows: RA rows, one k-group (tid&7) ---
     const int grp = tid & 7;
-    unsigned a_img[4];
-    int a_bh[4], a_bw[4];
-    bool a_ok[4];
+    unsigned a_img[RA];
+    int a_bh[RA], a_bw[RA];
+    bool a_ok[RA];
     const int PHW = g.PH * g.PW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i) {
         int m = m0 + (tid >> 3) + 32 * i;
         a_ok[i] = m < p.M;
         int mm = a_ok[i] ? m : 0;
@@ -304,9 +305,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
 
     KState ks_t;   // this thread's k-group
     kstate_init(ks_t, g, grp);
-    unsigned a_off[4] = {OOB, OOB, OOB, OOB};   // row byte offsets of the current tap
+    unsigned a_off[RA];   // row byte offsets of the current tap
+#pragma unroll
+    for (int i = 0; i < RA; ++i) a_off[i] = OOB;
 
-    float4 ra[4];
+    float4 ra[RA];
     float4 rb[NB];
 
     // The loader is cut into 4 parts so that it can either run as one burst before the MFMAs
@@ -314,14 +317,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     auto load_part = [&](int ks, int part) {
         const bool kv = kstate_valid(ks_t, g);
         if (part == 0) {
-            if (ks_t.j == 0) {   // new tap (or flat order): recompute the 4 row offsets
+            if (ks_t.j == 0 && !((p.dbg & 4) && ks > 1)) {   // new tap (or flat order): recompute the row offsets
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < RA; ++i)
                     a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], ks_t, a_ok[i]);
             }
         } else if (part == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RA; ++i)
                 ra[i] = bload4(rsA, (kv && a_off[i] != OOB) ? a_off[i] + (unsigned)ks_t.c4 * 16u : OOB);
         } else {
             constexpr int H0 = (NB + 1) / 2;
@@ -365,7 +368,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         float* As = As_base + buf * ASZ;
         float* Bs = Bs_base + buf * BSZ;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RA; ++i)
             *reinterpret_cast<float4*>(&As[((tid >> 3) + 32 * i) * LDA + grp * 4]) = ra[i];
         if (!B_NMAJOR) {
 #pragma unroll
@@ -398,7 +401,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         const float* Bs = Bs_base + (DBUF ? (ks & 1) : 0) * BSZ;
         const bool more = ks + 1 < p.nk;
         if (more) {
-            kstate_next(ks_t, g);
+            if (!(p.dbg & 4)) kstate_next(ks_t, g);        // dbg 4: loads still issue, from stale addresses
             if (!(p.dbg & 1) && !IL) load_tiles(ks + 1);   // global -> registers, one burst
         }
 #pragma unroll
@@ -478,6 +481,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, DBUF>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
+// 256-row tiles for the narrow GEMMs (N <= 64: 7x7 stems, stride-2 dgrad): per MFMA half the weight
+// tile traffic, barriers and address work of the 128-row tile
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR>
+__global__ void __launch_bounds__(256, 2) conv_igemm_tall_kernel(const ConvKP p) {
+    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false, 256>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
 // Several small problems in one launch (blockIdx.z picks the piece): the border terms of the
 // reflect-pad dgrad.  Each piece has its own extent; surplus workgroups exit at once.
 constexpr int MAXP = 9;
@@ -491,13 +501,13 @@ __device__ __forceinline__ int multi_piece(const MultiKP& mp, int L) {
     while (k + 1 < mp.n && L >= mp.start[k + 1]) ++k;
     return k;
 }
-template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR>
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, int BMT = 128>
 __global__ void __launch_bounds__(256, 2) conv_igemm_multi_kernel(const MultiKP mp) {
     const int k = multi_piece(mp, blockIdx.x);
     const ConvKP& p = mp.p[k];
-    const int gx = (p.N + BN - 1) / BN, gy = (p.M + BM - 1) / BM;
+    const int gx = (p.N + BN - 1) / BN, gy = (p.M + BMT - 1) / BMT;
     const int local = blockIdx.x - mp.start[k];
-    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false>(p, local % gx, local / gx, gx, gy);
+    conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, false, BMT>(p, local % gx, local / gx, gx, gy);
 }
 
 // Batched plain GEMMs (blockIdx.z = batch): the 16 Winograd-domain products.  Each batch is
@@ -2162,6 +2172,17 @@ int launch_conv_t(const ConvKP& p, hipStream_t st) {
     return mmh::check_launch("conv_igemm_kernel");
 }
 
+template <int BN, int WM, int WN, bool NMAJOR>
+int launch_conv_tall_t(const ConvKP& p, hipStream_t st) {
+    constexpr size_t lds = (256 * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_igemm_tall_kernel<BN, WM, WN, NMAJOR>, lds);
+    if (ready != 0) return ready;
+    dim3 grid((p.N + BN - 1) / BN, (p.M + 255) / 256);
+    hipLaunchKernelGGL((conv_igemm_tall_kernel<BN, WM, WN, NMAJOR>), grid, dim3(256), lds, st, p);
+    return mmh::check_launch("conv_igemm_tall_kernel");
+}
+
 template <int BN, int WM, int WN>
 int launch_conv_bf16_t(const ConvKP& p, hipStream_t st) {
     constexpr size_t lds = (size_t)(BM + BN) * LDH * 2;
@@ -2199,6 +2220,8 @@ int launch_conv_bf16(ConvKP& p, hipStream_t st) {
     return launch_conv_bf16_t<32, 4, 1>(p, st);
 }
 
+int g_conv_tall = 1;    // 256x64 block tile for the stride-2 dgrad with N <= 64 (+6 %); 2: also plain fprop/dgrad
+int g_conv_xcd1 = 1;    // XCD-banded row tiles also when there is a single column tile (halo rows meet in one L2)
 int g_conv_bn256 = 1;   // 128x256 block tile (wave tile 64x128) when N % 256 == 0: +2.4 % on fprop
 
 template <bool NMAJOR>
@@ -2209,10 +2232,14 @@ int launch_conv(const ConvKP& p, hipStream_t st) {
         const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
         return launch_conv_t<256, 2, 2, NMAJOR, false>(p, st);
     }
+    if (g_conv_tall == 2 && p.N > 32 && p.N <= 64 && p.M >= 256 * 512) {   // measured: no gain on the stems (A/B only)
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd1 && (p.M + 255) / 256 >= 8) ? 1 : 0;
+        return launch_conv_tall_t<64, 4, 1, NMAJOR>(p, st);
+    }
     {
         const int BNsel = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);
         const int gx = (p.N + BNsel - 1) / BNsel, gy = (p.M + BM - 1) / BM;
-        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && (gx > 1 || g_conv_xcd1) && gy >= 8) ? 1 : 0;
     }
     if (p.N > 64)
         return g_conv_dbuf ? launch_conv_t<128, 2, 2, NMAJOR, true>(p, st)
@@ -2274,7 +2301,7 @@ int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* b
 // Gradient w.r.t. the conv input.  out: [B, OH, OW, Cin] with channel stride out_cs, where
 // (OH,OW) is the padded domain for reflect mode and (H,W) otherwise.
 int g_dgrad_s2_multi = 1;   // stride-2 dgrad / ConvTranspose fprop: 4 parity classes in one multi-piece launch
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int BMT = 128>
 int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st);
 
 int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx,
@@ -2347,7 +2374,10 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
         for (int i = 0; i < ncls; ++i) mp.p[mp.n++] = classes[ncls == 4 ? order[i] : i];
         const int C = d->Cin;
         if (C > 64) return launch_multi_t<128, 2, 2>(mp, false, st);
-        if (C > 32) return launch_multi_t<64, 2, 2>(mp, false, st);
+        if (C > 32) {
+            if (g_conv_tall && mp.p[0].M >= 256 * 128) return launch_multi_t<64, 4, 1, 256>(mp, false, st);
+            return launch_multi_t<64, 2, 2>(mp, false, st);
+        }
         return launch_multi_t<32, 4, 1>(mp, false, st);
     }
     return 0;
@@ -2366,15 +2396,21 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
 // launch after the main kernel.  Versus the padded-domain + fold route this saves the 6.3 % ring
 // rows, the misaligned 66-pixel rows and the fold pass.
 // ---------------------------------------------------------------------------
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, int BMT>
 int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st) {
     int total = 0;
     for (int i = 0; i < mp.n; ++i) {
         mp.start[i] = total;
-        total += ((mp.p[i].N + BN - 1) / BN) * ((mp.p[i].M + BM - 1) / BM);
+        total += ((mp.p[i].N + BN - 1) / BN) * ((mp.p[i].M + BMT - 1) / BMT);
     }
     mp.start[mp.n] = total;
-    if (bf16) {
+    if (BMT != BM) {
+        constexpr size_t lds = (BMT * LDA + BN * LDA) * sizeof(float);
+        static int ready = -1;
+        if (ready != 0) ready = allow_lds(conv_igemm_multi_kernel<BN, WM, WN, true, BMT>, lds);
+        if (ready != 0) return ready;
+        hipLaunchKernelGGL((conv_igemm_multi_kernel<BN, WM, WN, true, BMT>), dim3(total), dim3(256), lds, st, mp);
+    } else if (bf16) {
         constexpr size_t lds = (size_t)(BM + BN) * LDH * 2;
         static int ready = -1;
         if (ready != 0) ready = allow_lds(conv_igemm_bf16_multi_kernel<BN, WM, WN>, lds);
@@ -3013,6 +3049,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_bn256")) { g_conv_bn256 = value; return 0; }
     if (!strcmp(key, "wino_bn256")) { g_wino_bn256 = value; return 0; }
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
+    if (!strcmp(key, "conv_xcd1")) { g_conv_xcd1 = value; return 0; }
+    if (!strcmp(key, "conv_tall")) { g_conv_tall = value; return 0; }
     if (!strcmp(key, "wgrad_slots")) { g_wgrad_slots = value; return 0; }
     if (!strcmp(key, "wgrad_dbuf")) { g_wgrad_dbuf = value; return 0; }
     if (!strcmp(key, "wgrad_bn256")) { g_wgrad_bn256 = value; return 0; }
@@ -3134,6 +3172,36 @@ int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int 
                 "mmh_wino_input_dy: fold needs (H+1) %% 6 >= 2 and ceil((H+2)/6) == ceil(H/6) (W alike)");
     return mmh::wino6_input_dy(static_cast<const float*>(dy), static_cast<float*>(V), static_cast<float*>(Yh), B, H, W,
                                C, g_wino_xcd, fold ? 1 : 0, mmh::as_stream(s));
+}
+
+int mmh_wino_input_normact(const void* x, int B, int H, int W, int C, int reflect, void* V, const void* scale,
+                           const void* shift, int groups, int relu, float drop_p, const void* drows,
+                           mmh_stream_t s) {
+    MMH_REQUIRE(x && V && scale && shift && B > 0 && wino_hw_ok(H, W, 6) && C % 8 == 0 && reflect >= 0 && reflect <= 1 &&
+                    (groups == 1 || groups == B) && drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (drows == nullptr) &&
+                    (drop_p == 0.f || relu),
+                "mmh_wino_input_normact: bad arguments (tile 6, fp32, C %% 8 == 0, groups 1 | B, dropout rows iff p > 0)");
+    return mmh::wino6_input_normact(static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C, reflect,
+                                    g_wino_xcd, static_cast<const float*>(scale), static_cast<const float*>(shift),
+                                    groups, relu, drop_p, static_cast<const uint32_t*>(drows), mmh::as_stream(s));
+}
+
+int mmh_wino_input_dy_normbwd(const void* g, const void* x, int B, int H, int W, int C, void* V, void* Yh, int fold,
+                              const void* mean, const void* invstd, const void* gamma, const void* s1,
+                              const void* s2, double count, const void* scale, const void* shift,
+                              const void* drows, int groups, int relu, float drop_p, mmh_stream_t s) {
+    MMH_REQUIRE(g && x && V && Yh && mean && invstd && s1 && s2 && scale && shift && B > 0 && wino_hw_ok(H, W, 6) &&
+                    C % 8 == 0 && count > 0 && (groups == 1 || groups == B) && drop_p >= 0.f && drop_p < 1.f &&
+                    (drop_p == 0.f) == (drows == nullptr),
+                "mmh_wino_input_dy_normbwd: bad arguments (tile 6, fp32, C %% 8 == 0, groups 1 | B)");
+    MMH_REQUIRE(!fold || (wino_fold_ok(H, W) && (H + 7) / 6 == (H + 5) / 6 && (W + 7) / 6 == (W + 5) / 6),
+                "mmh_wino_input_dy_normbwd: fold needs (H+1) %% 6 >= 2 and ceil((H+2)/6) == ceil(H/6) (W alike)");
+    return mmh::wino6_input_dy_normbwd(
+        static_cast<const float*>(g), static_cast<const float*>(x), static_cast<float*>(V), static_cast<float*>(Yh), B,
+        H, W, C, g_wino_xcd, fold ? 1 : 0, static_cast<const float*>(mean), static_cast<const float*>(invstd),
+        static_cast<const float*>(gamma), static_cast<const float*>(s1), static_cast<const float*>(s2), count,
+        static_cast<const float*>(scale), static_cast<const float*>(shift), static_cast<const uint32_t*>(drows), groups,
+        relu, drop_p, mmh::as_stream(s));
 }
 
 int mmh_wino_dy(const void* dy, int B, int H, int W, int C, int tile, int dtype, void* Yh, mmh_stream_t s) {

@@ -224,6 +224,48 @@ __device__ __forceinline__ uint64_t mix_u64(uint64_t seed, uint64_t idx) {
     return z ^ (z >> 31);
 }
 
+// Dropout decisions of one site as a bit array (bit e of byte i = element 8 i + e is kept), drawn once
+// per iteration and read by every kernel that needs them: the norm-apply fused into a Winograd input
+// transform and the norm backward kernels that decide again instead of reading stored keep bits.
+// mask (uint8 per element, test hook) replaces the hash.
+__global__ void dropout_bits_kernel(int64_t n8, uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                    uint8_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    unsigned b = 0;
+    if (mask) {
+        const uint2 m = reinterpret_cast<const uint2*>(mask)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b |= (((e < 4 ? m.x >> (8 * e) : m.y >> (8 * (e - 4))) & 0xffu) ? 1u : 0u) << e;
+    } else {
+        const uint64_t h0 = mix_u64(seed, (uint64_t)i * 2), h1 = mix_u64(seed, (uint64_t)i * 2 + 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            b |= ((unsigned)((e < 4 ? h0 >> (16 * e) : h1 >> (16 * (e - 4))) & 0xffffu) >= thr16 ? 1u : 0u) << e;
+    }
+    bits[i] = (uint8_t)b;
+}
+
+// The same decisions as ROW WORDS for the kernels that walk a channel along an image row (the Winograd
+// transforms with the norm arithmetic inside, wino6.hip): rows[((b*H + h)*nW32 + j)*C + c] bit k = element
+// (b, h, 32 j + k, c).  One thread per (image row, word, channel); its 32 source bytes are shared with 7 neighbours.
+__global__ void dropout_rows_kernel(const uint8_t* __restrict__ bits, int64_t nrows, int W, int C, int nW32,
+                                    uint32_t* __restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * nW32 * C) return;
+    const int c = (int)(i % C);
+    const int64_t t = i / C;
+    const int j = (int)(t % nW32);
+    const int64_t row = t / nW32;
+    const int c8 = C / 8;
+    const uint8_t* src = bits + (row * W + 32 * j) * c8 + (c >> 3);
+    const int nw = min(32, W - 32 * j);
+    uint32_t word = 0;
+#pragma unroll 8
+    for (int k = 0; k < nw; ++k) word |= ((uint32_t)(src[(int64_t)k * c8] >> (c & 7)) & 1u) << k;
+    rows[i] = word;
+}
+
 __global__ void scale_shift_act_kernel(const void* __restrict__ x, int in_lp, const float* __restrict__ scale,
                                        const float* __restrict__ shift,
                                        const float* __restrict__ residual, void* __restrict__ out,
@@ -420,7 +462,7 @@ __global__ void __launch_bounds__(TPB) scale_shift_act_v2(
             f8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float t = xv.v[e] * sc.v[e] + sf.v[e];
+                float t = __builtin_fmaf(xv.v[e], sc.v[e], sf.v[e]);
                 if (relu) t = t > 0.f ? t : 0.f;
                 o.v[e] = t;
             }
@@ -528,11 +570,15 @@ __global__ void __launch_bounds__(TPB) norm_stats_partial_v2(const void* __restr
 }
 
 // column reductions, second generation (MODE as in col_reduce_partial below; same partial layout)
-template <int MODE, bool AW, bool XW>
+// RC (MODE 1, fp32): no keep bits were stored (the norm's apply pass ran inside the consuming conv's
+// input transform, wino6.hip): the lane decides again - kept by the dropout bit array `bits` (1 bit per
+// element, NULL = no dropout) and fma(x, scale, shift) > 0, the very expression the forward evaluated
+template <int MODE, bool AW, bool XW, bool RC = false>
 __global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
         const void* __restrict__ a, bool ah16, const uint8_t* __restrict__ bits, const void* __restrict__ x,
         bool xh16, const float* __restrict__ mean, const float* __restrict__ invstd, int64_t rows, int C, int c8,
-        int rpi, int chunks, int64_t rows_per_chunk, int masked, float dsc, float* __restrict__ ws) {
+        int rpi, int chunks, int64_t rows_per_chunk, int masked, float dsc, float* __restrict__ ws,
+        const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr, int relu = 0) {
     constexpr int NOUT = MODE == 0 ? 1 : 2;
     __shared__ float sh[NOUT][TPB * 8];
     const int tid = threadIdx.x;
@@ -544,10 +590,14 @@ __global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    f8 mu, is;
+    f8 mu, is, sc, sf;
     if (MODE == 1) {
         mu = ld8<false>(mean, (int64_t)grp * c8 + q, false);
         is = ld8<false>(invstd, (int64_t)grp * c8 + q, false);
+        if (RC) {
+            sc = ld8<false>(scale, (int64_t)grp * c8 + q, false);
+            sf = ld8<false>(shift, (int64_t)grp * c8 + q, false);
+        }
     }
     for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rpi * UNR) {
         Raw8<AW> gr[UNR];
@@ -561,7 +611,8 @@ __global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
                 ldraw(gr[u], a, i8);
                 if (MODE == 1) {
                     ldraw(xr[u], x, i8);
-                    if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
+                    if (RC) kb[u] = bits ? bits[i8] : 0xffu;
+                    else if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
                 }
             }
         }
@@ -575,7 +626,10 @@ __global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
             for (int e = 0; e < 8; ++e) {
                 float gg = gv.v[e];
                 if (MODE == 1) {
-                    if (masked) gg = (kb[u] >> (e < 4 ? e : e + 4)) & 1u ? gg * dsc : 0.f;
+                    if (RC) {
+                        const bool keep = ((kb[u] >> e) & 1u) && (!relu || __builtin_fmaf(xv.v[e], sc.v[e], sf.v[e]) > 0.f);
+                        gg = keep ? gg * dsc : 0.f;
+                    } else if (masked) gg = (kb[u] >> (e < 4 ? e : e + 4)) & 1u ? gg * dsc : 0.f;
                     s2[e] += gg * ((xv.v[e] - mu.v[e]) * is.v[e]);
                 }
                 s1[e] += gg;
@@ -599,12 +653,13 @@ __global__ void __launch_bounds__(TPB) col_reduce_partial_v2(
     }
 }
 
-template <bool GW, bool XW, bool DW>
+template <bool GW, bool XW, bool DW, bool RC = false>      // RC: as in col_reduce_partial_v2
 __global__ void __launch_bounds__(TPB) norm_bwd_apply_v2(
         const void* __restrict__ g, bool gh16, const uint8_t* __restrict__ bits, const void* __restrict__ x,
         bool xh16, const float* __restrict__ mean, const float* __restrict__ invstd,
         const float* __restrict__ gamma, const float* __restrict__ s1, const float* __restrict__ s2,
-        float inv_count, int64_t rows, RowGeom rg, int masked, float dsc, void* __restrict__ dx, bool dh16) {
+        float inv_count, int64_t rows, RowGeom rg, int masked, float dsc, void* __restrict__ dx, bool dh16,
+        const float* __restrict__ scale = nullptr, const float* __restrict__ shift = nullptr, int relu = 0) {
     const int q = threadIdx.x & (rg.c8 - 1), rsub = threadIdx.x / rg.c8;
     const int grp = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rg.rows_per_chunk;
@@ -612,6 +667,8 @@ __global__ void __launch_bounds__(TPB) norm_bwd_apply_v2(
     const int64_t gi = (int64_t)grp * rg.c8 + q;
     const f8 mu = ld8<false>(mean, gi, false), is = ld8<false>(invstd, gi, false);
     const f8 a1 = ld8<false>(s1, gi, false), a2 = ld8<false>(s2, gi, false);
+    f8 sc, sf;
+    if (RC) { sc = ld8<false>(scale, gi, false); sf = ld8<false>(shift, gi, false); }
     float k0[8], k1[8], k2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -632,7 +689,8 @@ __global__ void __launch_bounds__(TPB) norm_bwd_apply_v2(
                 const int64_t i8 = (gbase + rr) * rg.c8 + q;
                 ldraw(gr[u], g, i8);
                 ldraw(xr[u], x, i8);
-                if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
+                if (RC) kb[u] = bits ? bits[i8] : 0xffu;
+                else if (masked) kb[u] = reinterpret_cast<const uint16_t*>(bits)[i8];
             }
         }
 #pragma unroll
@@ -643,10 +701,14 @@ __global__ void __launch_bounds__(TPB) norm_bwd_apply_v2(
             f8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float gg = gv.v[e];
-                if (masked) gg = (kb[u] >> (e < 4 ? e : e + 4)) & 1u ? gg * dsc : 0.f;
                 // dx = k0*(dz - s1/count) - xhat*k0*s2/count, xhat = (x-mu)*invstd
-                o.v[e] = k0[e] * (gg - k1[e]) - (xv.v[e] - mu.v[e]) * k2[e];
+                if (RC) {
+                    const bool keep = ((kb[u] >> e) & 1u) && (!relu || __builtin_fmaf(xv.v[e], sc.v[e], sf.v[e]) > 0.f);
+                    o.v[e] = mmh::norm_bwd_elem(gv.v[e], keep, dsc, xv.v[e], mu.v[e], k0[e], k1[e], k2[e]);
+                } else {
+                    const bool keep = !masked || ((kb[u] >> (e < 4 ? e : e + 4)) & 1u);
+                    o.v[e] = mmh::norm_bwd_elem(gv.v[e], keep, masked ? dsc : 1.f, xv.v[e], mu.v[e], k0[e], k1[e], k2[e]);
+                }
             }
             st8<DW>(dx, (gbase + rr) * rg.c8 + q, o, dh16);
         }
@@ -1443,6 +1505,66 @@ int mmh_norm_bwd_apply(const void* g, const void* out, const void* x, const void
                        (float)(1.0 / count), n4, rows, C / 4, masked, 1.f / (1.f - drop_p),
                        dx, dx_dtype);
     return mmh::check_launch("norm_bwd_apply");
+}
+
+int mmh_dropout_bits(int64_t n, float drop_p, uint64_t seed, const void* mask, void* bits, mmh_stream_t s) {
+    MMH_REQUIRE(n > 0 && n % 8 == 0 && bits && drop_p > 0.f && drop_p < 1.f, "mmh_dropout_bits: bad arguments");
+    const int64_t n8 = n / 8;
+    hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)mmh::cdiv(n8, TPB)), dim3(TPB), 0, mmh::as_stream(s), n8,
+                       (uint32_t)((double)drop_p * 65536.0), seed, static_cast<const uint8_t*>(mask),
+                       static_cast<uint8_t*>(bits));
+    return mmh::check_launch("dropout_bits");
+}
+
+int mmh_dropout_bits_rows(const void* bits, int64_t image_rows, int W, int C, void* rows, mmh_stream_t s) {
+    MMH_REQUIRE(bits && rows && image_rows > 0 && W > 0 && C > 0 && C % 8 == 0, "mmh_dropout_bits_rows: bad arguments");
+    const int nW32 = (W + 31) / 32;
+    const int64_t n = image_rows * nW32 * C;
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)mmh::cdiv(n, TPB)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const uint8_t*>(bits), image_rows, W, C, nW32, static_cast<uint32_t*>(rows));
+    return mmh::check_launch("dropout_rows");
+}
+
+int mmh_norm_bwd_reduce_rc(const void* g, const void* x, const void* mean, const void* invstd, const void* scale,
+                           const void* shift, const void* dbits, int groups, int64_t rows, int C, int relu,
+                           float drop_p, void* s1, void* s2, void* ws, size_t ws_bytes, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_norm_bwd_reduce_rc", C)) return rc;
+    MMH_REQUIRE(row_geom_ok(C), "mmh_norm_bwd_reduce_rc: C/8 must be a power of two <= 256");
+    MMH_REQUIRE(g && x && mean && invstd && scale && shift && s1 && s2 && ws && groups > 0 && rows > 0 &&
+                    drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (dbits == nullptr),
+                "mmh_norm_bwd_reduce_rc: bad arguments");
+    MMH_REQUIRE(ws_bytes >= mmh_norm_bwd_ws_bytes(groups, rows, C), "mmh_norm_bwd_reduce_rc: workspace too small");
+    ColGeom cg = col_geom(groups, rows, C);
+    hipStream_t st = mmh::as_stream(s);
+    const int c8 = C / 8;
+    hipLaunchKernelGGL((col_reduce_partial_v2<1, false, false, true>), dim3(cg.chunks, groups), dim3(TPB), 0, st, g,
+                       false, static_cast<const uint8_t*>(dbits), x, false, static_cast<const float*>(mean),
+                       static_cast<const float*>(invstd), rows, C, c8, TPB / c8, cg.chunks, cg.rows_per_chunk, 3,
+                       1.f / (1.f - drop_p), static_cast<float*>(ws), static_cast<const float*>(scale),
+                       static_cast<const float*>(shift), relu);
+    hipLaunchKernelGGL(col_reduce_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, st,
+                       static_cast<const float*>(ws), groups, C, cg.chunks, 2,
+                       static_cast<float*>(s1), static_cast<float*>(s2), 0);
+    return mmh::check_launch("norm_bwd_reduce_rc");
+}
+
+int mmh_norm_bwd_apply_rc(const void* g, const void* x, const void* mean, const void* invstd, const void* gamma,
+                          const void* s1, const void* s2, const void* scale, const void* shift, const void* dbits,
+                          double count, int groups, int64_t rows, int C, int relu, float drop_p, void* dx,
+                          mmh_stream_t s) {
+    if (int rc = check_cols("mmh_norm_bwd_apply_rc", C)) return rc;
+    MMH_REQUIRE(row_geom_ok(C), "mmh_norm_bwd_apply_rc: C/8 must be a power of two <= 256");
+    MMH_REQUIRE(g && x && mean && invstd && s1 && s2 && scale && shift && dx && count > 0 && groups > 0 && rows > 0 &&
+                    drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (dbits == nullptr),
+                "mmh_norm_bwd_apply_rc: bad arguments");
+    const RowGeom rg = row_geom(groups, rows, C);
+    hipLaunchKernelGGL((norm_bwd_apply_v2<false, false, false, true>), dim3(rg.chunks, groups), dim3(TPB), 0,
+                       mmh::as_stream(s), g, false, static_cast<const uint8_t*>(dbits), x, false,
+                       static_cast<const float*>(mean), static_cast<const float*>(invstd),
+                       static_cast<const float*>(gamma), static_cast<const float*>(s1), static_cast<const float*>(s2),
+                       (float)(1.0 / count), rows, rg, 3, 1.f / (1.f - drop_p), dx, false,
+                       static_cast<const float*>(scale), static_cast<const float*>(shift), relu);
+    return mmh::check_launch("norm_bwd_apply_rc");
 }
 
 size_t mmh_colsum_ws_bytes(int64_t rows, int C) {

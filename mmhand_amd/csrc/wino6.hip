@@ -190,6 +190,119 @@ __global__ void __launch_bounds__(256) wino6_input_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Norm arithmetic inside the transforms.  The window is taken of relu(x*scale + shift) * keep / (1-p)
+// instead of x - the InstanceNorm / BatchNorm apply, ReLU and dropout that stand between the conv that
+// wrote x and this one (models/Generator.py:66-77) - so that activation is never written to HBM.
+// scale / shift [groups][C] (groups = B or 1).  Dropout decisions come as ROW WORDS (mmh_dropout_bits_rows):
+// drows[((b*H + h)*nW32 + j)*C + c] bit k = element (b, h, 32 j + k, c) is kept, so a thread (one channel,
+// 8 columns of 8 rows) needs two words per row instead of a bit per element.
+// Structure: every load of the window is issued before any arithmetic (two separate loop nests; DROP and
+// relu are not branches) - with the arithmetic in the load loop the 64 loads serialise (2x the time).
+struct NormPro {
+    const float* scale;
+    const float* shift;
+    const uint32_t* drows;
+    int nW32;           // ceil(W / 32)
+    int per_image;      // groups == B
+    float floor_;       // ReLU: 0, none: -inf
+    float dsc;          // 1 / (1 - p)
+};
+
+// row / column geometry of one 8x8 window: source coordinates (reflect- or zero-padded), validity
+struct WinGeom {
+    int hh[8], ww[8];
+    bool okh[8], okw[8];
+};
+__device__ __forceinline__ void win_geom(WinGeom& g, int ty, int tx, int org, int H, int W, int reflect) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int hh = 6 * ty - org + r, ww = 6 * tx - org + r;
+        bool okh, okw;
+        if (reflect == 1) {
+            okh = hh <= H; okw = ww <= W;
+            hh = hh < 0 ? -hh : hh; ww = ww < 0 ? -ww : ww;
+            hh = hh >= H ? 2 * (H - 1) - hh : hh; ww = ww >= W ? 2 * (W - 1) - ww : ww;
+            okh = okh && hh >= 0; okw = okw && ww >= 0;
+        } else {
+            okh = hh >= 0 && hh < H; okw = ww >= 0 && ww < W;
+        }
+        g.hh[r] = okh ? hh : 0; g.ww[r] = okw ? ww : 0;
+        g.okh[r] = okh; g.okw[r] = okw;
+    }
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(256) wino6_input_normact_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                  int B, int H, int W, int C, int reflect,
+                                                                  int xcd_remap, const NormPro np) {
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const long long i = (long long)blk * blockDim.x + threadIdx.x;
+    if (i >= tiles * C) return;
+    const int c = (int)(i % C);
+    const long long tile = i / C;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    WinGeom wg;
+    win_geom(wg, ty, tx, 1, H, W, reflect);
+    float d[8][8], colv[8], o8[8];
+    uint32_t lo[DROP ? 8 : 1], hi[DROP ? 8 : 1];
+    const int gi = (np.per_image ? b : 0) * C + c;
+    const float sc = np.scale[gi], sf = np.shift[gi];
+    int wq0 = 6 * tx - 1;
+    wq0 = (wq0 < 0 ? 0 : wq0) >> 5;
+    const int wq1 = wq0 + 1 < np.nW32 ? wq0 + 1 : wq0;
+    // ---- loads
+    // 32-bit element offsets (host: numel < 2^31): one address register per load instead of a pair
+    unsigned co[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) co[q] = (unsigned)wg.ww[q] * (unsigned)C + (unsigned)c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const unsigned row = (unsigned)(b * H + wg.hh[r]);
+        const unsigned ro = row * (unsigned)W * (unsigned)C;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[r][q] = x[ro + co[q]];     // clamped coordinates: always in range
+        if (DROP) {
+            lo[r] = np.drows[(row * (unsigned)np.nW32 + (unsigned)wq0) * (unsigned)C + (unsigned)c];
+            hi[r] = np.drows[(row * (unsigned)np.nW32 + (unsigned)wq1) * (unsigned)C + (unsigned)c];
+        }
+    }
+    // ---- arithmetic
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float t = __builtin_fmaf(d[r][q], sc, sf);
+            t = fmaxf(t, np.floor_);
+            bool keep = wg.okh[r] && wg.okw[q];         // padding and ragged-tile positions stay zero
+            if (DROP) {
+                const uint32_t wsel = (wg.ww[q] >> 5) == wq0 ? lo[r] : hi[r];
+                keep = keep && ((wsel >> (wg.ww[q] & 31)) & 1u);
+                t *= np.dsc;
+            }
+            d[r][q] = keep ? t : 0.f;
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = d[r][q];
+        w6_bt(colv, o8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
+    }
+    const long long plane = tiles * C;
+    float* out = V + tile * C + c;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        w6_bt(d[r], o8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+    }
+}
+
 __device__ __forceinline__ void stat_add(float v, float& n, float& s) { n += 1.f; s += v; }
 __device__ __forceinline__ void stat_add(F2, float&, float&) {}
 
@@ -327,6 +440,46 @@ __global__ void __launch_bounds__(256) wino6_dy_kernel(const float* __restrict__
     }
 }
 
+// Both backward transforms of a loaded window d: Yh = A d' A^T of the inner 6x6 tile, V = B^T d B
+template <typename T>
+__device__ __forceinline__ void dy_transforms(T (&d)[8][8], float* __restrict__ V, float* __restrict__ Yh,
+                                              long long plane, long long at, int fold) {
+    T colv[8], o8[8];
+    {   // Yh from the inner 6x6 tile (rows / columns org..org+5 of the window)
+        T t[8][6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) colv[r] = fold ? d[r + 2][q + 2] : d[r + 1][q + 1];
+            w6_a(colv, o8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
+        }
+        T* out = reinterpret_cast<T*>(Yh) + at;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            w6_a(t[r], o8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) colv[r] = d[r][q];
+        w6_bt(colv, o8);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
+    }
+    T* out = reinterpret_cast<T*>(V) + at;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        w6_bt(d[r], o8);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+    }
+}
+
 // Backward of one conv needs BOTH transforms of dy: V' = B^T d B of the zero-padded 8x8 window (the
 // dgrad GEMM operand) and Yh = A dY A^T of the 6x6 tile inside it (the wgrad GEMM operand).  One
 // kernel loads the window once (one read of dy instead of two).
@@ -359,40 +512,95 @@ __global__ void __launch_bounds__(256) wino6_input_dy_kernel(const float* __rest
             d[r][q] = (okh && ww >= 0 && ww < W) ? in[(((long long)b * H + hh) * W + ww) * C2 + c] : zero_of(T{});
         }
     }
-    const long long plane = tiles * C2;
-    {   // Yh from the inner 6x6 tile (rows / columns org..org+5 of the window)
-        T t[8][6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) colv[r] = fold ? d[r + 2][q + 2] : d[r + 1][q + 1];
-            w6_a(colv, o8);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) t[r][q] = o8[r];
-        }
-        T* out = reinterpret_cast<T*>(Yh) + tile * C2 + c;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            w6_a(t[r], o8);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
-        }
-    }
+    dy_transforms(d, V, Yh, tiles * C2, tile * C2 + c, fold);
+}
+
+// Norm backward inside the transform: dy is not read but computed per element from the gradient g of the
+// norm's OUTPUT, the norm's input x and the per-(group, channel) sums of mmh_norm_bwd_reduce_rc - the
+// arithmetic of norm_bwd_apply_v2<.., RC> (pointwise.hip; mmh::norm_bwd_elem) - so the gradient of the conv
+// output between that conv and its norm is never written to HBM.  Loads first, arithmetic after, as in
+// wino6_input_normact_kernel; x is staged four rows at a time (96 instead of 128 live window registers).
+struct NormBwdPro {
+    const float* x;         // the norm's input = this conv's forward output
+    const float* mean;
+    const float* invstd;
+    const float* gamma;     // NULL: 1
+    const float* s1;
+    const float* s2;
+    float inv_count;
+    int relu;
+    NormPro np;             // scale / shift / dropout row words of the forward apply (the keep decision)
+};
+
+template <bool DROP>
+__global__ void __launch_bounds__(256, 4) wino6_input_dy_normbwd_kernel(const float* __restrict__ g, float* __restrict__ V,
+                                                                     float* __restrict__ Yh, int B, int H, int W,
+                                                                     int C, int xcd_remap, int fold,
+                                                                     const NormBwdPro nb) {
+    const int org = fold ? 2 : 1;
+    const int TH = (H + 5) / 6, TW = (W + 5) / 6;
+    const long long tiles = (long long)B * TH * TW;
+    unsigned blk = blockIdx.x;
+    if (xcd_remap) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    const long long i = (long long)blk * blockDim.x + threadIdx.x;
+    if (i >= tiles * C) return;
+    const int c = (int)(i % C);
+    const long long tile = i / C;
+    const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
+    WinGeom wg;
+    win_geom(wg, ty, tx, org, H, W, 0);
+    const int gi = (nb.np.per_image ? b : 0) * C + c;
+    const float sc = nb.np.scale[gi], sf = nb.np.shift[gi], mu = nb.mean[gi], is = nb.invstd[gi];
+    const float k0 = (nb.gamma ? nb.gamma[c] : 1.f) * is;
+    const float k1 = nb.s1[gi] * nb.inv_count;
+    const float k2 = k0 * is * (nb.s2[gi] * nb.inv_count);
+    int wq0 = 6 * tx - org;
+    wq0 = (wq0 < 0 ? 0 : wq0) >> 5;
+    const int wq1 = wq0 + 1 < nb.np.nW32 ? wq0 + 1 : wq0;
+    float d[8][8];
+    uint32_t lo[2], hi[2];
+    unsigned co[8], ro[8];     // 32-bit element offsets (host: numel < 2^31)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) colv[r] = d[r][q];
-        w6_bt(colv, o8);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) d[r][q] = o8[r];
+        co[q] = (unsigned)wg.ww[q] * (unsigned)C + (unsigned)c;
+        ro[q] = (unsigned)(b * H + wg.hh[q]) * (unsigned)W * (unsigned)C;
     }
-    T* out = reinterpret_cast<T*>(V) + tile * C2 + c;
+    // two window rows per stage: their g, x and dropout words are loaded together, then turned into dy; the
+    // scheduling barrier keeps the next stage's loads behind this stage's arithmetic (all 128 window loads
+    // in flight at once need > 168 registers and spill)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        w6_bt(d[r], o8);
+    for (int stage = 0; stage < 4; ++stage) {
+        float xw[2][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) out[(long long)(r * 8 + q) * plane] = o8[q];
+        for (int r = 0; r < 2; ++r) {
+            const int rr = 2 * stage + r;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                d[rr][q] = g[ro[rr] + co[q]];
+                xw[r][q] = nb.x[ro[rr] + co[q]];
+            }
+            if (DROP) {
+                const unsigned row = (unsigned)(b * H + wg.hh[rr]);
+                lo[r] = nb.np.drows[(row * (unsigned)nb.np.nW32 + (unsigned)wq0) * (unsigned)C + (unsigned)c];
+                hi[r] = nb.np.drows[(row * (unsigned)nb.np.nW32 + (unsigned)wq1) * (unsigned)C + (unsigned)c];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rr = 2 * stage + r;
+                bool keep = !nb.relu || __builtin_fmaf(xw[r][q], sc, sf) > 0.f;
+                if (DROP) {
+                    const uint32_t wsel = (wg.ww[q] >> 5) == wq0 ? lo[r] : hi[r];
+                    keep = keep && ((wsel >> (wg.ww[q] & 31)) & 1u);
+                }
+                const float o = mmh::norm_bwd_elem(d[rr][q], keep, nb.np.dsc, xw[r][q], mu, k0, k1, k2);
+                d[rr][q] = (wg.okh[rr] && wg.okw[q]) ? o : 0.f;
+            }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    dy_transforms(d, V, Yh, tiles * C, tile * C + c, fold);
 }
 
 // dw[3][3][Cin][Cout] (+)= G^T dU G, dU: [64][Cin][Cout]
@@ -469,6 +677,40 @@ int wino6_dy(const float* dy, float* Yh, int B, int H, int W, int C, hipStream_t
         hipLaunchKernelGGL(wino6_dy_kernel<float>, dim3((unsigned)((tiles * C + 255) / 256)), dim3(256), 0, st, dy, Yh, B,
                            H, W, C);
     return check_launch("wino6_dy_kernel");
+}
+
+int wino6_input_normact(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd,
+                        const float* scale, const float* shift, int groups, int relu, float drop_p,
+                        const uint32_t* drows, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    const unsigned nblk = (unsigned)((tiles * C + 255) / 256);
+    const int remap = (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0;
+    NormPro np{scale, shift, drows, (W + 31) / 32, groups == 1 ? 0 : 1, relu ? 0.f : -INFINITY, 1.f / (1.f - drop_p)};
+    if (drows)
+        hipLaunchKernelGGL(wino6_input_normact_kernel<true>, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C, reflect,
+                           remap, np);
+    else
+        hipLaunchKernelGGL(wino6_input_normact_kernel<false>, dim3(nblk), dim3(256), 0, st, x, V, B, H, W, C, reflect,
+                           remap, np);
+    return check_launch("wino6_input_normact_kernel");
+}
+
+int wino6_input_dy_normbwd(const float* g, const float* x, float* V, float* Yh, int B, int H, int W, int C, int xcd,
+                           int fold, const float* mean, const float* invstd, const float* gamma, const float* s1,
+                           const float* s2, double count, const float* scale, const float* shift,
+                           const uint32_t* drows, int groups, int relu, float drop_p, hipStream_t st) {
+    const long long tiles = (long long)B * ((H + 5) / 6) * ((W + 5) / 6);
+    const unsigned nblk = (unsigned)((tiles * C + 255) / 256);
+    const int remap = (xcd && nblk % 8 == 0 && nblk >= 64) ? 1 : 0;
+    NormBwdPro nb{x, mean, invstd, gamma, s1, s2, (float)(1.0 / count), relu,
+                  NormPro{scale, shift, drows, (W + 31) / 32, groups == 1 ? 0 : 1, 0.f, 1.f / (1.f - drop_p)}};
+    if (drows)
+        hipLaunchKernelGGL(wino6_input_dy_normbwd_kernel<true>, dim3(nblk), dim3(256), 0, st, g, V, Yh, B, H, W, C, remap,
+                           fold, nb);
+    else
+        hipLaunchKernelGGL(wino6_input_dy_normbwd_kernel<false>, dim3(nblk), dim3(256), 0, st, g, V, Yh, B, H, W, C, remap,
+                           fold, nb);
+    return check_launch("wino6_input_dy_normbwd_kernel");
 }
 
 int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, int fold,

@@ -91,6 +91,13 @@ SIGNATURES = {
     "mmh_norm_bwd_ws_bytes": (_sz, [_i, _i64, _i]),
     "mmh_norm_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp]),
+    "mmh_dropout_bits": (_i, [_i64, _f, _u64, _vp, _vp, _vp]),
+    "mmh_dropout_bits_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "mmh_norm_bwd_reduce_rc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "mmh_norm_bwd_apply_rc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _vp]),
+    "mmh_wino_input_normact": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "mmh_wino_input_dy_normbwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp,
+                                       _vp, _i, _i, _f, _vp]),
     "mmh_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),

@@ -200,20 +200,27 @@ class _Net(nn.Module):
         return self
 
     # -- functional layers
-    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False, to_norm=False):
-        """x: an fp32 NHWC tensor, or a (proxy, x16) pair from a producer that wrote it in 16 bits.
+    def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False, to_norm=False,
+             g_defer=False):
+        """x: an fp32 NHWC tensor, a (proxy, x16) pair from a producer that wrote it in 16 bits, or a
+        (proxy, NormDefer) pair from a norm whose apply pass runs inside this conv (normact(defer)).
         y_lp (see _lp_edge): the consumer (normact / the PATBlock gate) takes the output in 16 bits ->
-        returns a (proxy, y16) pair."""
+        returns a (proxy, y16) pair.  g_defer: the norm behind this conv defers its backward apply
+        pass to this conv's backward (ops.USE_NORM_FUSION)."""
         x16 = None
         if isinstance(x, tuple):
             x, x16 = x
+        if isinstance(x16, ops.NormDefer):
+            return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, None,
+                                      False, bool(to_norm and self.norm == "instance" and self.training), x16, g_defer)
         # to_norm: the output goes straight into this net's norm layer; under InstanceNorm the conv bias then
         # has an identically zero gradient (ops.EXACT_NULL_BIAS_GRAD)
         nb = bool(to_norm and self.norm == "instance" and self.training)
         if y_lp:
             p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True, nb)
             return p, y16
-        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, False, nb)
+        return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, False, nb,
+                                  None, g_defer)
 
     def _lp_edge(self, cp, stride=1, reflect=True):
         """16-bit hand-over to the 3x3 / pad 1 conv (or ConvTranspose2d) `cp` (training, 16-bit mode, all
@@ -250,9 +257,11 @@ class _Net(nn.Module):
             return p, y16
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, False, nb)
 
-    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0):
+    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0, defer=0):
         """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
-        x may itself be a (proxy, x16) pair from a 16-bit convolution (conv(y_lp=True))."""
+        x may itself be a (proxy, x16) pair from a 16-bit convolution (conv(y_lp=True)).
+        defer (1 | 2, training fp32): only the statistics are finalised here; returns a (proxy, NormDefer)
+        pair for the conv that consumes it (2: the backward apply pass goes to the producing conv)."""
         x16 = None
         if isinstance(x, tuple):
             x, x16 = x
@@ -264,6 +273,18 @@ class _Net(nn.Module):
                 mask = self._mask_src[site]
             else:
                 seed = ops.next_dropout_seed()
+        if defer:
+            assert self.training and x16 is None and residual is None and not out_lp
+            if self.norm == "instance":
+                args, groups = (None, None, None, None, None, "instance"), x.shape[0]
+                sync = None
+            else:
+                np_ = bag[idx]
+                np_.num_batches_tracked += 1
+                args, groups = (np_.weight, np_.bias, None, np_.running_mean, np_.running_var, "batch"), 1
+                sync = self.sync_group
+            p, scale, shift, drows = ops.NormActFn.apply(x, *args, relu, drop_p, seed, mask, sync, 0, None, defer)
+            return p, ops.NormDefer(x.detach(), scale, shift, groups, relu, drop_p, drows)
         if self.norm == "instance":
             return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", relu,
                                        drop_p, seed, mask, None, out_lp, x16)
@@ -278,14 +299,32 @@ class _Net(nn.Module):
         y = ops.AffineActFn.apply(x, scale, shift, relu)
         return y if residual is None else y + residual
 
+    def _norm_fusion(self, c1, c2, x):
+        """fp32 training, both convs of a two-conv block on Winograd F(6x6,3x3): 1 = the apply pass of the norm
+        between them runs inside c2's input transform; 2 = its backward apply pass inside c1's backward
+        transform too (needs c1's bias gradient to be null or absent: the fused transform leaves no dy to sum)."""
+        if not (ops.USE_NORM_FUSION and self.training and not self.bf16 and torch.is_tensor(x)
+                and ops.KEEP_WINOGRAD_INPUT):
+            return 0
+        B, H, W, Cin = x.shape
+        C1, C2 = c1.weight.shape[3], c2.weight.shape[3]
+        if not (ops.norm_fusion_ok(C1) and ops._wino_tile(B, H, W, C1, C2, 3, 1, 1, False) == 6):
+            return 0
+        null_db = c1.bias is None or (self.norm == "instance" and ops.EXACT_NULL_BIAS_GRAD)
+        if (null_db and ops.FUSE_WINO6_BWD and ops._wino_tile(B, H, W, Cin, C1, 3, 1, 1, False) == 6
+                and ops._wino_tile(B, H, W, Cin, C1, 3, 1, 1, False, "dgrad") == 6):
+            return 2
+        return 1
+
     def two_conv_block(self, blk, x, site, last_norm, residual=None):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets)."""
         i2 = 6 if self.use_dropout else 5
         # 16-bit mode: every tensor that faces one of these convolutions (input, output, both gradients)
         # lives in HBM in 16 bits only, as under apex O1; without a last norm the caller (the PATBlock
         # gate) receives the (proxy, y16) pair
-        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True)
-        y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]))
+        fuse = self._norm_fusion(blk[1], blk[i2], x)
+        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2)
+        y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
         y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm)
         if last_norm:
             y = self.normact(blk, i2 + 1, y, False, residual=residual)

@@ -244,7 +244,7 @@ _pending_stats = {}
 
 
 def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False,
-               fold=False):
+               fold=False, pro=None):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
     keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor).
     bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32.
@@ -265,7 +265,12 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     if timed:       # HIP events on the launch stream (bench.py roofline): the GEMM launch alone, and
         e0, e1, o0, o1 = fprop_timer.bracket_op()       # the whole op (both transforms + GEMM)
         o0.record()
-    L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, 2 if fold else int(bool(reflect)), tile, dt, _ptr(V), _stream())
+    if pro is not None:     # the norm-apply / ReLU / dropout in front of this conv, inside the transform (NormDefer)
+        assert tile == 6 and not bf16 and not fold and tuple(pro.x.shape) == tuple(x.shape)
+        L.call("mmh_wino_input_normact", _ptr(pro.x), B, H, W_, Cin, int(bool(reflect)), _ptr(V), _ptr(pro.scale),
+               _ptr(pro.shift), pro.groups, int(pro.relu), float(pro.drop_p), _ptr(pro.drows), _stream())
+    else:
+        L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, 2 if fold else int(bool(reflect)), tile, dt, _ptr(V), _stream())
     if timed:
         e0.record()
     L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
@@ -285,11 +290,14 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     return (y, V) if keep_V else y
 
 
-def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=False, bf16=False):
-    """3x3 / stride 1 / pad 1 conv by Winograd (fp32, or bf16 Winograd-domain tensors with tile 2)."""
-    _chk(x, "x"); _chk(w, "w")
+def raw_conv_fprop_wino(x, w, bias, reflect, act=L.ACT_NONE, tile=4, keep_V=False, bf16=False, pro=None):
+    """3x3 / stride 1 / pad 1 conv by Winograd (fp32, or bf16 Winograd-domain tensors with tile 2).
+    pro (NormDefer): x is only a shape carrier; the conv runs on dropout(relu(pro.x * scale + shift))."""
+    if pro is None:
+        _chk(x, "x")
+    _chk(w, "w")
     return _wino_conv(x, wino_weights(w, tile, False, bf16), bias, w.shape[3], reflect, act, tile, time_it=True,
-                      keep_V=keep_V, bf16=bf16, want_stats=True)
+                      keep_V=keep_V, bf16=bf16, want_stats=True, pro=pro)
 
 
 def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
@@ -345,20 +353,32 @@ def raw_conv_wgrad_wino(x, dy, reflect, tile=4, V=None, bf16=False, out=None):
     return dw
 
 
-def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None):
+def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None, nbd=None):
     """dgrad and wgrad of a 3x3 / stride 1 / pad 1 conv by Winograd F(6x6,3x3) with ONE pass over
     dy for both of its transforms (mmh_wino_input_dy).  V = the forward pass's transformed input.
-    Returns (dx, dw)."""
-    _chk(dy, "dy"); _chk(w, "w")
+    nbd (NormBwdDefer): dy does not exist - the transform computes it per element from the gradient
+    of the norm that follows this conv (mmh_wino_input_dy_normbwd).  Returns (dx, dw)."""
+    _chk(w, "w")
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
     P, tile = 64, 6
     tiles = B * (-(-H // tile)) * (-(-W_ // tile))
     assert tuple(V.shape) == (P, tiles, Cin) and V.is_contiguous() and V.dtype == torch.float32
-    Vd = _empty((P, tiles, Cout), dy)
-    Yh = _empty((P, tiles, Cout), dy)
     fold = bool(reflect) and _fold_same_grid(H, W_)
-    L.call("mmh_wino_input_dy", _ptr(dy), B, H, W_, Cout, tile, L.F32, _ptr(Vd), _ptr(Yh), int(fold), _stream())
+    if nbd is not None:
+        dy = nbd.g
+        assert tuple(dy.shape) == (B, H, W_, Cout) and tuple(nbd.x.shape) == tuple(dy.shape)
+        Vd = _empty((P, tiles, Cout), dy)
+        Yh = _empty((P, tiles, Cout), dy)
+        L.call("mmh_wino_input_dy_normbwd", _ptr(nbd.g), _ptr(nbd.x), B, H, W_, Cout, _ptr(Vd), _ptr(Yh), int(fold),
+               _ptr(nbd.mean), _ptr(nbd.invstd), _ptr(nbd.gamma), _ptr(nbd.s1), _ptr(nbd.s2), float(nbd.count),
+               _ptr(nbd.scale), _ptr(nbd.shift), _ptr(nbd.drows), nbd.groups, int(nbd.relu), float(nbd.drop_p),
+               _stream())
+    else:
+        _chk(dy, "dy")
+        Vd = _empty((P, tiles, Cout), dy)
+        Yh = _empty((P, tiles, Cout), dy)
+        L.call("mmh_wino_input_dy", _ptr(dy), B, H, W_, Cout, tile, L.F32, _ptr(Vd), _ptr(Yh), int(fold), _stream())
     # dgrad: correlation with the flipped filter; reflect padding: folded in the output transform
     # (padded-domain tiles) or, where the size does not allow it, the eight border GEMMs
     M = _empty((P, tiles, Cin), dy)
@@ -368,6 +388,7 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None):
     L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, int(fold),
            _stream())
     if reflect and not fold:
+        assert nbd is None, "the border GEMMs read dy: the caller materialises it (Conv2dFn.backward)"
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         ws = _ws(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)), dy)
         L.call("mmh_conv2d_dgrad_border", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, 3,
@@ -784,6 +805,78 @@ def lp_grad_in(g, what):
 def lp_grads_reset():
     """drop gradients parked by a backward pass that did not finish"""
     _lp_grads.clear()
+    _nb_defer.clear()
+
+
+# Norm-apply fused into the neighbouring convolutions (fp32, Winograd F(6x6,3x3) stack; models/Generator.py:66-77
+# conv -> norm -> ReLU -> Dropout -> pad -> conv).  Forward: NormActFn(defer) only finalises the statistics
+# and returns a NormDefer; the consuming Conv2dFn applies scale / shift / ReLU / dropout inside its input
+# transform.  Backward: NormActFn runs the reduction pass and (defer == 2) parks a NormBwdDefer under the
+# proxy gradient it returns; the producing Conv2dFn applies it inside its backward transform - or
+# materialises it with mmh_norm_bwd_apply_rc where that path does not apply.  MMH_FUSE_NORMACT=0: off.
+USE_NORM_FUSION = os.environ.get("MMH_FUSE_NORMACT", "1") != "0"
+
+
+class NormDefer:
+    """a normalised activation that exists only as (conv output x, scale, shift, dropout bits)"""
+    __slots__ = ("x", "scale", "shift", "groups", "relu", "drop_p", "drows")
+
+    def __init__(self, x, scale, shift, groups, relu, drop_p, drows):
+        self.x, self.scale, self.shift, self.groups = x, scale, shift, groups
+        self.relu, self.drop_p, self.drows = relu, drop_p, drows
+
+
+class NormBwdDefer:
+    """the gradient of a norm's input as (gradient g of its output, its input x, sums s1 / s2, ...)"""
+    __slots__ = ("g", "x", "mean", "invstd", "gamma", "s1", "s2", "count", "scale", "shift", "dbits", "drows", "groups",
+                 "rows", "relu", "drop_p")
+
+
+_nb_defer = {}
+
+
+def norm_bwd_defer_out(ent):
+    p = lp_proxy(ent.x.shape, ent.x.device)
+    _nb_defer[p.data_ptr()] = (p, ent)
+    return p
+
+
+def norm_bwd_defer_in(g, what):
+    ent = _nb_defer.pop(g.data_ptr(), None) if g is not None else None
+    if ent is None or tuple(ent[1].x.shape) != tuple(g.shape):
+        raise RuntimeError(f"{what}: expected the deferred gradient of a fused norm (NormBwdDefer) on this edge")
+    return ent[1]
+
+
+def raw_norm_bwd_apply_rc(e):
+    """materialise a NormBwdDefer: dx of the norm's input (fp32)"""
+    dx = torch.empty_like(e.x)
+    L.call("mmh_norm_bwd_apply_rc", _ptr(e.g), _ptr(e.x), _ptr(e.mean), _ptr(e.invstd), _ptr(e.gamma), _ptr(e.s1),
+           _ptr(e.s2), _ptr(e.scale), _ptr(e.shift), _ptr(e.dbits), float(e.count), e.groups, e.rows, e.x.shape[3],
+           int(e.relu), float(e.drop_p), _ptr(dx), _stream())
+    return dx
+
+
+def raw_dropout_bits(shape, drop_p, seed, mask, device, rows=False):
+    """uint8 [numel/8]: bit e of byte i = element 8 i + e is kept (mmh_dropout_bits).  rows: also the same
+    decisions as int32 row words [B*H, ceil(W/32), C] (mmh_dropout_bits_rows) -> (bits, rows)"""
+    n = 1
+    for d in shape:
+        n *= d
+    bits = torch.empty((n // 8,), dtype=torch.uint8, device=device)
+    L.call("mmh_dropout_bits", n, float(drop_p), seed, _ptr(mask), _ptr(bits), _stream())
+    if not rows:
+        return bits
+    B, H, W_, Cc = shape
+    drows = torch.empty((B * H, (W_ + 31) // 32, Cc), dtype=torch.int32, device=device)
+    L.call("mmh_dropout_bits_rows", _ptr(bits), B * H, W_, Cc, _ptr(drows), _stream())
+    return bits, drows
+
+
+def norm_fusion_ok(C):
+    """channel counts the fused / decide-again norm kernels take (C/8 a power of two <= 256)"""
+    c8 = C // 8
+    return USE_NORM_FUSION and C % 8 == 0 and 1 <= c8 <= 256 and (c8 & (c8 - 1)) == 0
 
 
 # Weight / bias gradients written straight into the parameter's .grad view of the flat gradient buffer
@@ -934,12 +1027,16 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False,
-                null_bias_grad=False):
+                null_bias_grad=False, pro=None, g_defer=False):
         """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
         the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
         GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
         ctx.set_materialize_grads(False)    # no full-size zero "gradient" for the non-differentiable 16-bit output
+        # pro (NormDefer): x is the proxy of a normalised activation that was never written; the norm-apply runs
+        # inside this conv's input transform.  g_defer: the norm behind this conv sends its input gradient
+        # as a NormBwdDefer (see USE_NORM_FUSION)
+        ctx.g_defer = bool(g_defer)
         # null_bias_grad: the output feeds an InstanceNorm directly - the bias gradient is identically zero
         ctx.skip_db = bool(null_bias_grad and EXACT_NULL_BIAS_GRAD)
         ctx.bias_p = bias
@@ -953,6 +1050,18 @@ class Conv2dFn(torch.autograd.Function):
         ctx.x_lp = x16 is not None
         ctx.y_lp = bool(y_lp)
         k = w.shape[0]
+        ctx.stem16 = False
+        if pro is not None:
+            assert wt == 6 and not bf16 and x16 is None and not y_lp, "a deferred norm needs the fp32 F(6x6,3x3) path"
+            if KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
+                y, V = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, keep_V=True, pro=pro)
+                ctx.wino_V = wt
+                ctx.save_for_backward(V, w, y if act != L.ACT_NONE else None)
+                return y
+            assert not ctx.needs_input_grad[1], "a deferred norm in front of a trainable conv needs MMH_WINOGRAD_KEEP_INPUT=1"
+            y = raw_conv_fprop_wino(x, w, bias, reflect, act, wt, pro=pro)
+            ctx.save_for_backward(None, w, y if act != L.ACT_NONE else None)
+            return y
         chain = bool(bf16) and lp16_chain_ok(Cin, w.shape[3], k, stride, pad, reflect, bf16)
         if x16 is not None:
             assert chain and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape), \
@@ -1012,7 +1121,7 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
         if g is None:
-            return (None,) * 12
+            return (None,) * 14
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
         bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
         want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
@@ -1034,7 +1143,7 @@ class Conv2dFn(torch.autograd.Function):
                                                                      out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:
@@ -1046,17 +1155,27 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
-        g = g.contiguous()
-        if act != L.ACT_NONE:
-            g = raw_act_bwd(g, y, act)
-        if (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-                and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6):
-            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x, dw_out=wt_)      # x is the saved V here
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        fused_bwd = (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0]
+                     and ctx.needs_input_grad[1]
+                     and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6)
+        nbd = None
+        if ctx.g_defer:     # the norm behind this conv parked its input gradient as a NormBwdDefer
+            nbd = norm_bwd_defer_in(g, "Conv2dFn")
+            Hx, Wx = ctx.x_shape[1], ctx.x_shape[2]
+            if not (fused_bwd and act == L.ACT_NONE and not want_db and (not reflect or _fold_same_grid(Hx, Wx))):
+                g = raw_norm_bwd_apply_rc(nbd)      # no fused transform on this path: materialise it
+                nbd = None
+        if nbd is None:
+            g = g.contiguous()
+            if act != L.ACT_NONE:
+                g = raw_act_bwd(g, y, act)
+        if fused_bwd:
+            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, x, dw_out=wt_, nbd=nbd)    # x is the saved V here
             dw = _finish_param_grad(dw, wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
@@ -1068,7 +1187,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -1078,7 +1197,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
         if want_db:
             db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
@@ -1238,7 +1357,7 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
-                seed, mask, sync_group, out_lp=0, x16=None):
+                seed, mask, sync_group, out_lp=0, x16=None, defer=0):
         """out_lp (True bf16 | 2 fp16): the output is written in that 16-bit type only - it feeds a
         16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass.
         x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
@@ -1263,6 +1382,19 @@ class NormActFn(torch.autograd.Function):
             mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
         scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
                                                  running_var)
+        ctx.defer = int(defer)
+        if defer:
+            # defer 1: the apply pass runs inside the consuming conv's input transform (the caller builds the
+            # NormDefer from the returned scale / shift / dropout bits); no output, no keep bits: the backward
+            # decides again.  defer 2: the backward's apply pass goes to the producing conv too.
+            assert x16 is None and not out_lp and residual is None and x.dtype == torch.float32 and norm_fusion_ok(x.shape[3])
+            dbits, drows = raw_dropout_bits(x.shape, drop_p, seed, mask, x.device, rows=True) if drop_p > 0 else (None, None)
+            ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group, False)
+            ctx.save_for_backward(x, dbits, mean, invstd, gamma, scale, shift, drows)
+            ctx.mark_non_differentiable(scale, shift)
+            if drows is not None:
+                ctx.mark_non_differentiable(drows)
+            return lp_proxy(x.shape, x.device), scale, shift, drows
         masked = bool(relu or drop_p > 0)
         if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
             out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True,
@@ -1280,9 +1412,11 @@ class NormActFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g, _g16=None):
+    def backward(ctx, g, _g16=None, _a=None, _b=None):
         if g is None:
-            return (None,) * 14
+            return (None,) * 15
+        if ctx.defer:
+            return NormActFn._backward_deferred(ctx, g)
         x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
         groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         if has_res and relu:
@@ -1312,7 +1446,34 @@ class NormActFn(torch.autograd.Function):
         dres = g if has_res else None
         if ctx.in_lp:
             dx = lp_grad_out(dx)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_deferred(ctx, g):
+        x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
+        groups, rows, count, relu, drop_p, sync_group, _ = ctx.cfg
+        g = g.contiguous()
+        Cc = x.shape[3]
+        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
+        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+        L.call("mmh_norm_bwd_reduce_rc", _ptr(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
+               _ptr(dbits), groups, rows, Cc, int(relu), drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
+        dgamma = dbeta = None
+        if gamma is not None:
+            dgamma = s2.sum(0) if groups > 1 else s2.reshape(-1).clone()
+            dbeta = s1.sum(0) if groups > 1 else s1.reshape(-1).clone()
+        if sync_group is not None:
+            import torch.distributed as dist
+            packed = torch.cat([s1, s2], 0)
+            collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
+            dist.all_reduce(packed, group=sync_group)
+            s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
+        e = NormBwdDefer()
+        e.g, e.x, e.mean, e.invstd, e.gamma, e.s1, e.s2, e.count = g, x, mean, invstd, gamma, s1, s2, count
+        e.scale, e.shift, e.dbits, e.drows = scale, shift, dbits, drows
+        e.groups, e.rows, e.relu, e.drop_p = groups, rows, relu, drop_p
+        dx = norm_bwd_defer_out(e) if ctx.defer == 2 else raw_norm_bwd_apply_rc(e)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class AffineActFn(torch.autograd.Function):

@@ -1,0 +1,196 @@
+"""Norm-apply fused into the neighbouring convolutions (fp32 Winograd F(6x6,3x3) stack;
+models/Generator.py:66-77, models/Discriminator.py:29-34: conv -> norm -> ReLU -> Dropout -> pad -> conv).
+
+The fused transforms evaluate the same expressions as the stand-alone kernels, so with the same dropout
+decisions (an injected mask) the forward is compared bit for bit: the input transform with the norm-apply
+inside against transform(apply(x)), the decide-again backward kernels against the keep-bit kernels.  The
+backward transform with the norm backward inside is a different instantiation of the same arithmetic than
+transform(apply_rc(...)): the compiler rounds a few of its intermediate products differently, the results
+agree to a few ulps of the largest element (checked at 2e-6 of it); whole two-conv blocks with the fusion
+on are compared with the fusion off: forward bit for bit, gradients at 1e-6 relative L1."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_but_for_ulps(a, b):
+    return float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def _mk(shape, seed, dev, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale + shift).to(dev)
+
+
+def _mask(shape, seed, dev):
+    return (torch.rand(shape, generator=torch.Generator().manual_seed(seed)) >= 0.5).to(torch.uint8).to(dev)
+
+
+def test_dropout_bits_pack_mask_and_rate(dev):
+    from mmhand_amd import ops
+    shape = (2, 5, 7, 64)
+    m = _mask(shape, 1, dev)
+    bits = ops.raw_dropout_bits(shape, 0.5, 0, m, dev)
+    ref = (m.reshape(-1, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, ref)
+    big = (8, 64, 64, 256)
+    for p in (0.5, 0.25):
+        b = ops.raw_dropout_bits(big, p, 12345, None, dev)
+        kept = sum(int(((b >> e) & 1).sum()) for e in range(8)) / (b.numel() * 8)
+        assert abs(kept - (1 - p)) < 2e-3, kept
+    assert not torch.equal(ops.raw_dropout_bits(big, 0.5, 1, None, dev), ops.raw_dropout_bits(big, 0.5, 2, None, dev))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 64), (1, 3, 70, 16), (2, 2, 33, 8)])
+def test_dropout_row_words_hold_the_same_decisions(shape, dev):
+    """mmh_dropout_bits_rows: [B*H][ceil(W/32)][C] words, bit k of word j = element (row, 32 j + k, c)"""
+    from mmhand_amd import ops
+    B, H, W, C = shape
+    m = _mask(shape, 3, dev)
+    _, rows = ops.raw_dropout_bits(shape, 0.5, 0, m, dev, rows=True)
+    assert rows.shape == (B * H, (W + 31) // 32, C) and rows.dtype == torch.int32
+    mm = m.reshape(B * H, W, C).to(torch.int64)
+    for j in range(rows.shape[1]):
+        seg = mm[:, 32 * j:32 * j + 32]                                      # [rows, <=32, C]
+        w = (seg << torch.arange(seg.shape[1], device=dev, dtype=torch.int64)[None, :, None]).sum(1)
+        assert torch.equal(rows[:, j].to(torch.int64) & 0xffffffff, w)
+
+
+@pytest.mark.parametrize("groups_is_b", [True, False])
+@pytest.mark.parametrize("relu,drop", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("shape,reflect", [((2, 24, 18, 128), True), ((3, 13, 20, 64), False), ((1, 12, 12, 256), True),
+                                           ((1, 14, 70, 64), True), ((2, 12, 41, 64), False)])     # rows of 2-3 dropout words
+def test_input_transform_with_norm_apply_inside(groups_is_b, relu, drop, shape, reflect, dev):
+    from mmhand_amd import lib as L, ops
+    B, H, W, C = shape
+    groups = B if groups_is_b else 1
+    x = _mk(shape, 1, dev, 2.0, 0.5)
+    scale = _mk((groups, C), 2, dev, 0.3, 1.0)
+    shift = _mk((groups, C), 3, dev, 0.5)
+    m = _mask(shape, 4, dev) if drop else None
+    p = 0.5 if drop else 0.0
+    a = ops.raw_scale_shift_act(x, scale, shift, None, relu, p, 0, m)
+    tiles = B * (-(-H // 6)) * (-(-W // 6))
+    V_ref = torch.empty((64, tiles, C), device=dev)
+    L.call("mmh_wino_input", ops._ptr(a), B, H, W, C, int(reflect), 6, L.F32, ops._ptr(V_ref), ops._stream())
+    drows = ops.raw_dropout_bits(shape, p, 0, m, dev, rows=True)[1] if drop else None
+    V = torch.full((64, tiles, C), float("nan"), device=dev)
+    L.call("mmh_wino_input_normact", ops._ptr(x), B, H, W, C, int(reflect), ops._ptr(V), ops._ptr(scale), ops._ptr(shift),
+           groups, int(relu), p, ops._ptr(drows), ops._stream())
+    assert torch.equal(V, V_ref)
+
+
+@pytest.mark.parametrize("groups_is_b", [True, False])
+@pytest.mark.parametrize("relu,drop", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("shape", [(3, 14, 12, 128), (1, 13, 75, 64)])
+def test_decide_again_backward_kernels_match_keep_bit_kernels(groups_is_b, relu, drop, shape, dev):
+    from mmhand_amd import lib as L, ops
+    B, H, W, C = shape
+    groups = B if groups_is_b else 1
+    rows = (B // groups) * H * W
+    x = _mk(shape, 1, dev, 2.0, 0.5)
+    g = _mk(shape, 5, dev)
+    gamma = None if groups_is_b else _mk((C,), 6, dev, 0.1, 1.0)
+    beta = None if groups_is_b else _mk((C,), 7, dev, 0.1)
+    m = _mask(shape, 4, dev) if drop else None
+    p = 0.5 if drop else 0.0
+    mean, m2, _ = ops.raw_norm_stats(x, groups)
+    scale, shift, invstd = ops.raw_norm_finalize(mean, m2, rows, gamma, beta, None, None)
+    masked = 2 if (relu or drop) else 0
+    kb = ops.raw_scale_shift_act(x, scale, shift, None, relu, p, 0, m, keep_bits=True)[1] if masked else None
+    lib = L.load()
+    ws = torch.empty(lib.mmh_norm_bwd_ws_bytes(groups, rows, C) // 4 + 4, device=dev)
+    P, st = ops._ptr, ops._stream
+    s1 = torch.empty((groups, C), device=dev); s2 = torch.empty_like(s1)
+    L.call("mmh_norm_bwd_reduce", P(g), P(kb), P(x), P(mean), P(invstd), groups, rows, C, masked, p, P(s1), P(s2), P(ws),
+           ws.numel() * 4, L.F32, L.F32, st())
+    dx = torch.empty_like(x)
+    L.call("mmh_norm_bwd_apply", P(g), P(kb), P(x), P(mean), P(invstd), P(gamma), P(s1), P(s2), float(rows), groups, rows, C,
+           masked, p, P(dx), L.F32, L.F32, L.F32, st())
+    dbits, drows = ops.raw_dropout_bits(shape, p, 0, m, dev, rows=True) if drop else (None, None)
+    r1 = torch.empty_like(s1); r2 = torch.empty_like(s1)
+    L.call("mmh_norm_bwd_reduce_rc", P(g), P(x), P(mean), P(invstd), P(scale), P(shift), P(dbits), groups, rows, C, int(relu),
+           p, P(r1), P(r2), P(ws), ws.numel() * 4, st())
+    assert torch.equal(r1, s1) and torch.equal(r2, s2)
+    rdx = torch.empty_like(x)
+    L.call("mmh_norm_bwd_apply_rc", P(g), P(x), P(mean), P(invstd), P(gamma), P(s1), P(s2), P(scale), P(shift), P(dbits),
+           float(rows), groups, rows, C, int(relu), p, P(rdx), st())
+    assert torch.equal(rdx, dx)
+    # ... and the backward transform with the same arithmetic inside
+    for fold in (0, 1) if ops._fold_same_grid(H, W) else (0,):
+        tiles = B * (-(-H // 6)) * (-(-W // 6))
+        V_ref = torch.empty((64, tiles, C), device=dev); Y_ref = torch.empty_like(V_ref)
+        L.call("mmh_wino_input_dy", P(dx), B, H, W, C, 6, L.F32, P(V_ref), P(Y_ref), fold, st())
+        V = torch.full_like(V_ref, float("nan")); Y = torch.full_like(V_ref, float("nan"))
+        L.call("mmh_wino_input_dy_normbwd", P(g), P(x), B, H, W, C, P(V), P(Y), fold, P(mean), P(invstd), P(gamma), P(s1),
+               P(s2), float(rows), P(scale), P(shift), P(drows), groups, int(relu), p, st())
+        assert _same_but_for_ulps(V, V_ref) and _same_but_for_ulps(Y, Y_ref), fold
+
+
+@pytest.mark.parametrize("norm", ["instance", "batch"])
+@pytest.mark.parametrize("last_norm,frozen", [(True, False), (False, False), (True, True)])
+def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, dev, monkeypatch):
+    """RP-conv-norm-ReLU-dropout-RP-conv(-norm): fusion on against fusion off, bit for bit; frozen: weights
+    without gradients (the discriminators inside the generator step) - there the deferred gradient of the
+    norm's input is materialised (mmh_norm_bwd_apply_rc) instead of computed inside the backward transform."""
+    from mmhand_amd import networks, ops
+    torch.manual_seed(0)
+
+    class Net(networks._Net):
+        def __init__(self):
+            super().__init__(norm, True)
+            self.blk = networks.Bag()
+            self._conv(self.blk, 1, 128, 128, 3)
+            self._normp(self.blk, 2, 128)
+            self._conv(self.blk, 6, 128, 128, 3)
+            self._normp(self.blk, 7, 128)
+
+    net = Net().init_weights("normal", seed=3).to(dev)
+    net.flatten_parameters()
+    net.train()
+    shape = (2, 22, 16, 128)
+    x = _mk(shape, 1, dev)
+    gy = _mk(shape, 2, dev)
+    mask = _mask(shape, 5, dev)
+    if frozen:
+        for p in net.parameters():
+            p.requires_grad_(False)
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(ops, "USE_NORM_FUSION", fuse)
+        net._mask_src = {"site": mask}
+        xin = x.clone().requires_grad_(True)
+        net.zero_grad()
+        want = net._norm_fusion(net.blk[1], net.blk[6], xin)
+        assert want == (2 if fuse else 0)      # BatchNorm convs have no bias, InstanceNorm ones a null bias gradient
+        L_calls = []
+        real = ops.L.call
+
+        def spy(name, *a):
+            L_calls.append(name)
+            return real(name, *a)
+        monkeypatch.setattr(ops.L, "call", spy)
+        y = net.two_conv_block(net.blk, xin, "site", last_norm)
+        y.backward(gy)
+        monkeypatch.setattr(ops.L, "call", real)
+        if fuse:
+            assert "mmh_wino_input_normact" in L_calls and "mmh_norm_bwd_reduce_rc" in L_calls
+            assert ("mmh_wino_input_dy_normbwd" in L_calls) == (not frozen)
+            assert ("mmh_norm_bwd_apply_rc" in L_calls) == frozen
+            assert L_calls.count("mmh_scale_shift_act") == (1 if last_norm else 0)
+        else:
+            assert "mmh_wino_input_normact" not in L_calls
+        res[fuse] = (y.detach().clone(), xin.grad.clone(), None if frozen else net.flat_grad.clone())
+        assert not ops._nb_defer and not ops._lp_grads
+    assert torch.equal(res[True][0], res[False][0])         # forward: bit for bit
+    for a, b in zip(res[True][1:], res[False][1:]):
+        if a is not None:
+            assert float((a - b).abs().sum() / b.abs().sum()) < 1e-6, float((a - b).abs().max())
+
+
+def test_deferred_gradient_on_a_foreign_edge_fails_loudly(dev):
+    from mmhand_amd import ops
+    g = ops.lp_proxy((1, 12, 12, 64), dev)
+    with pytest.raises(RuntimeError, match="NormBwdDefer"):
+        ops.norm_bwd_defer_in(g, "test")
