@@ -334,6 +334,9 @@ int mmh_dropout_bits(int64_t n, float drop_p, uint64_t seed, const void* mask, v
  * rows (uint32) [image_rows = B*H][ceil(W/32)][C], bit k of word j = element (row, 32 j + k, c)      */
 int mmh_dropout_bits_rows(const void* bits, int64_t image_rows, int W, int C, void* rows,
                           mmh_stream_t s);
+/* both arrays of an [image_rows][W][C] tensor in one launch (same decisions as the two calls above) */
+int mmh_dropout_bits_both(int64_t image_rows, int W, int C, float drop_p, uint64_t seed,
+                          const void* mask, void* bits, void* rows, mmh_stream_t s);
 int mmh_norm_bwd_reduce_rc(const void* g, const void* x, const void* mean, const void* invstd,
                            const void* scale, const void* shift, const void* dbits, int groups,
                            int64_t rows_per_group, int C, int relu, float drop_p, void* s1,

@@ -227,23 +227,55 @@ __device__ __forceinline__ uint64_t mix_u64(uint64_t seed, uint64_t idx) {
 // Dropout decisions of one site as a bit array (bit e of byte i = element 8 i + e is kept), drawn once
 // per iteration and read by every kernel that needs them: the norm-apply fused into a Winograd input
 // transform and the norm backward kernels that decide again instead of reading stored keep bits.
-// mask (uint8 per element, test hook) replaces the hash.
-__global__ void dropout_bits_kernel(int64_t n8, uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
-                                    uint8_t* __restrict__ bits) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
+// mask (uint8 per element, test hook) replaces the hash.  p = 0.5 (the reference's nn.Dropout(0.5)): the
+// 64 bits of one hash are 64 decisions (8 bytes); other p: 16-bit uniforms against the threshold.
+__device__ __forceinline__ unsigned drop_byte(int64_t i, uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask) {
     unsigned b = 0;
     if (mask) {
         const uint2 m = reinterpret_cast<const uint2*>(mask)[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) b |= (((e < 4 ? m.x >> (8 * e) : m.y >> (8 * (e - 4))) & 0xffu) ? 1u : 0u) << e;
+    } else if (thr16 == 0x8000u) {
+        b = (unsigned)(mix_u64(seed, (uint64_t)(i >> 3)) >> (8 * (i & 7))) & 0xffu;
     } else {
         const uint64_t h0 = mix_u64(seed, (uint64_t)i * 2), h1 = mix_u64(seed, (uint64_t)i * 2 + 1);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             b |= ((unsigned)((e < 4 ? h0 >> (16 * e) : h1 >> (16 * (e - 4))) & 0xffffu) >= thr16 ? 1u : 0u) << e;
     }
-    bits[i] = (uint8_t)b;
+    return b;
+}
+
+__global__ void dropout_bits_kernel(int64_t n8, uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                    uint8_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    bits[i] = (uint8_t)drop_byte(i, thr16, seed, mask);
+}
+
+// Both layouts in one launch: one workgroup per image row (b, h) draws the row's bytes (global + LDS) and
+// transposes them into the row words (see dropout_rows_kernel below).
+__global__ void __launch_bounds__(TPB) dropout_both_kernel(int W, int C, int nW32, uint32_t thr16, uint64_t seed,
+                                                           const uint8_t* __restrict__ mask, uint8_t* __restrict__ bits,
+                                                           uint32_t* __restrict__ rows) {
+    extern __shared__ uint8_t sm_bits[];
+    const int c8 = C / 8;
+    const int64_t row = blockIdx.x;
+    const int nb = W * c8;
+    for (int i = threadIdx.x; i < nb; i += TPB) {
+        const unsigned b = drop_byte(row * nb + i, thr16, seed, mask);
+        bits[row * nb + i] = (uint8_t)b;
+        sm_bits[i] = (uint8_t)b;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nW32 * C; t += TPB) {
+        const int c = t % C, j = t / C;
+        const int nw = min(32, W - 32 * j);
+        const uint8_t* src = sm_bits + 32 * j * c8 + (c >> 3);
+        uint32_t word = 0;
+        for (int k = 0; k < nw; ++k) word |= ((uint32_t)(src[k * c8] >> (c & 7)) & 1u) << k;
+        rows[(row * nW32 + j) * C + c] = word;
+    }
 }
 
 // The same decisions as ROW WORDS for the kernels that walk a channel along an image row (the Winograd
@@ -1514,6 +1546,24 @@ int mmh_dropout_bits(int64_t n, float drop_p, uint64_t seed, const void* mask, v
                        (uint32_t)((double)drop_p * 65536.0), seed, static_cast<const uint8_t*>(mask),
                        static_cast<uint8_t*>(bits));
     return mmh::check_launch("dropout_bits");
+}
+
+int mmh_dropout_bits_both(int64_t image_rows, int W, int C, float drop_p, uint64_t seed, const void* mask, void* bits,
+                          void* rows, mmh_stream_t s) {
+    MMH_REQUIRE(bits && rows && image_rows > 0 && image_rows < (1ll << 31) && W > 0 && C > 0 && C % 8 == 0 &&
+                    drop_p > 0.f && drop_p < 1.f,
+                "mmh_dropout_bits_both: bad arguments");
+    const int nW32 = (W + 31) / 32;
+    const size_t lds = (size_t)W * (C / 8);
+    const uint32_t thr16 = (uint32_t)((double)drop_p * 65536.0);
+    if (lds > 48 * 1024) {      // a row that does not fit LDS: the two stand-alone kernels
+        if (int rc = mmh_dropout_bits(image_rows * W * C, drop_p, seed, mask, bits, s)) return rc;
+        return mmh_dropout_bits_rows(bits, image_rows, W, C, rows, s);
+    }
+    hipLaunchKernelGGL(dropout_both_kernel, dim3((unsigned)image_rows), dim3(TPB), lds, mmh::as_stream(s), W, C, nW32,
+                       thr16, seed, static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(bits),
+                       static_cast<uint32_t*>(rows));
+    return mmh::check_launch("dropout_both");
 }
 
 int mmh_dropout_bits_rows(const void* bits, int64_t image_rows, int W, int C, void* rows, mmh_stream_t s) {

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp]),
     "mmh_dropout_bits": (_i, [_i64, _f, _u64, _vp, _vp, _vp]),
     "mmh_dropout_bits_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "mmh_dropout_bits_both": (_i, [_i64, _i, _i, _f, _u64, _vp, _vp, _vp, _vp]),
     "mmh_norm_bwd_reduce_rc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "mmh_norm_bwd_apply_rc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _vp]),
     "mmh_wino_input_normact": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),

@@ -864,12 +864,12 @@ def raw_dropout_bits(shape, drop_p, seed, mask, device, rows=False):
     for d in shape:
         n *= d
     bits = torch.empty((n // 8,), dtype=torch.uint8, device=device)
-    L.call("mmh_dropout_bits", n, float(drop_p), seed, _ptr(mask), _ptr(bits), _stream())
     if not rows:
+        L.call("mmh_dropout_bits", n, float(drop_p), seed, _ptr(mask), _ptr(bits), _stream())
         return bits
     B, H, W_, Cc = shape
     drows = torch.empty((B * H, (W_ + 31) // 32, Cc), dtype=torch.int32, device=device)
-    L.call("mmh_dropout_bits_rows", _ptr(bits), B * H, W_, Cc, _ptr(drows), _stream())
+    L.call("mmh_dropout_bits_both", B * H, W_, Cc, float(drop_p), seed, _ptr(mask), _ptr(bits), _ptr(drows), _stream())
     return bits, drows
 
 

@@ -50,6 +50,13 @@ def test_dropout_row_words_hold_the_same_decisions(shape, dev):
     m = _mask(shape, 3, dev)
     _, rows = ops.raw_dropout_bits(shape, 0.5, 0, m, dev, rows=True)
     assert rows.shape == (B * H, (W + 31) // 32, C) and rows.dtype == torch.int32
+    # the two stand-alone calls give the same arrays as the single launch, with the hash as with a mask
+    for mk, p_ in ((m, 0.5), (None, 0.5), (None, 0.3)):
+        b1, r1 = ops.raw_dropout_bits(shape, p_, 77, mk, dev, rows=True)
+        b2 = ops.raw_dropout_bits(shape, p_, 77, mk, dev)
+        r2 = torch.empty_like(r1)
+        ops.L.call("mmh_dropout_bits_rows", ops._ptr(b2), B * H, W, C, ops._ptr(r2), ops._stream())
+        assert torch.equal(b1, b2) and torch.equal(r1, r2)
     mm = m.reshape(B * H, W, C).to(torch.int64)
     for j in range(rows.shape[1]):
         seg = mm[:, 32 * j:32 * j + 32]                                      # [rows, <=32, C]
