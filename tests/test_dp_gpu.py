@@ -17,17 +17,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _opt(norm, B, distributed, rank=0):
+def _opt(norm, B, distributed, rank=0, wide=False):
     from mmhand_amd.options import default_train_opt
-    return default_train_opt(batchSize=B, ngf=8, ndf=8, n_layers_D=2, G_n_blocks=2, norm=norm,
+    # wide: ngf = ndf = 32 at 64x64 - the 3x3 stack runs on Winograd F(6x6,3x3) with the norm between its
+    # convs applied inside their transforms (ops.USE_NORM_FUSION), as at full size
+    return default_train_opt(batchSize=B, ngf=32 if wide else 8, ndf=32 if wide else 8, n_layers_D=2,
+                             G_n_blocks=1 if wide else 2, norm=norm, fineSize=64 if wide else 32,
                              no_dropout=True, no_dropout_D=True, pool_size=0, name="dp",
                              checkpoints_dir="/tmp/mmh_dp_gpu", local_rank=0, distributed=distributed)
 
 
-def _run(norm, batch, distributed):
+def _run(norm, batch, distributed, wide=False):
     from mmhand_amd.mmhand_model import MMHandModel
     random.seed(0)
-    model = MMHandModel(_opt(norm, batch["H1"].shape[0], distributed))
+    model = MMHandModel(_opt(norm, batch["H1"].shape[0], distributed, wide=wide))
     out = []
     for _ in range(2):
         model.set_input(batch)
@@ -38,31 +41,44 @@ def _run(norm, batch, distributed):
     return out, sd
 
 
-def _worker(rank, world, port, norm, tmp):
+def _worker(rank, world, port, norm, tmp, wide=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0", MMH_DP_LOG="1", MMH_BUCKET_MB="0.02")
     sys.path.insert(0, ROOT)
     from oracle import mmhand_ref as O
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    full = O.synthetic_batch(4, 32, 32, seed=7)
+    S = 64 if wide else 32
+    full = O.synthetic_batch(4, S, S, seed=7)
     shard = {k: v[rank * 2:(rank + 1) * 2] for k, v in full.items()}
-    losses, sd = _run(norm, shard, True)
-    from mmhand_amd import mmhand_model, ops
+    from mmhand_amd import lib, mmhand_model, ops
+    fused = []
+    real = lib.call
+
+    def spy(name, *a):
+        if name in ("mmh_wino_input_normact", "mmh_wino_input_dy_normbwd"):
+            fused.append(name)
+        return real(name, *a)
+    lib.call = spy
+    losses, sd = _run(norm, shard, True, wide)
+    lib.call = real
     torch.save({"losses": losses, "sd": sd, "log": list(mmhand_model._LAST_BUCKET_LOG or []),
-                "syncbn": dict(ops.collective_counter)}, os.path.join(tmp, f"rank{rank}.pt"))
+                "syncbn": dict(ops.collective_counter), "fused": len(fused)}, os.path.join(tmp, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm,port", [("instance", 29621), ("batch", 29622)])
-def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_path):
+@pytest.mark.parametrize("norm,port,wide", [("instance", 29621, False), ("batch", 29622, False), ("batch", 29623, True)])
+def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, wide, dev, tmp_path):
     from oracle import mmhand_ref as O
     from tests.golden.recipe import is_null_grad_bias
-    mp.spawn(_worker, args=(2, port, norm, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, norm, str(tmp_path), wide), nprocs=2, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
-    full = O.synthetic_batch(4, 32, 32, seed=7)
-    ref_losses, ref_sd = _run(norm, full, False)
+    S = 64 if wide else 32
+    full = O.synthetic_batch(4, S, S, seed=7)
+    ref_losses, ref_sd = _run(norm, full, False, wide)
+    # wide: the fused norm kernels ran under SyncBN (statistics and backward sums all-reduced around them)
+    assert (r0["fused"] > 0) == wide, r0["fused"]
     # replicas stay identical
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
@@ -70,7 +86,9 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_pat
     # all_reduce per site backward.  G: 3 stems x 3 + n_blocks x 4 + 2 up = 19 sites here (47 at full
     # size); D: 1 + 2 + 2 x n_layers_D = 7 per pass (9 at full size), 6 passes per iteration (2 in the
     # G step, 2 per discriminator step) -> 61 + 61 here, 101 + 101 at full size.  --norm instance: none.
-    if norm == "batch":
+    if norm == "batch" and wide:
+        assert r0["syncbn"]["all_gather"] == r0["syncbn"]["all_reduce"] > 0, r0["syncbn"]
+    elif norm == "batch":
         assert r0["syncbn"] == {"all_gather": 2 * (19 + 6 * 7), "all_reduce": 2 * (19 + 6 * 7)}, r0["syncbn"]
     else:
         assert r0["syncbn"] == {}, r0["syncbn"]
@@ -90,9 +108,17 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, dev, tmp_pat
     if norm == "instance":
         assert np.allclose(mean_losses, np.array(ref_losses), rtol=2e-4), (mean_losses, ref_losses)
     # parameters after two steps == single-process training on the concatenated batch
+    # (wide: two Adam SIGN steps of lr = 2e-4 each - an element whose gradient is within rounding of zero
+    # flips with the summation order, tests/test_winograd_step_gpu.py - so up to 4 lr apart, few of them)
     for k, v in ref_sd.items():
         if v.is_floating_point() and not is_null_grad_bias("G", k, norm):
-            assert torch.allclose(r0["sd"][k], v, atol=2e-4 + 1e-3 * v.abs().max().item()), k
+            if wide:
+                if "running" in k:
+                    continue
+                assert torch.allclose(r0["sd"][k], v, atol=4.2 * 2e-4 + 1e-3 * v.abs().max().item()), k
+                assert float(((r0["sd"][k] - v).abs() > 1e-4).float().mean()) < 0.25, k
+            else:
+                assert torch.allclose(r0["sd"][k], v, atol=2e-4 + 1e-3 * v.abs().max().item()), k
 
 
 def _worker_overflow(rank, world, port, tmp):

@@ -128,7 +128,10 @@ def test_optimize_parameters_winograd_vs_oracle(norm, dev, monkeypatch):
     assert drift["wino"] < 2e-2 and drift["wino"] <= 3 * max(drift["direct"], drift["oracle32"], 1e-3 / 3), drift
     # the path under test really ran: per iteration G has 6*NB convs on F(6x6,3x3) (+ 2*NLD per
     # Discriminator pass), forward AND fused backward
-    assert spy.n("mmh_wino_input_dy", 6) >= 3 * 6 * NB, spy.calls
+    # ... with the norm between the two convs of every block applied inside their transforms (2 blocks per
+    # PATBlock forward, their backward inside the producing conv's fused backward transform)
+    assert spy.n("mmh_wino_input_normact") >= 3 * 2 * NB and spy.n("mmh_wino_input_dy_normbwd") >= 3 * 2 * NB, spy.calls
+    assert spy.n("mmh_wino_input_dy", 6) + spy.n("mmh_wino_input_dy_normbwd") >= 3 * 6 * NB, spy.calls
     assert spy.calls[("gemm_planes", 64)] >= 3 * 3 * 6 * NB, spy.calls
     # F(4x4,3x3) only where the benchmark uses it too (the 64->64 VGG conv); never F(2x2,3x3)
     assert spy.calls[("gemm_planes", 36)] <= 3 * 3 and spy.calls[("gemm_planes", 16)] == 0, spy.calls
