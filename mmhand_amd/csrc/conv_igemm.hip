@@ -3181,6 +3181,7 @@ int mmh_wino_input_normact(const void* x, int B, int H, int W, int C, int reflec
                     (groups == 1 || groups == B) && drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f) == (drows == nullptr) &&
                     (drop_p == 0.f || relu),
                 "mmh_wino_input_normact: bad arguments (tile 6, fp32, C %% 8 == 0, groups 1 | B, dropout rows iff p > 0)");
+    MMH_REQUIRE((long long)B * H * W * C < (1ll << 31), "mmh_wino_input_normact: 32-bit element offsets (numel < 2^31)");
     return mmh::wino6_input_normact(static_cast<const float*>(x), static_cast<float*>(V), B, H, W, C, reflect,
                                     g_wino_xcd, static_cast<const float*>(scale), static_cast<const float*>(shift),
                                     groups, relu, drop_p, static_cast<const uint32_t*>(drows), mmh::as_stream(s));
@@ -3194,6 +3195,7 @@ int mmh_wino_input_dy_normbwd(const void* g, const void* x, int B, int H, int W,
                     C % 8 == 0 && count > 0 && (groups == 1 || groups == B) && drop_p >= 0.f && drop_p < 1.f &&
                     (drop_p == 0.f) == (drows == nullptr),
                 "mmh_wino_input_dy_normbwd: bad arguments (tile 6, fp32, C %% 8 == 0, groups 1 | B)");
+    MMH_REQUIRE((long long)B * H * W * C < (1ll << 31), "mmh_wino_input_dy_normbwd: 32-bit element offsets (numel < 2^31)");
     MMH_REQUIRE(!fold || (wino_fold_ok(H, W) && (H + 7) / 6 == (H + 5) / 6 && (W + 7) / 6 == (W + 5) / 6),
                 "mmh_wino_input_dy_normbwd: fold needs (H+1) %% 6 >= 2 and ceil((H+2)/6) == ceil(H/6) (W alike)");
     return mmh::wino6_input_dy_normbwd(

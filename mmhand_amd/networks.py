@@ -308,7 +308,7 @@ class _Net(nn.Module):
             return 0
         B, H, W, Cin = x.shape
         C1, C2 = c1.weight.shape[3], c2.weight.shape[3]
-        if not (ops.norm_fusion_ok(C1) and ops._wino_tile(B, H, W, C1, C2, 3, 1, 1, False) == 6):
+        if not (ops.norm_fusion_ok(C1) and B * H * W * C1 < 2 ** 31 and ops._wino_tile(B, H, W, C1, C2, 3, 1, 1, False) == 6):
             return 0
         null_db = c1.bias is None or (self.norm == "instance" and ops.EXACT_NULL_BIAS_GRAD)
         if (null_db and ops.FUSE_WINO6_BWD and ops._wino_tile(B, H, W, Cin, C1, 3, 1, 1, False) == 6

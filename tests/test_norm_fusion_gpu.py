@@ -67,7 +67,8 @@ def test_dropout_row_words_hold_the_same_decisions(shape, dev):
 @pytest.mark.parametrize("groups_is_b", [True, False])
 @pytest.mark.parametrize("relu,drop", [(True, True), (True, False), (False, False)])
 @pytest.mark.parametrize("shape,reflect", [((2, 24, 18, 128), True), ((3, 13, 20, 64), False), ((1, 12, 12, 256), True),
-                                           ((1, 14, 70, 64), True), ((2, 12, 41, 64), False)])     # rows of 2-3 dropout words
+                                           ((1, 14, 70, 64), True), ((2, 12, 41, 64), False),      # rows of 2-3 dropout words
+                                           ((32, 64, 64, 256), True)])                              # the benchmark's shape
 def test_input_transform_with_norm_apply_inside(groups_is_b, relu, drop, shape, reflect, dev):
     from mmhand_amd import lib as L, ops
     B, H, W, C = shape
@@ -90,7 +91,7 @@ def test_input_transform_with_norm_apply_inside(groups_is_b, relu, drop, shape, 
 
 @pytest.mark.parametrize("groups_is_b", [True, False])
 @pytest.mark.parametrize("relu,drop", [(True, True), (True, False), (False, False)])
-@pytest.mark.parametrize("shape", [(3, 14, 12, 128), (1, 13, 75, 64)])
+@pytest.mark.parametrize("shape", [(3, 14, 12, 128), (1, 13, 75, 64), (32, 64, 64, 256)])
 def test_decide_again_backward_kernels_match_keep_bit_kernels(groups_is_b, relu, drop, shape, dev):
     from mmhand_amd import lib as L, ops
     B, H, W, C = shape
