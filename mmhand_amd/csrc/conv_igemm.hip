@@ -82,6 +82,8 @@ constexpr int BM = 128;   // rows (pixels, or (tap,ci) for wgrad) per workgroup
 constexpr int BK = 32;    // contraction depth per k-step
 constexpr int LDA = 36;   // LDS row pitch (floats) of a [row][k] tile: conflict-free ds_read_b128
 constexpr int LDW = 132;  // LDS row pitch of the wgrad [pixel][128] tile
+constexpr int TABP = 8;   // pitch of the per-row source-offset tables of conv_igemm_body (taps per axis <= 8)
+constexpr size_t tab_bytes(int rows) { return (size_t)rows * TABP * 2 * sizeof(int); }
 
 // How a (pixel, tap) pair maps to a source pixel.
 struct Gather {
@@ -98,6 +100,7 @@ struct Gather {
     int reflect;                // mirror v into [0, srcH)
     int chunk_major;            // k order: 1 = (super-chunk, tap, chunk), 0 = flat (tap, group)
     int cw;                     // chunks (of 8 groups = 32 channels) per tap visit, chunk_major only
+    int dc4, dtw, dth;          // flat order: advance of (group, tap column, tap row) per k-step (kstate_next)
 };
 
 struct ConvKP {
@@ -146,8 +149,15 @@ __device__ __forceinline__ void kstate_next(KState& s, const Gather& g) {
             if (++s.tw == g.TW) { s.tw = 0; if (++s.th == g.TH) { s.th = 0; s.c4 += 8 * g.cw; } }
         }
     } else {
-        s.c4 += 8;
-        while (s.c4 >= g.C4) { s.c4 -= g.C4; if (++s.tw == g.TW) { s.tw = 0; ++s.th; } }
+        // 8 groups further in the flat (tap, group) order: fixed deltas with two carries, no loop
+        // (dc4 = 8 % C4, dtw = (8 / C4) % TW, dth = (8 / C4) / TW; set_korder)
+        s.c4 += g.dc4;
+        const int cy = s.c4 >= g.C4 ? 1 : 0;
+        s.c4 -= cy ? g.C4 : 0;
+        s.tw += g.dtw + cy;
+        const int cy2 = s.tw >= g.TW ? 1 : 0;
+        s.tw -= cy2 ? g.TW : 0;
+        s.th += g.dth + cy2;
     }
 }
 __device__ __forceinline__ bool kstate_valid(const KState& s, const Gather& g) {
@@ -303,6 +313,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         }
     }
 
+    // Flat (tap, channel) k order (small Cin: the 7x7 stems, 3 -> 64 convs): every k-step is another tap, and
+    // recomputing RA reflected / bounds-checked source offsets per thread and k-step costs 9 % of the kernel
+    // (tools/ablate_narrow.py).  Instead the workgroup tabulates once, per tile row, the source row of
+    // each vertical tap and the source column of each horizontal tap (-1 = padding): two LDS reads per
+    // row and k-step replace the arithmetic.
+    int* const tabH = reinterpret_cast<int*>(smem + NBUF * (ASZ + BSZ));     // [BMT][TABP] (img*srcH + vh)*srcW
+    int* const tabW = tabH + BMT * TABP;                                    // [BMT][TABP] vw
+    const bool use_tab = !g.chunk_major && g.TH <= TABP && g.TW <= TABP && !(p.dbg & 8);
+    if (use_tab) {
+        for (int r = tid; r < BMT; r += 256) {
+            const int m = m0 + r;
+            const bool okm = m < p.M;
+            const int mm = okm ? m : 0;
+            const int b = mm / PHW;
+            const int rr = mm - b * PHW;
+            const int ph = rr / g.PW;
+            const int pw = rr - ph * g.PW;
+            const int bh = ph * g.ap_h + g.a0_h, bw = pw * g.ap_w + g.a0_w;
+#pragma unroll
+            for (int t = 0; t < TABP; ++t) {
+                int vh = bh + t * g.at_h, vw = bw + t * g.at_w;
+                bool okh = okm && t < g.TH, okw = t < g.TW;
+                if (g.reflect) {
+                    vh = vh < 0 ? -vh : vh; vw = vw < 0 ? -vw : vw;
+                    vh = vh >= g.srcH ? 2 * (g.srcH - 1) - vh : vh;
+                    vw = vw >= g.srcW ? 2 * (g.srcW - 1) - vw : vw;
+                } else {
+                    okh = okh && vh >= 0; okw = okw && vw >= 0;
+                    vh >>= g.shift; vw >>= g.shift;
+                    okh = okh && vh < g.srcH; okw = okw && vw < g.srcW;
+                }
+                tabH[r * TABP + t] = okh ? (b * g.srcH + vh) * g.srcW : -1;
+                tabW[r * TABP + t] = okw ? vw : -1;
+            }
+        }
+        __syncthreads();
+    }
+
     KState ks_t;   // this thread's k-group
     kstate_init(ks_t, g, grp);
     unsigned a_off[RA];   // row byte offsets of the current tap
@@ -317,7 +365,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     auto load_part = [&](int ks, int part) {
         const bool kv = kstate_valid(ks_t, g);
         if (part == 0) {
-            if (ks_t.j == 0 && !((p.dbg & 4) && ks > 1)) {   // new tap (or flat order): recompute the row offsets
+            if (use_tab) {
+                const bool kvt = kstate_valid(ks_t, g);
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int row = (tid >> 3) + 32 * i;
+                    const int hv = tabH[row * TABP + (kvt ? ks_t.th : 0)], wv = tabW[row * TABP + ks_t.tw];
+                    a_off[i] = (hv >= 0 && wv >= 0) ? (unsigned)(hv + wv) * g.src_cs * 4u : OOB;
+                }
+            } else if (ks_t.j == 0 && !((p.dbg & 4) && ks > 1)) {   // new tap: recompute the row offsets
 #pragma unroll
                 for (int i = 0; i < RA; ++i)
                     a_off[i] = gather_base(g, a_img[i], a_bh[i], a_bw[i], ks_t, a_ok[i]);
@@ -2145,7 +2201,10 @@ void set_korder(Gather& g, int& nk, int& Kflat) {
         g.cw = (g_conv_cw > 0 && chunks % g_conv_cw == 0) ? g_conv_cw
                : (chunks % 2 == 0 ? 2 : 1);   // 2: +2.7 % speed over 1 at equal HBM traffic; 4: +1.3 % more
                                               // speed but +23..36 % fabric reads (working set > 4 MiB L2)
-    } else { g.chunk_major = 0; g.cw = 1; nk = (Kflat + BK - 1) / BK; }
+    } else {
+        g.chunk_major = 0; g.cw = 1; nk = (Kflat + BK - 1) / BK;
+        g.dc4 = 8 % g.C4; g.dtw = (8 / g.C4) % g.TW; g.dth = (8 / g.C4) / g.TW;
+    }
 }
 
 // Dynamic LDS above 64 KiB must be opted into once per kernel.
@@ -2163,7 +2222,7 @@ int g_conv_xcd = 1;    // XCD-aware tile mapping on/off
 
 template <int BN, int WM, int WN, bool NMAJOR, bool DBUF>
 int launch_conv_t(const ConvKP& p, hipStream_t st) {
-    constexpr size_t lds = (DBUF ? 2 : 1) * (BM * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float);
+    constexpr size_t lds = (DBUF ? 2 : 1) * (BM * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float) + tab_bytes(BM);
     static int ready = -1;
     if (ready != 0) ready = allow_lds(conv_igemm_kernel<BN, WM, WN, NMAJOR, DBUF>, lds);
     if (ready != 0) return ready;
@@ -2174,7 +2233,7 @@ int launch_conv_t(const ConvKP& p, hipStream_t st) {
 
 template <int BN, int WM, int WN, bool NMAJOR>
 int launch_conv_tall_t(const ConvKP& p, hipStream_t st) {
-    constexpr size_t lds = (256 * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float);
+    constexpr size_t lds = (256 * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float) + tab_bytes(256);
     static int ready = -1;
     if (ready != 0) ready = allow_lds(conv_igemm_tall_kernel<BN, WM, WN, NMAJOR>, lds);
     if (ready != 0) return ready;
@@ -2405,7 +2464,7 @@ int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st) {
     }
     mp.start[mp.n] = total;
     if (BMT != BM) {
-        constexpr size_t lds = (BMT * LDA + BN * LDA) * sizeof(float);
+        constexpr size_t lds = (BMT * LDA + BN * LDA) * sizeof(float) + tab_bytes(BMT);
         static int ready = -1;
         if (ready != 0) ready = allow_lds(conv_igemm_multi_kernel<BN, WM, WN, true, BMT>, lds);
         if (ready != 0) return ready;
@@ -2417,7 +2476,7 @@ int launch_multi_t(MultiKP& mp, bool bf16, hipStream_t st) {
         if (ready != 0) return ready;
         hipLaunchKernelGGL((conv_igemm_bf16_multi_kernel<BN, WM, WN>), dim3(total), dim3(256), lds, st, mp);
     } else {
-        constexpr size_t lds = (BM * LDA + BN * LDA) * sizeof(float);
+        constexpr size_t lds = (BM * LDA + BN * LDA) * sizeof(float) + tab_bytes(BM);
         static int ready = -1;
         if (ready != 0) ready = allow_lds(conv_igemm_multi_kernel<BN, WM, WN, true>, lds);
         if (ready != 0) return ready;
@@ -2832,7 +2891,7 @@ __global__ void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict_
 // ------------------------------------------------------------------ Winograd host side
 template <int BN, int WM, int WN, bool NMAJOR>
 int launch_batched_t(const BatchKP& bp, int nbatch, hipStream_t st) {
-    constexpr size_t lds = (BM * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float);
+    constexpr size_t lds = (BM * LDA + (NMAJOR ? BN * LDA : BK * BN)) * sizeof(float) + tab_bytes(BM);
     static int ready = -1;
     if (ready != 0) ready = allow_lds(conv_igemm_batched_kernel<BN, WM, WN, NMAJOR>, lds);
     if (ready != 0) return ready;

@@ -18,7 +18,7 @@ for (H, Cin, Cout, k, s, p, refl) in [(256, 44, 64, 7, 1, 3, True), (256, 24, 64
     fw = lambda: ops.raw_conv_wgrad(x, dy, k, s, p, refl)
     for nm, f, key in (("fprop", fn, b"conv_dbg"), ("wgrad", fw, b"conv_dbg")):
         out = []
-        for dbg in (0, 1, 4):
+        for dbg in (0, 8, 1, 4):
             rc = L.mmh_set_option(key, dbg)
             if rc: out.append("n/a"); continue
             f(); torch.cuda.synchronize()
