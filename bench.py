@@ -116,7 +116,7 @@ def cpu_baseline_child(H, W, norm, budget_s):
                       f"{norm}, dropout on, after 2 warm-up steps ({warm:.1f}s), {nthreads} threads of "
                       f"{os.cpu_count()} logical CPUs (oneDNN is fastest near 16 threads on this host and "
                       f"an order of magnitude slower at 128+: tools/cpu_probe.py); "
-                      f"oracle/mmhand_ref.py StepOracle"}), flush=True)
+                      f"oracle/mmhand_ref.py StepOracle"}), file=_OUT, flush=True)
 
 
 def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300):
@@ -172,10 +172,14 @@ def infer_main(a):
         "direct_equiv_tflops": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3, 1),
         "direct_equiv_frac_of_peak": round(611.68 * (a.size * a.size / 65536.0) * ips / 1e3 /
                                            (PEAK_BF16_MFMA_TF if a.dtype == "bf16" else PEAK_F32_MFMA_TF), 4)}),
-        flush=True)
+        file=_OUT, flush=True)
+
+
+_OUT = sys.stdout       # the JSON line(s) go here; everything else the process prints goes to stderr
 
 
 def main():
+    sys.stdout = sys.stderr     # stdout carries exactly ONE JSON line (warnings of the model go to stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -380,7 +384,7 @@ def main():
         line.update(side)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=_OUT, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
