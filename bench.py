@@ -175,11 +175,21 @@ def infer_main(a):
         file=_OUT, flush=True)
 
 
-_OUT = sys.stdout       # the JSON line(s) go here; everything else the process prints goes to stderr
+_OUT = sys.stdout       # the JSON line goes here; everything else the process prints goes to stderr
+
+
+def _json_only_stdout():
+    """stdout carries exactly ONE JSON line: file descriptor 1 is pointed at stderr for everything else the
+    process prints - Python (model warnings) and native libraries (RCCL's version banner) alike."""
+    global _OUT
+    sys.stdout.flush()
+    _OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
 
 def main():
-    sys.stdout = sys.stderr     # stdout carries exactly ONE JSON line (warnings of the model go to stderr)
+    _json_only_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
