@@ -67,7 +67,8 @@ def _worker(rank, world, port, norm, tmp, wide=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm,port,wide", [("instance", 29621, False), ("batch", 29622, False), ("batch", 29623, True)])
+@pytest.mark.parametrize("norm,port,wide", [("instance", 29621, False), ("batch", 29622, False), ("batch", 29623, True),
+                                            ("instance", 29624, True)])
 def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, wide, dev, tmp_path):
     from oracle import mmhand_ref as O
     from tests.golden.recipe import is_null_grad_bias
