@@ -273,6 +273,15 @@ class _Net(nn.Module):
                 mask = self._mask_src[site]
             else:
                 seed = ops.next_dropout_seed()
+        if defer == 3:      # written as usual; only its backward apply pass goes to the producing conv
+            assert self.training and x16 is None and not out_lp and not relu and not drop
+            if self.norm == "instance":
+                return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", False, 0.0, 0, None, None,
+                                           0, None, 3)
+            np_ = bag[idx]
+            np_.num_batches_tracked += 1
+            return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean, np_.running_var, "batch",
+                                       False, 0.0, 0, None, self.sync_group, 0, None, 3)
         if defer:
             assert self.training and x16 is None and residual is None and not out_lp
             if self.norm == "instance":
@@ -316,6 +325,18 @@ class _Net(nn.Module):
             return 2
         return 1
 
+    def _norm_bwd_fusion(self, c2, x):
+        """the norm behind conv c2 (3x3, input of x's spatial size and c2's input channels) can hand the apply pass
+        of its backward to c2's fused F(6x6,3x3) backward transform"""
+        if not (ops.USE_NORM_FUSION and self.training and not self.bf16 and ops.KEEP_WINOGRAD_INPUT and ops.FUSE_WINO6_BWD):
+            return False
+        B, H, W, _ = x.shape
+        Cin, Cout = c2.weight.shape[2], c2.weight.shape[3]
+        null_db = c2.bias is None or (self.norm == "instance" and ops.EXACT_NULL_BIAS_GRAD)
+        return (null_db and ops.norm_fusion_ok(Cout) and B * H * W * Cout < 2 ** 31
+                and ops._wino_tile(B, H, W, Cin, Cout, 3, 1, 1, False) == 6
+                and ops._wino_tile(B, H, W, Cin, Cout, 3, 1, 1, False, "dgrad") == 6)
+
     def two_conv_block(self, blk, x, site, last_norm, residual=None):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets)."""
         i2 = 6 if self.use_dropout else 5
@@ -323,11 +344,14 @@ class _Net(nn.Module):
         # lives in HBM in 16 bits only, as under apex O1; without a last norm the caller (the PATBlock
         # gate) receives the (proxy, y16) pair
         fuse = self._norm_fusion(blk[1], blk[i2], x)
+        # the block's last norm (no ReLU / dropout; feeds the gate or the residual add): its backward apply pass
+        # inside conv 2's backward transform, as for the first norm
+        fuse_last = 3 if (last_norm and torch.is_tensor(x) and self._norm_bwd_fusion(blk[i2], x)) else 0
         y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2)
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
-        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm)
+        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm, g_defer=fuse_last == 3)
         if last_norm:
-            y = self.normact(blk, i2 + 1, y, False, residual=residual)
+            y = self.normact(blk, i2 + 1, y, False, residual=residual, defer=fuse_last)
         return y
 
 

@@ -1383,6 +1383,15 @@ class NormActFn(torch.autograd.Function):
         scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
                                                  running_var)
         ctx.defer = int(defer)
+        if defer == 3:
+            # defer 3 (a block's last norm: no ReLU, no dropout; its output feeds a gate / residual add and is
+            # written as usual): only the BACKWARD apply pass goes to the producing conv's backward transform
+            assert (x16 is None and not out_lp and not relu and drop_p == 0 and x.dtype == torch.float32
+                    and norm_fusion_ok(x.shape[3]))
+            out = raw_scale_shift_act(x, scale, shift, residual, False, 0.0, 0, None)
+            ctx.cfg = (groups, rows, count, False, 0.0, sync_group, residual is not None)
+            ctx.save_for_backward(x, None, mean, invstd, gamma, scale, shift, None)
+            return out
         if defer:
             # defer 1: the apply pass runs inside the consuming conv's input transform (the caller builds the
             # NormDefer from the returned scale / shift / dropout bits); no output, no keep bits: the backward
@@ -1451,7 +1460,7 @@ class NormActFn(torch.autograd.Function):
     @staticmethod
     def _backward_deferred(ctx, g):
         x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
-        groups, rows, count, relu, drop_p, sync_group, _ = ctx.cfg
+        groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
         g = g.contiguous()
         Cc = x.shape[3]
         ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
@@ -1472,8 +1481,8 @@ class NormActFn(torch.autograd.Function):
         e.g, e.x, e.mean, e.invstd, e.gamma, e.s1, e.s2, e.count = g, x, mean, invstd, gamma, s1, s2, count
         e.scale, e.shift, e.dbits, e.drows = scale, shift, dbits, drows
         e.groups, e.rows, e.relu, e.drop_p = groups, rows, relu, drop_p
-        dx = norm_bwd_defer_out(e) if ctx.defer == 2 else raw_norm_bwd_apply_rc(e)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+        dx = norm_bwd_defer_out(e) if ctx.defer >= 2 else raw_norm_bwd_apply_rc(e)
+        return dx, dgamma, dbeta, (g if has_res else None), None, None, None, None, None, None, None, None, None, None, None
 
 
 class AffineActFn(torch.autograd.Function):

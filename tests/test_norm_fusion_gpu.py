@@ -7,7 +7,7 @@ inside against transform(apply(x)), the decide-again backward kernels against th
 backward transform with the norm backward inside is a different instantiation of the same arithmetic than
 transform(apply_rc(...)): the compiler rounds a few of its intermediate products differently, the results
 agree to a few ulps of the largest element (checked at 2e-6 of it); whole two-conv blocks with the fusion
-on are compared with the fusion off: forward bit for bit, gradients at 1e-6 relative L1."""
+on are compared with the fusion off: forward bit for bit, gradients at 1e-5 relative L1."""
 import pytest
 import torch
 
@@ -184,8 +184,12 @@ def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, dev, monkeypat
         monkeypatch.setattr(ops.L, "call", real)
         if fuse:
             assert "mmh_wino_input_normact" in L_calls and "mmh_norm_bwd_reduce_rc" in L_calls
-            assert ("mmh_wino_input_dy_normbwd" in L_calls) == (not frozen)
-            assert ("mmh_norm_bwd_apply_rc" in L_calls) == frozen
+            # the backward apply pass of BOTH norms (the last one is written forward as usual) inside the producing
+            # conv's backward transform; materialised where that conv's weights are frozen
+            n_sites = 2 if last_norm else 1
+            assert L_calls.count("mmh_wino_input_dy_normbwd") == (0 if frozen else n_sites)
+            assert L_calls.count("mmh_norm_bwd_apply_rc") == (n_sites if frozen else 0)
+            assert "mmh_norm_bwd_apply" not in L_calls
             assert L_calls.count("mmh_scale_shift_act") == (1 if last_norm else 0)
         else:
             assert "mmh_wino_input_normact" not in L_calls
@@ -194,7 +198,8 @@ def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, dev, monkeypat
     assert torch.equal(res[True][0], res[False][0])         # forward: bit for bit
     for a, b in zip(res[True][1:], res[False][1:]):
         if a is not None:
-            assert float((a - b).abs().sum() / b.abs().sum()) < 1e-6, float((a - b).abs().max())
+            # (few-ulp differences of the two fused backward transforms, carried through two norms: 4e-6 measured)
+            assert float((a - b).abs().sum() / b.abs().sum()) < 1e-5, float((a - b).abs().max())
 
 
 def test_deferred_gradient_on_a_foreign_edge_fails_loudly(dev):
