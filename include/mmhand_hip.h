@@ -429,6 +429,17 @@ size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
                          void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
 
+/* wgrad of the 7x7 / stride 1 / ReflectionPad2d(3) stems (models/Generator.py:158-168,
+ * models/Discriminator.py:60-64; fp32, Cin 8 | 44 (where it beats the generic kernel), Cout == 64 dense, H % 2 == 0,
+ * W % 64 == 0): the input is reflect-padded once into ws, a workgroup stages the two input rows of a
+ * filter row and a 2 x 64 pixel tile in LDS and both MFMA operands are plain LDS reads - every input
+ * element is read 7 times instead of 49.  dw [7][7][Cin][64] (+)= ...; split-K slabs in ws, summed in a
+ * fixed order.                                                                              */
+int mmh_conv7_stem_wgrad_supported(const mmh_conv_desc* d);
+size_t mmh_conv7_stem_wgrad_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv7_stem_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
+                         void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
+
 /* ---- Adam (torch.optim.Adam, MMHandModel.py:90-98) over a flat buffer ------
  * step is the 1-based step count; no weight decay, no amsgrad.
  * skip_flag (device int32, may be NULL): when *skip_flag != 0 the launch leaves

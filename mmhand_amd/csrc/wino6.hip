@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(256) wino6_input_dy_kernel(const float* __rest
     const long long tile = i / C2;
     const int tx = (int)(tile % TW), ty = (int)((tile / TW) % TH), b = (int)(tile / ((long long)TW * TH));
     const T* in = reinterpret_cast<const T*>(dy);
-    T d[8][8], colv[8], o8[8];
+    T d[8][8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int hh = 6 * ty - org + r;

@@ -58,6 +58,9 @@ SIGNATURES = {
     "mmh_conv7_thin_dgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv7_thin_wgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv7_thin_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "mmh_conv7_stem_wgrad_supported": (_i, [_DP]),
+    "mmh_conv7_stem_wgrad_ws_bytes": (_sz, [_DP]),
+    "mmh_conv7_stem_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_conv2d_wgrad_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_wgrad": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_convT2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -166,6 +166,8 @@ KEEP_WINOGRAD_INPUT = os.environ.get("MMH_WINOGRAD_KEEP_INPUT", "1") != "0"
 # 7x7 convs with <= 4 output columns (Generator head fprop, Discriminator-stem dgrad towards the
 # generated image) on the vector-ALU kernel of conv_thin.hip; MMH_THIN=0 keeps them on the MFMA path
 USE_THIN = os.environ.get("MMH_THIN", "1") != "0"
+# fp32 wgrad of the 7x7 stems on the LDS-band kernel of conv_stem.hip; MMH_STEM_WGRAD=0: the generic direct wgrad
+USE_STEM_WGRAD = os.environ.get("MMH_STEM_WGRAD", "1") != "0"
 # F(6x6,3x3) backward: both transforms of dy (dgrad and wgrad operands) from one read of dy
 FUSE_WINO6_BWD = os.environ.get("MMH_FUSE_WINO6_BWD", "1") != "0"
 # --opt_level O1/O2: the 3x3 stride-1 convs with channels % 128 == 0 on bf16 Winograd F(2x2,3x3)
@@ -560,6 +562,15 @@ def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False, out=None):
         L.call("mmh_conv7_thin_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
                int(out is not None), _stream())
         _count_desc("valu", d)
+        return dw
+    if USE_STEM_WGRAD and not bf16 and L.load().mmh_conv7_stem_wgrad_supported(C.byref(d)):
+        # fp32 7x7 stems (Cin <= 44 -> 64): the input band of a filter row staged in LDS once instead of a
+        # per-tap gather from global memory (conv_stem.hip)
+        ws = _ws(L.load().mmh_conv7_stem_wgrad_ws_bytes(C.byref(d)), x)
+        dw = out if out is not None else _empty((k, k, Cin, Cout), x)
+        L.call("mmh_conv7_stem_wgrad", C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
+               int(out is not None), _stream())
+        _count_desc("mfma", d)
         return dw
     if bf16:
         d.dtype = _dt(bf16)
