@@ -273,6 +273,11 @@ int mmh_norm_stats(const void* x, int groups, int64_t rows_per_group, int C,
 int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, void* mean,
                          void* m2, mmh_stream_t s);
 
+/* mmh_norm_stats_merge + mmh_norm_finalize of a norm without affine parameters and running statistics
+ * (nn.InstanceNorm2d) in one launch: the same fp32 mean / M2 / scale / shift / invstd as the two calls.   */
+int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, int C, double count,
+                                  float eps, void* mean, void* m2, void* scale, void* shift,
+                                  void* invstd, mmh_stream_t s);
 /* scale = gamma*rsqrt(m2/count+eps), shift = beta - mean*scale, invstd.
  * gamma/beta may be NULL (affine=False).  If running_mean != NULL (batch
  * norm, groups==1) they are updated with momentum and the unbiased variance

@@ -128,8 +128,12 @@ __global__ void norm_stats_partial(const void* __restrict__ x, int xlp, int64_t 
     }
 }
 
+// scale != NULL: also the finalize step of a norm without affine parameters (InstanceNorm) - scale = invstd,
+// shift = -mean * invstd, exactly as norm_finalize_kernel computes them from the fp32 mean / M2 written here
 __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C, int chunks,
-                                 float* __restrict__ mean, float* __restrict__ m2) {
+                                 float* __restrict__ mean, float* __restrict__ m2, double count = 0.0,
+                                 float eps = 0.f, float* __restrict__ scale = nullptr,
+                                 float* __restrict__ shift = nullptr, float* __restrict__ invstd = nullptr) {
     // 32 channels x 8 chunk-lanes per block: each lane merges its chunks (Chan), then the 8
     // lanes are merged in a fixed order.
     __shared__ double sh[3][8][32];
@@ -147,10 +151,20 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
         }
     };
     if (ok) {
-        // 4 partial triples per iteration: their loads do not depend on the running merge, so 12 are
+        // 8 partial triples per iteration: their loads do not depend on the running merge, so 24 are
         // in flight instead of a load -> divide -> load chain (121 tiles per plane after a Winograd
-        // conv); the merge ORDER is unchanged (k ascending per lane)
+        // conv: two rounds per lane); the merge ORDER is unchanged (k ascending per lane)
         int k = kl;
+        for (; k + 56 < chunks; k += 64) {
+            float nb[8], mb[8], qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t o = ((int64_t)(grp * chunks + k + 8 * u) * 3) * C + c;
+                nb[u] = ws[o]; mb[u] = ws[o + C]; qb[u] = ws[o + 2 * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) merge(nb[u], mb[u], qb[u]);
+        }
         for (; k + 24 < chunks; k += 32) {
             float nb[4], mb[4], qb[4];
 #pragma unroll
@@ -178,8 +192,17 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
                 na = nt;
             }
         }
-        mean[i] = (float)ma;
-        m2[i] = (float)qa;
+        const float meanf = (float)ma, m2f = (float)qa;
+        mean[i] = meanf;
+        m2[i] = m2f;
+        if (scale) {
+            const float var = (float)((double)m2f / count);
+            const float is = 1.f / sqrtf(var + eps);
+            const float sc = 1.f * is;
+            scale[i] = sc;
+            shift[i] = 0.f - meanf * sc;
+            invstd[i] = is;
+        }
     }
 }
 
@@ -1395,6 +1418,17 @@ int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, vo
                        static_cast<const float*>(partials), groups, C, chunks, static_cast<float*>(mean),
                        static_cast<float*>(m2));
     return mmh::check_launch("norm_stats_merge");
+}
+
+int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, int C, double count, float eps,
+                                  void* mean, void* m2, void* scale, void* shift, void* invstd, mmh_stream_t s) {
+    MMH_REQUIRE(partials && mean && m2 && scale && shift && invstd && groups > 0 && chunks > 0 && C > 0 && count > 0,
+                "mmh_norm_stats_merge_finalize: bad arguments");
+    hipLaunchKernelGGL(norm_stats_final, dim3((groups * C + 31) / 32), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(partials), groups, C, chunks, static_cast<float*>(mean),
+                       static_cast<float*>(m2), count, eps, static_cast<float*>(scale), static_cast<float*>(shift),
+                       static_cast<float*>(invstd));
+    return mmh::check_launch("norm_stats_merge_finalize");
 }
 
 int mmh_norm_finalize(const void* mean, const void* m2, double count, const void* gamma,

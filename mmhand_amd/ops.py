@@ -1307,6 +1307,24 @@ def raw_norm_stats(x, groups):
     return mean, m2, rows
 
 
+def raw_norm_stats_finalize_pending(x, groups):
+    """InstanceNorm right after a Winograd F(6x6,3x3) conv: merge the per-tile partials of its output transform AND
+    finalise (scale = invstd, shift = -mean * invstd) in one launch -> (mean, scale, shift, invstd, rows), or None
+    when no partials are pending for x"""
+    B, H, W_, Cc = x.shape
+    pend = _pending_stats.get(x.data_ptr())
+    if pend is None or groups != B or pend[1] != tuple(x.shape):
+        return None
+    _pending_stats.clear()
+    stats = pend[0]
+    rows = H * W_
+    mean = _empty((groups, Cc), x); m2 = _empty((groups, Cc), x)
+    scale = torch.empty_like(mean); shift = torch.empty_like(mean); invstd = torch.empty_like(mean)
+    L.call("mmh_norm_stats_merge_finalize", _ptr(stats), groups, stats.shape[1], Cc, float(rows), EPS, _ptr(mean), _ptr(m2),
+           _ptr(scale), _ptr(shift), _ptr(invstd), _stream())
+    return mean, scale, shift, invstd, rows
+
+
 def raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var, momentum=0.1):
     groups, Cc = mean.shape
     scale = torch.empty_like(mean); shift = torch.empty_like(mean); invstd = torch.empty_like(mean)
@@ -1387,12 +1405,17 @@ class NormActFn(torch.autograd.Function):
             raise RuntimeError("NormActFn: dropout without a preceding ReLU is not supported")
         B = x.shape[0]
         groups = B if mode == "instance" else 1
-        mean, m2, rows = raw_norm_stats(x, groups)
-        count = rows
-        if mode == "batch" and sync_group is not None:
-            mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
-        scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
-                                                 running_var)
+        fast = raw_norm_stats_finalize_pending(x, groups) if (mode == "instance" and gamma is None and beta is None) else None
+        if fast is not None:
+            mean, scale, shift, invstd, rows = fast
+            count = rows
+        else:
+            mean, m2, rows = raw_norm_stats(x, groups)
+            count = rows
+            if mode == "batch" and sync_group is not None:
+                mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
+            scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
+                                                     running_var)
         ctx.defer = int(defer)
         if defer == 3:
             # defer 3 (a block's last norm: no ReLU, no dropout; its output feeds a gate / residual add and is

@@ -207,3 +207,27 @@ def test_deferred_gradient_on_a_foreign_edge_fails_loudly(dev):
     g = ops.lp_proxy((1, 12, 12, 64), dev)
     with pytest.raises(RuntimeError, match="NormBwdDefer"):
         ops.norm_bwd_defer_in(g, "test")
+
+
+def test_stats_merge_and_finalize_in_one_launch(dev):
+    """InstanceNorm after a Winograd F(6x6,3x3) conv: the per-tile partials of the output transform merged and
+    finalised by one kernel - the same fp32 mean / scale / shift / invstd as mmh_norm_stats_merge + mmh_norm_finalize,
+    and the statistics of the plane itself."""
+    from mmhand_amd import lib as L, ops
+    x = _mk((2, 20, 16, 128), 1, dev)
+    w = _mk((3, 3, 128, 128), 2, dev, 0.05)
+    y = ops.raw_conv_fprop_wino(x, w, None, True, 0, 6)
+    stats = ops._pending_stats[y.data_ptr()][0].clone()
+    B, H, W, C = y.shape
+    fast = ops.raw_norm_stats_finalize_pending(y, B)
+    assert fast is not None and not ops._pending_stats
+    mean, scale, shift, invstd, rows = fast
+    P, st = ops._ptr, ops._stream
+    m_ref = torch.empty((B, C), device=dev); m2_ref = torch.empty_like(m_ref)
+    L.call("mmh_norm_stats_merge", P(stats), B, stats.shape[1], C, P(m_ref), P(m2_ref), st())
+    sc_ref, sf_ref, is_ref = ops.raw_norm_finalize(m_ref, m2_ref, rows, None, None, None, None)
+    assert torch.equal(mean, m_ref) and torch.equal(scale, sc_ref) and torch.equal(shift, sf_ref) and torch.equal(invstd, is_ref)
+    yd = y.double().reshape(B, H * W, C)
+    assert torch.allclose(mean.double(), yd.mean(1), atol=1e-6)
+    assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + ops.EPS), rtol=1e-5)
+    assert ops.raw_norm_stats_finalize_pending(y, B) is None        # consumed
