@@ -72,6 +72,15 @@ int mmh_set_option(const char* key, int value);
 int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
                      const void* bias, void* y, int act, mmh_stream_t s);
 
+/* mmh_conv2d_fprop (fp32, no activation) that also writes, per (128-row tile, wave row) of the output GEMM,
+ * the count / mean / M2 of every output column: stats [chunks][3][Cout], chunks =
+ * mmh_conv2d_fprop_stats_chunks(d) (0: not available - B*Ho*Wo % 128 != 0 or a 16-bit dtype).  The norm
+ * behind the conv (models/Generator.py:158-175 stems and down convs) merges them with
+ * mmh_norm_stats_merge[_finalize] instead of reading y again; consecutive chunks cover consecutive pixels, so
+ * with Ho*Wo % 128 == 0 the chunks of an image are contiguous (InstanceNorm: groups = B).              */
+int mmh_conv2d_fprop_stats_chunks(const mmh_conv_desc* d);
+int mmh_conv2d_fprop_stats(const mmh_conv_desc* d, const void* x, const void* w, const void* bias,
+                           void* y, void* stats, mmh_stream_t s);
 /* Gradient w.r.t. x.  MMH_PAD_ZERO: dx is [B,H,W,Cin] (channel stride
  * dx_cs).  MMH_PAD_REFLECT: dx is the gradient on the padded domain,
  * [B,H+2p,W+2p,Cin]; fold it with mmh_reflect_fold.                        */

@@ -125,6 +125,8 @@ struct ConvKP {
     int accum;                  // epilogue adds into out instead of overwriting it
     int h16;                    // 16-bit kernels: 0 = bf16, 1 = fp16 operands
     int src16;                  // 16-bit kernels: the gathered tensor is already 16-bit in HBM (chunk-major k order only)
+    float* stats;               // fp32 fprop: per (row tile, wave row) the count / mean / M2 of every output column
+                                // [M/BM * WAVES_M][3][N] - the norm behind the conv merges them instead of reading y
 };
 
 struct KState { int th, tw, c4, j; };   // j: chunk index inside the current tap visit
@@ -527,6 +529,38 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
                     if (p.accum) v += p.out[off + n];
                     p.out[off + n] = apply_act(v, p.act);
                 }
+            }
+        }
+    }
+    if (p.stats) {
+        // statistics of this wave's WTM x WTN block of y per column (host: every row tile is full, no activation):
+        // a lane holds TM*16 rows of column n, its partner lane ^ 32 the other half; Chan merge of the two
+        constexpr float CNT = (float)(TM * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            const float b = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r] + b;
+            const float mean_l = sum * (1.f / CNT);
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dv = acc[i][j][r] + b - mean_l;
+                    m2 += dv * dv;
+                }
+            const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+            const float dm = mean_o - mean_l;
+            if (h == 0 && n < p.N) {
+                float* o = p.stats + ((size_t)(mt * WAVES_M + wm) * 3) * p.N + n;
+                o[0] = 2.f * CNT;
+                o[p.N] = mean_l + 0.5f * dm;
+                o[2 * p.N] = m2 + m2_o + dm * dm * (0.5f * CNT);
             }
         }
     }
@@ -2291,7 +2325,7 @@ int launch_conv(const ConvKP& p, hipStream_t st) {
         const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
         return launch_conv_t<256, 2, 2, NMAJOR, false>(p, st);
     }
-    if (g_conv_tall == 2 && p.N > 32 && p.N <= 64 && p.M >= 256 * 512) {   // measured: no gain on the stems (A/B only)
+    if (g_conv_tall == 2 && !p.stats && p.N > 32 && p.N <= 64 && p.M >= 256 * 512) {   // measured: no gain on the stems (A/B only)
         const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd1 && (p.M + 255) / 256 >= 8) ? 1 : 0;
         return launch_conv_tall_t<64, 4, 1, NMAJOR>(p, st);
     }
@@ -2323,9 +2357,19 @@ Gather fwd_gather(const mmh_conv_desc* d, const void* x) {
     return g;
 }
 
+// partial rows the fp32 direct fprop writes when asked for output statistics: (M / 128) row tiles x wave rows of the
+// kernel launch_conv picks for this N; 0 = not available (ragged row tiles, 16-bit, tall tiles)
+int fprop_stats_chunks(const mmh_conv_desc* d) {
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    if (is16(d->dtype) || M % BM != 0 || d->Cout % 4 != 0) return 0;
+    const int waves_m = d->Cout > 32 ? 2 : 4;
+    return (int)(M / BM) * waves_m;
+}
+
 int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y,
-             int act, hipStream_t st) {
+             int act, hipStream_t st, float* stats = nullptr) {
     ConvKP p{};
+    p.stats = stats;
     p.g = fwd_gather(d, x);
     set_korder(p.g, p.nk, p.Kflat);
     p.w = static_cast<const float*>(w);
@@ -3141,6 +3185,16 @@ int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w, const
     if (int rc = validate(d)) return rc;
     MMH_REQUIRE(x && w && y, "mmh_conv2d_fprop: NULL buffer");
     return do_fprop(d, x, w, bias, y, act, mmh::as_stream(s));
+}
+
+int mmh_conv2d_fprop_stats_chunks(const mmh_conv_desc* d) { return d ? fprop_stats_chunks(d) : 0; }
+
+int mmh_conv2d_fprop_stats(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y,
+                           void* stats, mmh_stream_t s) {
+    if (int rc = validate(d)) return rc;
+    MMH_REQUIRE(x && w && y && stats, "mmh_conv2d_fprop_stats: NULL buffer");
+    MMH_REQUIRE(fprop_stats_chunks(d) > 0, "mmh_conv2d_fprop_stats: needs fp32 and B*Ho*Wo %% 128 == 0");
+    return do_fprop(d, x, w, bias, y, MMH_ACT_NONE, mmh::as_stream(s), static_cast<float*>(stats));
 }
 
 int mmh_conv2d_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, int dx_cs,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "mmh_version": (_i, []),
     "mmh_set_option": (_i, [C.c_char_p, _i]),
     "mmh_conv2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mmh_conv2d_fprop_stats_chunks": (_i, [_DP]),
+    "mmh_conv2d_fprop_stats": (_i, [_DP, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_conv2d_dgrad": (_i, [_DP, _vp, _vp, _vp, _i, _vp]),
     "mmh_conv2d_dgrad_folded_ws_bytes": (_sz, [_DP]),
     "mmh_conv2d_dgrad_folded": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _vp]),

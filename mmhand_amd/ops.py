@@ -405,7 +405,9 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None, nbd=None):
     return dx, dw
 
 
-def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False):
+def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False, want_stats=False):
+    """want_stats: the output feeds an InstanceNorm directly - the direct fp32 kernel then leaves per-tile statistics
+    of y for it (as the Winograd output transform does; _pending_stats)"""
     _chk(x, "x"); _chk(w, "w")
     B, H, W_, Cin = x.shape
     k, _, wc, Cout = w.shape
@@ -445,6 +447,15 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False)
         d.dtype = _dt(bf16)
         w = bf16_weights(w, bf16)[1]
     _count_desc("mfma", d)
+    if (want_stats and FUSE_NORM_STATS and not bf16 and act == L.ACT_NONE and (d.Ho * d.Wo) % 128 == 0
+            and not (fprop_timer is not None and fprop_timer.want(d))):
+        chunks = L.load().mmh_conv2d_fprop_stats_chunks(C.byref(d))
+        if chunks > 0:
+            stats = _empty((B, chunks // B, 3, Cout), x)
+            L.call("mmh_conv2d_fprop_stats", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(stats), _stream())
+            _pending_stats.clear()
+            _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+            return y
     if fprop_timer is not None and fprop_timer.want(d):
         e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
         e0.record()
@@ -1122,7 +1133,7 @@ class Conv2dFn(torch.autograd.Function):
             ctx.wino_V = wt
             ctx.save_for_backward(V, w, y if act != L.ACT_NONE else None)
             return y
-        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act, bf16)
+        y = raw_conv_fprop(x, w, bias, stride, pad, reflect, act, bf16, want_stats=bool(null_bias_grad))
         ctx.save_for_backward(x, w, y if act != L.ACT_NONE else None)
         return y
 

@@ -231,3 +231,39 @@ def test_stats_merge_and_finalize_in_one_launch(dev):
     assert torch.allclose(mean.double(), yd.mean(1), atol=1e-6)
     assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + ops.EPS), rtol=1e-5)
     assert ops.raw_norm_stats_finalize_pending(y, B) is None        # consumed
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,reflect,H", [(8, 64, 7, 1, 3, True, 16), (64, 128, 3, 2, 1, False, 32),
+                                                            (128, 256, 3, 2, 1, False, 32), (4, 64, 3, 1, 1, False, 16)])
+def test_direct_fprop_leaves_output_statistics(Cin, Cout, k, stride, pad, reflect, H, dev, monkeypatch):
+    """The direct fp32 fprop (stems, stride-2 convs) writes per-tile count / mean / M2 of its output columns from its
+    epilogue; the InstanceNorm behind it merges them instead of reading y: same normalised output as from a pass over y."""
+    from mmhand_amd import lib as L, ops
+    B = 2
+    x = _mk((B, H, H, Cin), 1, dev)
+    w = _mk((k, k, Cin, Cout), 2, dev, 0.05)
+    bias = _mk((Cout,), 3, dev)
+    calls = []
+    real = L.call
+    monkeypatch.setattr(L, "call", lambda n, *a: (calls.append(n), real(n, *a))[1])
+    y = ops.raw_conv_fprop(x, w, bias, stride, pad, reflect, want_stats=True)
+    assert "mmh_conv2d_fprop_stats" in calls and y.data_ptr() in ops._pending_stats
+    y_plain = ops.raw_conv_fprop(x, w, bias, stride, pad, reflect)
+    assert torch.equal(y, y_plain)
+    ops._pending_stats.clear()
+    ops._pending_stats[y.data_ptr()] = None      # placeholder, replaced below
+    y2 = ops.raw_conv_fprop(x, w, bias, stride, pad, reflect, want_stats=True)
+    fast = ops.raw_norm_stats_finalize_pending(y2, B)
+    assert fast is not None
+    mean, scale, shift, invstd, rows = fast
+    yd = y2.double().reshape(B, -1, Cout)
+    assert rows == yd.shape[1]
+    assert torch.allclose(mean.double(), yd.mean(1), atol=2e-6)
+    assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + ops.EPS), rtol=2e-5)
+    # through the autograd function: statistics from the conv epilogue == statistics from a pass over y
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ops, "FUSE_NORM_STATS", fuse)
+        yy = ops.raw_conv_fprop(x, w, bias, stride, pad, reflect, want_stats=True)
+        outs.append(ops.NormActFn.apply(yy, None, None, None, None, None, "instance", True, 0.0, 0, None, None))
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
