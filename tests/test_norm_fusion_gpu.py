@@ -137,8 +137,10 @@ def test_decide_again_backward_kernels_match_keep_bit_kernels(groups_is_b, relu,
 
 
 @pytest.mark.parametrize("norm", ["instance", "batch"])
-@pytest.mark.parametrize("last_norm,frozen", [(True, False), (False, False), (True, True)])
-def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, dev, monkeypatch):
+@pytest.mark.parametrize("last_norm,frozen,shape", [(True, False, (2, 22, 16, 128)), (False, False, (2, 22, 16, 128)),
+                                                    (True, True, (2, 22, 16, 128)),
+                                                    (True, False, (1, 128, 130, 128))])   # configs[4]-sized maps, 5 row words
+def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, shape, dev, monkeypatch):
     """RP-conv-norm-ReLU-dropout-RP-conv(-norm): fusion on against fusion off, bit for bit; frozen: weights
     without gradients (the discriminators inside the generator step) - there the deferred gradient of the
     norm's input is materialised (mmh_norm_bwd_apply_rc) instead of computed inside the backward transform."""
@@ -157,7 +159,6 @@ def test_two_conv_block_fused_vs_unfused(norm, last_norm, frozen, dev, monkeypat
     net = Net().init_weights("normal", seed=3).to(dev)
     net.flatten_parameters()
     net.train()
-    shape = (2, 22, 16, 128)
     x = _mk(shape, 1, dev)
     gy = _mk(shape, 2, dev)
     mask = _mask(shape, 5, dev)
