@@ -1,7 +1,12 @@
 """Headline benchmark: 256x256 hand images/s for one full G+D step (optimize_parameters).
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Started without a launcher (no WORLD_SIZE in the environment) and with --gpus N > 1, bench.py starts
+its own N ranks as CHILD processes - one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before
+this process has touched the GPU - and relays rank 0's JSON line (the reference's launcher:
+scripts/mm-train-ratio.sh:19-21 + options/base_options.py:171-178).
 
 Workload (BASELINE.json configs[1]): RHD-shaped synthetic batch, 256x256, per-GPU batch 32, fp32,
 Generator (9 PATBlocks, ngf 64) + D_PB + D_PP + L1/perceptual/GAN losses + 3 Adams, dropout on,
@@ -86,14 +91,14 @@ CPU_THREADS = 16   # measured on the GPU box (256 logical CPUs): oneDNN conv fwd
                    # 16 threads (14 ms) and 14x slower at 128 (tools/cpu_probe.py)
 
 
-def cpu_baseline_child(H, W, norm, budget_s):
+def cpu_baseline_child(H, W, norm, budget_s, threads=CPU_THREADS, max_steps=10):
     """Runs in a child process that never touches the GPU.  Prints one JSON object.
     SURVEY.md §8(d) protocol: B=2, 256x256, fp32, 2 warm-up + 10 timed iterations (BASELINE.json
     configs[0]); the timed count shrinks only if the budget would be exceeded (stated in `sample`)."""
     import random
     from mmhand_amd.networks import Discriminator, Generator, VGGHead
     from oracle import mmhand_ref as O
-    nthreads = max(1, min(CPU_THREADS, len(os.sched_getaffinity(0))))
+    nthreads = max(1, min(threads, len(os.sched_getaffinity(0))))
     torch.set_num_threads(nthreads)
     g = Generator([3, 42, 6], 3, 64, norm, True, 9).init_weights("normal", 49)
     dpb = Discriminator(24, 64, norm, True, 3).init_weights("normal", 50)
@@ -104,37 +109,38 @@ def cpu_baseline_child(H, W, norm, budget_s):
     B = 2
     batch = O.synthetic_batch(B, H, W, seed=49)
     t0 = time.time()
-    for _ in range(2):
-        orc.step(batch)
+    nwarm = 0
+    while nwarm < 2 and (nwarm < 1 or time.time() - t0 < budget_s / 2):
+        orc.step(batch); nwarm += 1
     warm = time.time() - t0
     n, t1 = 0, time.time()
-    while n < 10 and (n < 2 or time.time() - t1 < budget_s):
+    while n < max_steps and (n < 1 or time.time() - t1 < budget_s):
         orc.step(batch); n += 1
     dt = (time.time() - t1) / n
     print(json.dumps({"value": round(B / dt, 4), "unit": "images/s", "cores": nthreads,
                       "kind": "port", "sample": f"{n} timed G+D steps at B={B}, {H}x{W}, fp32, --norm "
-                      f"{norm}, dropout on, after 2 warm-up steps ({warm:.1f}s), {nthreads} threads of "
-                      f"{os.cpu_count()} logical CPUs (oneDNN is fastest near 16 threads on this host and "
-                      f"an order of magnitude slower at 128+: tools/cpu_probe.py); "
-                      f"oracle/mmhand_ref.py StepOracle"}), file=_OUT, flush=True)
+                      f"{norm}, dropout on, after {nwarm} warm-up step(s) ({warm:.1f}s), {nthreads} threads of "
+                      f"{os.cpu_count()} logical CPUs; oracle/mmhand_ref.py StepOracle"}), file=_OUT, flush=True)
 
 
-def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300):
+def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=CPU_THREADS, max_steps=10):
     """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
     host's cores on a bounded sample of the same workload, in a child process with a hard timeout."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--size", str(H),
-           "--norm", norm, "--cpu-budget", str(budget_s)]
+           "--norm", norm, "--cpu-budget", str(budget_s), "--cpu-threads", str(threads), "--cpu-max-steps", str(max_steps)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env)
         for line in reversed(out.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"value": None, "unit": "images/s", "cores": CPU_THREADS, "kind": "port",
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": "child failed: " + out.stderr[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "images/s", "cores": CPU_THREADS, "kind": "port",
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": f"child exceeded the {hard_timeout_s}s hard timeout"}
 
 
@@ -188,6 +194,218 @@ def _json_only_stdout():
     sys.stdout = sys.stderr
 
 
+class StackMeter:
+    """HIP-event brackets around every C-ABI call of the 3x3 / stride-1 stack with 256 / 512 channels (SURVEY.md
+    §2.3 K4: the PATBlocks' and the Discriminators' residual convs) in 16-bit mode - fprop and the dgrad main term
+    (mmh_conv3x3_lp16), the reflect border terms of the dgrad (mmh_conv2d_dgrad_border) and the wgrad
+    (mmh_wgrad3x3_lp16) - during a few steps.  stack fraction = sum(algorithmic FLOPs 2.B.H.W.Cin.Cout.9 of every
+    pass) / sum(bracketed time) / peak: the north_star's ">= 40 % MFMA on the 3x3 generator conv stack" as measured."""
+    NAMES = ("mmh_conv3x3_lp16", "mmh_wgrad3x3_lp16", "mmh_conv2d_dgrad_border")
+
+    def __init__(self):
+        self.rec = []
+
+    def __enter__(self):
+        from mmhand_amd import lib as L
+        self.L, self.real = L, L.call
+
+        def timed(name, *args):
+            if name not in self.NAMES:
+                return self.real(name, *args)
+            d = next((getattr(x, "_obj", None) for x in args if isinstance(getattr(x, "_obj", None), L.ConvDesc)), None)
+            if d is None or d.kh != 3 or d.stride != 1 or min(d.Cin, d.Cout) < 256:
+                return self.real(name, *args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.real(name, *args)
+            e1.record()
+            kind = "border" if name.endswith("border") else ("wgrad" if "wgrad" in name else ("fprop", "dgrad")[int(args[1])])
+            flop = 0.0 if kind == "border" else 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * 9
+            self.rec.append((kind, (d.Cin, d.Cout), flop, e0, e1))
+            return r
+        L.call = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call = self.real
+
+    def summary(self, peak_tf):
+        torch.cuda.synchronize()
+        by = {}
+        for kind, shape, flop, e0, e1 in self.rec:
+            c = by.setdefault((kind, shape), [0, 0.0, 0.0])
+            c[0] += 1; c[1] += flop; c[2] += e0.elapsed_time(e1)
+        tot_f = sum(c[1] for c in by.values()); tot_ms = sum(c[2] for c in by.values())
+        per = {f"{k}_{ci}x{co}": {"launches": c[0], "ms": round(c[2], 3),
+                                  "tflops": round(c[1] / (c[2] * 1e-3) / 1e12, 1) if c[1] else None}
+               for (k, (ci, co)), c in sorted(by.items())}
+        return {"stack_frac": round(tot_f / (tot_ms * 1e-3) / 1e12 / peak_tf, 4) if tot_ms else None,
+                "stack_tflop": round(tot_f / 1e12, 3), "stack_ms": round(tot_ms, 2), "per_pass": per}, by
+
+
+def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, **opt_kw):
+    """A fresh MMHandModel with option overrides: images/s over `steps` optimize_parameters() calls (inputs resident),
+    measured like the headline region; optionally the 16-bit stack fraction from a separate bracketed pass."""
+    import gc
+    from mmhand_amd.mmhand_model import MMHandModel
+    from mmhand_amd.options import default_train_opt
+    kw = dict(batchSize=B, norm="instance", name="bench_side", local_rank=dev.index, checkpoints_dir="/tmp/mmh_bench")
+    kw.update(opt_kw)
+    model = MMHandModel(default_train_opt(**kw))
+    model.set_input(synthetic_batch_gpu(B, size, size, 49, dev))
+    for _ in range(warmup):
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 2), "steps": steps, "warmup": warmup}
+    if stack:
+        with StackMeter() as m:
+            for _ in range(stack_steps):
+                model.optimize_parameters()
+        summ, by = m.summary(PEAK_BF16_MFMA_TF)
+        out.update(summ)
+        c = by.get(("fprop", (512, 512)))
+        if c and c[2] > 0:
+            ach = c[1] / (c[2] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_BF16_MFMA_TF, 4),
+                               "kernel": f"conv_lp16h_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
+                                         f"{c[1] / c[0] / 1e9:.1f} GFLOP/launch, {c[2] / c[0]:.3f} ms avg over {c[0]} launches"}
+    out["losses_finite"] = all(torch.isfinite(v).item() for v in model.get_current_errors().values())
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_infer_run(dev, B, size, steps, bf16):
+    """configs[3]: Generator forward only, eval BatchNorm folded into the convs, hipGraph replay"""
+    import gc
+    from mmhand_amd.inference import InferenceGenerator
+    from mmhand_amd.networks import Generator
+    net = Generator([3, 42, 6], 3, 64, "batch", True, 9).init_weights("normal", 49).to(dev).eval()
+    gen = InferenceGenerator(net, use_graph=True, bf16=bf16)
+    b = synthetic_batch_gpu(B, size, size, 49, dev)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    for _ in range(2):
+        gen(g_in)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gen(g_in)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del gen, net
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"images_per_s": round(B / ms * 1e3, 2), "ms_per_batch": round(ms, 2), "batch": B, "steps": steps}
+
+
+def rccl_child_run(steps, warmup, batch, size, timeout_s=420):
+    """The same step through the data-parallel code path on RCCL with ONE rank, in a child process with a hard timeout:
+    init_process_group("nccl"), the parameter broadcast, the bucketed gradient all-reduces on the side stream and the
+    deferred optimizer steps (mmhand_amd/dp.py) all run on the real communicator.  A 1-GPU box cannot show scaling; it
+    can show that the path the N-GPU launch takes works on this hardware, and what it costs."""
+    import subprocess
+    env = dict(os.environ, MMH_FORCE_DP="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+           "--batch", str(batch), "--size", str(size), "--no-side-runs", "--no-cpu-baseline"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child exceeded {timeout_s}s"}
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            j = json.loads(line)
+            return {"images_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": steps,
+                    "rccl_ranks": j.get("rccl_ranks"), "backend": j.get("backend")}
+    return {"error": f"rc {out.returncode}: " + out.stderr[-400:]}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """python bench.py --gpus N without a launcher: start N ranks as child processes of this one (which
+    never touches the GPU: torch.cuda.device_count() does not initialise it) and relay rank 0's JSON
+    line.  A rank that fails ends the others (by their own PIDs) and its exit code becomes ours."""
+    import subprocess
+    if "--selftest-ranks" not in argv:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py --gpus {n}: this node exposes {have} GPU(s)", file=sys.stderr, flush=True)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // n))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=_OUT if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:      # a dead rank would leave the others waiting in a collective
+                    q.terminate()
+    return rc
+
+
+def init_rccl(dev, world=None, rank=None, port=None):
+    """torch.distributed over RCCL (backend "nccl" on ROCm), one node: rendezvous on 127.0.0.1 (the container
+    hostname may not resolve), RCCL's socket bootstrap on the loopback interface; the data path is xGMI / P2P."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    if world is None:
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    else:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port or _free_port()}", world_size=world,
+                                rank=rank, device_id=dev)
+
+
+def rccl_ranks(dev):
+    """the number of ranks RCCL really connects: an all-reduce(SUM) of ones"""
+    if not dist.is_initialized():
+        return 0
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def selftest_ranks():
+    """hidden --selftest-ranks: what a rank started by self_launch sees, without a GPU (gloo) - the CPU test of
+    the launcher (tests/test_host_cpu.py)"""
+    dist.init_process_group("gloo", init_method="env://")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"ranks": int(t.item()), "world": dist.get_world_size(),
+                          "local_rank": int(os.environ["LOCAL_RANK"])}), file=_OUT, flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     _json_only_stdout()
     ap = argparse.ArgumentParser()
@@ -199,39 +417,48 @@ def main():
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-winograd", action="store_true",
-                    help="direct implicit-GEMM kernels for every conv (default: Winograd F(6x6,3x3) for the "
-                         "fp32 3x3 stride-1 convs with >= 128x128 channels, F(2x2,3x3) in bf16)")
+                    help="direct implicit-GEMM kernels for every conv (default: fp32 runs the 3x3 stride-1 convs "
+                         "with >= 128x128 channels on Winograd F(6x6,3x3); 16-bit mode runs them direct on "
+                         "conv_lp16.hip either way)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = BASELINE.json configs[1] (default); bf16 = bf16 MFMA compute, fp32 master "
-                         "weights/accumulate/HBM tensors (the --opt_level O1 path; configs[2]/[4] precision)")
+                    help="f32 = BASELINE.json configs[1] (default); bf16 = the --opt_level O1 path (configs[2]/[4] "
+                         "precision): bf16 MFMA operands, every conv-facing tensor 16-bit in HBM, fp32 master "
+                         "weights / accumulation / statistics, dynamic loss scaling")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=60.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=CPU_THREADS, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-max-steps", type=int, default=10, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-all-cores", type=float, default=0.0, metavar="SECONDS",
+                    help="also time the CPU oracle with os.cpu_count() threads inside this budget (off by default)")
+    ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-side-runs", action="store_true",
-                    help="skip the extra driver-visible measurements (direct-kernel steps, set_input in the "
-                         "loop); profiling runs use this to keep the kernel trace to the headline path")
+                    help="skip the extra driver-visible measurements (direct-kernel steps, set_input in the loop, "
+                         "16-bit mode, --norm batch, RCCL world-1, inference, 512x512); profiling runs use this to "
+                         "keep the kernel trace to the headline path")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE.json configs[3]: Generator forward only, BN folded, hipGraph")
     a = ap.parse_args()
     if a.cpu_baseline_child:
-        return cpu_baseline_child(a.size, a.size, a.norm, a.cpu_budget)
+        return cpu_baseline_child(a.size, a.size, a.norm, a.cpu_budget, a.cpu_threads, a.cpu_max_steps)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing has touched the GPU yet (and this process never will).
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    if a.selftest_ranks:
+        return selftest_ranks()
     if a.mode == "infer":
         return infer_main(a)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or a.gpus > 1:
-        assert world == a.gpus, f"launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} inside a {world}-rank launch: start it with "
+                         f"--nproc-per-node {a.gpus} (or without a launcher: it starts its own ranks)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dp = os.environ.get("MMH_FORCE_DP") == "1" and "RANK" in os.environ
     if world > 1 or force_dp:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            # one node: RCCL's socket bootstrap on the loopback interface (the container hostname
-            # may not resolve); the data path is xGMI / P2P regardless
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        init_rccl(dev)
 
     from mmhand_amd import ops
     if a.no_winograd:
@@ -305,8 +532,10 @@ def main():
             d = tt.item()
         return d / n * 1e3
 
+    n_rccl = rccl_ranks(dev)
     side = {}
-    if not a.no_side_runs:
+    side_ok = not a.no_side_runs and world == 1 and not force_dp
+    if side_ok:
         # (1) the reference's set_input inside the loop: the batch comes from pinned HOST memory every
         # step (H2D over PCIe + the NHWC pack), as train.py:35 does per iteration
         host = {k: v.cpu().pin_memory() for k, v in batch.items()}
@@ -329,6 +558,41 @@ def main():
                                    "implicit-GEMM MFMA kernels (bench.py --no-winograd)"}
             ops.USE_WINOGRAD = True
             ops.bump_weights_epoch()
+    vgg_source = getattr(model, "vgg_source", "n/a")
+    ops.fprop_timer = None
+    if side_ok:
+        # (3)... fresh models: the 16-bit mode, the reference's default --norm batch, RCCL with one rank, the other
+        # BASELINE.json configs at their per-GPU shapes.  Each is guarded: a failure is reported under its key.
+        del model
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+        n_side = max(2, min(5, a.steps))
+
+        def guarded(key, fn):
+            try:
+                side[key] = fn()
+            except Exception as e:      # noqa: BLE001 - the headline line must survive a failing side run
+                side[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
+        if a.dtype == "f32":
+            guarded("bf16_path", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, stack=True, opt_level="O1",
+                                                             norm=a.norm),
+                                              note="configs[2]'s precision and per-GPU shape on one GPU: --opt_level O1 (bf16 "
+                                                   "MFMA operands, 16-bit conv-facing tensors, fp32 master weights, dynamic "
+                                                   "loss scaling); stack_frac = the 3x3 stride-1 256/512-channel stack, all "
+                                                   "three passes incl. reflect border terms, algorithmic FLOPs / kernel time / 2500 TF"))
+        guarded("norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch",
+                                                          opt_level="O1" if a.dtype == "bf16" else "O0"),
+                                           note="the reference's script default --norm batch (BatchNorm2d affine, conv bias off)"))
+        guarded("dp_rccl_world1", lambda: dict(rccl_child_run(n_side, 2, a.batch, a.size),
+                                               note="same fp32 step through the data-parallel path (MMH_FORCE_DP=1) on RCCL, "
+                                                    "world size 1, own process"))
+        guarded("size512_bf16_b4", lambda: dict(side_train_run(dev, 4, 512, n_side, opt_level="O1"),
+                                                note="configs[4] per-GPU shape: 512x512, batch 4 (16/4), bf16"))
+        guarded("infer_b64_f32", lambda: dict(side_infer_run(dev, 64, 256, n_side, False),
+                                              note="configs[3]: Generator forward, batch 64, BN folded, hipGraph replay"))
+        guarded("infer_b64_bf16", lambda: side_infer_run(dev, 64, 256, n_side, True))
 
     if rank == 0:
         imgs_per_s = world * a.batch * a.steps / dt
@@ -377,7 +641,7 @@ def main():
                        f"{'bf16 MFMA compute' if a.dtype == 'bf16' else 'fp32'}"
                        f"{f' (Winograd F({wtile}x{wtile},3x3) on the 3x3 stack)' if wino else ''}, G(9 PATBlocks,"
                        f" ngf64)+D_PB+D_PP+L1/perceptual/GAN+Adam, --norm {a.norm}, dropout on; VGG19[:4] "
-                       f"weights: {getattr(model, 'vgg_source', 'n/a')}",
+                       f"weights: {vgg_source}",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}"},
             # BASELINE.md §4's formula (2444.4 GFLOP of DIRECT convolution per image and step x images/s
             # / peak).  With Winograd on the 3x3 stack it exceeds 1.0, because F(6x6,3x3) executes 5.06x
@@ -390,10 +654,20 @@ def main():
             "peak_hbm_gib": peak_gib,
             "roofline": roof,
             "losses": {k: round(v, 5) for k, v in losses.items()},
+            # ranks the collective backend really connects (an all-reduce of ones); 0 = single process, no
+            # process group.  N > 1: gradients of G / D_PB / D_PP all-reduced over RCCL (mmhand_amd/dp.py)
+            "rccl_ranks": n_rccl, "backend": ("nccl(RCCL)" if dist.is_initialized() else None),
         }
         line.update(side)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not force_dp and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
+            # SURVEY.md §8(d) asks for os.cpu_count() threads.  On the GPU box's 256 logical CPUs oneDNN is far slower
+            # at 128+ threads than at 16 (tools/cpu_probe.py; one B=2 step did not finish in 240 s): opt-in, measured
+            # once and kept in profiles/r03_cpu_all_cores.json, not paid by every default run
+            if a.cpu_all_cores and (os.cpu_count() or 0) > CPU_THREADS:
+                allc = cpu_baseline(H, W, a.norm, budget_s=a.cpu_all_cores, hard_timeout_s=int(a.cpu_all_cores * 2 + 60),
+                                    threads=os.cpu_count(), max_steps=2)
+                line["cpu_baseline"]["all_cores"] = {k: allc.get(k) for k in ("value", "cores", "sample")}
         print(json.dumps(line), file=_OUT, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

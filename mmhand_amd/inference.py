@@ -197,8 +197,8 @@ class InferenceGenerator:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_out = self._eager(self._static_in)
-        # the captured launches read the derived weights (bf16 copies, Winograd-domain filters) made
-        # during the warm-up: hold them for as long as the graph lives (ops drops its cache at every
-        # weights-epoch bump)
-        self._derived = (dict(ops._wino_cache), dict(ops._bf16_cache))
+        # the captured launches read the derived weights (16-bit copies, flat-K stem copies, Winograd-domain
+        # filters) made during the warm-up by raw pointer: hold ALL of them for as long as the graph lives
+        # (ops drops its caches at every weights-epoch bump - any optimizer step, any re-fold)
+        self._derived = ops.derived_weights_snapshot()
         self._graph, self._key = g, key

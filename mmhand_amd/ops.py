@@ -90,9 +90,19 @@ def bump_weights_epoch():
     too.  Entries additionally hold a weak reference to the tensor object they were made from - a new
     tensor that happens to land on a freed tensor's address never hits a stale entry."""
     _weights_epoch[0] += 1
-    _bf16_cache.clear()
-    _flat8_cache.clear()
-    _wino_cache.clear()
+    for c in _DERIVED_CACHES():
+        c.clear()
+
+
+def derived_weights_snapshot():
+    """Every derived weight tensor alive right now (16-bit copies, flat-K copies, Winograd-domain filters), as
+    one object to hold on to: a captured hipGraph reads these tensors by raw pointer, and bump_weights_epoch()
+    - every optimizer step, every re-fold - empties the caches.  New caches must be added to _DERIVED_CACHES."""
+    return tuple(dict(c) for c in _DERIVED_CACHES())
+
+
+def _DERIVED_CACHES():
+    return (_bf16_cache, _flat8_cache, _wino_cache)
 
 
 def _cache_get(cache, key, w):

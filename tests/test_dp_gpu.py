@@ -166,3 +166,59 @@ def test_overflow_on_one_rank_skips_the_step_on_every_rank(dev, tmp_path):
         assert r["unchanged"] == {"netG": True, "netD_PP": True, "netD_PB": True}, r["unchanged"]
         assert r["skipped"] == 3 and r["steps"] == [1, 1, 1], (r["skipped"], r["steps"])
     assert torch.equal(r0["G"], r1["G"])
+
+
+def _worker_rccl(rank, world, port, norm, tmp):
+    """ONE rank on RCCL (backend "nccl"): the data-parallel path of MMHandModel on the real communicator"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      MMH_FORCE_DP="1", MMH_DP_LOG="1", MMH_BUCKET_MB="0.02", NCCL_SOCKET_IFNAME="lo")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    from oracle import mmhand_ref as O
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    t = torch.ones(1, device="cuda")
+    dist.all_reduce(t)
+    from mmhand_amd import mmhand_model
+    from mmhand_amd.mmhand_model import MMHandModel
+    random.seed(0)
+    batch = O.synthetic_batch(2, 32, 32, seed=7)
+    model = MMHandModel(_opt(norm, 2, True))
+    assert model.dp and model.comm_stream is not None
+    losses = []
+    for _ in range(2):
+        model.set_input(batch)
+        model.optimize_parameters()
+        losses.append([float(v) for v in model.get_current_errors().values()])
+    torch.cuda.synchronize()
+    sd = {n: getattr(model, n).flat_param.detach().cpu() for n in ("netG", "netD_PB", "netD_PP")}
+    torch.save({"losses": losses, "sd": sd, "ranks": int(t.item()), "backend": dist.get_backend(),
+                "log": list(mmhand_model._LAST_BUCKET_LOG or [])}, os.path.join(tmp, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("norm,port", [("instance", 29631), ("batch", 29632)])
+def test_rccl_one_rank_dp_step_equals_plain_step(norm, port, dev, tmp_path):
+    """RCCL under test: two optimize_parameters() through the data-parallel path - parameter
+    broadcast, bucketed all-reduce from the autograd hooks on the side stream (ProcessGroupNCCL stream semantics:
+    async_op + Work.wait() order the CURRENT stream behind the collective), deferred optimizer steps, SyncBN
+    collectives under --norm batch - on backend "nccl" with one rank must leave exactly the parameters of the
+    single-process step: a SUM over one rank is the identity and 1/world = 1."""
+    mp.spawn(_worker_rccl, args=(1, port, norm, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
+    assert r["ranks"] == 1 and r["backend"] == "nccl"
+    assert any(e[1] == "bucket" for e in r["log"])
+    from oracle import mmhand_ref as O
+    from mmhand_amd.mmhand_model import MMHandModel
+    random.seed(0)
+    batch = O.synthetic_batch(2, 32, 32, seed=7)
+    model = MMHandModel(_opt(norm, 2, False))
+    losses = []
+    for _ in range(2):
+        model.set_input(batch)
+        model.optimize_parameters()
+        losses.append([float(v) for v in model.get_current_errors().values()])
+    torch.cuda.synchronize()
+    assert np.array_equal(np.array(losses), np.array(r["losses"])), (losses, r["losses"])
+    for n in ("netG", "netD_PB", "netD_PP"):
+        assert torch.equal(getattr(model, n).flat_param.detach().cpu(), r["sd"][n]), n

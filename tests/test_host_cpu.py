@@ -207,3 +207,26 @@ def test_draw_pose_from_cords_rasterisation():
     # the bone's angle, so the long axis follows the bone: 8 px to each side across it
     col = np.all(img[60] == cmap[3], axis=1)                             # row through the middle of finger 0, bone 1
     assert col[24 - 8] and col[24 + 8] and not col[24 - 10]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE around it (how the driver invokes it) starts N child ranks
+    itself and relays rank 0's JSON line (scripts/mm-train-ratio.sh:19-21 is the reference's launcher).  The
+    hidden --selftest-ranks makes each rank rendezvous over gloo instead of touching a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT")}
+    env["GLOO_SOCKET_IFNAME"] = "lo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-ranks"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # stdout carries exactly rank 0's line
+    assert json.loads(lines[0]) == {"ranks": 2, "world": 2, "local_rank": 0}
+
+
+def test_bench_refuses_a_mismatched_launch():
+    """--gpus N inside a launch of another size is an error, not a silent single-rank run"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "1-rank launch" in out.stderr

@@ -1,0 +1,111 @@
+"""Step-level parity of the 16-bit mode (--opt_level O1 = bf16, O1_FP16 = IEEE fp16; apex AMP in the reference,
+models/MMHandModel.py:99-108,294-330) against the fp64 oracle - not against this repo's own fp32 run.
+
+ngf = ndf = 64 (PATBlock channels 256 / 512, Discriminator trunk 256), 64x64 inputs, B = 2, dropout off: every
+second-generation 16-bit kernel of the benchmarked 16-bit path is engaged (asserted from the C-ABI calls): the halo
+kernel (mmh_conv3x3_lp16: fprop and dgrad of the 3x3 stride-1 stack), the ring wgrad (mmh_wgrad3x3_lp16), the general
+kernel (mmh_conv_lp16: stride-2 convs, ConvTranspose2d, VGG conv1_2), the flat-K stems (mmh_conv_lp16_flat) and the
+flat-row wgrad (mmh_wgrad_lp16_flat), with 16-bit tensors on every conv-facing edge.
+
+Two free-running iterations of optimize_parameters():
+  * the six losses of both iterations: <= 2e-2 (bf16) / 5e-3 (fp16) relative;
+  * the generated image of iteration 1: <= 2e-2 / 3e-3;
+  * the Generator's parameter gradients of iteration 1 (identical weights on both sides), per tensor, relative L1
+    against fp64 (NOT a cosine; the loss scale divided out): no further from fp64 than 1.2 x what PyTorch's own
+    mixed precision does to the same tensor - the CPU oracle under torch.autocast(bf16 | fp16) against the oracle in
+    fp64, tests/golden/lp16_cond.npz written by tests/golden/make_lp16_cond.py - and <= 0.25 (bf16) / 0.08 (fp16)
+    outright.  Measured there: bf16 median 1.7e-1 (max 2.3e-1), fp16 median 5.3e-2 (max 7.1e-2) per tensor - the
+    image is at 1.3e-2 / 1.6e-3, and ReLU masks of pre-activations within that distance of zero flip, which the
+    backward pass amplifies layer by layer (the head's weight gradient is at 9e-3, three layers further back 1.3e-1).
+    The 5e-2 / 1e-2 that VERDICT r2 #5 proposed is out of reach of ANY 16-bit implementation of this network,
+    PyTorch's included; the HIP path measures bf16 1.56e-1 / 2.1e-1, i.e. slightly closer to fp64 than autocast."""
+import random
+import statistics
+from collections import Counter, OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmhand_ref as O
+from oracle import ops_ref as R
+from tests.golden import recipe as RC
+from tests.test_model_gpu import logical_grads
+
+pytestmark = pytest.mark.gpu
+NGF, SIZE, NB, NLD = 64, 64, 2, 3
+
+
+def _opt(level, **kw):
+    from mmhand_amd.options import default_train_opt
+    args = dict(batchSize=2, ngf=NGF, ndf=NGF, n_layers_D=NLD, G_n_blocks=NB, norm="instance", no_dropout=True,
+                no_dropout_D=True, pool_size=2, name="lp16step", checkpoints_dir="/tmp/mmh_pytest_ckpt",
+                local_rank=0, fineSize=SIZE, opt_level=level)
+    args.update(kw)
+    return default_train_opt(**args)
+
+
+@pytest.mark.parametrize("level,loss_tol,grad_tol,img_tol", [("O1", 2e-2, 0.25, 2e-2), ("O1_FP16", 5e-3, 0.08, 3e-3)],
+                         ids=["bf16", "fp16"])
+def test_optimize_parameters_16bit_vs_fp64_oracle(level, loss_tol, grad_tol, img_tol, dev, monkeypatch):
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    calls = Counter()
+    real = lib.call
+
+    def spy(name, *a):
+        calls[name] += 1
+        return real(name, *a)
+    monkeypatch.setattr(lib, "call", spy)
+    import os
+    from tests.golden.make_lp16_cond import SEED, nets
+    cond = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lp16_cond.npz")))
+    tag = "fp16" if level.endswith("FP16") else "bf16"
+    model = MMHandModel(_opt(level))
+    assert model.bf16 and model.loss_scaling
+    for net, sd in zip((model.netG, model.netD_PB, model.netD_PP, model.vgg), nets()):   # the fixture's weights
+        net.load_state_dict(sd)
+    # a loss scale of 2^16 overflows fp16 gradients here (apex would skip and halve for its first iterations):
+    # start the three scalers where the first iteration is clean, so that both iterations step
+    scale0 = 1024.0 if level.endswith("FP16") else 65536.0
+    model._scaler[:, 0] = scale0
+    sds = [OrderedDict((k, v.cpu()) for k, v in n.state_dict().items())
+           for n in (model.netG, model.netD_PB, model.netD_PP)]
+    vgg = OrderedDict((k, v.cpu()) for k, v in model.vgg.state_dict().items())
+    f64 = lambda sd: OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items())  # noqa: E731
+    o64 = O.StepOracle(f64(sds[0]), f64(sds[1]), f64(sds[2]), f64(vgg), "instance", False, False, NB, NLD, pool_size=2,
+                       rng=random.Random(49))
+    random.seed(49)
+    rows = []
+    for it in range(2):
+        batch = O.synthetic_batch(2, SIZE, SIZE, seed=SEED + it)
+        want = list(o64.step({k: v.double() for k, v in batch.items()}).values())
+        model.set_input(batch)
+        model.optimize_parameters()
+        got = [float(v) for v in model.get_current_errors().values()]
+        assert np.allclose(got, want, rtol=loss_tol), (level, it, got, want)
+        if it == 0:
+            assert np.allclose(want, cond["losses64"], rtol=1e-9), (want, cond["losses64"])      # same problem as the fixture
+            e_img = R.rel_l1(model.fake_p2, o64.fake_p2.detach())
+            assert e_img < img_tol, e_img
+            gg = logical_grads(model.netG)
+            og = dict((k, t.grad) for k, t in o64.G.named_parameters())
+            for k, g in gg.items():
+                if RC.is_null_grad_bias("G", k, "instance") or og.get(k) is None:
+                    continue
+                rows.append((k, R.rel_l1(g.double() / scale0, og[k]), float(cond[f"{tag}/{k}"])))
+    model._settle_overflow(drain=True)
+    assert model.skipped_steps == 0, model.skipped_steps
+    report = "\n".join(f"{k:55s} hip {e:.2e}   torch.autocast {c:.2e}" for k, e, c in rows)
+    med = statistics.median(e for _, e, _ in rows)
+    print(f"\n[{level}] image {e_img:.2e} (autocast {float(cond[tag + '/image']):.2e}); G gradients vs fp64: median {med:.2e} "
+          f"(autocast {statistics.median(c for _, _, c in rows):.2e}), max {max(e for _, e, _ in rows):.2e}\n" + report)
+    for k, e, c in rows:
+        assert e <= grad_tol and e <= 1.2 * c + 1e-3, (k, e, c, "\n" + report)
+    assert med <= 1.1 * statistics.median(c for _, _, c in rows), (med, "\n" + report)
+    # the second-generation 16-bit kernels ran: 6 convs per PATBlock fprop + their dgrad on the halo kernel, ...
+    assert calls["mmh_conv3x3_lp16"] >= 2 * (6 * NB * 2), calls
+    assert calls["mmh_wgrad3x3_lp16"] >= 2 * 6 * NB, calls
+    assert calls["mmh_conv_lp16"] >= 2 * 10 and calls["mmh_conv_lp16_flat"] >= 2 * 5, calls
+    assert calls["mmh_wgrad_lp16_flat"] >= 2 * 4, calls
+    assert calls["mmh_wino_gemm"] == 0, calls            # no Winograd in 16-bit mode on these shapes

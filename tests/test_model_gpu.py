@@ -339,10 +339,60 @@ def test_inference_generator_16bit_chain_full_width(lp, dev):
     e_plain = R.rel_l1(plain([t.to(dev) for t in g_in]), ref)
     gen = InferenceGenerator(net, use_graph=True, bf16=lp)
     assert gen._lp_chain_ok()
-    out = gen([t.to(dev) for t in g_in])
+    out = gen([t.to(dev) for t in g_in]).clone()           # __call__ returns the graph's static output tensor
     e_chain = R.rel_l1(out, ref)
     assert 1e-6 < e_chain < 1.1 * e_plain + 1e-4, (e_chain, e_plain)
     assert e_chain < (8e-2 if lp is True else 1.2e-2), e_chain
-    out2 = gen([t.to(dev) for t in g_in])                   # graph replay
+    # The captured launches read derived weight tensors (16-bit [tap][N][K] copies, the stems' flat-K copies) by raw
+    # pointer.  A weights-epoch bump (every Adam step, refold(), a second folded generator) empties ops' caches: the
+    # graph must hold its own references, or a replay reads freed - here: deliberately overwritten - memory.
+    from mmhand_amd import ops
+    ops.bump_weights_epoch()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]     # land on whatever was freed
+    b2 = O.synthetic_batch(2, 64, 64, seed=6)
+    g2 = [b2["H1"], torch.cat((b2["P1"], b2["P2"]), 1), torch.cat((b2["D1"], b2["D2"]), 1)]
+    rep2 = gen([t.to(dev) for t in g2]).clone()             # graph replay, other inputs
+    out2 = gen([t.to(dev) for t in g_in]).clone()           # graph replay, first inputs again
     assert torch.equal(out, out2)
+    eager = InferenceGenerator(net, use_graph=False, bf16=lp)
+    assert torch.equal(rep2, eager([t.to(dev) for t in g2]))
+    assert not torch.equal(rep2, out)
+    del junk
     net.bf16 = False
+
+
+def test_get_current_visuals_strip(dev):
+    """SURVEY §8(f)-4 / models/MMHandModel.py:343-369: get_current_visuals() after a step returns the
+    H1 | P1 | D1 | H2 | P2 | D2 | fake strip of sample 0: [H, 7W, 3] uint8; the image / depth / generated panels are
+    util.tensor2im of the model's tensors (pinned by tests/golden/visuals.npz on the CPU side); the pose panels are
+    draw_pose_from_map skeletons: non-empty, coloured only from labelcolormap(22), covering the joints that
+    map_to_cord (bit-exact on the device) finds.  (The cv2 rasterisation itself is parity-unpinned: no cv2 here.)"""
+    from mmhand_amd import visuals as V
+    from mmhand_amd.mmhand_model import MMHandModel
+    Hs = 64
+    model = MMHandModel(_small_opt("instance", fineSize=Hs))
+    batch = O.synthetic_batch(S["B"], Hs, Hs, seed=11)
+    model.set_input(batch)
+    model.optimize_parameters()
+    vis = model.get_current_visuals()
+    assert list(vis) == ["vis"]
+    strip = vis["vis"]
+    assert isinstance(strip, np.ndarray) and strip.dtype == np.uint8 and strip.shape == (Hs, 7 * Hs, 3)
+    panel = lambda i: strip[:, Hs * i:Hs * (i + 1)]                                  # noqa: E731
+    for i, t in ((0, batch["H1"]), (2, batch["D1"]), (3, batch["H2"]), (5, batch["D2"])):
+        assert np.array_equal(panel(i), V.tensor2im(t)), i
+    assert np.array_equal(panel(6), V.tensor2im(model.fake_p2))
+    assert panel(6).std() > 0           # the generated image is not a constant
+    cmap = {tuple(c) for c in V.labelcolormap(22)}
+    for i, P in ((1, batch["P1"]), (4, batch["P2"])):
+        p = panel(i)
+        colours = {tuple(c) for c in p.reshape(-1, 3)}
+        assert colours <= cmap and len(colours) >= 3, (i, colours - cmap)      # background + palm + finger bones
+        assert (p.reshape(-1, 3) != 0).any(1).mean() > 0.01
+        cords = V.map_to_cord(P[0].to(dev))
+        assert cords.shape == (21, 2) and (cords >= 0).all()
+        hit = [(p[min(max(int((cords[a][0] + cords[b][0]) // 2), 0), Hs - 1),
+                  min(max(int((cords[a][1] + cords[b][1]) // 2), 0), Hs - 1)] != 0).any()
+               for (a, b), _ in V.BONES]
+        assert np.mean(hit) > 0.7, hit          # a bone's midpoint lies inside its ellipse unless a later bone covers it
