@@ -55,6 +55,11 @@ int wino6_input_dy_normbwd(const float* g, const float* x, float* V, float* Yh, 
 int wino6_input_dy(const float* dy, float* V, float* Yh, int B, int H, int W, int C, int xcd, int fold,
                    hipStream_t st);
 int wino6_dw(const float* dU, float* dw, int Cin, int Cout, int accumulate, hipStream_t st);
+// 16-bit wgrad of the 3x3 stride-1 stack with all nine taps resident (wgrad_lp16t.hip)
+bool wgrad_lp16t_supported(const mmh_conv_desc* d);
+int wgrad_lp16t_splits(const mmh_conv_desc* d);
+int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16, float* slab, const void* zeros,
+                       hipStream_t st);
 extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;

@@ -1717,7 +1717,10 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 // all nine taps; 1040-1170 TFLOP/s on the PATBlock shapes), 17 = conv_lp16p_kernel (the same pipelining
 // on 256-pixel row tiles, the activation tile re-fetched per tap; also what images smaller than 16x16
 // take), 16 = without the pipelining (6-13 % slower), 32 = MFMA 32x32x16 (a further 6-9 % slower)
-namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 1; }
+// wgrad kernel (mmh_set_option "lp16_wgrad_ring"): 2 = wgrad_lp16t_kernel (default: nine taps of a 64 x 128 tile resident,
+// the input halo of a 4 x 16 pixel block staged once: wgrad_lp16t.hip), 1 = wgrad_lp16r_kernel (one tap of a 256 x 256
+// tile per workgroup, ring of five LDS slots), 0 = wgrad_lp16_kernel (the same with two stages)
+namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 2; }
 using mmh::g_lp16_shape;
 
 extern "C" {
@@ -2062,7 +2065,9 @@ static int lp16_wgrad_splits(const mmh_conv_desc* d) {
 
 size_t mmh_wgrad3x3_lp16_ws_bytes(const mmh_conv_desc* d) {
     if (!d || d->Cin % 256 || d->Cout % 256) return 0;
-    return (size_t)lp16_wgrad_splits(d) * 9 * d->Cin * d->Cout * sizeof(float);
+    int S = lp16_wgrad_splits(d);
+    if (mmh::wgrad_lp16t_supported(d)) S = std::max(S, mmh::wgrad_lp16t_splits(d));    // whichever kernel is selected
+    return (size_t)S * 9 * d->Cin * d->Cout * sizeof(float);
 }
 
 // dw [3][3][Cin][Cout] (fp32) (+)= wgrad of the 3x3 / stride 1 / pad 1 conv from 16-bit x and dy.
@@ -2089,6 +2094,13 @@ int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16,
     p.CT = d->Cin / 256; p.NT = d->Cout / 256;
     p.items = p.S * p.CT * p.NT * 9;
     hipStream_t st = mmh::as_stream(s);
+    if (mmh::g_lp16_wgrad_ring == 2 && mmh::wgrad_lp16t_supported(d)) {
+        if (int rc = mmh::launch_wgrad_lp16t(d, x16, dy16, p.slab, zeros, st)) return rc;
+        const int64_t n4t = (int64_t)9 * d->Cin * d->Cout / 4;
+        hipLaunchKernelGGL(lp16_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4t, 256), 4096)), dim3(256),
+                           0, st, p.slab, static_cast<float*>(dw), n4t, mmh::wgrad_lp16t_splits(d), accumulate);
+        return mmh::check_launch("lp16_slab_reduce_kernel");
+    }
     static int ready = -1;
     if (ready != 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16_kernel<false>),

@@ -1,0 +1,322 @@
+// 16-bit wgrad of the 3x3 / stride-1 / pad-1 stack with ALL NINE TAPS resident: gfx950, third generation.
+//
+// dw[tap][ci][co] = sum over output pixels p of x[p + off(tap)][ci] * dy[p][co]   (models/Generator.py:40-113:
+// the weight gradient of every PATBlock / ResnetBlock convolution; 54 + 2 x 6 launches per training step).
+//
+// wgrad_lp16r_kernel (conv_lp16.hip) gives a workgroup ONE tap of a 256 x 256 (ci, co) tile: per 64-pixel k-step it
+// stages 32 KiB of x and 32 KiB of dy for 8.4 MFLOP - 128 FLOP per staged byte, 32 B/clk/CU at the MFMA rate - and
+// the nine taps of a tile re-stage the same dy and (shifted by one pixel) the same x: measured DMA-bound (its DMA
+// stream alone takes 64 % of the kernel), FETCH + WRITE 1.83 x the algorithmic bytes.
+//
+// Here a workgroup owns (64 ci) x (128 co) x (9 taps) = 73,728 outputs (144 accumulator VGPRs per lane) and walks
+// blocks of 4 x 16 output pixels.  Per block it stages, ONCE, the block's 6 x 18 input halo [halo pixel][64 ci] (the
+// padding - reflect or zero - folded into the DMA's per-lane source address) and its dy tile [64 pixels][128 co]:
+// 31 KiB for 9.4 MFLOP = 304 FLOP per staged byte, 13.5 B/clk/CU.  The nine taps read the SAME halo image at nine
+// row offsets: tap (kh, kw) of the k16-step of block row kk contracts halo rows (kk + kh) * 20 + kw + 0..15.
+//
+// LDS images (both operands are k-major in HBM - the contraction index, the pixel, is the slow index of NHWC - so
+// both MFMA operands are read TRANSPOSED with ds_read_b64_tr_b16; a transposed 4 x 16 block touches 4 consecutive
+// k rows x 64 B):
+//   x halo  [6 halo rows x pitch 20][128 B]: rows r and r + 2 would share banks -> the 64-byte halves of a row are
+//           swapped when bit 1 of the row index is set.  The pitch is a multiple of 4, so that bit - and with it the
+//           lane's swizzled address - depends on the tap only through kw: three address registers serve all nine
+//           taps, everything else is an immediate offset;
+//   dy tile [64][256 B]: the four rows of a block share banks -> 16-byte chunk index XOR (row & 3) << 2.
+// As the LDS-DMA writes linearly (lane i -> base + 16 i) the swizzles are applied to the per-lane GLOBAL source
+// address and again on the read address (MI355X guide: both sides or neither).
+//
+// Pipeline: ring of four 32-KiB stages; a stage is issued three blocks ahead and waited for (vmcnt(4): every wave
+// issues exactly four loads per stage, also past the end of its range, where they read the zero page) one k16-step
+// before its first use, at the one barrier per block.  Fragments: the three A fragments of the next filter row are
+// requested while the current row's three MFMAs (32x32x16) run.
+//
+// Split-K over block ranges (one round of workgroups, split-major work list so that the tiles of one split sit on
+// one XCD and share its L2), fp32 slabs [split][tap][Cin][Cout], fixed-order reduction (lp16_slab_reduce_kernel).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+
+constexpr int TCI = 64, TCO = 128;          // tile: input channels x output channels (x 9 taps)
+constexpr int BR = 4, BC = 16;              // pixel block: rows x columns = 64 pixels = 4 k16-steps
+constexpr int HP = 20;                      // halo pitch (18 used columns; a multiple of 4: see above)
+constexpr int XROWB = TCI * 2;              // 128 B per halo pixel
+constexpr int DROWB = TCO * 2;              // 256 B per dy pixel
+constexpr int XSTAGE = 128 * XROWB;         // 120 halo rows, padded to 16 DMA instructions: 16 KiB
+constexpr int DSTAGE = BR * BC * DROWB;     // 16 KiB
+constexpr int TSTAGE = XSTAGE + DSTAGE;     // 32 KiB
+constexpr int RING = 4;
+
+struct LpWgradTP {
+    const char* x;          // 16-bit activations [B][H][W][Cin], pixel stride x_cs elements
+    const char* dy;         // 16-bit output gradients [B][H][W][Cout], pixel stride dy_cs
+    const char* zeros;      // >= 256 zero bytes
+    float* slab;            // [S][9][Cin][Cout]
+    int B, H, W, Cin, Cout, x_cs, dy_cs;
+    int reflect;
+    int TR, TC;             // blocks per image: rows, columns
+    int nblk, bps;          // blocks in all, blocks per split
+    int CT, NT, S, items;
+};
+
+// One LDS-DMA instruction (1 KiB per wave: lane i -> lds_base + 16 i) as inline asm.  Why not the builtin: hipcc tracks a
+// __builtin_amdgcn_global_load_lds as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next
+// ds_read_b64_tr_b16 it cannot prove disjoint - i.e. right behind every issue, which drains the whole ring once per
+// block (seen in the ISA of wgrad_lp16r_kernel: its "three halves in flight" never are).  The asm form is invisible
+// to that pass; the waits that order the DMA against the reads are the explicit counted vmcnt + barrier below.
+// M0 carries the LDS base (wave-uniform); nothing else in this kernel uses M0.
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+}
+
+template <bool H16>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (H16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 8 consecutive k rows (k = 8 h .. 8 h + 7 of the k16-step) of one column per lane: two transposed reads 4 rows apart
+template <int ROWBYTES>
+__device__ __forceinline__ bf16x8 tr_frag(const char* a) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * ROWBYTES));
+    struct { s16x4 a, b; } both = {lo, hi};
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <bool H16>
+__global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int per_xcd = (p.items + 7) / 8;
+    int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int nt = item % p.NT; item /= p.NT;
+    const int ct = item % p.CT;
+    const int split = item / p.CT;
+    const int blk0 = split * p.bps;
+    const int blk1 = min(p.nblk, blk0 + p.bps);
+    const int nsteps = blk1 - blk0;
+
+    // ---- DMA roles.  x: instruction xi (0..15) fills halo rows 8 xi + lane / 8 (wave w: xi = w, w + 8); dy: instruction
+    // dj (0..15) fills tile rows 4 dj + lane / 16 (wave w: dj = 2 w, 2 w + 1).
+    int x_hy[2], x_hx[2];
+    unsigned x_coff[2];
+    bool x_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int hr = 8 * (wave + 8 * j) + (lane >> 3);
+        x_hy[j] = hr / HP;
+        x_hx[j] = hr - x_hy[j] * HP;
+        x_row[j] = hr < (BR + 2) * HP && x_hx[j] < BC + 2;
+        const unsigned lc = (unsigned)(lane & 7) ^ ((unsigned)((hr >> 1) & 1) << 2);
+        x_coff[j] = (unsigned)(ct * TCI) * 2u + lc * 16u;
+    }
+    int d_py[2], d_px[2];
+    unsigned d_coff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int dr = 4 * (2 * wave + j) + (lane >> 4);
+        d_py[j] = dr >> 4;
+        d_px[j] = dr & 15;
+        const unsigned lc = (unsigned)(lane & 15) ^ ((unsigned)(dr & 3) << 2);
+        d_coff[j] = (unsigned)(nt * TCO) * 2u + lc * 16u;
+    }
+    // the block the next issue() stages: (image, block row, block column), advanced once per issue
+    int nb = blk0;
+    int nb_img = nb / (p.TR * p.TC);
+    int nb_tr = (nb - nb_img * p.TR * p.TC) / p.TC;
+    int nb_tc = nb - (nb_img * p.TR + nb_tr) * p.TC;
+    int slot_next = 0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);                   // + 8 KiB for j = 1
+    const unsigned ddst = __builtin_amdgcn_readfirstlane(lds0 + XSTAGE + (unsigned)(2 * wave) * 1024u);    // + 1 KiB for j = 1
+    auto issue = [&]() {
+        const unsigned sbase = (unsigned)slot_next * TSTAGE;
+        slot_next = (slot_next + 1) & (RING - 1);
+        const bool live = nb < blk1;
+        const int r0 = nb_tr * BR, c0 = nb_tc * BC;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int ih = r0 + x_hy[j] - 1, iw = c0 + x_hx[j] - 1;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            }
+            const bool ok = live && x_row[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const char* g = ok ? p.x + (size_t)((nb_img * p.H + ih) * p.W + iw) * (size_t)(p.x_cs * 2) + x_coff[j]
+                               : p.zeros + (lane & 7) * 16;
+            dma16(g, xdst + sbase + (unsigned)j * 8192u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = r0 + d_py[j], ow = c0 + d_px[j];
+            const bool ok = live && oh < p.H && ow < p.W;
+            const char* g = ok ? p.dy + (size_t)((nb_img * p.H + oh) * p.W + ow) * (size_t)(p.dy_cs * 2) + d_coff[j]
+                               : p.zeros + (lane & 15) * 16;
+            dma16(g, ddst + sbase + (unsigned)j * 1024u);
+        }
+        ++nb;
+        if (++nb_tc == p.TC) {
+            nb_tc = 0;
+            if (++nb_tr == p.TR) { nb_tr = 0; ++nb_img; }
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- fragment addresses.  Lane: k row t = 8 h + q of the k16-step (second read: + 4), columns 16 G1 + 4 p2 .. + 3 of
+    // the wave's 32 (ci for A, co for B)
+    const int G1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p2 = lane & 3;
+    const int tk = 8 * h + q;
+    unsigned a_base[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int row = tk + kw;                                    // + (kk + kh) * HP rows: an immediate
+        const int col = wr * 32 + 16 * G1 + 4 * p2;                 // element of the 64-channel halo row
+        const unsigned chunk = (unsigned)(col >> 3) ^ ((unsigned)((row >> 1) & 1) << 2);
+        a_base[kw] = (unsigned)row * XROWB + (chunk << 4) + (unsigned)(col & 4) * 2u;
+    }
+    unsigned b_base;
+    {
+        const int col = wc * 32 + 16 * G1 + 4 * p2;                 // element of the 128-channel dy row
+        const unsigned chunk = (unsigned)(col >> 3) ^ ((unsigned)q << 2);
+        b_base = (unsigned)tk * DROWB + (chunk << 4) + (unsigned)(col & 4) * 2u;
+    }
+
+    if (nsteps > 0) {
+        issue(); issue(); issue();
+        __builtin_amdgcn_s_waitcnt(0x0070 | 8);         // vmcnt(8): stage 0 has landed (stages 1, 2 may be in flight)
+        __syncthreads();
+
+        bf16x8 af[2][3], bfr[2];
+        {
+            const char* sX = smem;
+            bfr[0] = tr_frag<DROWB>(sX + XSTAGE + b_base);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) af[0][kw] = tr_frag<XROWB>(sX + a_base[kw]);
+        }
+        int slot = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            const char* sX = smem + slot * TSTAGE;
+            const int slot_n = (slot + 1) & (RING - 1);
+            const char* sXn = smem + slot_n * TSTAGE;
+#pragma unroll
+            for (int kk = 0; kk < BR; ++kk) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int g = kk * 3 + kh;                      // group of this step, 0..11
+                    const int cur = g & 1, nxt = cur ^ 1;
+                    if (kk == BR - 1 && kh == 0) {
+                        // stage s+1 (issued two blocks ago) must have landed before the last filter row of this
+                        // block prefetches from it; every wave is past block s-1, whose slot stage s+3 takes
+                        __builtin_amdgcn_s_waitcnt(0x0070 | 4);     // vmcnt(4) lgkmcnt(0)
+                        __syncthreads();
+                        issue();
+                    }
+                    // request the next group's fragments
+                    if (kh < 2) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            af[nxt][kw] = tr_frag<XROWB>(sX + a_base[kw] + (kk + kh + 1) * (HP * XROWB));
+                    } else if (kk < BR - 1) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            af[nxt][kw] = tr_frag<XROWB>(sX + a_base[kw] + (kk + 1) * (HP * XROWB));
+                        bfr[(kk + 1) & 1] = tr_frag<DROWB>(sX + XSTAGE + b_base + (kk + 1) * (16 * DROWB));
+                    } else if (s + 1 < nsteps) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) af[nxt][kw] = tr_frag<XROWB>(sXn + a_base[kw]);
+                        bfr[0] = tr_frag<DROWB>(sXn + XSTAGE + b_base);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[kh * 3 + kw] = mfma32<H16>(af[cur][kw], bfr[kk & 1], acc[kh * 3 + kw]);
+                }
+            }
+            slot = slot_n;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);     // drain the stages issued past the range before the LDS is released
+
+    float* slab = p.slab + (size_t)split * 9 * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ct * TCI + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int co = nt * TCO + wc * 32 + l31;
+            slab[((size_t)t * p.Cin + ci) * p.Cout + co] = acc[t][r];
+        }
+}
+
+}  // namespace
+
+namespace mmh {
+
+int wgrad_lp16t_splits(const mmh_conv_desc* d) {
+    const int tiles = (d->Cin / TCI) * (d->Cout / TCO);
+    const long long nblk = (long long)d->B * ((d->H + BR - 1) / BR) * ((d->W + BC - 1) / BC);
+    int S = std::max(1, 256 / tiles);                   // one round of workgroups, one per CU
+    S = (int)std::min<long long>(S, std::max<long long>(1, nblk / 4));
+    const long long bps = (nblk + S - 1) / S;
+    return (int)((nblk + bps - 1) / bps);
+}
+
+bool wgrad_lp16t_supported(const mmh_conv_desc* d) {
+    return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Cin % TCI == 0 && d->Cout % TCO == 0 &&
+           d->Ho == d->H && d->Wo == d->W && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16) &&
+           (d->pad_mode != MMH_PAD_REFLECT || (d->H >= 2 && d->W >= 2));
+}
+
+// slab: [S][9][Cin][Cout] fp32 with S = wgrad_lp16t_splits(d)
+int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16, float* slab, const void* zeros,
+                       hipStream_t st) {
+    LpWgradTP p{};
+    p.x = static_cast<const char*>(x16); p.dy = static_cast<const char*>(dy16);
+    p.zeros = static_cast<const char*>(zeros);
+    p.slab = slab;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
+    p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.TR = (d->H + BR - 1) / BR; p.TC = (d->W + BC - 1) / BC;
+    p.nblk = d->B * p.TR * p.TC;
+    p.S = wgrad_lp16t_splits(d);
+    p.bps = (p.nblk + p.S - 1) / p.S;
+    p.CT = d->Cin / TCI; p.NT = d->Cout / TCO;
+    p.items = p.S * p.CT * p.NT;
+    constexpr int lds = RING * TSTAGE;
+    static int ready = -1;
+    if (ready != 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16t_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16t_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        ready = e == hipSuccess ? 0 : fail("wgrad_lp16t_kernel: %s", hipGetErrorString(e));
+    }
+    if (ready != 0) return ready;
+    const int per_xcd = (p.items + 7) / 8;
+    if (d->dtype == MMH_FP16) hipLaunchKernelGGL(wgrad_lp16t_kernel<true>, dim3(8 * per_xcd), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(wgrad_lp16t_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, st, p);
+    return check_launch("wgrad_lp16t_kernel");
+}
+
+}  // namespace mmh

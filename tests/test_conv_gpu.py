@@ -350,13 +350,45 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
             dy = _mk((B, H, W, Cout), 3, dev)
             dyb = ops.lp16_twin(dy, True)
             outs = []
-            for ring in (0, 1, 1):
+            for ring in (0, 1, 1, 2, 2, 2):
                 lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", ring), "set")
                 outs.append(ops.raw_wgrad3x3_lp16(xb, dyb, True, True))
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+            # the tap-resident kernel (2, the default) sums the pixels in another order (4 x 16 blocks, other
+            # split ranges): equal to the ring kernel up to fp32 summation order, and reproducible run to run
+            assert torch.equal(outs[3], outs[4]) and torch.equal(outs[4], outs[5])
+            sc = float(outs[0].abs().max())
+            assert float((outs[3] - outs[0]).abs().max()) < 2e-5 * sc, (float((outs[3] - outs[0]).abs().max()), sc)
     finally:
         lib.check(L_.mmh_set_option(b"lp16_shape", 18), "set")
-        lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 1), "set")
+        lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 2), "set")
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 9, 11, 256, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
+                                  (2, 17, 33, 256, 256, True), (1, 4, 16, 256, 256, True), (5, 2, 2, 256, 256, True),
+                                  (2, 64, 64, 256, 256, False), (1, 6, 50, 512, 256, False)])
+def test_wgrad3x3_lp16_tap_resident_kernel(case, lp, dev):
+    """wgrad_lp16t_kernel (all nine taps of a 64 x 128 tile resident, 4 x 16 pixel blocks with their halo staged once;
+    mmh_wgrad3x3_lp16's default) against the fp64 oracle on operands rounded to the same type: reflect and zero padding,
+    ragged blocks (H % 4, W % 16 != 0), images smaller than a block, splits that end inside an image; and
+    accumulate-into-dw."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout, refl = case
+    L_ = lib.load()
+    assert L_.mmh_set_option(b"lp16_wgrad_ring", 2) == 0
+    x = _mk((B, H, W, Cin), 1, dev)
+    dy = _mk((B, H, W, Cout), 4, dev)
+    w = torch.zeros(3, 3, Cin, Cout)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    x16, dy16 = ops.lp16_twin(x, lp), ops.lp16_twin(dy, lp)
+    dw = ops.raw_wgrad3x3_lp16(x16, dy16, refl, lp)
+    _, _, dwr, _ = R.conv2d_grads(rb(x), w, None, rb(dy), 1, 1, refl)
+    assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
+    tgt = torch.full_like(dw, 0.5)
+    ops.raw_wgrad3x3_lp16(x16, dy16, refl, lp, out=tgt)
+    assert torch.allclose(tgt, dw + 0.5, rtol=0, atol=1e-5 * float(dw.abs().max()))
+    assert torch.equal(ops.raw_wgrad3x3_lp16(x16, dy16, refl, lp), dw)
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])

@@ -1,5 +1,6 @@
-"""wgrad_lp16_kernel (two 64-KiB stages) against wgrad_lp16r_kernel (ring of five 32-KiB half stages,
-mmh_set_option lp16_wgrad_ring): results vs each other (repeated runs) and time on the PATBlock shapes."""
+"""wgrad_lp16_kernel (0: two 64-KiB stages) against wgrad_lp16r_kernel (1: ring of five 32-KiB half stages) and
+wgrad_lp16t_kernel (2: nine taps of a 64 x 128 tile resident; mmh_set_option lp16_wgrad_ring): results vs each other
+(repeated runs) and time on the PATBlock shapes."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,12 +22,12 @@ for (B, H, W, Cin, Cout, refl) in ((2, 9, 11, 256, 256, True), (3, 17, 33, 256, 
     xb = ops.lp16_twin(x, True); dyb = ops.lp16_twin(dy, True)
     flop = 2.0 * B * H * W * Cin * Cout * 9
     res = {}
-    for ring in (0, 1):
+    for ring in (0, 1, 2):
         L.mmh_set_option(b"lp16_wgrad_ring", ring)
         outs = [ops.raw_wgrad3x3_lp16(xb, dyb, refl, True) for _ in range(3)]
         t = timeit(lambda: ops.raw_wgrad3x3_lp16(xb, dyb, refl, True))
         res[ring] = outs
         print(f"B{B} {H}x{W} {Cin}->{Cout} ring={ring}: {t*1e3:8.1f} us  {flop/t*1e-9:7.0f} TF", flush=True)
-    d = max((o - res[0][0]).abs().max().item() for o in res[0] + res[1])
+    d = max((o - res[0][0]).abs().max().item() for o in res[0] + res[1] + res[2])
     print(f"   max |diff| over runs and kernels: {d:.3e} (max |dw| {res[0][0].abs().max().item():.1f})" + ("  <-- MISMATCH" if d > 1e-2 * res[0][0].abs().max().item() else ""))
-L.mmh_set_option(b"lp16_wgrad_ring", 1)
+L.mmh_set_option(b"lp16_wgrad_ring", 2)
