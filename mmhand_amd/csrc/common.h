@@ -39,6 +39,19 @@ __device__ __forceinline__ float norm_bwd_elem(float g, bool keep, float dsc, fl
     return o;
 }
 
+// One LDS-DMA instruction (global_load_lds_dwordx4: 1 KiB per wave, lane i -> lds_base + 16 i) as inline asm.
+// Why not __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) tracks the builtin as a pending LDS store and emits
+// `s_waitcnt vmcnt(0)` in front of the next ds_read_b64_tr_b16 it cannot prove disjoint - right behind every issue,
+// which drains a multi-stage ring once per step (seen in the ISA of the wgrad kernels; plain ds_read_b128 reads are not
+// affected).  The asm form is invisible to that pass: the kernel orders DMA against reads itself (counted vmcnt +
+// barrier).  M0 carries the LDS base (must be wave-uniform); kernels that use this must not use M0 otherwise.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 // Winograd F(6x6,3x3) transforms (wino6.hip); tiles = B * ceil(H/6) * ceil(W/6), 64 planes
 int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st);
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st);

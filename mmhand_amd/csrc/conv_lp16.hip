@@ -69,6 +69,30 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 typedef __attribute__((address_space(3))) void* lds_vp;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Four consecutive output channels of one pixel from one lane (the accumulator layout of an MFMA 16x16x32 whose FIRST
+// operand is the weight fragment: row = channel 4 g4 + r, column = pixel l15): bias, activation, one 8- or 16-byte store.
+template <bool H16>
+__device__ __forceinline__ void store4(float* y, char* y16, size_t elem, f32x4 v, const float* bv, int act) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = v[r] + bv[r];
+        v[r] = act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (act == MMH_ACT_TANH ? tanhf(t) : t);
+    }
+    if (y16) {
+        if (H16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<h4*>(y16 + elem * 2) = o;
+        } else {
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            b4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<b4*>(y16 + elem * 2) = o;
+        }
+    } else {
+        *reinterpret_cast<f32x4*>(y + elem) = v;
+    }
+}
 template <bool H16>
 __device__ __forceinline__ f32x4 mfma16s(bf16x8 a, bf16x8 b, f32x4 c) {
     if (H16)
@@ -523,7 +547,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b0[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b0[j], af[i], acc[i][j]);
             af[i] = *reinterpret_cast<const bf16x8*>(a_addr(sA, dh, dw, i, 1));
         }
 #pragma unroll
@@ -556,7 +580,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], b1[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b1[j], af[i], acc[i][j]);
                 if (more) af[i] = *reinterpret_cast<const bf16x8*>(a_addr(sAn, dh2, dw2, i, 0));
             }
         }
@@ -568,27 +592,26 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
         kc = kc2; t = t2;
     }
 
+    // Epilogue.  The MFMAs above take the WEIGHT fragment as their first operand: D[row = output channel][col = pixel],
+    // i.e. lane (l15, g4) holds, per (i, j), the four consecutive channels n0 + wc*64 + j*16 + 4*g4 + 0..3 of pixel
+    // (oh0 + wr*8 + i, ow0 + l15): one 8-byte (16-bit output) or 16-byte (fp32) store per accumulator instead of four
+    // 2- / 4-byte ones - a quarter of the store instructions of the pixel-major layout, whose 128 scalar stores per lane
+    // took longer than a filter row of MFMAs.  The bias is read once per lane, not once per element.
+    float bv[4][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oh = oh0 + wr * 8 + i, ow = ow0 + 4 * g4 + r;
-            if (oh >= p.H || ow >= p.W) continue;
-            const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + 4 * g4 + r] : 0.f;
+    const int ow = ow0 + l15;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wc * 64 + j * 16 + l15;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[n];
-                v = act_apply(v, p.act);
-                if (p.y16) {
-                    if (H16) reinterpret_cast<_Float16*>(p.y16)[m * p.y_cs + n] = (_Float16)v;
-                    else reinterpret_cast<__bf16*>(p.y16)[m * p.y_cs + n] = (__bf16)v;
-                } else {
-                    p.y[m * p.y_cs + n] = v;
-                }
-            }
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int oh = oh0 + wr * 8 + i;
+        if (oh >= p.H || ow >= p.W) continue;
+        const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store4<H16>(p.y, p.y16, m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -737,36 +760,31 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16s<H16>(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16s<H16>(bfr[j], af[i], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    // epilogue: the weight fragment is the MFMA's first operand - lane (l15, g4) holds channels 4 g4 .. + 3 of pixel
+    // m0 + wr*128 + i*16 + l15 (store4: a quarter of the store instructions; the bias is read once per lane)
+    float bv[NJ][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wr * 128 + i * 16 + 4 * g4 + r;
-            if (m >= M) continue;
-            const int b = m / (p.MH * p.MW);
-            const int rem = m - b * (p.MH * p.MW);
-            const int mh = rem / p.MW, mw = rem - mh * p.MW;
-            const size_t opix = ((size_t)b * p.OH + (mh * p.os + oh0)) * p.OW + (mw * p.os + ow0);
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * (BNT / 4) + j * 16 + 4 * g4 + r] : 0.f;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wc * (BNT / 4) + j * 16 + l15;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[n];
-                v = act_apply(v, p.act);
-                if (p.y16) {
-                    if (H16) reinterpret_cast<_Float16*>(p.y16)[opix * p.y_cs + n] = (_Float16)v;
-                    else reinterpret_cast<__bf16*>(p.y16)[opix * p.y_cs + n] = (__bf16)v;
-                } else {
-                    p.y[opix * p.y_cs + n] = v;
-                }
-            }
-        }
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + l15;
+        if (m >= M) continue;
+        const int b = m / (p.MH * p.MW);
+        const int rem = m - b * (p.MH * p.MW);
+        const int mh = rem / p.MW, mw = rem - mh * p.MW;
+        const size_t opix = ((size_t)b * p.OH + (mh * p.os + oh0)) * p.OW + (mw * p.os + ow0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            store4<H16>(p.y, p.y16, opix * p.y_cs + (n0 + wc * (BNT / 4) + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+    }
 }
 
 
@@ -882,30 +900,25 @@ __global__ void __launch_bounds__(512, 2) conv_lp16f_kernel(const LpFlatKP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(bfr[j], af[i], acc[i][j]);
         }
     }
 
+    // epilogue: weight fragment first (see store4): lane (l15, g4) holds channels n0 + j*16 + 4 g4 .. + 3 of pixel
+    // m0 + wave*32 + i*16 + l15
+    float bv[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wave * 32 + i * 16 + 4 * g4 + r;
-            if (m >= M) continue;
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + j * 16 + 4 * g4 + r] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + j * 16 + l15;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[n];
-                v = act_apply(v, p.act);
-                if (p.y16) {
-                    if (H16) reinterpret_cast<_Float16*>(p.y16)[(size_t)m * p.y_cs + n] = (_Float16)v;
-                    else reinterpret_cast<__bf16*>(p.y16)[(size_t)m * p.y_cs + n] = (__bf16)v;
-                } else {
-                    p.y[(size_t)m * p.y_cs + n] = v;
-                }
-            }
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wave * 32 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store4<H16>(p.y, p.y16, (size_t)m * p.y_cs + (n0 + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+    }
 }
 
 // x fp32 [rows][C] -> 16-bit [rows][C8], channels zero-padded (the stems' input for conv_lp16f_kernel)
@@ -1387,8 +1400,8 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16r_kernel(const LpWgradKP p) 
             const int src = pix[j] + (ih - poh[j]) * p.W + (iw - pow_[j]);
             const char* gx = okx ? p.x + (size_t)src * p.x_cs * 2 + x_coff[j] : p.zeros + (lane & 31) * 16;
             const char* gd = ok ? p.dy + (size_t)pix[j] * p.dy_cs * 2 + d_coff[j] : p.zeros + (lane & 31) * 16;
-            __builtin_amdgcn_global_load_lds(gx, (lds_vp)(sX + (wave * 2 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gd, (lds_vp)(sD + (wave * 2 + j) * 1024), 16, 0, 0);
+            mmh::lds_dma16(gx, __builtin_amdgcn_readfirstlane(mmh::lds_addr_of(sX + (wave * 2 + j) * 1024)));
+            mmh::lds_dma16(gd, __builtin_amdgcn_readfirstlane(mmh::lds_addr_of(sD + (wave * 2 + j) * 1024)));
             pix[j] += 32;
             pow_[j] += 32;
             while (pow_[j] >= p.W) {
@@ -1558,8 +1571,8 @@ __device__ __forceinline__ void wgrad_lp16f_body(const LpWgradFKP& p) {
             const size_t src = ((size_t)pimg[j] * p.H + ih) * p.W + iw;
             const char* gx = okx ? p.x + src * p.x_cs * 2 + x_coff[j] : p.zeros + (lane & 31) * 16;
             const char* gd = (ok && d_ok[j]) ? p.dy + (size_t)pix[j] * p.dy_cs * 2 + d_coff[j] : p.zeros + (lane & 31) * 16;
-            __builtin_amdgcn_global_load_lds(gx, (lds_vp)(sX + (wave * 2 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gd, (lds_vp)(sD + (wave * 2 + j) * 1024), 16, 0, 0);
+            mmh::lds_dma16(gx, __builtin_amdgcn_readfirstlane(mmh::lds_addr_of(sX + (wave * 2 + j) * 1024)));
+            mmh::lds_dma16(gd, __builtin_amdgcn_readfirstlane(mmh::lds_addr_of(sD + (wave * 2 + j) * 1024)));
             pix[j] += 32;
             pow_[j] += 32;
             while (pow_[j] >= p.Wo) {
@@ -1751,6 +1764,8 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     LpConvKP p{};
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     MMH_REQUIRE(N % TBN == 0, "mmh_conv3x3_lp16: output channels must be a multiple of 256 (got %d)", N);
+    MMH_REQUIRE((mode == 0 ? d->y_cs : d->x_cs) % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                "mmh_conv3x3_lp16: the output's pixel stride must be a multiple of 4 channels and y 16-byte aligned");
     p.x = static_cast<const char*>(x16);
     p.w = static_cast<const char*>(w16);
     p.zeros = static_cast<const char*>(zeros);
@@ -1887,6 +1902,8 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
         p.OH = d->H; p.OW = d->W; p.y_cs = d->x_cs;
     }
     const long long M = (long long)p.B * p.MH * p.MW;
+    MMH_REQUIRE(p.y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                "mmh_conv_lp16: the output's pixel stride must be a multiple of 4 channels and y 16-byte aligned");
     MMH_REQUIRE((long long)p.B * p.SH * p.SW * p.cs < (1ll << 31) && (long long)p.B * p.OH * p.OW < (1ll << 31) &&
                     p.SH < 16384 && p.SW < 32768,
                 "mmh_conv_lp16: tensor too large");
@@ -1955,6 +1972,8 @@ int mmh_conv_lp16_flat(const mmh_conv_desc* d, const void* x16p, int C8, const v
     const long long M = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(M * (long long)std::max(C8, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
                 "mmh_conv_lp16_flat: tensor too large");
+    MMH_REQUIRE(p.y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
+                "mmh_conv_lp16_flat: the output's pixel stride must be a multiple of 4 channels and y 16-byte aligned");
     p.MT = (int)((M + TBM - 1) / TBM);
     p.NT = d->Cout / 64;
     constexpr int lds = 2 * (TBM + 64) * ROWB;

@@ -28,7 +28,8 @@
 // Pipeline: ring of four 32-KiB stages; a stage is issued three blocks ahead and waited for (vmcnt(4): every wave
 // issues exactly four loads per stage, also past the end of its range, where they read the zero page) one k16-step
 // before its first use, at the one barrier per block.  Fragments: the three A fragments of the next filter row are
-// requested while the current row's three MFMAs (32x32x16) run.
+// requested while the current row's three MFMAs (32x32x16) run.  The LDS-DMA is issued as inline asm (mmh::lds_dma16:
+// hipcc would otherwise drain the ring behind every issue).
 //
 // Split-K over block ranges (one round of workgroups, split-major work list so that the tiles of one split sit on
 // one XCD and share its L2), fp32 slabs [split][tap][Cin][Cout], fixed-order reduction (lp16_slab_reduce_kernel).
@@ -64,16 +65,6 @@ struct LpWgradTP {
     int nblk, bps;          // blocks in all, blocks per split
     int CT, NT, S, items;
 };
-
-// One LDS-DMA instruction (1 KiB per wave: lane i -> lds_base + 16 i) as inline asm.  Why not the builtin: hipcc tracks a
-// __builtin_amdgcn_global_load_lds as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next
-// ds_read_b64_tr_b16 it cannot prove disjoint - i.e. right behind every issue, which drains the whole ring once per
-// block (seen in the ISA of wgrad_lp16r_kernel: its "three halves in flight" never are).  The asm form is invisible
-// to that pass; the waits that order the DMA against the reads are the explicit counted vmcnt + barrier below.
-// M0 carries the LDS base (wave-uniform); nothing else in this kernel uses M0.
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_base) : "memory", "m0");
-}
 
 template <bool H16>
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -140,7 +131,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
     int nb_tr = (nb - nb_img * p.TR * p.TC) / p.TC;
     int nb_tc = nb - (nb_img * p.TR + nb_tr) * p.TC;
     int slot_next = 0;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lds0 = mmh::lds_addr_of(smem);
     const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);                   // + 8 KiB for j = 1
     const unsigned ddst = __builtin_amdgcn_readfirstlane(lds0 + XSTAGE + (unsigned)(2 * wave) * 1024u);    // + 1 KiB for j = 1
     auto issue = [&]() {
@@ -160,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
             const bool ok = live && x_row[j] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             const char* g = ok ? p.x + (size_t)((nb_img * p.H + ih) * p.W + iw) * (size_t)(p.x_cs * 2) + x_coff[j]
                                : p.zeros + (lane & 7) * 16;
-            dma16(g, xdst + sbase + (unsigned)j * 8192u);
+            mmh::lds_dma16(g, xdst + sbase + (unsigned)j * 8192u);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -168,7 +159,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
             const bool ok = live && oh < p.H && ow < p.W;
             const char* g = ok ? p.dy + (size_t)((nb_img * p.H + oh) * p.W + ow) * (size_t)(p.dy_cs * 2) + d_coff[j]
                                : p.zeros + (lane & 15) * 16;
-            dma16(g, ddst + sbase + (unsigned)j * 1024u);
+            mmh::lds_dma16(g, ddst + sbase + (unsigned)j * 1024u);
         }
         ++nb;
         if (++nb_tc == p.TC) {

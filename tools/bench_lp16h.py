@@ -1,0 +1,29 @@
+"""conv_lp16h_kernel (mmh_conv3x3_lp16, lp16_shape 18) as the 16-bit training step calls it: fprop with bias and a
+16-bit epilogue, dgrad main term with a 16-bit epilogue, on the PATBlock shapes; interleaved rounds in one process."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mmhand_amd import ops, lib
+L = lib.load(); dev = torch.device("cuda:0")
+def timeit(fn, iters=10):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+B, H = 32, 64
+for (Cin, Cout) in ((256, 256), (512, 512), (512, 256)):
+    x = torch.randn(B, H, H, Cin, device=dev); dy = torch.randn(B, H, H, Cout, device=dev)
+    w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05; bias = torch.randn(Cout, device=dev)
+    xb, dyb = ops.lp16_twin(x, True), ops.lp16_twin(dy, True)
+    flop = 2.0 * B * H * H * Cin * Cout * 9
+    variants = {"fprop bias out16": lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True),
+                "fprop nobias out16": lambda: ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0, out16=True),
+                "fprop bias fp32": lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0),
+                "dgrad out16": lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)}
+    res = {k: [] for k in variants}
+    for f in variants.values(): f()
+    torch.cuda.synchronize()
+    for r in range(5):
+        for k, f in variants.items(): res[k].append(timeit(f))
+    print(f"{Cin}->{Cout}: " + " | ".join(f"{k}: {statistics.median(v)*1e3:.0f} us ({flop/statistics.median(v)/1e9:.0f} TF)" for k, v in res.items()), flush=True)
