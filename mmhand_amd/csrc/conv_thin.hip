@@ -96,9 +96,10 @@ __global__ void __launch_bounds__(256) thin_conv7_kernel(const ThinKP p) {
                     st[i] = make_float4(__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u),
                                         __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u));
                 } else {
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const h2 a = __builtin_bit_cast(h2, v[0]), c = __builtin_bit_cast(h2, v[1]);
-                    st[i] = make_float4((float)a[0], (float)a[1], (float)c[0], (float)c[1]);
+                    // (element-wise: hipcc / ROCm 7.2 dropped the conversion of the second dword when both were taken
+                    // through 2 x _Float16 vectors - channels 2, 3 came out as copies of 0, 1; tools/thin_probe.py)
+                    auto h = [](unsigned bits) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits); };
+                    st[i] = make_float4(h(v[0] & 0xffffu), h(v[0] >> 16), h(v[1] & 0xffffu), h(v[1] >> 16));
                 }
             } else {
                 const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, soff[i] == OOBT ? OOBT : soff[i] + c0 * 4u, 0, 0);

@@ -539,3 +539,21 @@ def test_winograd_all_passes(case, tile, act, dev):
         _, dxr, dwr, _ = R.conv2d_grads(x.cpu(), w.cpu(), None, dy.cpu(), 1, 1, refl)
         assert R.rel_l1(dx, dxr) < 2e-5, ("winograd dgrad", tile, R.rel_l1(dx, dxr))
         assert R.rel_l1(dw, dwr) < 2e-5, ("winograd wgrad", tile, R.rel_l1(dw, dwr))
+
+
+@pytest.mark.parametrize("lp", [0, True, 2], ids=["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 64, 64, 8, 64), (2, 32, 32, 24, 64), (1, 40, 72, 8, 64)])
+def test_thin_dgrad_every_dy_type(case, lp, dev):
+    """mmh_conv7_thin_dgrad (the Discriminator stems' gradient towards the generated image, models/MMHandModel.py:
+    238-243) with dy in fp32, bf16 and fp16 against the fp64 oracle on the same (rounded) operands.  The fp16 decode was
+    miscompiled once (channels 2, 3 of every 4 came out as copies of 0, 1): found by tests/test_lp16_step_gpu.py."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout = case
+    dy = _mk((B, H, W, Cout), 4, dev)
+    w = _mk((7, 7, Cin, Cout), 2, dev) * 0.02
+    rb = (lambda t: t.cpu()) if lp == 0 else ((lambda t: t.cpu().half().float()) if lp == 2 else
+                                                (lambda t: t.cpu().bfloat16().float()))
+    dyi = dy if lp == 0 else ops.lp16_twin(dy, lp)
+    dx = ops.raw_conv_dgrad_thin(dyi, w, (B, H, W, Cin), True)
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), w.cpu(), None, rb(dy), 1, 3, True)
+    assert R.rel_l1(dx[..., :3], dxr[..., :3]) < 5e-6, R.rel_l1(dx[..., :3], dxr[..., :3])
