@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import lib as L
 from . import ops
-from .networks import Discriminator, Generator, VGGHead
+from .networks import Discriminator, Generator, VGGHead, discriminators_lockstep
 from .ops import pad4
 
 
@@ -408,9 +408,11 @@ class MMHandModel(torch.nn.Module):
         o = self.opt
         with _frozen(self.netD_PB, self.netD_PP):
             nc = o.H_input_nc     # only the generated image inside the concat carries a gradient
-            pred_fake_PB = self.netD_PB.forward_nhwc(self._cat_PB(self.fake_nhwc, True), dx_channels=nc)
+            # both discriminators on the generated image: one after the other, or - under SyncBN - depth by depth
+            # side by side with their norm collectives packed (networks.discriminators_lockstep)
+            pred_fake_PB, pred_fake_PP = discriminators_lockstep([
+                (self.netD_PB, self._cat_PB(self.fake_nhwc, True), nc), (self.netD_PP, self._cat_PP(self.fake_nhwc), nc)])
             self.loss_G_GAN_PB = self.criterionGAN(pred_fake_PB, True)
-            pred_fake_PP = self.netD_PP.forward_nhwc(self._cat_PP(self.fake_nhwc), dx_channels=nc)
             self.loss_G_GAN_PP = self.criterionGAN(pred_fake_PP, True)
             if self.criterionL1 is not None:
                 losses = self.criterionL1(self.fake_nhwc, self.x_H2)
@@ -444,9 +446,10 @@ class MMHandModel(torch.nn.Module):
 
     def backward_D_basic(self, netD, real, fake, loss_id=0):
         o = self.opt
-        pred_real = netD.forward_nhwc(real)
+        # the real and the fake batch keep their own batch statistics (two passes, models/MMHandModel.py:263-274);
+        # under SyncBN they run side by side and share each depth's collective
+        pred_real, pred_fake = discriminators_lockstep([(netD, real, 0), (netD, fake.detach(), 0)])
         loss_D_real = self.criterionGAN(pred_real, True) * o.lambda_GAN
-        pred_fake = netD.forward_nhwc(fake.detach())
         loss_D_fake = self.criterionGAN(pred_fake, False) * o.lambda_GAN
         loss_D = (loss_D_real + loss_D_fake) * 0.5
         self.loss_backward(loss_D, loss_id)

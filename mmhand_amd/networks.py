@@ -108,6 +108,62 @@ def _norm_kind(norm_layer):
     raise NotImplementedError(f"normalization layer {norm_layer} is not supported")
 
 
+# SyncBN packing: norm sites that do not depend on each other - the three generator streams at
+# one depth, the passes of a discriminator (or of both) that run side by side - share ONE all-gather forward and ONE
+# all-reduce backward (ops.NormActMultiFn) instead of one tiny collective per site: 202 -> 100 per iteration at full
+# size.  Only taken where SyncBN is on (--norm batch under data parallelism); MMH_PACK_SYNCBN=0: one collective per site.
+import os as _os
+PACK_SYNCBN = _os.environ.get("MMH_PACK_SYNCBN", "1") != "0"
+
+
+def packing(*nets):
+    """the given networks run SyncBN and may pack its collectives"""
+    return bool(PACK_SYNCBN and nets and all(n.norm == "batch" and n.training and n.sync_group is not None for n in nets)
+                and len({id(n.sync_group) for n in nets}) == 1)
+
+
+def normact_multi(entries):
+    """entries: dicts with the arguments of _Net.normact (net, bag, idx, x, relu, and optionally drop, site, residual,
+    out_lp, defer) of norm sites that do not depend on each other -> list of what normact returns for each.  Under
+    SyncBN the sites become one autograd node with packed collectives; otherwise this is a plain loop."""
+    nets = [e["net"] for e in entries]
+    if len(entries) < 2 or not packing(*nets):
+        return [e["net"].normact(e["bag"], e["idx"], e["x"], e["relu"], e.get("drop", False), e.get("site"),
+                                 e.get("residual"), e.get("out_lp", 0), e.get("defer", 0)) for e in entries]
+    flat, meta = [], []
+    for e in entries:
+        net, x = e["net"], e["x"]
+        x16 = None
+        if isinstance(x, tuple):
+            x, x16 = x
+        relu, drop, defer, out_lp = e["relu"], e.get("drop", False), e.get("defer", 0), e.get("out_lp", 0)
+        drop_p = 0.5 if drop else 0.0
+        mask, seed = None, 0
+        if drop_p > 0:
+            if net._mask_src is not None:
+                mask = net._mask_src[e.get("site")]
+            else:
+                seed = ops.next_dropout_seed()
+        np_ = e["bag"][e["idx"]]
+        np_.num_batches_tracked += 1
+        if defer:
+            assert x16 is None and not out_lp and (defer == 3 or e.get("residual") is None)
+        flat += [x, np_.weight, np_.bias, e.get("residual"), np_.running_mean, np_.running_var, relu, drop_p, seed, mask,
+                 out_lp, x16, defer, None]
+        meta.append((x, relu, drop_p, out_lp, defer))
+    outs = ops.NormActMultiFn.apply(nets[0].sync_group, len(entries), *flat)
+    res = []
+    for i, (x, relu, drop_p, out_lp, defer) in enumerate(meta):
+        o = outs[i * ops.NORM_SITE_OUTS:(i + 1) * ops.NORM_SITE_OUTS]
+        if defer in (1, 2):
+            res.append((o[0], ops.NormDefer(x.detach(), o[1], o[2], 1, relu, drop_p, o[3])))
+        elif out_lp:
+            res.append((o[0], o[1]))
+        else:
+            res.append(o[0])
+    return res
+
+
 class _Net(nn.Module):
     """Shared machinery: flat buffers, init, norm/conv helpers."""
 
@@ -355,6 +411,34 @@ class _Net(nn.Module):
         return y
 
 
+def two_conv_blocks_lockstep(entries):
+    """_Net.two_conv_block for several independent blocks side by side (entries: dicts net, blk, x, site, last_norm,
+    residual): conv 1 of every block, their norms as one packed node, conv 2 of every block, the last norms as one
+    packed node.  Same arithmetic per block as two_conv_block."""
+    pre = []
+    for e in entries:
+        net, blk, x = e["net"], e["blk"], e["x"]
+        i2 = 6 if net.use_dropout else 5
+        fuse = net._norm_fusion(blk[1], blk[i2], x)
+        fuse_last = 3 if (e["last_norm"] and torch.is_tensor(x) and net._norm_bwd_fusion(blk[i2], x)) else 0
+        y = net.conv(blk[1], x, 1, 1, True, y_lp=net._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2)
+        pre.append((i2, fuse, fuse_last, y))
+    ys = normact_multi([dict(net=e["net"], bag=e["blk"], idx=2, x=y, relu=True, drop=e["net"].use_dropout and e["net"].training,
+                             site=e["site"], out_lp=e["net"]._lp_edge(e["blk"][i2]), defer=fuse)
+                        for e, (i2, fuse, fuse_last, y) in zip(entries, pre)])
+    zs = []
+    for e, (i2, fuse, fuse_last, _), y in zip(entries, pre, ys):
+        net, blk = e["net"], e["blk"]
+        zs.append(net.conv(blk[i2], y, 1, 1, True, y_lp=net._lp_out(blk[i2]), to_norm=e["last_norm"], g_defer=fuse_last == 3))
+    last = [i for i, e in enumerate(entries) if e["last_norm"]]
+    if last:
+        outs = normact_multi([dict(net=entries[i]["net"], bag=entries[i]["blk"], idx=pre[i][0] + 1, x=zs[i], relu=False,
+                                   residual=entries[i].get("residual"), defer=pre[i][2]) for i in last])
+        for i, o in zip(last, outs):
+            zs[i] = o
+    return zs
+
+
 # ----------------------------------------------------------------------------- Generator
 class Generator(_Net):
     """Three-stream PATN generator (models/Generator.py:133-313)."""
@@ -400,13 +484,44 @@ class Generator(_Net):
             self._normp(up, 3 * i + 1, c // 2)
         self._conv(up, 3 * n_downsampling + 1, ngf, output_nc, 7, bias=True)
 
+    def _down_lockstep(self, x1, x2, x3):
+        """the three down-sampling streams (stem + n_down stride-2 convs each) depth by depth: same layers and
+        hand-over types as the per-stream loop of forward_nhwc, the three norms of a depth as one packed node"""
+        m = self.model
+        ds = [m[f"stream{s}_down"] for s in (1, 2, 3)]
+        xs = [x1, x2, x3]
+        first = [d[4] if self.n_down > 0 else None for d in ds]
+        ys = []
+        for d, x in zip(ds, xs):
+            Bx, Hx, Wx, _ = x.shape
+            ys.append(self.conv(d[1], x, 1, 3, True, y_lp=self._lp_out_stem(d[1], Bx, Hx, Wx, x.requires_grad), to_norm=True))
+        xs = normact_multi([dict(net=self, bag=d, idx=2, x=y, relu=True, out_lp=self._lp_edge(f, 2, False))
+                            for d, y, f in zip(ds, ys, first)])
+        for i in range(self.n_down):
+            ys, lps = [], []
+            for s, d, x in zip((1, 2, 3), ds, xs):
+                cp = d[4 + 3 * i]
+                if i + 1 < self.n_down:
+                    out_lp = self._lp_edge(d[4 + 3 * (i + 1)], 2, False)
+                elif s != 1 and self.n_blocks > 0:
+                    out_lp = self._lp_edge(m["att"][0][f"conv_block_stream{s}"][1])
+                else:
+                    out_lp = 0
+                lps.append(out_lp)
+                ys.append(self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True))
+            xs = normact_multi([dict(net=self, bag=d, idx=5 + 3 * i, x=y, relu=True, out_lp=lp)
+                                for d, y, lp in zip(ds, ys, lps)])
+        return xs
+
     def forward_nhwc(self, x1, x2, x3):
         """x1,x2,x3: NHWC (channels zero-padded to 4) -> NHWC [B,H,W,pad4(output_nc)]."""
         m = self.model
         xs = []
+        if packing(self):       # SyncBN: the three streams side by side, one packed collective per depth
+            x1, x2, x3 = self._down_lockstep(x1, x2, x3)
         # 16-bit mode: the tensors between the 3x3 convs and their norms travel in 16 bits (see two_conv_block);
         # the 7x7 stems read fp32 inputs and write fp32
-        for s, x in zip((1, 2, 3), (x1, x2, x3)):
+        for s, x in (() if packing(self) else zip((1, 2, 3), (x1, x2, x3))):
             d = m[f"stream{s}_down"]
             first = d[4] if self.n_down > 0 else None
             Bx, Hx, Wx, _ = x.shape
@@ -423,13 +538,19 @@ class Generator(_Net):
                 x = self.normact(d, 5 + 3 * i, self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True), True,
                                  out_lp=out_lp)
             xs.append(x)
-        x1, x2, x3 = xs
+        if not packing(self):
+            x1, x2, x3 = xs
         for b in range(self.n_blocks):
             blk = m["att"][b]
             p = f"model.att.{b}.conv_block_stream"
-            s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True)
-            s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
-            s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
+            if packing(self):
+                s1, s2, s3 = two_conv_blocks_lockstep(
+                    [dict(net=self, blk=blk[f"conv_block_stream{s}"], x=x, site=p + str(s), last_norm=s == 1)
+                     for s, x in zip((1, 2, 3), (x1, x2, x3))])
+            else:
+                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True)
+                s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
+                s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)
             more = b + 1 < self.n_blocks
             cat_lp = self._lp_edge(m["att"][b + 1]["conv_block_stream2"][1]) if more else 0
@@ -518,6 +639,40 @@ class Discriminator(_Net):
         assert Cc == self.input_nc
         x = ops.PackFn.apply(pad4(Cc), input.float(), True, Cc)
         return ops.nhwc_to_nchw_view(self.forward_nhwc(x))
+
+
+def discriminators_lockstep(entries):
+    """Several Discriminator passes side by side - entries: [(net, x NHWC, dx_channels)], the same network twice (its
+    real and its fake batch: models/MMHandModel.py:263-274) or two networks on their own inputs (D_PB and D_PP inside
+    the generator step, :238-243) -> [logits].  Every pass keeps its OWN batch statistics, exactly as separate calls
+    of forward_nhwc do (one after the other wherever SyncBN packing is off); what they share under SyncBN is the
+    collective: one all-gather / all-reduce per depth for all of them (packing())."""
+    nets = [e[0] for e in entries]
+    if len(entries) < 2 or not packing(*nets) or len({(n.n_down, n.n_blocks) for n in nets}) != 1:
+        return [net.forward_nhwc(x, dx_channels=dxc) for net, x, dxc in entries]
+    n0 = nets[0]
+    ys = []
+    for net, x, dxc in entries:
+        Bx, Hx, Wx, _ = x.shape
+        ys.append(net.conv(net.model[1], x, 1, 3, True, dx_channels=dxc, to_norm=True,
+                           y_lp=net._lp_out_stem(net.model[1], Bx, Hx, Wx, x.requires_grad, dxc)))
+    ys = normact_multi([dict(net=net, bag=net.model, idx=2, x=y, relu=True,
+                             out_lp=net._lp_edge(net.model[4] if net.n_down > 0 else None, 2, False))
+                        for net, y in zip(nets, ys)])
+    for i in range(n0.n_down):
+        zs = []
+        for net, y in zip(nets, ys):
+            cp = net.model[4 + 3 * i]
+            zs.append(net.conv(cp, y, 2, 1, False, y_lp=net._lp_out(cp, 2, False), to_norm=True))
+        ys = normact_multi([dict(net=net, bag=net.model, idx=5 + 3 * i, x=z, relu=True,
+                                 out_lp=net._lp_edge(net.model[4 + 3 * (i + 1)], 2, False) if i + 1 < net.n_down else 0)
+                            for net, z in zip(nets, zs)])
+    base = 4 + 3 * n0.n_down
+    for b in range(n0.n_blocks):
+        ys = two_conv_blocks_lockstep([dict(net=net, blk=net.model[base + b]["conv_block"], x=y,
+                                            site=f"model.{base + b}.conv_block", last_norm=True, residual=y)
+                                       for net, y in zip(nets, ys)])
+    return ys
 
 
 # ----------------------------------------------------------------------------- VGG19[:4]

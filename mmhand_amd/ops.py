@@ -1399,6 +1399,197 @@ def _sync_stats(mean, m2, rows, group):
 collective_counter = {}
 
 
+def _sync_stats_multi(items, group):
+    """SyncBN statistics of several norm sites with ONE collective: items = [(mean [1,C], m2 [1,C], rows), ...] ->
+    [(gmean, gm2, count), ...].  The sites' (count, mean, M2) triples travel as one flat message (all_gather of
+    sum 3 C_i floats per rank); each site then merges its [world][3][C] block with Chan's formula on the device."""
+    import torch.distributed as dist
+    if len(items) == 1:
+        return [_sync_stats(*items[0], group)]
+    world = dist.get_world_size(group)
+    collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
+    collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(items)
+    packed = torch.cat([torch.cat([torch.full_like(m, float(rows)), m, m2], 0).reshape(-1) for m, m2, rows in items])
+    gathered = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
+    if packed.is_cuda:
+        dist.all_gather_into_tensor(gathered.view(-1), packed, group=group)
+    else:
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed, group=group)
+        gathered = torch.stack(parts)
+    out, off = [], 0
+    for m, m2, rows in items:
+        Cc = m.shape[1]
+        blk = gathered[:, off:off + 3 * Cc].reshape(world * 3, Cc).contiguous()        # [world][3][C]
+        off += 3 * Cc
+        if m.is_cuda:
+            gmean, gm2 = torch.empty_like(m), torch.empty_like(m2)
+            L.call("mmh_norm_stats_merge", _ptr(blk), 1, world, Cc, _ptr(gmean), _ptr(gm2), _stream())
+        else:
+            t = blk.view(world, 3, Cc)
+            gmean = t[:, 1].mean(0, keepdim=True)
+            gm2 = t[:, 2].sum(0, keepdim=True) + rows * ((t[:, 1] - gmean) ** 2).sum(0, keepdim=True)
+        out.append((gmean.contiguous(), gm2.contiguous(), rows * world))
+    return out
+
+
+def _sync_bwd_sums_multi(pairs, group):
+    """the backward sums (s1, s2) of several norm sites all-reduced as ONE message; pairs = [(s1, s2), ...]"""
+    import torch.distributed as dist
+    collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
+    if len(pairs) > 1:
+        collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(pairs)
+    packed = torch.cat([torch.cat([s1, s2], 0).reshape(-1) for s1, s2 in pairs])
+    dist.all_reduce(packed, group=group)
+    out, off = [], 0
+    for s1, s2 in pairs:
+        n = s1.numel()
+        out.append((packed[off:off + n].view_as(s1).contiguous(), packed[off + n:off + 2 * n].view_as(s2).contiguous()))
+        off += 2 * n
+    return out
+
+
+class _SiteCtx:
+    """What the norm forward / backward phases below need of an autograd ctx, for ONE site of a multi-site node"""
+
+    def __init__(self):
+        self.saved_tensors, self.nondiff = (), []
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+    def mark_non_differentiable(self, *t):
+        self.nondiff += list(t)
+
+
+# The norm node in four phases, so that several sites can share their collectives (NormActMultiFn):
+#   forward:  _norm_fwd_local (statistics of this rank) -> [SyncBN: all-gather + merge] -> _norm_fwd_finish
+#   backward: _norm_bwd_local (sums of this rank)       -> [SyncBN: all-reduce]         -> _norm_bwd_finish
+def _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16):
+    ctx.in_lp = x16 is not None
+    ctx.out_lp = bool(out_lp)
+    if x16 is not None:
+        assert tuple(x16.shape) == tuple(x.shape) and x16.is_contiguous()
+        x = x16
+    else:
+        _chk(x, "x")
+    if drop_p > 0 and not relu:
+        # the keep bits are (out > 0): exact only behind a ReLU (the reference never drops without one)
+        raise RuntimeError("NormActFn: dropout without a preceding ReLU is not supported")
+    B = x.shape[0]
+    groups = B if mode == "instance" else 1
+    fast = raw_norm_stats_finalize_pending(x, groups) if (mode == "instance" and gamma is None and beta is None) else None
+    if fast is not None:
+        return x, groups, fast, None, None, fast[4]
+    mean, m2, rows = raw_norm_stats(x, groups)
+    return x, groups, None, mean, m2, rows
+
+
+def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask,
+                     sync_group, out_lp, x16, defer):
+    x, groups, fast, mean, m2, rows = st
+    if fast is not None:
+        mean, scale, shift, invstd, rows = fast
+        count = rows
+    else:
+        count = rows
+        if synced is not None:
+            mean, m2, count = synced
+        scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var)
+    ctx.defer = int(defer)
+    if defer == 3:
+        # defer 3 (a block's last norm: no ReLU, no dropout; its output feeds a gate / residual add and is
+        # written as usual): only the BACKWARD apply pass goes to the producing conv's backward transform
+        assert (x16 is None and not out_lp and not relu and drop_p == 0 and x.dtype == torch.float32
+                and norm_fusion_ok(x.shape[3]))
+        out = raw_scale_shift_act(x, scale, shift, residual, False, 0.0, 0, None)
+        ctx.cfg = (groups, rows, count, False, 0.0, sync_group, residual is not None)
+        ctx.save_for_backward(x, None, mean, invstd, gamma, scale, shift, None)
+        return (out,)
+    if defer:
+        # defer 1: the apply pass runs inside the consuming conv's input transform (the caller builds the
+        # NormDefer from the returned scale / shift / dropout bits); no output, no keep bits: the backward
+        # decides again.  defer 2: the backward's apply pass goes to the producing conv too.
+        assert x16 is None and not out_lp and residual is None and x.dtype == torch.float32 and norm_fusion_ok(x.shape[3])
+        dbits, drows = raw_dropout_bits(x.shape, drop_p, seed, mask, x.device, rows=True) if drop_p > 0 else (None, None)
+        ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group, False)
+        ctx.save_for_backward(x, dbits, mean, invstd, gamma, scale, shift, drows)
+        ctx.mark_non_differentiable(scale, shift)
+        if drows is not None:
+            ctx.mark_non_differentiable(drows)
+        return lp_proxy(x.shape, x.device), scale, shift, drows
+    masked = bool(relu or drop_p > 0)
+    if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
+        out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True,
+                                      out_lp=out_lp)
+    else:
+        out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, out_lp=out_lp), None
+    ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
+               residual is not None)
+    ctx.save_for_backward(x, kb, mean, invstd, gamma)
+    if out_lp:
+        if residual is not None:
+            raise RuntimeError("NormActFn: a 16-bit output together with a residual is not supported")
+        ctx.mark_non_differentiable(out)
+        return lp_proxy(x.shape, x.device), out
+    return (out,)
+
+
+def _norm_bwd_local(ctx, g):
+    """this rank's sums (s1 = sum dz, s2 = sum dz * xhat per plane) -> (g, s1, s2)"""
+    groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
+    if ctx.defer:
+        x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
+        g = g.contiguous()
+        Cc = x.shape[3]
+        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
+        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+        L.call("mmh_norm_bwd_reduce_rc", _ptr(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
+               _ptr(dbits), groups, rows, Cc, int(relu), drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
+        return g, s1, s2
+    x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
+    if has_res and relu:
+        raise RuntimeError("NormActFn: residual together with ReLU is not on the reference path")
+    # a 16-bit edge on the output: its gradient comes from a 16-bit convolution's dgrad, in 16 bits
+    g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
+    Cc = x.shape[3]
+    masked = 2 if (relu or drop_p > 0) else 0
+    ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
+    s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+    L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
+           rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _tdt(g), _tdt(x), _stream())
+    return g, s1, s2
+
+
+def _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2):
+    """s1l / s2l: this rank's sums (the affine parameters' gradients), s1 / s2: the global ones -> (dx, dgamma, dbeta, dres)"""
+    groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
+    gamma = ctx.saved_tensors[4]
+    dgamma = dbeta = None
+    if gamma is not None:
+        dgamma = s2l.sum(0) if groups > 1 else s2l.reshape(-1).clone()
+        dbeta = s1l.sum(0) if groups > 1 else s1l.reshape(-1).clone()
+    if ctx.defer:
+        x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
+        e = NormBwdDefer()
+        e.g, e.x, e.mean, e.invstd, e.gamma, e.s1, e.s2, e.count = g, x, mean, invstd, gamma, s1, s2, count
+        e.scale, e.shift, e.dbits, e.drows = scale, shift, dbits, drows
+        e.groups, e.rows, e.relu, e.drop_p = groups, rows, relu, drop_p
+        dx = norm_bwd_defer_out(e) if ctx.defer >= 2 else raw_norm_bwd_apply_rc(e)
+        return dx, dgamma, dbeta, (g if has_res else None)
+    x, out, mean, invstd, gamma = ctx.saved_tensors
+    Cc = x.shape[3]
+    masked = 2 if (relu or drop_p > 0) else 0
+    dx = torch.empty_like(x)        # a 16-bit x came from a 16-bit convolution: its gradient goes back in 16 bits
+    L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
+           _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
+           _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
+    dres = g if has_res else None
+    if ctx.in_lp:
+        dx = lp_grad_out(dx)
+    return dx, dgamma, dbeta, dres
+
+
 class NormActFn(torch.autograd.Function):
     """[Batch|Instance]Norm2d (training statistics) -> ReLU -> Dropout (+ residual add).
 
@@ -1412,132 +1603,98 @@ class NormActFn(torch.autograd.Function):
         16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass.
         x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
         the autograd edge.  Statistics and all arithmetic are fp32 either way (apex O1 keeps
-        batch_norm in fp32 on fp16 conv outputs)."""
+        batch_norm in fp32 on fp16 conv outputs).
+        Returns out | (proxy, out16) with out_lp | (proxy, scale, shift, drows) with defer 1 / 2."""
         ctx.set_materialize_grads(False)
-        ctx.in_lp = x16 is not None
-        ctx.out_lp = bool(out_lp)
-        if x16 is not None:
-            assert tuple(x16.shape) == tuple(x.shape) and x16.is_contiguous()
-            x = x16
-        else:
-            _chk(x, "x")
-        if drop_p > 0 and not relu:
-            # the keep bits are (out > 0): exact only behind a ReLU (the reference never drops without one)
-            raise RuntimeError("NormActFn: dropout without a preceding ReLU is not supported")
-        B = x.shape[0]
-        groups = B if mode == "instance" else 1
-        fast = raw_norm_stats_finalize_pending(x, groups) if (mode == "instance" and gamma is None and beta is None) else None
-        if fast is not None:
-            mean, scale, shift, invstd, rows = fast
-            count = rows
-        else:
-            mean, m2, rows = raw_norm_stats(x, groups)
-            count = rows
-            if mode == "batch" and sync_group is not None:
-                mean, m2, count = _sync_stats(mean, m2, rows, sync_group)
-            scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean,
-                                                     running_var)
-        ctx.defer = int(defer)
-        if defer == 3:
-            # defer 3 (a block's last norm: no ReLU, no dropout; its output feeds a gate / residual add and is
-            # written as usual): only the BACKWARD apply pass goes to the producing conv's backward transform
-            assert (x16 is None and not out_lp and not relu and drop_p == 0 and x.dtype == torch.float32
-                    and norm_fusion_ok(x.shape[3]))
-            out = raw_scale_shift_act(x, scale, shift, residual, False, 0.0, 0, None)
-            ctx.cfg = (groups, rows, count, False, 0.0, sync_group, residual is not None)
-            ctx.save_for_backward(x, None, mean, invstd, gamma, scale, shift, None)
-            return out
-        if defer:
-            # defer 1: the apply pass runs inside the consuming conv's input transform (the caller builds the
-            # NormDefer from the returned scale / shift / dropout bits); no output, no keep bits: the backward
-            # decides again.  defer 2: the backward's apply pass goes to the producing conv too.
-            assert x16 is None and not out_lp and residual is None and x.dtype == torch.float32 and norm_fusion_ok(x.shape[3])
-            dbits, drows = raw_dropout_bits(x.shape, drop_p, seed, mask, x.device, rows=True) if drop_p > 0 else (None, None)
-            ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group, False)
-            ctx.save_for_backward(x, dbits, mean, invstd, gamma, scale, shift, drows)
-            ctx.mark_non_differentiable(scale, shift)
-            if drows is not None:
-                ctx.mark_non_differentiable(drows)
-            return lp_proxy(x.shape, x.device), scale, shift, drows
-        masked = bool(relu or drop_p > 0)
-        if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
-            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True,
-                                          out_lp=out_lp)
-        else:
-            out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, out_lp=out_lp), None
-        ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
-                   residual is not None)
-        ctx.save_for_backward(x, kb, mean, invstd, gamma)
-        if out_lp:
-            if residual is not None:
-                raise RuntimeError("NormActFn: a 16-bit output together with a residual is not supported")
-            ctx.mark_non_differentiable(out)
-            return lp_proxy(x.shape, x.device), out
-        return out
+        st = _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16)
+        synced = None
+        if mode == "batch" and sync_group is not None and st[2] is None:
+            synced = _sync_stats(st[3], st[4], st[5], sync_group)
+        outs = _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed,
+                                mask, sync_group, out_lp, x16, defer)
+        return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
     def backward(ctx, g, _g16=None, _a=None, _b=None):
         if g is None:
             return (None,) * 15
-        if ctx.defer:
-            return NormActFn._backward_deferred(ctx, g)
-        x, out, mean, invstd, gamma = ctx.saved_tensors     # `out` here = the keep-bits array (or None)
-        groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
-        if has_res and relu:
-            raise RuntimeError("NormActFn: residual together with ReLU is not on the reference path")
-        # a 16-bit edge on the output: its gradient comes from a 16-bit convolution's dgrad, in 16 bits
-        g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
-        Cc = x.shape[3]
-        masked = 2 if (relu or drop_p > 0) else 0
-        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
-        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
-        L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
-               rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _tdt(g), _tdt(x), _stream())
-        dgamma = dbeta = None
-        if gamma is not None:
-            dgamma = s2.sum(0) if groups > 1 else s2.reshape(-1).clone()
-            dbeta = s1.sum(0) if groups > 1 else s1.reshape(-1).clone()
+        sync_group = ctx.cfg[5]
+        g, s1l, s2l = _norm_bwd_local(ctx, g)
+        s1, s2 = s1l, s2l
         if sync_group is not None:
-            import torch.distributed as dist
-            packed = torch.cat([s1, s2], 0)
-            collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
-            dist.all_reduce(packed, group=sync_group)
-            s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
-        dx = torch.empty_like(x)        # a 16-bit x came from a 16-bit convolution: its gradient goes back in 16 bits
-        L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
-               _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
-               _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
-        dres = g if has_res else None
-        if ctx.in_lp:
-            dx = lp_grad_out(dx)
+            (s1, s2), = _sync_bwd_sums_multi([(s1l, s2l)], sync_group)
+        dx, dgamma, dbeta, dres = _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
+
+NORM_SITE_ARGS = 14     # per site: x, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask, out_lp, x16, defer, _
+NORM_SITE_OUTS = 4
+
+
+class NormActMultiFn(torch.autograd.Function):
+    """Several BatchNorm sites that do not depend on each other - the three generator streams at one depth, the real and
+    the fake pass of a discriminator - as ONE autograd node, so that under SyncBN (apex convert_syncbn_model,
+    models/MMHandModel.py:109-116) their statistics travel in one all-gather and their backward sums in one all-reduce
+    instead of one collective per site (101 + 101 latency-bound collectives per iteration).
+    Arithmetic per site is NormActFn's, phase by phase.
+
+    apply(sync_group, n, *flat): flat = n x NORM_SITE_ARGS entries
+        (x, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask, out_lp, x16, defer, None)
+    returns n x NORM_SITE_OUTS entries: per site NormActFn's outputs padded with None."""
+
     @staticmethod
-    def _backward_deferred(ctx, g):
-        x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
-        groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
-        g = g.contiguous()
-        Cc = x.shape[3]
-        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
-        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
-        L.call("mmh_norm_bwd_reduce_rc", _ptr(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
-               _ptr(dbits), groups, rows, Cc, int(relu), drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
-        dgamma = dbeta = None
-        if gamma is not None:
-            dgamma = s2.sum(0) if groups > 1 else s2.reshape(-1).clone()
-            dbeta = s1.sum(0) if groups > 1 else s1.reshape(-1).clone()
+    def forward(ctx, sync_group, n, *flat):
+        ctx.set_materialize_grads(False)
+        assert len(flat) == n * NORM_SITE_ARGS
+        sites, args, states = [], [], []
+        for i in range(n):
+            a = flat[i * NORM_SITE_ARGS:(i + 1) * NORM_SITE_ARGS]
+            x, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, out_lp, x16, defer, _ = a
+            sc = _SiteCtx()
+            states.append(_norm_fwd_local(sc, x, gamma, beta, "batch", relu, drop_p, out_lp, x16))
+            sites.append(sc)
+            args.append(a)
+        synced = [None] * n
         if sync_group is not None:
-            import torch.distributed as dist
-            packed = torch.cat([s1, s2], 0)
-            collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
-            dist.all_reduce(packed, group=sync_group)
-            s1, s2 = packed[:groups].contiguous(), packed[groups:].contiguous()
-        e = NormBwdDefer()
-        e.g, e.x, e.mean, e.invstd, e.gamma, e.s1, e.s2, e.count = g, x, mean, invstd, gamma, s1, s2, count
-        e.scale, e.shift, e.dbits, e.drows = scale, shift, dbits, drows
-        e.groups, e.rows, e.relu, e.drop_p = groups, rows, relu, drop_p
-        dx = norm_bwd_defer_out(e) if ctx.defer >= 2 else raw_norm_bwd_apply_rc(e)
-        return dx, dgamma, dbeta, (g if has_res else None), None, None, None, None, None, None, None, None, None, None, None
+            synced = _sync_stats_multi([(st[3], st[4], st[5]) for st in states], sync_group)
+        outs, saved, counts = [], [], []
+        for sc, st, sy, a in zip(sites, states, synced, args):
+            x, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, out_lp, x16, defer, _ = a
+            o = _norm_fwd_finish(sc, st, sy, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, sync_group,
+                                 out_lp, x16, defer)
+            outs += list(o) + [None] * (NORM_SITE_OUTS - len(o))
+            saved += list(sc.saved_tensors)
+            counts.append(len(sc.saved_tensors))
+            if sc.nondiff:
+                ctx.mark_non_differentiable(*sc.nondiff)
+            sc.saved_tensors = ()
+        ctx.save_for_backward(*saved)
+        ctx.sites, ctx.counts, ctx.sync_group = sites, counts, sync_group
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = len(ctx.sites)
+        saved, off = ctx.saved_tensors, 0
+        for sc, c in zip(ctx.sites, ctx.counts):
+            sc.saved_tensors = saved[off:off + c]
+            off += c
+        live = [i for i in range(n) if grads[i * NORM_SITE_OUTS] is not None]
+        loc = {i: _norm_bwd_local(ctx.sites[i], grads[i * NORM_SITE_OUTS]) for i in live}
+        glob = {i: (loc[i][1], loc[i][2]) for i in live}
+        if ctx.sync_group is not None and live:
+            red = _sync_bwd_sums_multi([glob[i] for i in live], ctx.sync_group)
+            glob = dict(zip(live, red))
+        out = [None, None]
+        for i in range(n):
+            if i in loc:
+                g, s1l, s2l = loc[i]
+                dx, dgamma, dbeta, dres = _norm_bwd_finish(ctx.sites[i], g, s1l, s2l, *glob[i])
+            else:
+                dx = dgamma = dbeta = dres = None
+            out += [dx, dgamma, dbeta, dres] + [None] * (NORM_SITE_ARGS - 4)
+            ctx.sites[i].saved_tensors = ()
+        return tuple(out)
 
 
 class AffineActFn(torch.autograd.Function):

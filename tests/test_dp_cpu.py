@@ -41,6 +41,37 @@ def _w_sync_stats(rank, world, port):
     dist.destroy_process_group()
 
 
+def _w_sync_stats_packed(rank, world, port):
+    """several norm sites, ONE collective each way (ops._sync_stats_multi / _sync_bwd_sums_multi): the same global
+    statistics and sums as one collective per site"""
+    _init(rank, world, port)
+    from mmhand_amd import ops
+    g = torch.Generator().manual_seed(11)
+    items, fulls = [], []
+    for Cc in (8, 16, 4):
+        full = torch.randn((4, 3, 5, Cc), generator=g) * 2 + 1
+        x = full[rank * 2:(rank + 1) * 2].reshape(-1, Cc)
+        mean = x.mean(0, keepdim=True)
+        items.append((mean.contiguous(), ((x - mean) ** 2).sum(0, keepdim=True).contiguous(), x.shape[0]))
+        fulls.append(full.reshape(-1, Cc))
+    ops.collective_counter.clear()
+    packed = ops._sync_stats_multi(items, dist.group.WORLD)
+    assert ops.collective_counter == {"all_gather": 1, "packed_sites": 3}, ops.collective_counter
+    for (gmean, gm2, count), it, ff in zip(packed, items, fulls):
+        smean, sm2, scount = ops._sync_stats(*it, dist.group.WORLD)
+        assert count == scount == ff.shape[0]
+        assert torch.allclose(gmean, smean, atol=1e-6) and torch.allclose(gm2, sm2, rtol=1e-5)
+        assert torch.allclose(gmean[0], ff.mean(0), atol=1e-5)
+        assert torch.allclose(gm2[0] / count, ff.var(0, unbiased=False), rtol=1e-4)
+    pairs = [(torch.full((1, c), float(rank + 1)), torch.arange(c, dtype=torch.float32).view(1, c) * (rank + 1)) for c in (8, 4)]
+    ops.collective_counter.clear()
+    red = ops._sync_bwd_sums_multi(pairs, dist.group.WORLD)
+    assert ops.collective_counter["all_reduce"] == 1
+    for (s1, s2), c in zip(red, (8, 4)):
+        assert torch.equal(s1, torch.full((1, c), 3.0)) and torch.equal(s2, torch.arange(c, dtype=torch.float32).view(1, c) * 3)
+    dist.destroy_process_group()
+
+
 def _w_grad_average(rank, world, port):
     """sum over ranks of shard gradients x 1/world == gradient of the loss on the global batch
     (InstanceNorm: samples independent; losses are means)."""
@@ -128,6 +159,6 @@ def _w_options(rank, world, port):
 
 
 @pytest.mark.parametrize("worker,port", [(_w_sync_stats, 29611), (_w_grad_average, 29612),
-                                          (_w_options, 29613), (_w_grad_buckets, 29614)])
+                                          (_w_options, 29613), (_w_grad_buckets, 29614), (_w_sync_stats_packed, 29615)])
 def test_world2_gloo(worker, port):
     mp.spawn(worker, args=(2, port), nprocs=2, join=True)

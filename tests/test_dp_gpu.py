@@ -41,9 +41,10 @@ def _run(norm, batch, distributed, wide=False):
     return out, sd
 
 
-def _worker(rank, world, port, norm, tmp, wide=False):
+def _worker(rank, world, port, norm, tmp, wide=False, pack=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK="0", MMH_DP_LOG="1", MMH_BUCKET_MB="0.02")
+                      WORLD_SIZE=str(world), LOCAL_RANK="0", MMH_DP_LOG="1", MMH_BUCKET_MB="0.02",
+                      MMH_PACK_SYNCBN="1" if pack else "0")
     sys.path.insert(0, ROOT)
     from oracle import mmhand_ref as O
     torch.cuda.set_device(0)
@@ -67,12 +68,13 @@ def _worker(rank, world, port, norm, tmp, wide=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("norm,port,wide", [("instance", 29621, False), ("batch", 29622, False), ("batch", 29623, True),
-                                            ("instance", 29624, True)])
-def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, wide, dev, tmp_path):
+@pytest.mark.parametrize("norm,port,wide,pack", [("instance", 29621, False, True), ("batch", 29622, False, True),
+                                                 ("batch", 29623, True, True), ("instance", 29624, True, True),
+                                                 ("batch", 29625, False, False)])
+def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, wide, pack, dev, tmp_path):
     from oracle import mmhand_ref as O
     from tests.golden.recipe import is_null_grad_bias
-    mp.spawn(_worker, args=(2, port, norm, str(tmp_path), wide), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, norm, str(tmp_path), wide, pack), nprocs=2, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "rank1.pt"))
     S = 64 if wide else 32
@@ -84,16 +86,23 @@ def test_two_ranks_equal_one_rank_on_concatenated_batch(norm, port, wide, dev, t
     # replicas stay identical
     for k in r0["sd"]:
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
-    # SyncBN collectives per iteration (--norm batch): one all_gather per norm site forward and one
-    # all_reduce per site backward.  G: 3 stems x 3 + n_blocks x 4 + 2 up = 19 sites here (47 at full
-    # size); D: 1 + 2 + 2 x n_layers_D = 7 per pass (9 at full size), 6 passes per iteration (2 in the
-    # G step, 2 per discriminator step) -> 61 + 61 here, 101 + 101 at full size.  --norm instance: none.
+    # SyncBN collectives per iteration (--norm batch).  One per norm SITE (MMH_PACK_SYNCBN=0, what apex does): G has
+    # 3 stems x 3 + n_blocks x 4 + 2 up = 19 sites here (47 at full size); D 1 + 2 + 2 x n_layers_D = 7 per pass (9 at
+    # full size), 6 passes per iteration (2 in the G step, 2 per discriminator step) -> 61 all-gathers + 61 all-reduces
+    # here, 101 + 101 at full size.  PACKED (default; networks.normact_multi): the three generator streams share one
+    # collective per depth - 3 (stem, two downs) + 2 per PATBlock + 2 up = 9 here (23 at full size) - and so do the
+    # discriminator passes that run side by side - D_PB and D_PP in the generator step, the real and the fake batch in
+    # each discriminator step: 7 per pair, three pairs -> 30 + 30 here, 50 + 50 at full size.  --norm instance: none.
+    sb = dict(r0["syncbn"])
+    packed = sb.pop("packed_sites", 0)
     if norm == "batch" and wide:
-        assert r0["syncbn"]["all_gather"] == r0["syncbn"]["all_reduce"] > 0, r0["syncbn"]
+        assert sb["all_gather"] == sb["all_reduce"] > 0 and packed > 0, r0["syncbn"]
+    elif norm == "batch" and pack:
+        assert sb == {"all_gather": 2 * (9 + 3 * 7), "all_reduce": 2 * (9 + 3 * 7)} and packed > 0, r0["syncbn"]
     elif norm == "batch":
-        assert r0["syncbn"] == {"all_gather": 2 * (19 + 6 * 7), "all_reduce": 2 * (19 + 6 * 7)}, r0["syncbn"]
+        assert sb == {"all_gather": 2 * (19 + 6 * 7), "all_reduce": 2 * (19 + 6 * 7)} and packed == 0, r0["syncbn"]
     else:
-        assert r0["syncbn"] == {}, r0["syncbn"]
+        assert sb == {}, r0["syncbn"]
     # gradient buckets (20 KB here) went out in reverse layer order DURING the backward pass: the
     # Generator's first bucket (its last layers) was issued before the gradients of its first
     # layers existed, and both ranks issued their collectives in the same order
