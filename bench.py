@@ -282,6 +282,48 @@ def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, **
     return out
 
 
+def gradient_parity_run(dev, size, norm):
+    """the trade the headline path makes, on the driver line.  Parameter gradients of the full-size Generator
+    (ngf 64, 9 PATBlocks, B=2) through the Winograd F(6x6,3x3) path against the same gradients through the direct
+    implicit-GEMM kernels: relative L1 per tensor.  (Against the fp64 oracle the direct kernels are at 1e-6 ... 1e-3 per
+    tensor and Winograd at <= 5e-3, median <= 2e-3: tests/test_winograd_step_gpu.py; no oracle is imported here.)"""
+    import gc
+    import statistics
+    from mmhand_amd import ops
+    from mmhand_amd.networks import Generator
+    B = 2
+    b = synthetic_batch_gpu(B, size, size, 49, dev)
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    probe = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3)).to(dev)
+    res, old = {}, ops.USE_WINOGRAD
+    try:
+        for wino in (False, True):
+            ops.USE_WINOGRAD = wino
+            ops.bump_weights_epoch()
+            net = Generator([3, 42, 6], 3, 64, norm, False, 9).init_weights("normal", 49).to(dev).train()
+            net.flatten_parameters()
+            out = net(g_in)
+            (out * probe).sum().backward()
+            res[wino] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+            del net, out
+    finally:
+        ops.USE_WINOGRAD = old
+        ops.bump_weights_epoch()
+    rel = lambda a, c: float((a.double() - c.double()).abs().sum() / c.double().abs().sum().clamp_min(1e-30))   # noqa: E731
+    errs = sorted(rel(res[True][1][n], g) for n, g in res[False][1].items() if float(g.abs().sum()) > 0)
+    out = {"winograd_vs_direct": {"output_rel_l1": float(f"{rel(res[True][0], res[False][0]):.3e}"),
+                                  "grad_rel_l1_median": float(f"{statistics.median(errs):.3e}"),
+                                  "grad_rel_l1_p90": float(f"{errs[(len(errs) * 9) // 10]:.3e}"),
+                                  "grad_rel_l1_max": float(f"{errs[-1]:.3e}"), "tensors": len(errs)},
+           "note": f"full-size Generator (ngf 64, 9 PATBlocks, {size}x{size}, B={B}, --norm {norm}, dropout off), gradients of "
+                   "sum(out * probe) per parameter tensor; the headline path (Winograd) against direct_path's kernels, whose "
+                   "own distance from the fp64 oracle is 1e-6 (tests/test_winograd_step_gpu.py)"}
+    del res
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def side_infer_run(dev, B, size, steps, bf16):
     """configs[3]: Generator forward only, eval BatchNorm folded into the convs, hipGraph replay"""
     import gc
@@ -582,6 +624,8 @@ def main():
                                                    "MFMA operands, 16-bit conv-facing tensors, fp32 master weights, dynamic "
                                                    "loss scaling); stack_frac = the 3x3 stride-1 256/512-channel stack, all "
                                                    "three passes incl. reflect border terms, algorithmic FLOPs / kernel time / 2500 TF"))
+        if a.dtype == "f32" and not a.no_winograd:
+            guarded("gradient_parity", lambda: gradient_parity_run(dev, a.size, a.norm))
         guarded("norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch",
                                                           opt_level="O1" if a.dtype == "bf16" else "O0"),
                                            note="the reference's script default --norm batch (BatchNorm2d affine, conv bias off)"))

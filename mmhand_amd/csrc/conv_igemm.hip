@@ -504,6 +504,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     }
 
     // --- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---
+    // (the bias of the lane's TN columns is read ONCE: inside the store loop the compiler has to reload it per element -
+    // it cannot prove that the stores to p.out leave p.bias alone - and waits for every reload)
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+        bv[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -524,8 +532,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
+                    float v = acc[i][j][r] + bv[j];
                     if (p.accum) v += p.out[off + n];
                     p.out[off + n] = apply_act(v, p.act);
                 }
@@ -1343,6 +1350,12 @@ __device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const in
         }
     }
 
+    float bv[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + l31;
+        bv[jn] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1363,8 +1376,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const in
             for (int jn = 0; jn < TN; ++jn) {
                 const int n = n0 + wn * WTN + jn * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][jn][r];
-                    if (p.bias) v += p.bias[n];
+                    float v = acc[i][jn][r] + bv[jn];
                     if (p.accum) v += p.out[off + n];
                     p.out[off + n] = apply_act(v, p.act);
                 }
