@@ -22,6 +22,7 @@
 // GEMM view: M = B*H*W output pixels, N output channels (rows of the weight operand), K = taps * C.
 // Requires C % 64 == 0, N % 256 == 0 (the 256 / 512-channel PATBlock and Discriminator trunks).
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -597,6 +598,218 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
     // (oh0 + wr*8 + i, ow0 + l15): one 8-byte (16-bit output) or 16-byte (fp32) store per accumulator instead of four
     // 2- / 4-byte ones - a quarter of the store instructions of the pixel-major layout, whose 128 scalar stores per lane
     // took longer than a filter row of MFMAs.  The bias is read once per lane, not once per element.
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + 4 * g4 + r] : 0.f;
+    const int ow = ow0 + l15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int oh = oh0 + wr * 8 + i;
+        if (oh >= p.H || ow >= p.W) continue;
+        const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store4<H16>(p.y, p.y16, m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_lp16h2_kernel: conv_lp16h_kernel with the fragment ADDRESS arithmetic taken out of the k-loop.
+// conv_lp16h_kernel recomputes, per A fragment and k-step, the halo row of the tap and its swizzle key: its loop body
+// holds 142 vector-ALU instructions beside 64 MFMAs per wave, and with two waves per SIMD that is MORE vector issue
+// time (2 x 142 x 4 cycles) than the MFMAs leave free (8 of every 16 cycles): the MFMA stream waits on address
+// arithmetic.  Here
+//   * halo row (hy, hx) sits at LDS row hy * 20 + hx (pitch 20: even, so the row's bank parity is hx & 1) and its
+//     16-byte chunks are XOR-ed with (hx >> 1) & 7 - a key that does not depend on hy: a fragment's 16 lanes read 16
+//     consecutive hx, i.e. 8 (even, odd) row pairs with 8 different keys - conflict-free - and the lane's address
+//     depends on the tap only through dw: lane_base[dw] + (wr*8 + i + dh) * 2560 - the row part is an IMMEDIATE;
+//   * six lane-constant A addresses (3 dw x 2 halves of the k-step) and two for B; per k-step the stage offset and
+//     dh rows are added as scalars (a handful of vector adds instead of ~100) - the taps stay a run-time loop (unrolled
+//     nine-fold the compiler keeps every per-tap DMA address alive and spills);
+//   * LDS is addressed through 32-bit local pointers (no 64-bit flat address arithmetic).  SIGN = +1 fprop, -1 dgrad.
+// Same tile, weights path, pipelining (fragments of the next half k-step requested while the current half multiplies,
+// one barrier per k-step in its middle) and epilogue as conv_lp16h_kernel; LDS 2 x 45 KiB + 2 x 32 KiB = 154 KiB.
+constexpr int HP2 = 20;                                     // halo pitch
+constexpr int HROWS2 = HW_ * HP2;                           // 360 LDS rows per stage
+constexpr int HSTAGE_A2 = HROWS2 * ROWB;                    // 46080 = 45 KiB
+constexpr int HROUNDS2 = (HROWS2 + 63) / 64;                // 6
+
+typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
+__device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>(addr); }
+
+template <bool H16, int SIGN>
+__global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const sAh = smem;                         // [2][HSTAGE_A2]
+    char* const sBh = smem + 2 * HSTAGE_A2;         // [2][HSTAGE_B]
+    const int tid = threadIdx.x;
+    // wave index as a SCALAR: everything derived from it (DMA destinations, row roles) stays in SGPRs
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int per_xcd = (p.MT * p.NT + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.MT * p.NT) return;
+    const int mt = tile / p.NT, nt = tile - mt * p.NT;
+    const int n0 = nt * TBN;
+    const int TX = (p.W + HT - 1) / HT, TY = (p.H + HT - 1) / HT;
+    const int b = mt / (TX * TY);
+    const int trem = mt - b * (TX * TY);
+    const int ty = trem / TX, tx = trem - ty * TX;
+    const int oh0 = ty * HT, ow0 = tx * HT;
+
+    // halo DMA roles: round rd covers LDS rows rd*64 .. +63 (row = hy * 20 + hx); wave w rows rd*64 + w*8 + lane/8
+    unsigned a_off[HROUNDS2];
+#pragma unroll
+    for (int rd = 0; rd < HROUNDS2; ++rd) {
+        const int r = rd * 64 + wave * 8 + (lane >> 3);
+        const int hy = r / HP2, hx = r - hy * HP2;
+        int ih = oh0 + hy - 1, iw = ow0 + hx - 1;
+        const bool row = r < HROWS2 && hx < HW_;
+        if (p.reflect) {
+            ih = ih < 0 ? -ih : ih;
+            iw = iw < 0 ? -iw : iw;
+            ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+            iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+        }
+        const bool ok = row && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const unsigned q = (unsigned)((lane & 7) ^ ((hx >> 1) & 7));
+        a_off[rd] = ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + q * 16u
+                       : (row ? 0xfffffffeu : 0xffffffffu);        // ...fe: zero page, ...ff: no row
+    }
+    unsigned b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
+        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;
+    }
+    const int KC = p.C / TBK;
+    auto issue_halo = [&](int kc) {
+        char* sA = sAh + (kc & 1) * HSTAGE_A2;
+        const char* xb = p.x + (size_t)kc * (TBK * 2);
+#pragma unroll
+        for (int rd = 0; rd < HROUNDS2; ++rd) {
+            if (a_off[rd] != 0xffffffffu) {
+                const char* g = a_off[rd] != 0xfffffffeu ? xb + a_off[rd] : p.zeros + (lane & 7) * 16;
+                __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (rd * 8 + wave) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int kc, int t) {             // weight tile of (chunk kc, tap t) -> stage (9 kc + t) & 1
+        char* sB = sBh + ((kc + t) & 1) * HSTAGE_B;     // 9 kc + t and kc + t have the same parity
+        const char* wbase = p.w + ((size_t)t * p.N * p.C + (size_t)kc * TBK) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    // lane-constant LDS byte addresses (32-bit) of stage 0: A [dw][half], B [half]; the k-step adds the stage offset
+    // and dh rows (scalars), the fragment index i an immediate
+    const unsigned lds0 = mmh::lds_addr_of(smem);
+    // (named scalars, not an array: a select over array elements comes back from the compiler as a run-time indexed
+    // load from a SCRATCH copy of the array)
+    auto a_lane = [&](int dw, int hf) -> unsigned {
+        const unsigned hx = (unsigned)(dw + l15);
+        return lds0 + (unsigned)(wr * 8 * HP2) * ROWB + hx * ROWB + ((((unsigned)(4 * hf + g4)) ^ ((hx >> 1) & 7u)) << 4);
+    };
+    const unsigned aA00 = a_lane(0, 0), aA01 = a_lane(0, 1), aA10 = a_lane(1, 0), aA11 = a_lane(1, 1), aA20 = a_lane(2, 0),
+                   aA21 = a_lane(2, 1);
+    unsigned aB[2];
+    {
+        const unsigned bkey = (unsigned)(l15 >> 1);     // weight rows wc*64 + j*16 + l15: key (row >> 1) & 7 = l15 >> 1
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            aB[hf] = lds0 + 2 * HSTAGE_A2 + (unsigned)(wc * 64 + l15) * ROWB + ((((unsigned)(4 * hf + g4)) ^ bkey) << 4);
+    }
+    auto selA = [&](int dw, int hf) -> unsigned {       // dw is wave-uniform, hf a constant: two selects
+        return hf ? (dw == 0 ? aA01 : (dw == 1 ? aA11 : aA21)) : (dw == 0 ? aA00 : (dw == 1 ? aA10 : aA20));
+    };
+    auto tap_dh = [&](int t) { const int kh = t / 3; return SIGN > 0 ? kh : 2 - kh; };
+    auto tap_dw = [&](int t) { const int kw = t - 3 * (t / 3); return SIGN > 0 ? kw : 2 - kw; };
+    const int nk = 9 * KC;
+
+    bf16x8 af[8], b0[4], b1[4];
+    issue_halo(0);
+    issue_w(0, 0);
+    issue_w(0, 1);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    {
+        const unsigned a0 = selA(tap_dw(0), 0) + (unsigned)tap_dh(0) * (HP2 * ROWB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(aB[0] + j * (16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = lds_frag(a0 + i * (HP2 * ROWB));
+    }
+    int kc = 0, t = 0;                  // (chunk, tap) of k-step ks
+    for (int ks = 0; ks < nk; ++ks) {
+        const int dh = tap_dh(t), dw = tap_dw(t);
+        const unsigned sb = (unsigned)(ks & 1) * HSTAGE_B;
+        // addresses of this k-step's second half and of the next k-step's first half: a few scalar-operand adds
+        const unsigned a1 = selA(dw, 1) + (unsigned)((kc & 1) * HSTAGE_A2 + dh * (HP2 * ROWB));
+        const unsigned bb1 = aB[1] + sb;
+        int kc2 = kc, t2 = t + 1;
+        if (t2 == 9) { t2 = 0; ++kc2; }
+        const unsigned a0n = selA(tap_dw(t2), 0) + (unsigned)((kc2 & 1) * HSTAGE_A2 + tap_dh(t2) * (HP2 * ROWB));
+        const unsigned bb0n = aB[0] + (HSTAGE_B - sb);
+        // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = lds_frag(bb1 + j * (16 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b0[j], af[i], acc[i][j]);
+            af[i] = lds_frag(a1 + i * (HP2 * ROWB));
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- middle of the k-step: the weight stage ks is read; stage ks+1 (issued one k-step ago) must have
+        // landed.  The halo of the next chunk, issued right after the weights at t == 0, may stay in flight across
+        // the barrier of t == 1 (it is needed nine k-steps after its issue): the wait then leaves the newest
+        // HROUNDS2 - 1 loads outstanding (every wave issues HROUNDS2 - 1 or HROUNDS2 of them)
+        if (t == 1 && kc + 1 < KC) __builtin_amdgcn_s_waitcnt(0x0070 | (HROUNDS2 - 1));
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+        if (ks + 2 < nk) {
+            int kc3 = kc, t3 = t + 2;
+            if (t3 >= 9) { t3 -= 9; ++kc3; }
+            issue_w(kc3, t3);
+        }
+        if (t == 0 && kc + 1 < KC) issue_halo(kc + 1);
+        // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
+        const bool more = ks + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = lds_frag(bb0n + j * (16 * ROWB));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b1[j], af[i], acc[i][j]);
+            if (more) af[i] = lds_frag(a0n + i * (HP2 * ROWB));
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        kc = kc2; t = t2;
+    }
+
     float bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1725,7 +1938,8 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 
 }  // namespace
 
-// fprop / dgrad kernel (mmh_set_option "lp16_shape"): 18 = conv_lp16h_kernel (default: MFMA 16x16x32,
+// fprop / dgrad kernel (mmh_set_option "lp16_shape"): 19 = conv_lp16h2_kernel (default: conv_lp16h_kernel with the
+// fragment address arithmetic out of the k-loop), 18 = conv_lp16h_kernel (MFMA 16x16x32,
 // fragment reads pipelined into the MFMA stream, activation halo of a 16x16 pixel tile resident in LDS for
 // all nine taps; 1040-1170 TFLOP/s on the PATBlock shapes), 17 = conv_lp16p_kernel (the same pipelining
 // on 256-pixel row tiles, the activation tile re-fetched per tap; also what images smaller than 16x16
@@ -1733,7 +1947,7 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 // wgrad kernel (mmh_set_option "lp16_wgrad_ring"): 2 = wgrad_lp16t_kernel (default: nine taps of a 64 x 128 tile resident,
 // the input halo of a 4 x 16 pixel block staged once: wgrad_lp16t.hip), 1 = wgrad_lp16r_kernel (one tap of a 256 x 256
 // tile per workgroup, ring of five LDS slots), 0 = wgrad_lp16_kernel (the same with two stages)
-namespace mmh { int g_lp16_shape = 18; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 2; }
+namespace mmh { int g_lp16_shape = 19; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 2; }
 using mmh::g_lp16_shape;
 
 extern "C" {
@@ -1795,6 +2009,30 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
         ready = e == hipSuccess ? 0 : mmh::fail("conv_lp16_kernel: %s", hipGetErrorString(e));
     }
     if (ready != 0) return ready;
+    if (g_lp16_shape == 19 && d->H >= HT && d->W >= HT) {       // halo kernel, fragment addresses precomputed (default)
+        constexpr int lds2 = 2 * HSTAGE_A2 + 2 * HSTAGE_B;
+        static int ready19 = -1;
+        if (ready19 != 0) {
+            hipError_t e = hipSuccess;
+            const void* fs[4] = {reinterpret_cast<const void*>(conv_lp16h2_kernel<false, 1>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<false, -1>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, 1>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1>)};
+            for (const void* f : fs)
+                if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            ready19 = e == hipSuccess ? 0 : mmh::fail("conv_lp16h2_kernel: %s", hipGetErrorString(e));
+        }
+        if (ready19 != 0) return ready19;
+        LpConvKP ph = p;
+        ph.MT = d->B * ((d->H + HT - 1) / HT) * ((d->W + HT - 1) / HT);
+        const dim3 grid(8 * ((ph.MT * ph.NT + 7) / 8));
+        hipStream_t st = mmh::as_stream(s);
+        if (p.h16 && mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<true, 1>), grid, dim3(512), lds2, st, ph);
+        else if (p.h16) hipLaunchKernelGGL((conv_lp16h2_kernel<true, -1>), grid, dim3(512), lds2, st, ph);
+        else if (mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<false, 1>), grid, dim3(512), lds2, st, ph);
+        else hipLaunchKernelGGL((conv_lp16h2_kernel<false, -1>), grid, dim3(512), lds2, st, ph);
+        return mmh::check_launch("conv_lp16h2_kernel");
+    }
     if (g_lp16_shape == 18 && d->H >= HT && d->W >= HT) {       // activation tile (halo) resident in LDS for all nine taps
         constexpr int lds = 2 * HSTAGE_A + 2 * HSTAGE_B;
         static int ready18 = -1;
@@ -1814,7 +2052,7 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
         else hipLaunchKernelGGL(conv_lp16h_kernel<false>, dim3(8 * pxh), dim3(512), lds, mmh::as_stream(s), ph);
         return mmh::check_launch("conv_lp16h_kernel");
     }
-    if (g_lp16_shape == 17 || g_lp16_shape == 18) {       // 16x16x32 with the fragment reads pipelined into the MFMA stream
+    if (g_lp16_shape == 17 || g_lp16_shape == 18 || g_lp16_shape == 19) {       // 16x16x32 with the fragment reads pipelined into the MFMA stream
         static int ready17 = -1;
         if (ready17 != 0) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16p_kernel<false>),

@@ -285,7 +285,7 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
         R.rel_l1(y, yf), R.rel_l1(dx, dxf), R.rel_l1(dw, dwf))
 
 
-@pytest.mark.parametrize("shape", [16, 17, 18, 32])
+@pytest.mark.parametrize("shape", [16, 17, 18, 19, 32])
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 9, 11, 64, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
                                   (1, 20, 12, 256, 256, True), (2, 17, 33, 256, 256, True), (1, 32, 48, 64, 256, False)])
@@ -320,7 +320,7 @@ def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
                 _, _, dwr, _ = R.conv2d_grads(rb(x), rb(w), None, rb(dy), 1, 1, refl)
                 assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
     finally:
-        lib.check(lib.load().mmh_set_option(b"lp16_shape", 18), "set")
+        lib.check(lib.load().mmh_set_option(b"lp16_shape", 19), "set")
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["fprop", "dgrad"])
@@ -341,7 +341,7 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
         lib.check(L_.mmh_set_option(b"lp16_shape", 16), "set")
         ref = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
         scale = float(ref.abs().max())
-        for shape in (17, 18):
+        for shape in (17, 18, 19):
             lib.check(L_.mmh_set_option(b"lp16_shape", shape), "set")
             for _ in range(3):
                 y = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
@@ -360,7 +360,7 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
             sc = float(outs[0].abs().max())
             assert float((outs[3] - outs[0]).abs().max()) < 2e-5 * sc, (float((outs[3] - outs[0]).abs().max()), sc)
     finally:
-        lib.check(L_.mmh_set_option(b"lp16_shape", 18), "set")
+        lib.check(L_.mmh_set_option(b"lp16_shape", 19), "set")
         lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 2), "set")
 
 

@@ -30,4 +30,4 @@ for (Cin, Cout, mode) in ((512, 512, 0), (256, 256, 0), (512, 256, 0), (256, 512
         print(f"{Cin}->{Cout} mode{mode} shape={shape}: {t*1e3:8.1f} us  {flop/t*1e-9:7.0f} TF", flush=True)
     d = max((res[16][0] - res[17][0]).abs().max().item(), (res[16][0] - res[18][0]).abs().max().item())
     print(f"   max |diff| between the two kernels: {d:.3e} (max |y| {res[16][0].abs().max().item():.2f})")
-L.mmh_set_option(b"lp16_shape", 18)
+L.mmh_set_option(b"lp16_shape", 19)

@@ -12,18 +12,24 @@ def timeit(fn, iters=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 B, H = 32, 64
+def setshape(v): lib.check(L.mmh_set_option(b"lp16_shape", v), "set")
 for (Cin, Cout) in ((256, 256), (512, 512), (512, 256)):
     x = torch.randn(B, H, H, Cin, device=dev); dy = torch.randn(B, H, H, Cout, device=dev)
     w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05; bias = torch.randn(Cout, device=dev)
     xb, dyb = ops.lp16_twin(x, True), ops.lp16_twin(dy, True)
     flop = 2.0 * B * H * H * Cin * Cout * 9
-    variants = {"fprop bias out16": lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True),
-                "fprop nobias out16": lambda: ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0, out16=True),
-                "fprop bias fp32": lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0),
-                "dgrad out16": lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)}
+    def mk(shape, fn):
+        def run():
+            setshape(shape)
+            return fn()
+        return run
+    fp = lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True)
+    dg = lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)
+    variants = {"h(18) fprop": mk(18, fp), "h2(19) fprop": mk(19, fp), "h(18) dgrad": mk(18, dg), "h2(19) dgrad": mk(19, dg)}
     res = {k: [] for k in variants}
     for f in variants.values(): f()
     torch.cuda.synchronize()
     for r in range(5):
         for k, f in variants.items(): res[k].append(timeit(f))
     print(f"{Cin}->{Cout}: " + " | ".join(f"{k}: {statistics.median(v)*1e3:.0f} us ({flop/statistics.median(v)/1e9:.0f} TF)" for k, v in res.items()), flush=True)
+setshape(19)

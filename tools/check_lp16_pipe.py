@@ -26,4 +26,4 @@ for variant in (17, 18):
             outs = [ops.raw_conv3x3_lp16(xb, wd, None, refl and mode == 0, 0, True, mode) for _ in range(3)]
             d = max((o - ref).abs().max().item() for o in outs)
             print(f"variant {variant} B{B} {H}x{W} {Cin}->{Cout} refl={refl} mode{mode}: max |diff| vs 16 = {d:.3e}" + ("   <-- MISMATCH" if d > 1e-3 else ""), flush=True)
-L.mmh_set_option(b"lp16_shape", 18)
+L.mmh_set_option(b"lp16_shape", 19)
