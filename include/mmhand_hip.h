@@ -421,6 +421,12 @@ int mmh_mse_fwd(const void* a, const void* b, int64_t n, float weight,
 int mmh_mse_bwd(const void* a, const void* b, int64_t n, float weight,
                 double denom, const void* gscalar, void* da, mmh_stream_t s);
 
+/* MaxPool2d(2, 2) of vgg19.features (indices 4, 9, 18, 27, 36) for --perceptual_layers > 3
+ * (losses/L1_plus_perceptualLoss.py:22-27 slices the feature stack at any index).  NHWC fp32, even H and W, C % 4 == 0.
+ * bwd: dx [B,H,W,C] receives g [B,H/2,W/2,C] at the first maximum of each window (scan order), zeros elsewhere.  */
+int mmh_maxpool2x2_fwd(const void* x, int B, int H, int W, int C, void* y, mmh_stream_t s);
+int mmh_maxpool2x2_bwd(const void* x, const void* g, int B, int H, int W, int C, void* dx, mmh_stream_t s);
+
 /* ---- thin 7x7 convolutions (at most 4 output channels) on the vector ALU -----
  * The Generator head ReflectionPad2d(3)+Conv2d(64,3,7)+Tanh (models/Generator.py:255-259)
  * and the dgrad of the Discriminator stems (models/Discriminator.py:79-84) with respect

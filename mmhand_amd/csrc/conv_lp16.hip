@@ -622,9 +622,13 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h_kernel(const LpConvKP p) {
 // time (2 x 142 x 4 cycles) than the MFMAs leave free (8 of every 16 cycles): the MFMA stream waits on address
 // arithmetic.  Here
 //   * halo row (hy, hx) sits at LDS row hy * 20 + hx (pitch 20: even, so the row's bank parity is hx & 1) and its
-//     16-byte chunks are XOR-ed with (hx >> 1) & 7 - a key that does not depend on hy: a fragment's 16 lanes read 16
-//     consecutive hx, i.e. 8 (even, odd) row pairs with 8 different keys - conflict-free - and the lane's address
-//     depends on the tap only through dw: lane_base[dw] + (wr*8 + i + dh) * 2560 - the row part is an IMMEDIATE;
+//     16-byte chunks are XOR-ed with hx & 6 - a key that does not depend on hy, so the lane's address depends on the
+//     tap only through dw: lane_base[dw] + (wr*8 + i + dh) * 2560 - the row part is an IMMEDIATE.  hx & 6 (not
+//     (row >> 1) & 7 as in conv_lp16h_kernel): ds_read_b128 serves a wave in groups {lanes 0-3, 12-15, 20-27}, ...
+//     (MI355X guide), i.e. 8 rows with chunk c and the 8 rows between them with chunk c ^ 1; with (row >> 1) & 7 those
+//     16 slots are distinct only when the fragment starts on an even row (dw = 0, 2) and 4 of 16 lanes collide on an
+//     odd start (the 25 M conflict cycles per launch the round-2 profile could not place); hx & 6 is conflict-free
+//     for every start (checked by enumeration over the real lane groups);
 //   * six lane-constant A addresses (3 dw x 2 halves of the k-step) and two for B; per k-step the stage offset and
 //     dh rows are added as scalars (a handful of vector adds instead of ~100) - the taps stay a run-time loop (unrolled
 //     nine-fold the compiler keeps every per-tap DMA address alive and spills);
@@ -675,7 +679,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
         }
         const bool ok = row && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        const unsigned q = (unsigned)((lane & 7) ^ ((hx >> 1) & 7));
+        const unsigned q = (unsigned)((lane & 7) ^ (hx & 6));
         a_off[rd] = ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + q * 16u
                        : (row ? 0xfffffffeu : 0xffffffffu);        // ...fe: zero page, ...ff: no row
     }
@@ -721,7 +725,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     // load from a SCRATCH copy of the array)
     auto a_lane = [&](int dw, int hf) -> unsigned {
         const unsigned hx = (unsigned)(dw + l15);
-        return lds0 + (unsigned)(wr * 8 * HP2) * ROWB + hx * ROWB + ((((unsigned)(4 * hf + g4)) ^ ((hx >> 1) & 7u)) << 4);
+        return lds0 + (unsigned)(wr * 8 * HP2) * ROWB + hx * ROWB + ((((unsigned)(4 * hf + g4)) ^ (hx & 6u)) << 4);
     };
     const unsigned aA00 = a_lane(0, 0), aA01 = a_lane(0, 1), aA10 = a_lane(1, 0), aA11 = a_lane(1, 1), aA20 = a_lane(2, 0),
                    aA21 = a_lane(2, 1);
@@ -784,12 +788,12 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         if (t == 1 && kc + 1 < KC) __builtin_amdgcn_s_waitcnt(0x0070 | (HROUNDS2 - 1));
         else __builtin_amdgcn_s_waitcnt(0x0070);
         __syncthreads();
-        if (ks + 2 < nk) {
+        if (ks + 2 < nk && !(p.dbg & 1)) {      // dbg: timing-only ablations (mmh_set_option "lp16_dbg"; results wrong)
             int kc3 = kc, t3 = t + 2;
             if (t3 >= 9) { t3 -= 9; ++kc3; }
             issue_w(kc3, t3);
         }
-        if (t == 0 && kc + 1 < KC) issue_halo(kc + 1);
+        if (t == 0 && kc + 1 < KC && !(p.dbg & 2)) issue_halo(kc + 1);
         // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
         const bool more = ks + 1 < nk;
         if (more) {

@@ -1374,6 +1374,64 @@ int check_cols(const char* who, int C) {
     return 0;
 }
 
+
+// MaxPool2d(2, 2) on NHWC fp32 (the pooling layers of vgg19.features when --perceptual_layers reaches past index 3:
+// losses/L1_plus_perceptualLoss.py:22-27).  One lane per (output pixel, 4 channels).  Backward: the gradient goes to the
+// FIRST maximum of the window in scan order (0,0), (0,1), (1,0), (1,1) - what torch's max_pool2d does.
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const float4* r0 = reinterpret_cast<const float4*>(x) + (((int64_t)b * H + 2 * oh) * W + 2 * ow) * C4 + c;
+        const float4* r1 = r0 + (int64_t)W * C4;
+        const float4 a = r0[0], bb = r0[C4], cc = r1[0], d = r1[C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, bb.x), fmaxf(cc.x, d.x)); m.y = fmaxf(fmaxf(a.y, bb.y), fmaxf(cc.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, bb.z), fmaxf(cc.z, d.z)); m.w = fmaxf(fmaxf(a.w, bb.w), fmaxf(cc.w, d.w));
+        reinterpret_cast<float4*>(y)[i] = m;
+    }
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dx,
+                                    int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        int64_t t = i / C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int64_t o0 = (((int64_t)b * H + 2 * oh) * W + 2 * ow) * C4 + c, o1 = o0 + (int64_t)W * C4;
+        const float4* xv = reinterpret_cast<const float4*>(x);
+        const float4 v[4] = {xv[o0], xv[o0 + C4], xv[o1], xv[o1 + C4]};
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 o[4];
+        auto route = [&](float va, float vb, float vc, float vd, float gg, float& oa, float& ob, float& oc, float& od) {
+            int k = 0; float m = va;
+            if (vb > m) { m = vb; k = 1; }
+            if (vc > m) { m = vc; k = 2; }
+            if (vd > m) { m = vd; k = 3; }
+            oa = k == 0 ? gg : 0.f; ob = k == 1 ? gg : 0.f; oc = k == 2 ? gg : 0.f; od = k == 3 ? gg : 0.f;
+        };
+        route(v[0].x, v[1].x, v[2].x, v[3].x, gv.x, o[0].x, o[1].x, o[2].x, o[3].x);
+        route(v[0].y, v[1].y, v[2].y, v[3].y, gv.y, o[0].y, o[1].y, o[2].y, o[3].y);
+        route(v[0].z, v[1].z, v[2].z, v[3].z, gv.z, o[0].z, o[1].z, o[2].z, o[3].z);
+        route(v[0].w, v[1].w, v[2].w, v[3].w, gv.w, o[0].w, o[1].w, o[2].w, o[3].w);
+        float4* dv = reinterpret_cast<float4*>(dx);
+        dv[o0] = o[0]; dv[o0 + C4] = o[1]; dv[o1] = o[2]; dv[o1 + C4] = o[3];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1778,6 +1836,24 @@ int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight, double den
                        (float)((double)weight / denom), static_cast<const float*>(gscalar),
                        static_cast<float*>(da));
     return mmh::check_launch("l1_bwd");
+}
+
+int mmh_maxpool2x2_fwd(const void* x, int B, int H, int W, int C, void* y, mmh_stream_t s) {
+    MMH_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0,
+                "mmh_maxpool2x2_fwd: NHWC fp32, even H and W, C %% 4 == 0");
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x), static_cast<float*>(y), B, H, W, C / 4);
+    return mmh::check_launch("maxpool2_fwd");
+}
+
+int mmh_maxpool2x2_bwd(const void* x, const void* g, int B, int H, int W, int C, void* dx, mmh_stream_t s) {
+    MMH_REQUIRE(x && g && dx && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0,
+                "mmh_maxpool2x2_bwd: NHWC fp32, even H and W, C %% 4 == 0");
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(x), static_cast<const float*>(g), static_cast<float*>(dx), B, H, W, C / 4);
+    return mmh::check_launch("maxpool2_bwd");
 }
 
 int mmh_mse_fwd(const void* a, const void* b, int64_t n, float weight, double denom, void* out,

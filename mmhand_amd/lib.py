@@ -114,6 +114,8 @@ SIGNATURES = {
     "mmh_l1_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_l1_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
     "mmh_mse_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
+    "mmh_maxpool2x2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mmh_maxpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mmh_mse_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
     "mmh_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp, _vp, _vp]),
     "mmh_grad_nonfinite": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),

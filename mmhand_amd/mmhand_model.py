@@ -243,12 +243,8 @@ class MMHandModel(torch.nn.Module):
             self.fake_PB_pool = ImagePool(opt.pool_size)
             self.criterionGAN = GANLoss()
             if opt.L1_type == "l1_plus_perL1":
-                if getattr(opt, "perceptual_layers", 3) != 3:
-                    # the reference slices vgg19.features up to (and including) this index
-                    # (L1_plus_perceptualLoss.py:24-27); only its shipped value is built here
-                    raise NotImplementedError("--perceptual_layers %r: only 3 (vgg19.features[0:4]) is built"
-                                              % (opt.perceptual_layers,))
-                self.vgg = VGGHead().to(self.device)
+                # the reference slices vgg19.features up to (and including) this index (L1_plus_perceptualLoss.py:24-27)
+                self.vgg = VGGHead(int(getattr(opt, "perceptual_layers", 3))).to(self.device)
                 self.vgg.bf16 = self.bf16
                 vgg_path = getattr(opt, "vgg_weights", None)
                 if vgg_path:
@@ -261,7 +257,7 @@ class MMHandModel(torch.nn.Module):
                                 "(--vgg_random_init); the reference uses torchvision's pretrained VGG19")
                 else:
                     raise RuntimeError(
-                        "--L1_type l1_plus_perL1 needs torchvision's pretrained vgg19.features[0:4] "
+                        "--L1_type l1_plus_perL1 needs torchvision's pretrained vgg19.features "
                         "(losses/L1_plus_perceptualLoss.py:22), which cannot be downloaded here: pass "
                         "--vgg_weights <state_dict file with 0.weight/0.bias/2.weight/2.bias, or the "
                         "torchvision 'features.' keys>, or opt in to random weights with --vgg_random_init")

@@ -676,23 +676,46 @@ def discriminators_lockstep(entries):
 
 
 # ----------------------------------------------------------------------------- VGG19[:4]
-class VGGHead(nn.Module):
-    """vgg19.features[0:4] (conv3x3 3->64 + ReLU, conv3x3 64->64 + ReLU), frozen
-    (losses/L1_plus_perceptualLoss.py:22-27).  torchvision weights are not available offline:
-    load them with load_state_dict({'0.weight','0.bias','2.weight','2.bias'}) when present."""
+# torchvision vgg19 "E" configuration: features[i] = conv3x3 (channels below) / ReLU / MaxPool2d(2, 2) ("M")
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
 
-    def __init__(self):
+
+def vgg19_layers(upto):
+    """[(index, kind, cin, cout)] of vgg19.features[0 : upto + 1] - the slice losses/L1_plus_perceptualLoss.py:22-27 takes
+    (`for i, layer in enumerate(vgg): add; if i == perceptual_layers: break`); kind in conv | relu | pool"""
+    out, i, cin = [], 0, 3
+    for v in VGG19_CFG:
+        if v == "M":
+            out.append((i, "pool", cin, cin)); i += 1
+        else:
+            out.append((i, "conv", cin, v)); out.append((i + 1, "relu", v, v)); i += 2; cin = v
+    if not 0 <= upto < len(out):
+        raise ValueError("--perceptual_layers %r: vgg19.features has indices 0..%d" % (upto, len(out) - 1))
+    return out[:upto + 1]
+
+
+class VGGHead(nn.Module):
+    """vgg19.features[0 : perceptual_layers + 1], frozen (losses/L1_plus_perceptualLoss.py:22-27; the shipped value 3 is
+    conv3x3 3->64 + ReLU, conv3x3 64->64 + ReLU).  torchvision weights are not available offline: load them with
+    load_state_dict({'0.weight','0.bias','2.weight','2.bias', ...}) or a torchvision vgg19 state_dict."""
+
+    def __init__(self, perceptual_layers=3):
         super().__init__()
         self.bf16 = False
+        self.layers = vgg19_layers(perceptual_layers)
         self.net = Bag()
-        self.net.put(0, ConvParam(3, 64, 3, True))
-        self.net.put(2, ConvParam(64, 64, 3, True))
+        for i, kind, cin, cout in self.layers:
+            if kind == "conv":
+                self.net.put(i, ConvParam(cin, cout, 3, True))
+        self.conv_ids = [i for i, kind, _, _ in self.layers if kind == "conv"]
+        self.out_channels = self.layers[-1][3]
         for p in self.parameters():
             p.requires_grad_(False)
 
     def init_random(self, seed=1234):
         g = torch.Generator().manual_seed(seed)
-        for m in (self.net[0], self.net[2]):
+        for i in self.conv_ids:
+            m = self.net[i]
             fan_in = m.cin * 9
             m.set_logical(torch.randn(m.cout, m.cin, 3, 3, generator=g) * math.sqrt(2.0 / fan_in),
                           torch.randn(m.cout, generator=g) * 0.05)
@@ -703,14 +726,21 @@ class VGGHead(nn.Module):
         return type(sd)((k.replace("net.", "", 1), v) for k, v in sd.items())
 
     def load_state_dict(self, sd, strict=True):
-        """Accepts {'0.weight','0.bias','2.weight','2.bias'} or a torchvision vgg19 state_dict
-        ('features.0.weight', ...; later layers and the classifier are ignored)."""
+        """Accepts {'0.weight','0.bias','2.weight','2.bias', ...} or a torchvision vgg19 state_dict
+        ('features.0.weight', ...; layers beyond the slice and the classifier are ignored)."""
         if any(k.startswith("features.") for k in sd):
+            keep = {str(i) for i in self.conv_ids}
             sd = {k[len("features."):]: v for k, v in sd.items()
-                  if k.startswith("features.") and k.split(".")[1] in ("0", "2")}
+                  if k.startswith("features.") and k.split(".")[1] in keep}
         return super().load_state_dict({"net." + k: v for k, v in sd.items()}, strict)
 
     def forward_nhwc(self, x):
-        a, b = self.net[0], self.net[2]
-        y = ops.Conv2dFn.apply(x, a.weight, a.bias, 1, 1, False, L.ACT_RELU, self.bf16)
-        return ops.Conv2dFn.apply(y, b.weight, b.bias, 1, 1, False, L.ACT_RELU, self.bf16)
+        n = len(self.layers)
+        for pos, (i, kind, _, _) in enumerate(self.layers):
+            if kind == "conv":
+                m = self.net[i]
+                relu = pos + 1 < n and self.layers[pos + 1][1] == "relu"        # the ReLU rides in the conv epilogue
+                x = ops.Conv2dFn.apply(x, m.weight, m.bias, 1, 1, False, L.ACT_RELU if relu else L.ACT_NONE, self.bf16)
+            elif kind == "pool":
+                x = ops.MaxPool2x2Fn.apply(x)
+        return x

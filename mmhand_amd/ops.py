@@ -1853,6 +1853,28 @@ class MSEMeanFn(torch.autograd.Function):
         return _pair_loss_bwd("mse", ctx, g)
 
 
+class MaxPool2x2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) on NHWC fp32: the pooling layers of vgg19.features beyond index 3
+    (losses/L1_plus_perceptualLoss.py:22-27, --perceptual_layers)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "x")
+        B, H, W_, Cc = x.shape
+        y = _empty((B, H // 2, W_ // 2, Cc), x)
+        L.call("mmh_maxpool2x2_fwd", _ptr(x), B, H, W_, Cc, _ptr(y), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, H, W_, Cc = x.shape
+        dx = torch.empty_like(x)
+        L.call("mmh_maxpool2x2_bwd", _ptr(x), _ptr(g.contiguous()), B, H, W_, Cc, _ptr(dx), _stream())
+        return dx
+
+
 # --------------------------------------------------------------------------- layout
 def _plane(t, nchw):
     """PlaneSrc for a logical-NCHW tensor (any strides) or a physical NHWC tensor."""

@@ -155,18 +155,32 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def vgg_features(vgg, x):
-    """vgg19.features[0:4]: conv3x3(3->64)+ReLU, conv3x3(64->64)+ReLU."""
-    y = torch.relu(F.conv2d(x, vgg["0.weight"], vgg["0.bias"], 1, 1))
-    return torch.relu(F.conv2d(y, vgg["2.weight"], vgg["2.bias"], 1, 1))
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
 
 
-def l1_plus_perceptual(vgg, fake, real, lambda_l1, lambda_p, percep_is_l1=1):
+def vgg_features(vgg, x, perceptual_layers=3):
+    """vgg19.features[0 : perceptual_layers + 1] as losses/L1_plus_perceptualLoss.py:22-27 slices it (default 3: conv3x3
+    3->64 + ReLU, conv3x3 64->64 + ReLU); torchvision's "E" configuration: conv3x3 pad 1 / ReLU / MaxPool2d(2, 2)."""
+    i = 0
+    for v in VGG19_CFG:
+        if i > perceptual_layers:
+            break
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2); i += 1
+        else:
+            x = F.conv2d(x, vgg["%d.weight" % i], vgg["%d.bias" % i], 1, 1); i += 1
+            if i <= perceptual_layers:
+                x = torch.relu(x)
+            i += 1
+    return x
+
+
+def l1_plus_perceptual(vgg, fake, real, lambda_l1, lambda_p, percep_is_l1=1, perceptual_layers=3):
     loss_l1 = F.l1_loss(fake, real) * lambda_l1
     mean = torch.tensor(IMAGENET_MEAN, dtype=fake.dtype).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=fake.dtype).view(1, 3, 1, 1)
-    f = vgg_features(vgg, ((fake + 1) / 2 - mean) / std)
-    r = vgg_features(vgg, ((real + 1) / 2 - mean) / std).detach()
+    f = vgg_features(vgg, ((fake + 1) / 2 - mean) / std, perceptual_layers)
+    r = vgg_features(vgg, ((real + 1) / 2 - mean) / std, perceptual_layers).detach()
     lp = (F.l1_loss(f, r) if percep_is_l1 == 1 else F.mse_loss(f, r)) * lambda_p
     return loss_l1 + lp, loss_l1, lp
 
@@ -203,7 +217,7 @@ class StepOracle:
     def __init__(self, sd_G, sd_DPB, sd_DPP, vgg, norm="batch", use_dropout=False,
                  use_dropout_D=False, n_blocks=9, n_layers_D=3, lr=2e-4, beta1=0.5,
                  lambda_A=10.0, lambda_B=10.0, lambda_GAN=5.0, pool_size=50, DG_ratio=1,
-                 masks=None, rng=random, percep_is_l1=1):
+                 masks=None, rng=random, percep_is_l1=1, perceptual_layers=3):
         self.G = _Net(sd_G, norm, use_dropout)
         self.DPB = _Net(sd_DPB, norm, use_dropout_D)
         self.DPP = _Net(sd_DPP, norm, use_dropout_D)
@@ -212,6 +226,7 @@ class StepOracle:
         self.lA, self.lB, self.lG = lambda_A, lambda_B, lambda_GAN
         self.DG_ratio = DG_ratio
         self.percep_is_l1 = percep_is_l1
+        self.perceptual_layers = perceptual_layers
         self.masks = masks
         self.opt_G = torch.optim.Adam(self.G.parameters(), lr=lr, betas=(beta1, 0.999))
         self.opt_DPB = torch.optim.Adam(self.DPB.parameters(), lr=lr, betas=(beta1, 0.999))
@@ -244,7 +259,7 @@ class StepOracle:
         g_pb = gan_loss(self._d(self.DPB, torch.cat((fake, batch["P2"]), 1)), True)
         g_pp = gan_loss(self._d(self.DPP, torch.cat((fake, batch["H1"]), 1)), True)
         l_tot, l_l1, l_p = l1_plus_perceptual(self.vgg, fake, batch["H2"], self.lA, self.lB,
-                                               self.percep_is_l1)
+                                               self.percep_is_l1, self.perceptual_layers)
         pair_gan = (g_pb * self.lG + g_pp * self.lG) / 2
         (l_tot + pair_gan).backward()
         self.opt_G.step()

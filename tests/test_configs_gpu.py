@@ -138,8 +138,8 @@ def test_vgg_weights_policy(dev, tmp_path):
               checkpoints_dir=str(tmp_path), local_rank=0)
     with pytest.raises(RuntimeError, match="vgg_weights"):
         MMHandModel(default_train_opt(vgg_random_init=False, **kw))
-    with pytest.raises(NotImplementedError):
-        MMHandModel(default_train_opt(perceptual_layers=8, **kw))
+    with pytest.raises(ValueError, match="perceptual_layers"):
+        MMHandModel(default_train_opt(perceptual_layers=37, **kw))         # vgg19.features has indices 0..36
     tv = {"features." + k: v for k, v in RC.vgg_recipe().items()}
     tv["features.5.weight"] = torch.zeros(128, 64, 3, 3)           # later layers are ignored
     tv["classifier.0.weight"] = torch.zeros(8, 8)

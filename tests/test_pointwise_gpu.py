@@ -168,6 +168,41 @@ def test_perceptual_criterion_l1_and_mse_vs_reference_fixture(dev):
     assert abs(l.item() - lr.item()) < 1e-5 * abs(lr.item()) and R.rel_l1(a.grad, ar.grad) < TOL
 
 
+@pytest.mark.parametrize("pl", [0, 2, 4, 8, 13])
+def test_perceptual_layers_other_than_3_vs_oracle(pl, dev):
+    """--perceptual_layers slices vgg19.features at ANY index (losses/L1_plus_perceptualLoss.py:22-27: the loop adds
+    layers 0 .. perceptual_layers): a conv without its ReLU (0, 2), through MaxPool2d (4, 13), deeper convs (8, 13).
+    Features, the three losses and the gradient w.r.t. the generated image against the fp64 oracle (whose layer table
+    is torchvision's published "E" configuration - torchvision itself is absent here)."""
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import L1PlusPerceptualLoss
+    from mmhand_amd.networks import VGGHead
+    vgg = VGGHead(pl).init_random(seed=5)
+    sd = {k: v.double() for k, v in vgg.state_dict().items()}
+    vgg.to(dev)
+    g = torch.Generator().manual_seed(pl)
+    fake_c = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    real_c = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    real = ops.raw_pack([(real_c.to(dev), True, 3)], 2, 32, 32, 4, dev)
+    fake_nchw = fake_c.to(dev).requires_grad_(True)
+    fake = ops.PackFn.apply(4, fake_nchw, True, 3)
+    crit = L1PlusPerceptualLoss(10.0, 10.0, vgg, 1)
+    feats = ops.nhwc_to_nchw_view(crit.features(fake)).detach()
+    tot, l1, lp = crit(fake, real)
+    tot.backward()
+    fr = fake_c.double().requires_grad_(True)
+    mean = torch.tensor(O.IMAGENET_MEAN, dtype=torch.float64).view(1, 3, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD, dtype=torch.float64).view(1, 3, 1, 1)
+    want_feats = O.vgg_features(sd, ((fr + 1) / 2 - mean) / std, pl)
+    assert tuple(feats.shape) == tuple(want_feats.shape)
+    assert R.rel_l1(feats, want_feats.detach()) < 1e-5, R.rel_l1(feats, want_feats.detach())
+    wt, wl1, wlp = O.l1_plus_perceptual(sd, fr, real_c.double(), 10.0, 10.0, 1, pl)
+    wt.backward()
+    for got, want in ((tot, wt), (l1, wl1), (lp, wlp)):
+        assert abs(got.item() - want.item()) < 1e-4 * abs(want.item()), (pl, got.item(), want.item())
+    assert R.rel_l1(fake_nchw.grad, fr.grad) < 1e-3, (pl, R.rel_l1(fake_nchw.grad, fr.grad))
+
+
 def test_adam_matches_torch_fixture(dev):
     from mmhand_amd import ops
     fix = dict(np.load(os.path.join(G, "adam.npz")))
