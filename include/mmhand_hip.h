@@ -47,14 +47,19 @@ typedef struct mmh_conv_desc {
     int32_t Ho, Wo;       /* output (y) spatial size                        */
     int32_t x_cs, y_cs;   /* channel strides of x and y buffers (>= C)      */
     int32_t dtype;        /* MMH_F32, or MMH_BF16 / MMH_FP16 = 16-bit MFMA  */
-                          /* compute (bf16, or IEEE fp16 as apex O1 uses):  */
-                          /* x, y, dy, dx stay fp32 in HBM (rounded to bf16 */
-                          /* while staged), fp32 accumulate; `w` must then  */
-                          /* be a tensor made by mmh_prep_weights_bf16      */
-                          /* (fprop / convT dgrad: w_t, or w_flat when Cin    */
-                          /* % 64 != 0; dgrad / convT fprop: w_plain, Cout  */
-                          /* % 64 == 0).  wgrad also rounds x and dy to     */
-                          /* bf16 (no channel rule).                        */
+                          /* operands (bf16, or IEEE fp16 as apex O1 uses), */
+                          /* fp32 accumulation.  What is 16-bit IN HBM is   */
+                          /* said per entry point: the first-generation     */
+                          /* kernels (mmh_conv2d_*, mmh_convT2d_*) read     */
+                          /* fp32 x / dy and round while staging unless     */
+                          /* their io16 / lp16 argument says a tensor is    */
+                          /* 16-bit; the conv_lp16 family (mmh_conv3x3_lp16,*/
+                          /* mmh_conv_lp16, mmh_conv_lp16_flat, mmh_wgrad*  */
+                          /* _lp16*) takes 16-bit x / dy and writes fp32 or */
+                          /* 16-bit outputs (y_is16).  `w` is then a tensor */
+                          /* made by mmh_prep_weights_bf16 / _fp16 (fprop / */
+                          /* convT dgrad: w_t, or w_flat when Cin % 64 != 0;*/
+                          /* dgrad / convT fprop: w_plain, Cout % 64 == 0). */
 } mmh_conv_desc;
 
 const char* mmh_last_error(void);

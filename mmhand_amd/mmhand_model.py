@@ -614,10 +614,10 @@ class MMHandModel(torch.nn.Module):
 
     def save_train_state(self, label):
         """<label>_net_amp.pth — the file the reference's distributed runs fill with apex's
-        loss-scaler state (models/base_model.py:54-56).  There is no loss scaler here (fp32 / bf16);
-        the file carries what a resumed run needs instead: the three Adam states (step count and the
-        flat exp_avg / exp_avg_sq buffers, in flatten_parameters() order) and the skipped-step
-        count.  The learning-rate schedule is positioned by --epoch_count as in the reference
+        loss-scaler state (models/base_model.py:54-56).  Here it carries what a resumed run needs: the
+        three dynamic loss scalers ({scale, clean steps} per loss, what apex's amp.state_dict() holds), the
+        three Adam states (step count and the flat exp_avg / exp_avg_sq buffers, in
+        flatten_parameters() order) and the skipped-step count.  The learning-rate schedule is positioned by --epoch_count as in the reference
         (network_utils.py:92-95), so scheduler state is not stored.  The reference's loader feeds
         any *amp* file to amp.load_state_dict inside try/except, so it ignores this one."""
         self._settle_overflow(drain=True)

@@ -11,6 +11,8 @@ Differences, all deliberate:
     weights, accumulation and statistics plus apex's dynamic loss scaling (three device-resident
     scalers, skip / back off / grow); O1_FP16/O2_FP16 = the same with IEEE fp16 operands (apex's own
     numerics); BF16 = the bf16 compute without a scaler;
+  * conv biases that feed an InstanceNorm get their exact (zero) gradient by default instead of the reference's
+    rounding noise (ops.EXACT_NULL_BIAS_GRAD; MMH_NULL_BIAS_GRAD=compute restores it; INTEGRATION.md §2b);
   * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline) and
     --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
