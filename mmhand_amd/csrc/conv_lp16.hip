@@ -736,11 +736,16 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         for (int hf = 0; hf < 2; ++hf)
             aB[hf] = lds0 + 2 * HSTAGE_A2 + (unsigned)(wc * 64 + l15) * ROWB + ((((unsigned)(4 * hf + g4)) ^ bkey) << 4);
     }
-    auto selA = [&](int dw, int hf) -> unsigned {       // dw is wave-uniform, hf a constant: two selects
-        return hf ? (dw == 0 ? aA01 : (dw == 1 ? aA11 : aA21)) : (dw == 0 ? aA00 : (dw == 1 ? aA10 : aA20));
+    // The half-0 address of tap (dh, dw) in halo stage st: aA00 + [dw == 1] * d1 + [dw == 2] * d2 + st * HSTAGE_A2 +
+    // dh * 2560 - two multiply-adds by 0 / 1 scalars instead of a three-way select (which the compiler turns into
+    // scalar branches at the head of every k-step); the half-1 address of the same tap is that ^ 64 (every offset
+    // added is a multiple of the 128-byte row).  Taps advance by counters, not by t / 3 and t % 3.
+    const unsigned d1 = aA10 - aA00, d2 = aA20 - aA00;
+    (void)aA01; (void)aA11; (void)aA21;
+    auto a_half0 = [&](int dh, int dw, int st) -> unsigned {
+        const unsigned m1 = dw == 1 ? 1u : 0u, m2 = dw == 2 ? 1u : 0u;
+        return aA00 + m1 * d1 + m2 * d2 + (unsigned)(st * HSTAGE_A2 + dh * (HP2 * ROWB));
     };
-    auto tap_dh = [&](int t) { const int kh = t / 3; return SIGN > 0 ? kh : 2 - kh; };
-    auto tap_dw = [&](int t) { const int kw = t - 3 * (t / 3); return SIGN > 0 ? kw : 2 - kw; };
     const int nk = 9 * KC;
 
     bf16x8 af[8], b0[4], b1[4];
@@ -749,23 +754,22 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     issue_w(0, 1);
     __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
+    int kc = 0, t = 0, kh = 0, kw = 0;                  // (chunk, tap = 3 kh + kw) of k-step ks
+    unsigned a_cur = a_half0(SIGN > 0 ? 0 : 2, SIGN > 0 ? 0 : 2, 0);
     {
-        const unsigned a0 = selA(tap_dw(0), 0) + (unsigned)tap_dh(0) * (HP2 * ROWB);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = lds_frag(aB[0] + j * (16 * ROWB));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = lds_frag(a0 + i * (HP2 * ROWB));
+        for (int i = 0; i < 8; ++i) af[i] = lds_frag(a_cur + i * (HP2 * ROWB));
     }
-    int kc = 0, t = 0;                  // (chunk, tap) of k-step ks
     for (int ks = 0; ks < nk; ++ks) {
-        const int dh = tap_dh(t), dw = tap_dw(t);
         const unsigned sb = (unsigned)(ks & 1) * HSTAGE_B;
-        // addresses of this k-step's second half and of the next k-step's first half: a few scalar-operand adds
-        const unsigned a1 = selA(dw, 1) + (unsigned)((kc & 1) * HSTAGE_A2 + dh * (HP2 * ROWB));
+        const unsigned a1 = a_cur ^ 64u;                // second half of this tap
         const unsigned bb1 = aB[1] + sb;
-        int kc2 = kc, t2 = t + 1;
-        if (t2 == 9) { t2 = 0; ++kc2; }
-        const unsigned a0n = selA(tap_dw(t2), 0) + (unsigned)((kc2 & 1) * HSTAGE_A2 + tap_dh(t2) * (HP2 * ROWB));
+        int kc2 = kc, t2 = t + 1, kh2 = kh, kw2 = kw + 1;
+        if (kw2 == 3) { kw2 = 0; ++kh2; }
+        if (t2 == 9) { t2 = 0; kh2 = 0; ++kc2; }
+        const unsigned a0n = a_half0(SIGN > 0 ? kh2 : 2 - kh2, SIGN > 0 ? kw2 : 2 - kw2, kc2 & 1);
         const unsigned bb0n = aB[0] + (HSTAGE_B - sb);
         // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
 #pragma unroll
@@ -811,7 +815,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        kc = kc2; t = t2;
+        kc = kc2; t = t2; kh = kh2; kw = kw2; a_cur = a0n;
     }
 
     float bv[4][4];
