@@ -2621,7 +2621,7 @@ int do_dgrad_reflect1(const mmh_conv_desc* d, const void* dy, const void* w, voi
     if (!bf16 && g_conv_bn256 == 2 && C % 256 == 0) {   // measured: no gain for the [n][k] weight tile
         if (with_main) mp.p[n - 1].xcd_remap = (g_conv_xcd && C / 256 > 1 && (main.M + BM - 1) / BM >= 8) ? 1 : 0;
         rc = launch_multi_t<256, 2, 2>(mp, false, st);
-    } else if (C > 64 && !(g_border_bn64 && !with_main && !bf16)) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);
+    } else if (C > 64 && !(g_border_bn64 && !with_main && (!bf16 || C <= 256))) rc = launch_multi_t<128, 2, 2>(mp, bf16, st);   // 16-bit border-only: 64-wide tiles up to 256 channels (35 vs 43 us; 512: 74 vs 66)
     else if (C > 32) rc = launch_multi_t<64, 2, 2>(mp, bf16, st);   // border-only: narrower tiles, 2x the workgroups
     else rc = launch_multi_t<32, 4, 1>(mp, bf16, st);
     if (rc) return rc;
