@@ -273,7 +273,7 @@ def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, **
             ach = c[1] / (c[2] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_MFMA_TF, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_BF16_MFMA_TF, 4),
-                               "kernel": f"conv_lp16h_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
+                               "kernel": f"conv_lp16h2_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
                                          f"{c[1] / c[0] / 1e9:.1f} GFLOP/launch, {c[2] / c[0]:.3f} ms avg over {c[0]} launches"}
     out["losses_finite"] = all(torch.isfinite(v).item() for v in model.get_current_errors().values())
     del model
@@ -648,7 +648,7 @@ def main():
                       f"[{tiles}x512].[512x512] (F({wtile}x{wtile},3x3)) of the 3x3 512->512 fprop @{hs}x{hs}")
         else:
             k_flop = 2.0 * a.batch * hs * hs * 512 * 512 * 9
-            k_name = (("conv_lp16h_kernel<bf16> (16-bit operands by LDS-DMA, 16x16-pixel tile x 256 channels with its halo "
+            k_name = (("conv_lp16h2_kernel<bf16> (16-bit operands by LDS-DMA, 16x16-pixel tile x 256 channels with its halo "
                        "resident in LDS for all nine taps, MFMA 16x16x32, fragment reads pipelined into the MFMA stream)"
                        if (a.dtype == "bf16" and ops.lp16_v2_ok(512, 512, 3, 1, 1, 0)) else
                        "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else

@@ -219,6 +219,10 @@ int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16,
                       void* ws, size_t ws_bytes, int accumulate, const void* zeros,
                       mmh_stream_t s);
 int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d);
+/* mode 2 of mmh_conv3x3_lp16: the dgrad of a ReflectionPad2d(1) conv complete in one launch -
+ * the gradient of the pad ring is folded onto rows 1 / H-2 and columns 1 / W-2 inside the halo
+ * kernel (H, W multiples of 16, Cin % 256 == 0), so no mmh_conv2d_dgrad_border call follows.     */
+int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d);
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
                      const void* bias, void* y, int y_is16, int act, const void* zeros,
                      mmh_stream_t s);

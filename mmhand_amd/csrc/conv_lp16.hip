@@ -643,7 +643,7 @@ constexpr int HROUNDS2 = (HROWS2 + 63) / 64;                // 6
 typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
 __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>(addr); }
 
-template <bool H16, int SIGN>
+template <bool H16, int SIGN, bool FOLD>
 __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const sAh = smem;                         // [2][HSTAGE_A2]
@@ -683,12 +683,13 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         a_off[rd] = ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + q * 16u
                        : (row ? 0xfffffffeu : 0xffffffffu);        // ...fe: zero page, ...ff: no row
     }
-    unsigned b_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (wave * 4 + j) * 8 + (lane >> 3);
-        const unsigned q = (unsigned)((lane & 7) ^ ((r >> 1) & 7));
-        b_off[j] = (unsigned)(n0 + r) * (unsigned)p.C * 2u + q * 16u;
+    // weight DMA: wave w, round j moves rows (w * 4 + j) * 8 + lane / 8 of the [256][64] tile.  The swizzle key (r >> 1) & 7
+    // = (4 j + lane / 16) & 7 splits into a lane part and bit 0 of j: ONE lane offset, ^ 64 (chunk ^ 4) for odd j; the row
+    // advance of j is a scalar added to the base pointer
+    unsigned b_off0;
+    {
+        const int r = wave * 32 + (lane >> 3);
+        b_off0 = (unsigned)(n0 + r) * (unsigned)p.C * 2u + (unsigned)((lane & 7) ^ ((r >> 1) & 7)) * 16u;
     }
     const int KC = p.C / TBK;
     auto issue_halo = [&](int kc) {
@@ -707,7 +708,8 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         const char* wbase = p.w + ((size_t)t * p.N * p.C + (size_t)kc * TBK) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds(wbase + b_off[j], (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(wbase + (size_t)(j * 8) * p.C * 2 + ((j & 1) ? (b_off0 ^ 64u) : b_off0),
+                                             (lds_vp)(sB + (wave * 4 + j) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[8][4];
@@ -748,6 +750,27 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     };
     const int nk = 9 * KC;
 
+    // FOLD (dgrad of a ReflectionPad2d(1) conv; H, W multiples of 16): the gradient of the pad ring, folded back onto
+    // rows 1 / H-2 and columns 1 / W-2, is computed HERE with the weight fragments the k-step holds anyway - instead of
+    // eight border GEMMs + an add kernel per conv (mmh_conv2d_dgrad_border: 46-70 us, 90 times per step).
+    //   ring row -1 -> row 1 (top tiles, taps kh = 0): one extra A fragment (halo row of dy row 0) into acc[1], by the
+    //       waves that own tile rows 0-7; ring row H -> row H-2 (bottom tiles, kh = 2) into acc[6] likewise;
+    //   ring column -1 -> column 1 (left tiles, taps kw = 0): the ring values of the tile's 16 ROWS form one MFMA
+    //       column block (lane <-> tile row, its fragment read down the halo column of dy column 0) accumulated in DT
+    //       by waves wr = 0; ring column W -> column W-2 (right tiles, kw = 2) by waves wr = 1; after the loop DT goes
+    //       through LDS to the lanes that hold pixel column 1 / 14;
+    //   the four ring corners (one tap each) are single-lane fragments into acc[1] / acc[6].
+    // Cost: 8 MFMAs on 64 in a third of the k-steps of edge tiles.
+    const bool fold_on = FOLD && !(p.dbg & 4);
+    const bool f_top = fold_on && !(p.dbg & 16) && ty == 0 && wr == 0, f_bot = fold_on && !(p.dbg & 16) && ty == TY - 1 && wr == 1;
+    const bool f_left = fold_on && !(p.dbg & 8) && tx == 0, f_right = fold_on && !(p.dbg & 8) && tx == TX - 1;
+    const bool f_col = (f_left && wr == 0) || (f_right && wr == 1);
+    f32x4 DT[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) DT[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // lane <-> tile row l15: halo row (l15 + dh) * 20 + hx, hx = 1 (left) or 16 (right): both have key hx & 6 == 0
+    const unsigned baseT = lds0 + (unsigned)l15 * (HP2 * ROWB) + (unsigned)(wr == 0 ? 1 : 16) * ROWB + ((unsigned)g4 << 4);
+
     bf16x8 af[8], b0[4], b1[4];
     issue_halo(0);
     issue_w(0, 0);
@@ -771,6 +794,22 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         if (t2 == 9) { t2 = 0; kh2 = 0; ++kc2; }
         const unsigned a0n = a_half0(SIGN > 0 ? kh2 : 2 - kh2, SIGN > 0 ? kw2 : 2 - kw2, kc2 & 1);
         const unsigned bb0n = aB[0] + (HSTAGE_B - sb);
+        // fold roles of this k-step (wave-uniform): row fold (top: kh = 0, waves wr = 0 -> acc[1]; bottom: kh = 2, wr = 1
+        // -> acc[6]), column fold (-> DT), corner (a row-fold k-step of a left / right tile with kw = 0 / 2).  Their
+        // fragments are fetched BEFORE the MFMA block of each half so that the LDS latency hides behind it.
+        const bool do_row = FOLD && ((f_top && kh == 0) || (f_bot && kh == 2));
+        const bool do_col = FOLD && f_col && kw == (wr == 0 ? 0 : 2);
+        const bool do_cnr = do_row && ((kw == 0 && f_left) || (kw == 2 && f_right));
+        const bool do_any = do_row || do_col;
+        // fragment addresses of the fold terms (half 0; half 1 is ^ 64): the tap's halo row 1 (top) / 16 (bottom) at this
+        // lane's column; the halo column 1 / 16 at this lane's row; lane 1 / 14 of the dw = 0 / 2 variant for the corner
+        const unsigned f_dhb = (unsigned)((2 - kh) * (HP2 * ROWB)), f_st = (unsigned)((kc & 1) * HSTAGE_A2);
+        const unsigned f_rsel = (unsigned)((wr == 0 ? 1 : 8) * (HP2 * ROWB));
+        bf16x8 axr, axc;
+        if (FOLD && do_any) {
+            axr = lds_frag(a_cur - f_dhb + f_rsel);
+            axc = lds_frag(baseT + f_st + f_dhb);
+        }
         // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = lds_frag(bb1 + j * (16 * ROWB));
@@ -785,6 +824,31 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        if (FOLD && do_any) {     // the fold terms of this half (b0 = this tap's weights); fragments fetched above
+            if (do_row) {
+                if (wr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b0[j], axr, acc[1][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b0[j], axr, acc[6][j]);
+                }
+            }
+            if (do_col)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) DT[j] = mfma16s<H16>(b0[j], axc, DT[j]);
+            if (do_cnr) {         // once per chunk in the four corner tiles: not worth registers for a prefetch
+                axr = lds_frag((kw == 0 ? aA00 : aA20) + f_st + f_rsel);
+                if (l15 != (kw == 0 ? 1 : 14)) axr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (wr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b0[j], axr, acc[1][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b0[j], axr, acc[6][j]);
+                }
+            }
+        }
         // ---- middle of the k-step: the weight stage ks is read; stage ks+1 (issued one k-step ago) must have
         // landed.  The halo of the next chunk, issued right after the weights at t == 0, may stay in flight across
         // the barrier of t == 1 (it is needed nine k-steps after its issue): the wait then leaves the newest
@@ -798,24 +862,80 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             issue_w(kc3, t3);
         }
         if (t == 0 && kc + 1 < KC && !(p.dbg & 2)) issue_halo(kc + 1);
-        // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
-        const bool more = ks + 1 < nk;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b0[j] = lds_frag(bb0n + j * (16 * ROWB));
+        if (FOLD && do_any) {     // the fold fragments of half 1
+            axr = lds_frag((a_cur - f_dhb + f_rsel) ^ 64u);
+            axc = lds_frag((baseT + f_st + f_dhb) ^ 64u);
         }
+        // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
+        // (after the last k-step these reads fetch fragments nobody uses, from addresses inside the stages: cheaper
+        // than a branch around each of them)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(bb0n + j * (16 * ROWB));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b1[j], af[i], acc[i][j]);
-            if (more) af[i] = lds_frag(a0n + i * (HP2 * ROWB));
+            af[i] = lds_frag(a0n + i * (HP2 * ROWB));
         }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        if (FOLD && do_any) {     // the fold terms of this half (b1 = this tap's weights); fragments fetched above
+            if (do_row) {
+                if (wr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b1[j], axr, acc[1][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b1[j], axr, acc[6][j]);
+                }
+            }
+            if (do_col)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) DT[j] = mfma16s<H16>(b1[j], axc, DT[j]);
+            if (do_cnr) {         // once per chunk in the four corner tiles: not worth registers for a prefetch
+                axr = lds_frag(((kw == 0 ? aA00 : aA20) + f_st + f_rsel) ^ 64u);
+                if (l15 != (kw == 0 ? 1 : 14)) axr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (wr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b1[j], axr, acc[1][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b1[j], axr, acc[6][j]);
+                }
+            }
+        }
         kc = kc2; t = t2; kh = kh2; kw = kw2; a_cur = a0n;
+    }
+
+    if (FOLD && (f_left || f_right)) {
+        // the column folds: DT [channel 4 g4 + r of block j][tile row l15] -> LDS X[side][256 channels][16 rows] -> the
+        // lanes that hold pixel column 1 (left) / 14 (right) of each tile row
+        float* X = reinterpret_cast<float*>(smem);
+        __syncthreads();                    // every wave is done reading the last stages
+        if (f_col) {
+            float* xs = X + (wr == 0 ? 0 : 4096);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + l15] = DT[j][r];
+        }
+        __syncthreads();
+        if ((f_left && l15 == 1) || (f_right && l15 == 14)) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (!(side == 0 ? (f_left && l15 == 1) : (f_right && l15 == 14))) continue;
+                const float* xs = X + side * 4096;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] += xs[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + wr * 8 + i];
+            }
+        }
     }
 
     float bv[4][4];
@@ -1975,14 +2095,24 @@ int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d) {
            d->Ho == d->H && d->Wo == d->W && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16);
 }
 
+int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d) {
+    return mmh_conv3x3_lp16_supported(d) && d->pad_mode == MMH_PAD_REFLECT && d->H % HT == 0 && d->W % HT == 0 &&
+           d->H >= HT && d->W >= HT && d->Cin % TBN == 0 && g_lp16_shape == 19;
+}
+
 // mode 0: fprop  y[B,H,W,Cout] = conv(x16 [B,H,W,Cin], w16 = w_t [tap][Cout][Cin]) (+bias, act)
 // mode 1: dgrad  dx[B,H,W,Cin] = zero-padded correlation of dy16 [B,H,W,Cout] with the flipped filter,
 //                w16 = w_plain [tap][Cin][Cout]; for MMH_PAD_REFLECT this is the main term only
 //                (the caller adds the border terms: mmh_conv2d_dgrad_border)
+// mode 2: dgrad of a reflect-padded conv COMPLETE: mode 1 plus the pad ring's gradient folded onto rows 1 / H-2 and
+//                columns 1 / W-2 inside the kernel (mmh_conv3x3_lp16_fold_supported; no border call follows)
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
                      void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
-    MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1),
+    MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1 || mode == 2),
                 "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
+    MMH_REQUIRE(mode != 2 || mmh_conv3x3_lp16_fold_supported(d),
+                "mmh_conv3x3_lp16: mode 2 (dgrad with the reflect fold) needs MMH_PAD_REFLECT, H and W multiples of 16 and "
+                "the halo kernel (lp16_shape 19)");
     LpConvKP p{};
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     MMH_REQUIRE(N % TBN == 0, "mmh_conv3x3_lp16: output channels must be a multiple of 256 (got %d)", N);
@@ -1995,7 +2125,7 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     p.bias = static_cast<const float*>(bias);
     p.B = d->B; p.H = d->H; p.W = d->W; p.C = K; p.cs = mode == 0 ? d->x_cs : d->y_cs;
     p.N = N; p.y_cs = mode == 0 ? d->y_cs : d->x_cs;
-    p.tap_sign = mode == 0 ? 1 : -1;        // dgrad: dx[i] = sum_t w[t] dy[i + 1 - t]
+    p.tap_sign = mode == 0 ? 1 : -1;        // dgrad (modes 1, 2): dx[i] = sum_t w[t] dy[i + 1 - t]
     p.reflect = (mode == 0 && d->pad_mode == MMH_PAD_REFLECT) ? 1 : 0;
     p.act = act;
     p.h16 = d->dtype == MMH_FP16;
@@ -2022,10 +2152,12 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
         static int ready19 = -1;
         if (ready19 != 0) {
             hipError_t e = hipSuccess;
-            const void* fs[4] = {reinterpret_cast<const void*>(conv_lp16h2_kernel<false, 1>),
-                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<false, -1>),
-                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, 1>),
-                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1>)};
+            const void* fs[6] = {reinterpret_cast<const void*>(conv_lp16h2_kernel<false, 1, false>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<false, -1, false>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, 1, false>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1, false>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<false, -1, true>),
+                                 reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1, true>)};
             for (const void* f : fs)
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
             ready19 = e == hipSuccess ? 0 : mmh::fail("conv_lp16h2_kernel: %s", hipGetErrorString(e));
@@ -2035,10 +2167,13 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
         ph.MT = d->B * ((d->H + HT - 1) / HT) * ((d->W + HT - 1) / HT);
         const dim3 grid(8 * ((ph.MT * ph.NT + 7) / 8));
         hipStream_t st = mmh::as_stream(s);
-        if (p.h16 && mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<true, 1>), grid, dim3(512), lds2, st, ph);
-        else if (p.h16) hipLaunchKernelGGL((conv_lp16h2_kernel<true, -1>), grid, dim3(512), lds2, st, ph);
-        else if (mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<false, 1>), grid, dim3(512), lds2, st, ph);
-        else hipLaunchKernelGGL((conv_lp16h2_kernel<false, -1>), grid, dim3(512), lds2, st, ph);
+        if (mode == 2) {
+            if (p.h16) hipLaunchKernelGGL((conv_lp16h2_kernel<true, -1, true>), grid, dim3(512), lds2, st, ph);
+            else hipLaunchKernelGGL((conv_lp16h2_kernel<false, -1, true>), grid, dim3(512), lds2, st, ph);
+        } else if (p.h16 && mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<true, 1, false>), grid, dim3(512), lds2, st, ph);
+        else if (p.h16) hipLaunchKernelGGL((conv_lp16h2_kernel<true, -1, false>), grid, dim3(512), lds2, st, ph);
+        else if (mode == 0) hipLaunchKernelGGL((conv_lp16h2_kernel<false, 1, false>), grid, dim3(512), lds2, st, ph);
+        else hipLaunchKernelGGL((conv_lp16h2_kernel<false, -1, false>), grid, dim3(512), lds2, st, ph);
         return mmh::check_launch("conv_lp16h2_kernel");
     }
     if (g_lp16_shape == 18 && d->H >= HT && d->W >= HT) {       // activation tile (halo) resident in LDS for all nine taps

@@ -516,9 +516,12 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
         # adds the eight border terms (small 16-bit GEMMs + border_add) exactly as the other paths do
         if dy16 is None:
             dy16 = lp16_twin(dy, bf16)
+        d.dtype = _dt(bf16)
+        if reflect and USE_LP16_FOLD and L.load().mmh_conv3x3_lp16_fold_supported(C.byref(d)):
+            # H, W multiples of 16: the halo kernel folds the pad ring's gradient in itself (mode 2), no border call
+            return raw_conv3x3_lp16(dy16, w, None, True, L.ACT_NONE, bf16, 2, out16=out16)
         dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16)
         if reflect:
-            d.dtype = _dt(bf16)
             ws = torch.empty(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)) // 4 + 4, dtype=torch.float32,
                              device=dx.device)
             # border GEMMs read the 16-bit dy; io16 bit 0 = dy is 16-bit, bit 1 = dx is 16-bit
@@ -630,6 +633,10 @@ def lp16_twin(x, bf16=True):
     return out
 
 
+# dgrad of the reflect-padded 3x3 convs: border terms inside the halo kernel (mmh_conv3x3_lp16 mode 2) where it applies
+USE_LP16_FOLD = os.environ.get("MMH_LP16_FOLD", "1") != "0"
+
+
 def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
     """mode 0 fprop (N = Cout), 1 dgrad (N = Cin)"""
     n = Cout if mode == 0 else Cin
@@ -638,7 +645,8 @@ def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
 
 def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
     """mode 0: y = conv(x16, w) (+bias, act); mode 1: dx = zero-pad correlation of x16 (= dy) with the
-    flipped filter (the caller adds the reflect border terms).  w: the fp32 physical weight."""
+    flipped filter (the caller adds the reflect border terms); mode 2: the complete dgrad of a
+    ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight."""
     B, H, W_, Cx = x16.shape
     _, _, Cin, Cout = w.shape
     assert x16.dtype == _wd(bf16) and x16.is_contiguous() and Cx == (Cin if mode == 0 else Cout)

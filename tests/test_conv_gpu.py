@@ -364,6 +364,55 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
         lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 2), "set")
 
 
+@pytest.mark.parametrize("out16", [False, True], ids=["dx32", "dx16"])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 256, 64), (1, 32, 16, 256, 256), (1, 16, 48, 256, 128), (2, 32, 32, 512, 256),
+                                  (1, 48, 64, 256, 64)])
+def test_conv3x3_lp16_reflect_fold_dgrad(case, lp, out16, dev):
+    """mmh_conv3x3_lp16 mode 2: the dgrad of a ReflectionPad2d(1) conv with the pad ring's gradient (rows, columns and the
+    four corners) folded inside the halo kernel, against the fp64 oracle on operands rounded to the same type - single-tile
+    images (every fold in one work-group), one-tile-wide and one-tile-high images, and interior tiles that fold nothing -
+    and against the path it replaces (mode 1 + mmh_conv2d_dgrad_border).  models/Generator.py:39-66 (ReflectionPad2d(1) +
+    Conv2d(3) in the residual blocks)."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout = case
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    dy = _mk((B, H, W, Cout), 4, dev)
+    ops.bump_weights_epoch()
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    dy16 = ops.lp16_twin(dy, lp)
+    d = ops.conv_desc(B, H, W, Cin, Cout, 3, 1, 1, True)
+    d.dtype = ops._dt(lp)
+    import ctypes
+    assert lib.load().mmh_conv3x3_lp16_fold_supported(ctypes.byref(d)) == 1
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dx = ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, True, bf16=lp, dy16=dy16, out16=out16)
+        assert calls.get("mmh_conv3x3_lp16") == 1 and "mmh_conv2d_dgrad_border" not in calls, calls
+        ops.USE_LP16_FOLD = False
+        dx_old = ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, True, bf16=lp, dy16=dy16, out16=out16)
+        assert calls.get("mmh_conv2d_dgrad_border") == 1, calls
+    finally:
+        lib.call = orig
+        ops.USE_LP16_FOLD = True
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), rb(w), None, rb(dy), 1, 1, True)
+    tol = 5e-6 if not out16 else (2e-3 if lp == 2 else 8e-3)
+    assert R.rel_l1(dx.float(), dxr) < tol, R.rel_l1(dx.float(), dxr)
+    # the ring only: rows 1, H-2 and columns 1, W-2 are where a wrong fold would hide inside a whole-tensor norm
+    ring = torch.zeros(H, W, dtype=torch.bool)
+    ring[[1, H - 2], :] = True
+    ring[:, [1, W - 2]] = True
+    a, r = dx.float().cpu()[:, ring], dxr[:, ring]
+    assert float((a - r).abs().sum() / r.abs().sum()) < tol
+    sc = float(dx_old.float().abs().max())
+    assert float((dx.float() - dx_old.float()).abs().max()) < (2e-5 if not out16 else 1.6e-2) * sc
+
+
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 9, 11, 256, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
                                   (2, 17, 33, 256, 256, True), (1, 4, 16, 256, 256, True), (5, 2, 2, 256, 256, True),
