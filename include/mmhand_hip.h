@@ -226,6 +226,15 @@ int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d);
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
                      const void* bias, void* y, int y_is16, int act, const void* zeros,
                      mmh_stream_t s);
+/* fprop (16-bit y, no activation) that also writes the partial statistics of its output from the
+ * epilogue: stats [B][chunks][3][Cout] floats = count / mean / M2 per (image, half pixel tile,
+ * channel) of the values as stored - the mmh_norm_stats_merge[_finalize] layout, so the InstanceNorm
+ * behind the conv (models/Generator.py:66-77) does not read y for statistics.  chunks =
+ * mmh_conv3x3_lp16_stats_chunks(d) = 2 (H/16)(W/16); 0 = not available (H or W not a multiple of 16). */
+int mmh_conv3x3_lp16_stats_chunks(const mmh_conv_desc* d);
+int mmh_conv3x3_lp16_fprop_stats(const mmh_conv_desc* d, const void* x16, const void* w16,
+                                 const void* bias, void* y16, void* stats, const void* zeros,
+                                 mmh_stream_t s);
 
 /* The same machine for the other 3x3 / pad 1 convolutions of the step (stride 2 down-sampling,
  * ConvTranspose2d, 64 / 128 output channels): mode 0 fprop, mode 1 dgrad (stride 2: the four

@@ -51,6 +51,8 @@ struct LpConvKP {
     int MT, NT;             // row / column tiles
     int tap_inner;          // k order: 1 = (channel chunk, tap), 0 = (tap, channel chunk)
     int dbg;                // timing-only ablation bits (mmh_set_option "lp16_dbg"): results wrong
+    float* stats;           // conv_lp16h2_kernel fprop: per (image, half tile, channel) count / mean / M2 of the stored
+                            // outputs, [B][chunks][3][N] (mmh_norm_stats_merge layout), or nullptr
 };
 
 template <bool H16>
@@ -952,6 +954,48 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             store4<H16>(p.y, p.y16, m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+    }
+    if (SIGN > 0 && !FOLD && p.stats) {
+        // The InstanceNorm behind this conv (models/Generator.py:66-77) wants mean and M2 per (image, channel): each wave
+        // owns 8 rows x 16 pixels of 64 channels - count / mean / M2 of the values AS STORED (rounded to 16 bits) per
+        // wave and channel, merged later (Chan) by mmh_norm_stats_merge[_finalize]: y is not read again for statistics.
+        // Lane: 8 values per channel (two passes in registers), then four equal-count Chan merges across the 16 pixel
+        // lanes.  Host side guarantees H, W multiples of 16 (no ragged tiles), no activation.
+        const int chunks = TX * TY * 2;
+        float* sp = p.stats + ((size_t)(b * chunks + (ty * TX + tx) * 2 + wr) * 3) * p.N + n0 + wc * 64 + 4 * g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v[8], mean = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float t = acc[i][j][r] + bv[j][r];
+                    v[i] = H16 ? (float)(_Float16)t : (float)(__bf16)t;
+                    mean += v[i];
+                }
+                mean *= 0.125f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m2 = fmaf(v[i] - mean, v[i] - mean, m2);
+                // xor 1, 2, 4, 8 inside the 16 pixel lanes: ds_swizzle bit mode (and 0x1f, or 0, xor s)
+#define MMH_SWZ(val, s) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, val), 0x1f | ((s) << 10)))
+                {
+                    float mo = MMH_SWZ(mean, 1), qo = MMH_SWZ(m2, 1), dl = mo - mean;
+                    m2 = m2 + qo + dl * dl * 4.f; mean = 0.5f * (mean + mo);
+                    mo = MMH_SWZ(mean, 2); qo = MMH_SWZ(m2, 2); dl = mo - mean;
+                    m2 = m2 + qo + dl * dl * 8.f; mean = 0.5f * (mean + mo);
+                    mo = MMH_SWZ(mean, 4); qo = MMH_SWZ(m2, 4); dl = mo - mean;
+                    m2 = m2 + qo + dl * dl * 16.f; mean = 0.5f * (mean + mo);
+                    mo = MMH_SWZ(mean, 8); qo = MMH_SWZ(m2, 8); dl = mo - mean;
+                    m2 = m2 + qo + dl * dl * 32.f; mean = 0.5f * (mean + mo);
+                }
+#undef MMH_SWZ
+                if (l15 == 0) {
+                    sp[j * 16 + r] = 128.f;
+                    sp[p.N + j * 16 + r] = mean;
+                    sp[2 * p.N + j * 16 + r] = m2;
+                }
+            }
     }
 }
 
@@ -2106,8 +2150,8 @@ int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d) {
 //                (the caller adds the border terms: mmh_conv2d_dgrad_border)
 // mode 2: dgrad of a reflect-padded conv COMPLETE: mode 1 plus the pad ring's gradient folded onto rows 1 / H-2 and
 //                columns 1 / W-2 inside the kernel (mmh_conv3x3_lp16_fold_supported; no border call follows)
-int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
-                     void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
+static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
+                             void* y, int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s) {
     MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1 || mode == 2),
                 "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
     MMH_REQUIRE(mode != 2 || mmh_conv3x3_lp16_fold_supported(d),
@@ -2131,6 +2175,7 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     p.h16 = d->dtype == MMH_FP16;
     p.tap_inner = mmh::g_lp16_tap_inner;
     p.dbg = mmh::g_lp16_dbg;
+    p.stats = static_cast<float*>(stats);
     const long long M = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(M * (long long)std::max(p.cs, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
                 "mmh_conv3x3_lp16: tensor too large");
@@ -2234,6 +2279,25 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
     else
         hipLaunchKernelGGL(conv_lp16_kernel<false>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
     return mmh::check_launch("conv_lp16_kernel");
+}
+
+int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
+                     void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    return conv3x3_lp16_impl(d, mode, x16, w16, bias, y, y_is16, act, zeros, nullptr, s);
+}
+
+// fprop with a 16-bit output whose per-(image, half tile, channel) partial statistics come out of the epilogue:
+// chunks per image = 2 * (H / 16) * (W / 16) (0: not available - ragged tiles or another kernel selected)
+int mmh_conv3x3_lp16_stats_chunks(const mmh_conv_desc* d) {
+    if (!mmh_conv3x3_lp16_supported(d) || d->H % HT || d->W % HT || d->Cout % TBN || g_lp16_shape != 19) return 0;
+    return 2 * (d->H / HT) * (d->W / HT);
+}
+
+int mmh_conv3x3_lp16_fprop_stats(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y16,
+                                 void* stats, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(stats && mmh_conv3x3_lp16_stats_chunks(d) > 0,
+                "mmh_conv3x3_lp16_fprop_stats: needs H, W multiples of 16, Cout %% 256 == 0 and the halo kernel");
+    return conv3x3_lp16_impl(d, 0, x16, w16, bias, y16, 1, MMH_ACT_NONE, zeros, stats, s);
 }
 
 

@@ -643,7 +643,7 @@ def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
     return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 64 == 0 and Cout % 64 == 0 and n % 256 == 0
 
 
-def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
+def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_stats=False):
     """mode 0: y = conv(x16, w) (+bias, act); mode 1: dx = zero-pad correlation of x16 (= dy) with the
     flipped filter (the caller adds the reflect border terms); mode 2: the complete dgrad of a
     ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight."""
@@ -655,8 +655,18 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False):
     wp, wt = bf16_weights(w, bf16)
     N = Cout if mode == 0 else Cin
     y = torch.empty((B, H, W_, N), dtype=_wd(bf16) if out16 else torch.float32, device=x16.device)
-    L.call("mmh_conv3x3_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
-           int(out16), act, _ptr(zero_page(x16.device)), _stream())
+    chunks = (L.load().mmh_conv3x3_lp16_stats_chunks(C.byref(d))
+              if (want_stats and FUSE_NORM_STATS and mode == 0 and out16 and act == L.ACT_NONE) else 0)
+    if chunks:
+        # the InstanceNorm behind this conv merges these partials (raw_norm_stats_finalize_pending) instead of reading y
+        stats = torch.empty((B, chunks, 3, N), dtype=torch.float32, device=x16.device)
+        L.call("mmh_conv3x3_lp16_fprop_stats", C.byref(d), _ptr(x16), _ptr(wt), _ptr(bias), _ptr(y), _ptr(stats),
+               _ptr(zero_page(x16.device)), _stream())
+        _pending_stats.clear()
+        _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+    else:
+        L.call("mmh_conv3x3_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
+               int(out16), act, _ptr(zero_page(x16.device)), _stream())
     _count_desc("mfma", d)
     return y
 
@@ -1134,7 +1144,8 @@ class Conv2dFn(torch.autograd.Function):
                 e0, e1 = fprop_timer.bracket()
                 e0.record()
             if v2:
-                y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp))
+                y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp),
+                                     want_stats=bool(null_bias_grad and y_lp))
             else:
                 y = raw_conv_lp16g(d, 0, x16, w, bias, act, bf16, out16=bool(y_lp))
             if timed:

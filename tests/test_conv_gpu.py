@@ -364,6 +364,43 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
         lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 2), "set")
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, True), (3, 32, 48, 256, 512, True), (2, 64, 64, 256, 256, False)])
+def test_conv3x3_lp16_epilogue_statistics(case, lp, dev):
+    """mmh_conv3x3_lp16_fprop_stats: the partial statistics the halo kernel's epilogue writes (count / mean / M2 per
+    image, half tile and channel, of the 16-bit values as stored) merge to the mean and M2 of the stored tensor (fp64 on
+    the host), and the InstanceNorm path picks them up instead of launching mmh_norm_stats.  The conv output itself is
+    bit-identical to the call without statistics.  models/Generator.py:66-77 (Conv2d -> InstanceNorm2d)."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev) * 3.0           # a mean well away from zero: the M2 must not suffer
+    ops.bump_weights_epoch()
+    x16 = ops.lp16_twin(x, lp)
+    y_plain = ops.raw_conv3x3_lp16(x16, w, bias, refl, 0, lp, 0, out16=True)
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        y = ops.raw_conv3x3_lp16(x16, w, bias, refl, 0, lp, 0, out16=True, want_stats=True)
+        assert calls.get("mmh_conv3x3_lp16_fprop_stats") == 1 and y.data_ptr() in ops._pending_stats
+        mean, m2, rows = ops.raw_norm_stats(y, B)
+        assert "mmh_norm_stats" not in calls and calls.get("mmh_norm_stats_merge") == 1, calls
+    finally:
+        lib.call = orig
+    assert torch.equal(y, y_plain)
+    yd = y.double().cpu().reshape(B, H * W, Cout)
+    mr = yd.mean(1)
+    m2r = ((yd - mr[:, None, :]) ** 2).sum(1)
+    assert rows == H * W
+    assert float((mean.double().cpu() - mr).abs().max()) < 2e-6 * float(yd.abs().max())
+    assert float(((m2.double().cpu() - m2r).abs() / m2r).max()) < 2e-5
+
+
 @pytest.mark.parametrize("out16", [False, True], ids=["dx32", "dx16"])
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 256, 64), (1, 32, 16, 256, 256), (1, 16, 48, 256, 128), (2, 32, 32, 512, 256),

@@ -25,7 +25,9 @@ for (Cin, Cout) in ((256, 256), (512, 512), (512, 256)):
         return run
     fp = lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True)
     dg = lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)
-    variants = {"h(18) fprop": mk(18, fp), "h2(19) fprop": mk(19, fp), "h(18) dgrad": mk(18, dg), "h2(19) dgrad": mk(19, dg)}
+    fps = lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True, want_stats=True)
+    variants = {"h(18) fprop": mk(18, fp), "h2(19) fprop": mk(19, fp), "h2 fprop + statistics": mk(19, fps),
+                "h(18) dgrad": mk(18, dg), "h2(19) dgrad": mk(19, dg)}
     res = {k: [] for k in variants}
     for f in variants.values(): f()
     torch.cuda.synchronize()
