@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void conv_igemm_bf16_body_t(const ConvKP& p, const in
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NBL = BN / 32;            // 16-byte weight loads per thread per k-step
-    constexpr int ASZ = BM * LDH, BSZ = BN * LDH;
+    constexpr int ASZ = BM * LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* const As = reinterpret_cast<__bf16*>(smem);
     __bf16* const Bs = As + ASZ;
