@@ -11,7 +11,9 @@ x = torch.randn(B, H, W, Cin, device=dev); w = torch.randn(3, 3, Cin, Cout, devi
 dy = torch.randn(B, H, W, Cout, device=dev)
 xb = ops.lp16_twin(x, True); dyb = ops.lp16_twin(dy, True)
 for _ in range(3):
-    ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0, out16=True)
-    ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)
+    ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0, out16=True)                     # fprop
+    ops.raw_conv3x3_lp16(xb, w, None, True, 0, True, 0, out16=True, want_stats=True)    # fprop + statistics epilogue
+    ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)                   # zero-pad dgrad
+    ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, True, bf16=True, dy16=dyb, out16=True)    # reflect dgrad, ring folded
     ops.raw_wgrad3x3_lp16(xb, dyb, True, True)
 torch.cuda.synchronize()
