@@ -196,11 +196,11 @@ def _json_only_stdout():
 
 class StackMeter:
     """HIP-event brackets around every C-ABI call of the 3x3 / stride-1 stack with 256 / 512 channels (SURVEY.md
-    §2.3 K4: the PATBlocks' and the Discriminators' residual convs) in 16-bit mode - fprop and the dgrad main term
-    (mmh_conv3x3_lp16), the reflect border terms of the dgrad (mmh_conv2d_dgrad_border) and the wgrad
-    (mmh_wgrad3x3_lp16) - during a few steps.  stack fraction = sum(algorithmic FLOPs 2.B.H.W.Cin.Cout.9 of every
+    §2.3 K4: the PATBlocks' and the Discriminators' residual convs) in 16-bit mode - fprop (mmh_conv3x3_lp16,
+    mmh_conv3x3_lp16_fprop_stats), dgrad (mmh_conv3x3_lp16 mode 2, or mode 1 + the border terms of
+    mmh_conv2d_dgrad_border where the fold does not apply) and the wgrad (mmh_wgrad3x3_lp16) - during a few steps.  stack fraction = sum(algorithmic FLOPs 2.B.H.W.Cin.Cout.9 of every
     pass) / sum(bracketed time) / peak: the north_star's ">= 40 % MFMA on the 3x3 generator conv stack" as measured."""
-    NAMES = ("mmh_conv3x3_lp16", "mmh_wgrad3x3_lp16", "mmh_conv2d_dgrad_border")
+    NAMES = ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_fprop_stats", "mmh_wgrad3x3_lp16", "mmh_conv2d_dgrad_border")
 
     def __init__(self):
         self.rec = []
@@ -219,7 +219,14 @@ class StackMeter:
             e0.record()
             r = self.real(name, *args)
             e1.record()
-            kind = "border" if name.endswith("border") else ("wgrad" if "wgrad" in name else ("fprop", "dgrad")[int(args[1])])
+            if name.endswith("border"):
+                kind = "border"
+            elif "wgrad" in name:
+                kind = "wgrad"
+            elif name.endswith("fprop_stats"):
+                kind = "fprop"
+            else:       # mmh_conv3x3_lp16 mode: 0 fprop, 1 zero-pad dgrad (+ border call), 2 the complete reflect dgrad
+                kind = "fprop" if int(args[1]) == 0 else "dgrad"
             flop = 0.0 if kind == "border" else 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * 9
             self.rec.append((kind, (d.Cin, d.Cout), flop, e0, e1))
             return r
@@ -654,7 +661,7 @@ def main():
                        "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
                        "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
-        tname = "r02_traffic_bf16.json" if a.dtype == "bf16" else ("r02_traffic.json" if wino else "r01_traffic.json")
+        tname = "r03_traffic_bf16.json" if a.dtype == "bf16" else ("r02_traffic.json" if wino else "r01_traffic.json")
         tj = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tj) and a.batch == 32 and a.size == 256:
             tjd = json.load(open(tj))

@@ -179,3 +179,18 @@ def test_optimize_parameters_mse_perceptual_vs_oracle(dev):
         got = [float(v) for v in model.get_current_errors().values()]
         want = list(orc.step(batch).values())
         assert np.allclose(got, want, rtol=1e-3), (it, got, want)
+
+
+def test_bench_bf16_side_run_with_stack_meter(dev):
+    """bench.py's `bf16_path` side key (the driver-visible 16-bit numbers): one bracketed step of the full-width model at
+    64x64 (16x16 feature maps, so the halo kernel with the reflect fold, its statistics epilogue and the nine-tap wgrad
+    all run) goes through StackMeter without an error - it once indexed ("fprop", "dgrad") with the dgrad's mode 2 - and
+    reports every pass of the 256- and 512-channel convs, the dgrad WITHOUT border launches."""
+    import bench
+    out = bench.side_train_run(dev, 2, 64, 1, warmup=1, stack=True, stack_steps=1, opt_level="O1")
+    assert "error" not in out and out["losses_finite"] and out["stack_frac"] > 0
+    per = out["per_pass"]
+    for k in ("fprop_256x256", "dgrad_256x256", "wgrad_256x256", "fprop_512x512", "dgrad_512x512", "wgrad_512x512"):
+        assert per[k]["launches"] > 0 and per[k]["tflops"] > 0, (k, per)
+    assert not any(k.startswith("border") for k in per), per
+    assert out["roofline"]["frac"] > 0

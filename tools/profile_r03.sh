@@ -22,7 +22,7 @@ for f in $O/prof_f32 $O/prof_bf16; do find $f -name "*kernel_stats.csv" -exec cp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_ACTIVE"; do
   rm -rf /tmp/fs; rocprofv3 --pmc $c --output-format csv -d /tmp/fs -- python3 $R/tools/pmc_r03.py >/dev/null 2>&1
-  echo "== --pmc $c"; python3 $R/tools/pmc_summary.py /tmp/fs | grep -A2 "lp16\|cvt" | grep -v "^--"
+  echo "== --pmc $c"; python3 $R/tools/pmc_summary.py /tmp/fs | grep -A3 "lp16\|cvt" | grep -v "^--"
 done > $O/pmc_lp16.txt 2>&1
 cd $R
 rm -rf $O/prof_f32 $O/prof_bf16

@@ -36,10 +36,11 @@ if "wino_gemm" in pat:
           "= 154.6 GFLOP); bench.py's roofline.achieved = that FLOP count / its HIP-event mean over the fprop\n"
           "launches.  The other clusters: 512->256 / 256->512 and 256->256 convs (1/2 and 1/4 of the FLOPs).")
 elif "lp16" in pat:
-    print("conv_lp16h_kernel / conv_lp16p_kernel: workgroups = 8 x ceil(row tiles x column tiles / 8) with 256x256 tiles; (1024,1,1) = 512 row\n"
-          "tiles x 2 column tiles = the 3x3 512->512 convs at 64x64, B=32 (fprop and dgrad main term, 618.5 GFLOP per\n"
-          "launch) and the 512->256 / 256->512 dgrads; (512,1,1) = the 256-column convs.  bench.py --dtype bf16 times\n"
-          "the 512->512 fprop launches with HIP events.")
+    print("conv_lp16h2_kernel (also conv_lp16h / conv_lp16p): workgroups = 8 x ceil(pixel tiles x column tiles / 8), tiles of\n"
+          "256 pixels (16x16) x 256 channels; (1024,1,1) = 512 pixel tiles x 2 column tiles = the 3x3 convs with 512 output\n"
+          "columns at 64x64, B=32: 512->512 fprop and dgrad (618.5 GFLOP per launch; the reflect dgrad carries the ring fold)\n"
+          "and the dgrad of 512->256 (half the FLOPs; the fast end of the range); (512,1,1) = the 256-column convs:\n"
+          "256->256, and 512->256 fprop.  bench.py --dtype bf16 times the 512->512 fprop launches with HIP events.")
 elif "batched" in pat:
     print("workgroups (4, 64, 36) = 4 column tiles x 64 row tiles x 36 Winograd planes = [8192x512].[512x512] per\n"
           "plane: the F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches both have this\n"
