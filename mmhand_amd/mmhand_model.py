@@ -321,8 +321,15 @@ class MMHandModel(torch.nn.Module):
         self._bucket_log = [] if os.environ.get("MMH_DP_LOG") == "1" else None
         global _LAST_BUCKET_LOG
         _LAST_BUCKET_LOG = self._bucket_log
+        # SyncBN's small all-gathers / all-reduces are issued from inside the forward and backward passes; on the WORLD
+        # communicator they would queue behind whatever 32 MB gradient bucket is in flight.  The buckets therefore get a
+        # communicator of their own when any net runs SyncBN (MMH_DP_BUCKET_GROUP=0: everything on WORLD).
+        self._bucket_group = None
+        if (any(n.norm == "batch" for n in (self.netG, self.netD_PB, self.netD_PP))
+                and os.environ.get("MMH_DP_BUCKET_GROUP", "1") != "0"):
+            self._bucket_group = dist.new_group()
         self._buckets = {o: GradBuckets(list(o.net.parameters()), o.net.flat_grad, comm_stream=self.comm_stream,
-                                        log=self._bucket_log, name=n)
+                                        log=self._bucket_log, name=n, group=self._bucket_group)
                          for n, o in (("G", self.optimizer_G), ("D_PB", self.optimizer_D_PB),
                                       ("D_PP", self.optimizer_D_PP))}
 
