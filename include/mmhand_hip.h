@@ -467,6 +467,21 @@ size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
                          void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
 
+/* The same two convolutions from 16-bit tensors on the 16-column MFMA (conv7_n4.hip): an (8+6) x (16+6) pixel halo of
+ * the 64-channel input and the whole [49][4][64] filter resident in LDS, 4 of the 16 weight rows meaningful.
+ * mode 0: fprop of the Generator head (models/Generator.py:254-259): x16 [B,H,W,x_cs >= 64] 16-bit, w the head's fp32
+ *         weight [7][7][64][Cout <= 4], y fp32 [B,H,W,y_cs] (channels 0..3 written), +bias, activation.
+ * mode 1: gradient of a Discriminator stem towards its first four input channels (models/Discriminator.py:60-64 from
+ *         models/MMHandModel.py:238-243): x16 = dy16 [B,H,W,y_cs >= 64], w the stem's fp32 weight [7][7][Cin][64],
+ *         y = dx fp32 [B,H,W,x_cs]: channels [0,4) written, the others left alone (as mmh_conv7_thin_dgrad).  With
+ *         MMH_PAD_REFLECT the kernel runs over the padded domain into ws and the pad ring is folded back.
+ * ws (mmh_conv7_n4_lp16_ws_bytes): the 16-bit filter twin, built by the call, + the padded-domain gradient.        */
+int mmh_conv7_n4_lp16_supported(const mmh_conv_desc* d, int mode);
+size_t mmh_conv7_n4_lp16_ws_bytes(const mmh_conv_desc* d, int mode);
+int mmh_conv7_n4_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w,
+                      const void* bias, void* y, int act, void* ws, size_t ws_bytes,
+                      const void* zeros, mmh_stream_t s);
+
 /* wgrad of the 7x7 / stride 1 / ReflectionPad2d(3) stems (models/Generator.py:158-168,
  * models/Discriminator.py:60-64; fp32, Cin 8 | 44 (where it beats the generic kernel), Cout == 64 dense, H % 2 == 0,
  * W % 64 == 0): the input is reflect-padded once into ws, a workgroup stages the two input rows of a

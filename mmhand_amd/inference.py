@@ -101,7 +101,7 @@ class InferenceGenerator:
         """The folded forward with 16-bit activations between the kernels (BatchNorm folded, ReLU in the conv
         epilogues): stems on the flat-K kernel, stride-2 / transposed convs on conv_lp16g, the PATBlock convs
         on the halo kernel; the gate reads its two gates in 16 bits and writes the next block's concats in 16
-        bits.  fp32 only: the residual stream x1 (its conv reads a twin), the gate's s1, the head's input."""
+        bits.  fp32 only: the residual stream x1 (its conv reads a twin) and the gate's s1."""
         n, f, lp = self.net, self.f, self.bf16
         xs = []
         for s, x in zip((1, 2, 3), (x1, x2, x3)):
@@ -131,11 +131,17 @@ class InferenceGenerator:
             if more:
                 x2, x3 = res[3], res[4]
         y = x1
+        hw, hb = f[("head",)]
+        Bh, Hh, Wh = x1.shape[0], x1.shape[1] << n.n_down, x1.shape[2] << n.n_down
+        dh = ops.conv_desc(Bh, Hh, Wh, hw.shape[2], hw.shape[3], 7, 1, 3, True)
+        head16 = hw.shape[3] == 4 and ops.conv7_n4_ok(dh, 0, lp)       # the head reads 16 bits too (conv7_n4.hip)
         for i in range(n.n_down):
             w, b = f[("up", i)]
-            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU, lp, out16=i + 1 < n.n_down)
-        w, b = f[("head",)]
-        return ops.raw_conv_fprop(y, w, b, 1, 3, True, L.ACT_TANH, lp)
+            y = ops.raw_convT_fprop(y, w, b, L.ACT_RELU, lp, out16=i + 1 < n.n_down or head16)
+        if head16:
+            out = torch.empty((Bh, Hh, Wh, 4), dtype=torch.float32, device=y.device)
+            return ops.raw_conv7_n4(dh, 0, y, hw, hb, out, L.ACT_TANH, lp)
+        return ops.raw_conv_fprop(y, hw, hb, 1, 3, True, L.ACT_TANH, lp)
 
     def _forward_folded(self, x1, x2, x3):
         if self._lp_chain_ok():

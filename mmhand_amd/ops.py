@@ -131,6 +131,11 @@ def _wd(bf16):
     return (torch.float32, torch.bfloat16, torch.float16)[_lp(bf16)]
 
 
+def _lp_of(t):
+    """the `bf16` argument value matching a tensor's element type (0 fp32 | True bf16 | 2 fp16)"""
+    return {torch.float32: 0, torch.bfloat16: True, torch.float16: 2}[t.dtype]
+
+
 def bf16_weights(w, bf16=True):
     """(w_plain [k,k,Cin,Cout], w_t [k,k,Cout,Cin]) 16-bit copies of a physical fp32 weight; for
     Cin % 64 != 0 the second entry is w_flat [Cout, Kpad] (flat (tap, ci) contraction index)."""
@@ -428,7 +433,10 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False,
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
     y = _empty((B, d.Ho, d.Wo, Cout), x)
     if USE_THIN and k == 7 and stride == 1 and pad == 3 and Cout == 4 and Cin % 4 == 0:
-        # the Generator head (64 -> 3): 4 output columns waste an MFMA tile; fp32 vector-ALU kernel
+        # the Generator head (64 -> 3): 4 output columns waste a 32-wide MFMA tile.  16-bit mode: the 16-column MFMA
+        # over an LDS halo (conv7_n4.hip); fp32: vector-ALU kernel
+        if bf16 and conv7_n4_ok(d, 0, bf16):
+            return raw_conv7_n4(d, 0, lp16_twin(x, bf16), w, bias, y, act, bf16)
         L.call("mmh_conv7_thin_fprop", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), act, _stream())
         _count_desc("valu", d)
         return y
@@ -476,6 +484,35 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False,
     return y
 
 
+USE_CONV7_N4 = os.environ.get("MMH_CONV7_N4", "1") != "0"
+
+
+def conv7_n4_ok(d, mode, lp):
+    """7x7 conv with <= 4 output channels from a 64-channel 16-bit tensor on the 16-column MFMA (mmh_conv7_n4_lp16):
+    mode 0 the Generator head's fprop, 1 a Discriminator stem's gradient towards its first four input channels"""
+    if not (USE_CONV7_N4 and lp):
+        return False
+    keep = d.dtype
+    d.dtype = _dt(lp)
+    ok = bool(L.load().mmh_conv7_n4_lp16_supported(C.byref(d), mode))
+    d.dtype = keep
+    return ok
+
+
+def raw_conv7_n4(d, mode, x16, w, bias, y, act, lp):
+    """y: the fp32 output (mode 0) / dx whose channels [0,4) are written (mode 1)"""
+    assert x16.dtype == _wd(lp) and x16.is_contiguous()
+    keep = d.dtype
+    d.dtype = _dt(lp)
+    nbytes = L.load().mmh_conv7_n4_lp16_ws_bytes(C.byref(d), mode)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x16.device)
+    L.call("mmh_conv7_n4_lp16", C.byref(d), mode, _ptr(x16), _ptr(w), _ptr(bias), _ptr(y), act, _ptr(ws), ws.numel() * 4,
+           _ptr(zero_page(x16.device)), _stream())
+    d.dtype = keep
+    _count("mfma", 2.0 * d.B * d.H * d.W * 49 * 64 * 16)       # executed: 16 columns, 4 of them meaningful
+    return y
+
+
 def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     """dgrad of a 7x7 / stride 1 / pad 3 conv for the first 4 input channels only (the others are
     returned as zeros): the Discriminator stems seen from the generated image.  dy: fp32 or 16-bit."""
@@ -484,6 +521,8 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     Cout = w.shape[3]
     d = conv_desc(B, H, W_, Cin, Cout, 7, 1, 3, reflect)
     dx = torch.zeros((B, H, W_, Cin), dtype=torch.float32, device=dy.device)
+    if dy.dtype != torch.float32 and conv7_n4_ok(d, 1, _lp_of(dy)):
+        return raw_conv7_n4(d, 1, dy, w, None, dx, L.ACT_NONE, _lp_of(dy))
     ws = _ws(L.load().mmh_conv7_thin_dgrad_ws_bytes(C.byref(d)), dy)
     L.call("mmh_conv7_thin_dgrad", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), ws.numel() * 4, _tdt(dy),
            _stream())

@@ -179,6 +179,75 @@ def test_thin_conv7_dgrad_first_channels(case, dev):
     assert R.rel_l1(full, dxr) < TOL
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("case", [(2, 16, 16, True), (1, 20, 70, True), (2, 37, 130, True), (1, 8, 8, False), (3, 9, 17, False),
+                                  (1, 64, 64, True)])
+def test_conv7_n4_head_fprop(case, act, lp, dev):
+    """mmh_conv7_n4_lp16 mode 0 (the Generator head, models/Generator.py:254-259: ReflectionPad2d(3) + Conv2d(64, 3, 7) +
+    Tanh, the three outputs padded to four) on the 16-column MFMA from a 16-bit input: one tile, ragged tiles in both
+    directions, the smallest image, zero padding - against the fp64 oracle on operands rounded to the storage type, and
+    against the fp32 vector-ALU kernel it replaces in 16-bit mode (same input, fp32 weights there)."""
+    from mmhand_amd import lib, ops
+    B, H, W, refl = case
+    x = _mk((B, H, W, 64), 1, dev)
+    w = _mk((7, 7, 64, 4), 2, dev) * 0.05
+    bias = _mk((4,), 3, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        y = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, act, bf16=lp)
+    finally:
+        lib.call = orig
+    assert calls.get("mmh_conv7_n4_lp16") == 1 and "mmh_conv7_thin_fprop" not in calls, calls
+    yr = R.conv2d(rb(x), rb(w), bias.cpu(), 1, 3, refl, act)
+    assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+    y32 = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, act)           # fp32: the vector-ALU kernel
+    assert R.rel_l1(y, y32.cpu()) < (3e-3 if lp == 2 else 1.5e-2)
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 8, True), (1, 20, 70, 24, True), (2, 37, 66, 8, True), (1, 12, 12, 24, False),
+                                  (2, 8, 8, 8, True), (1, 64, 64, 24, True), (1, 9, 40, 4, True)])
+def test_conv7_n4_stem_dgrad(case, lp, dev):
+    """mmh_conv7_n4_lp16 mode 1: the gradient of a Discriminator stem (models/Discriminator.py:60-64) towards the generated
+    image's channels from a 16-bit dy - the flipped-filter correlation over the padded domain and the fold of the
+    ReflectionPad2d(3) ring (rows / columns 1..3 and H-4..H-2 receive mirrored terms; at H = 8 the two ranges touch) -
+    against the fp64 oracle on rounded operands; channels >= 4 stay zero.  Through ops.raw_conv_dgrad as the model calls it."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, refl = case
+    w = _mk((7, 7, Cin, 64), 2, dev) * 0.05
+    dy = _mk((B, H, W, 64), 4, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    dy16 = ops.lp16_twin(dy, lp)
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dx = ops.raw_conv_dgrad_thin(dy16, w, (B, H, W, Cin), refl)
+    finally:
+        lib.call = orig
+    assert calls.get("mmh_conv7_n4_lp16") == 1 and "mmh_conv7_thin_dgrad" not in calls, calls
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), rb(w), None, rb(dy), 1, 3, refl)
+    n = min(4, Cin)
+    assert R.rel_l1(dx[..., :n], dxr[..., :n]) < 5e-6, R.rel_l1(dx[..., :n], dxr[..., :n])
+    assert not dx[..., 4:].any()
+    # the ring rows / columns alone (a wrong fold would hide in the whole-tensor norm of a large image)
+    ring = torch.zeros(H, W, dtype=torch.bool)
+    ring[[1, 2, 3, H - 4, H - 3, H - 2], :] = True
+    ring[:, [1, 2, 3, W - 4, W - 3, W - 2]] = True
+    a, r = dx.cpu()[:, ring][..., :n], dxr[:, ring][..., :n]
+    assert float((a - r).abs().sum() / r.abs().sum()) < 5e-6
+
+
 @pytest.mark.parametrize("act", [1, 2])
 def test_conv2d_epilogue_act(act, dev):
     from mmhand_amd import ops
@@ -271,8 +340,9 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
     yf, dxf, dwf, _ = R.conv2d_grads(x.cpu(), w.cpu(), bias.cpu(), dy.cpu(), s, p, refl)
     # dgrad with Cout not a multiple of 64 keeps the fp32 kernel; fprop runs in bf16 (flat
     # (tap, ci) contraction for the small-Cin stems) except the 4-column head, which is on the
-    # fp32 vector-ALU kernel of conv_thin.hip in both precisions
-    y_ref = yf if (k == 7 and Cout == 4) else yr
+    # fp32 vector-ALU kernel of conv_thin.hip in both precisions unless conv7_n4.hip takes it (H, W >= 8)
+    head16 = k == 7 and Cout == 4 and ops.conv7_n4_ok(ops.conv_desc(B, H, W, Cin, Cout, k, s, p, refl), 0, lp)
+    y_ref = yf if (k == 7 and Cout == 4 and not head16) else yr     # the head: 16-column MFMA kernel where it applies
     dx_ref = dxr if Cout % 64 == 0 else dxf
     if not ops._wino_tile(B, H, W, Cin, Cout, k, s, p, True):
         assert R.rel_l1(y, y_ref) < 5e-5, ("fprop vs matching-precision oracle", R.rel_l1(y, y_ref))
@@ -629,11 +699,12 @@ def test_winograd_all_passes(case, tile, act, dev):
 
 @pytest.mark.parametrize("lp", [0, True, 2], ids=["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 64, 64, 8, 64), (2, 32, 32, 24, 64), (1, 40, 72, 8, 64)])
-def test_thin_dgrad_every_dy_type(case, lp, dev):
+def test_thin_dgrad_every_dy_type(case, lp, dev, monkeypatch):
     """mmh_conv7_thin_dgrad (the Discriminator stems' gradient towards the generated image, models/MMHandModel.py:
     238-243) with dy in fp32, bf16 and fp16 against the fp64 oracle on the same (rounded) operands.  The fp16 decode was
     miscompiled once (channels 2, 3 of every 4 came out as copies of 0, 1): found by tests/test_lp16_step_gpu.py."""
     from mmhand_amd import ops
+    monkeypatch.setattr(ops, "USE_CONV7_N4", False)     # the vector-ALU kernel itself (still the path for Cout != 64, H < 8)
     B, H, W, Cin, Cout = case
     dy = _mk((B, H, W, Cout), 4, dev)
     w = _mk((7, 7, Cin, Cout), 2, dev) * 0.02
