@@ -231,6 +231,13 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
  * channel) of the values as stored - the mmh_norm_stats_merge[_finalize] layout, so the InstanceNorm
  * behind the conv (models/Generator.py:66-77) does not read y for statistics.  chunks =
  * mmh_conv3x3_lp16_stats_chunks(d) = 2 (H/16)(W/16); 0 = not available (H or W not a multiple of 16). */
+/* dgrad (mode 1 | 2) with an fp32 dx that also receives `addend` (fp32, same layout as dx) in the epilogue:
+ * dx = dgrad(dy) + addend.  The conv's input has a second consumer - the residual stream of a PATBlock
+ * (models/Generator.py:115-130) or a ResnetBlock (models/Discriminator.py:50) - whose gradient
+ * autograd would otherwise add in a pass of its own (35 launches, 1.7 ms per 16-bit step).        */
+int mmh_conv3x3_lp16_dgrad_add_supported(const mmh_conv_desc* d);
+int mmh_conv3x3_lp16_dgrad_add(const mmh_conv_desc* d, int mode, const void* dy16, const void* w16,
+                               const void* addend, void* dx, const void* zeros, mmh_stream_t s);
 int mmh_conv3x3_lp16_stats_chunks(const mmh_conv_desc* d);
 int mmh_conv3x3_lp16_fprop_stats(const mmh_conv_desc* d, const void* x16, const void* w16,
                                  const void* bias, void* y16, void* stats, const void* zeros,

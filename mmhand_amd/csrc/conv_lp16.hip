@@ -53,6 +53,8 @@ struct LpConvKP {
     int dbg;                // timing-only ablation bits (mmh_set_option "lp16_dbg"): results wrong
     float* stats;           // conv_lp16h2_kernel fprop: per (image, half tile, channel) count / mean / M2 of the stored
                             // outputs, [B][chunks][3][N] (mmh_norm_stats_merge layout), or nullptr
+    const float* addend;    // conv_lp16h2_kernel, fp32 output: y += addend (same [M][y_cs] layout) - the other gradient
+                            // of a tensor with two consumers, added in the dgrad's epilogue instead of by a pass of its own
 };
 
 template <bool H16>
@@ -952,8 +954,11 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         if (oh >= p.H || ow >= p.W) continue;
         const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            store4<H16>(p.y, p.y16, m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4), acc[i][j], bv[j], p.act);
+        for (int j = 0; j < 4; ++j) {
+            const size_t elem = m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4);
+            if (SIGN < 0 && p.addend) acc[i][j] += *reinterpret_cast<const f32x4*>(p.addend + elem);
+            store4<H16>(p.y, p.y16, elem, acc[i][j], bv[j], p.act);
+        }
     }
     if (SIGN > 0 && !FOLD && p.stats) {
         // The InstanceNorm behind this conv (models/Generator.py:66-77) wants mean and M2 per (image, channel): each wave
@@ -2151,7 +2156,8 @@ int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d) {
 // mode 2: dgrad of a reflect-padded conv COMPLETE: mode 1 plus the pad ring's gradient folded onto rows 1 / H-2 and
 //                columns 1 / W-2 inside the kernel (mmh_conv3x3_lp16_fold_supported; no border call follows)
 static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
-                             void* y, int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s) {
+                             void* y, int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s,
+                             const void* addend = nullptr) {
     MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1 || mode == 2),
                 "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
     MMH_REQUIRE(mode != 2 || mmh_conv3x3_lp16_fold_supported(d),
@@ -2176,6 +2182,7 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
     p.tap_inner = mmh::g_lp16_tap_inner;
     p.dbg = mmh::g_lp16_dbg;
     p.stats = static_cast<float*>(stats);
+    p.addend = static_cast<const float*>(addend);
     const long long M = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(M * (long long)std::max(p.cs, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
                 "mmh_conv3x3_lp16: tensor too large");
@@ -2284,6 +2291,21 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
 int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
                      void* y, int y_is16, int act, const void* zeros, mmh_stream_t s) {
     return conv3x3_lp16_impl(d, mode, x16, w16, bias, y, y_is16, act, zeros, nullptr, s);
+}
+
+// dgrad (mode 1 | 2) with an fp32 dx that also receives `addend` (fp32, dx's layout): dx = dgrad(dy) + addend.  The
+// input of such a conv has a second consumer (the residual stream: PATBlock out = x1 + ..., models/Generator.py:115-130;
+// ResnetBlock out = x + conv_block(x), models/Discriminator.py:50) whose gradient autograd would add in a pass of its own.
+int mmh_conv3x3_lp16_dgrad_add_supported(const mmh_conv_desc* d) {
+    return mmh_conv3x3_lp16_supported(d) && d->H >= HT && d->W >= HT && d->Cin % TBN == 0 && g_lp16_shape == 19;
+}
+
+int mmh_conv3x3_lp16_dgrad_add(const mmh_conv_desc* d, int mode, const void* dy16, const void* w16, const void* addend,
+                               void* dx, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE((mode == 1 || mode == 2) && addend && mmh_conv3x3_lp16_dgrad_add_supported(d),
+                "mmh_conv3x3_lp16_dgrad_add: mode 1 | 2 on the halo kernel (H, W >= 16, Cin %% 256 == 0)");
+    MMH_REQUIRE((reinterpret_cast<uintptr_t>(addend) & 15) == 0, "mmh_conv3x3_lp16_dgrad_add: addend must be 16-byte aligned");
+    return conv3x3_lp16_impl(d, mode, dy16, w16, nullptr, dx, 0, MMH_ACT_NONE, zeros, nullptr, s, addend);
 }
 
 // fprop with a 16-bit output whose per-(image, half tile, channel) partial statistics come out of the epilogue:

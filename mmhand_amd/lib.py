@@ -93,6 +93,8 @@ SIGNATURES = {
     "mmh_wgrad3x3_lp16": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "mmh_conv3x3_lp16": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_conv3x3_lp16_stats_chunks": (_i, [_DP]),
+    "mmh_conv3x3_lp16_dgrad_add_supported": (_i, [_DP]),
+    "mmh_conv3x3_lp16_dgrad_add": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_conv3x3_lp16_fprop_stats": (_i, [_DP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_colsum_ws_bytes": (_sz, [_i64, _i]),
     "mmh_colsum": (_i, [_vp, _i64, _i, _i, _vp, _vp, _sz, _i, _i, _vp]),

@@ -257,7 +257,7 @@ class _Net(nn.Module):
 
     # -- functional layers
     def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False, to_norm=False,
-             g_defer=False):
+             g_defer=False, res_tok=None):
         """x: an fp32 NHWC tensor, a (proxy, x16) pair from a producer that wrote it in 16 bits, or a
         (proxy, NormDefer) pair from a norm whose apply pass runs inside this conv (normact(defer)).
         y_lp (see _lp_edge): the consumer (normact / the PATBlock gate) takes the output in 16 bits ->
@@ -272,11 +272,14 @@ class _Net(nn.Module):
         # to_norm: the output goes straight into this net's norm layer; under InstanceNorm the conv bias then
         # has an identically zero gradient (ops.EXACT_NULL_BIAS_GRAD)
         nb = bool(to_norm and self.norm == "instance" and self.training)
+        if x16 is not None:
+            res_tok = None      # tokens belong to fp32 block inputs (ops.ResidualToken)
         if y_lp:
-            p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True, nb)
+            p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True, nb,
+                                        None, False, res_tok)
             return p, y16
         return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, False, nb,
-                                  None, g_defer)
+                                  None, g_defer, res_tok)
 
     def _lp_edge(self, cp, stride=1, reflect=True):
         """16-bit hand-over to the 3x3 / pad 1 conv (or ConvTranspose2d) `cp` (training, 16-bit mode, all
@@ -313,7 +316,7 @@ class _Net(nn.Module):
             return p, y16
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, False, nb)
 
-    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0, defer=0):
+    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0, defer=0, res_tok=None):
         """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
         x may itself be a (proxy, x16) pair from a 16-bit convolution (conv(y_lp=True)).
         defer (1 | 2, training fp32): only the statistics are finalised here; returns a (proxy, NormDefer)
@@ -352,13 +355,13 @@ class _Net(nn.Module):
             return p, ops.NormDefer(x.detach(), scale, shift, groups, relu, drop_p, drows)
         if self.norm == "instance":
             return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", relu,
-                                       drop_p, seed, mask, None, out_lp, x16)
+                                       drop_p, seed, mask, None, out_lp, x16, 0, res_tok)
         np_ = bag[idx]
         if self.training:
             np_.num_batches_tracked += 1
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean,
                                        np_.running_var, "batch", relu, drop_p, seed, mask,
-                                       self.sync_group, out_lp, x16)
+                                       self.sync_group, out_lp, x16, 0, res_tok)
         scale = np_.weight / torch.sqrt(np_.running_var + ops.EPS)
         shift = np_.bias - np_.running_mean * scale
         y = ops.AffineActFn.apply(x, scale, shift, relu)
@@ -393,8 +396,17 @@ class _Net(nn.Module):
                 and ops._wino_tile(B, H, W, Cin, Cout, 3, 1, 1, False) == 6
                 and ops._wino_tile(B, H, W, Cin, Cout, 3, 1, 1, False, "dgrad") == 6)
 
-    def two_conv_block(self, blk, x, site, last_norm, residual=None):
-        """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets)."""
+    def _res_token(self, x):
+        """a token for a block input with two consumers (ops.ResidualToken): 16-bit training mode, fp32 tensor"""
+        return ops.ResidualToken() if (ops.USE_RESIDUAL_TOKENS and self.bf16 and self.training and torch.is_tensor(x)
+                                       and x.requires_grad) else None
+
+    def two_conv_block(self, blk, x, site, last_norm, residual=None, res_tok=None):
+        """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets).
+        res_tok: x is also read by the caller's residual add (the PATBlock gate); with residual is x (ResnetBlock)
+        the token is made here."""
+        if residual is not None and residual is x and last_norm:
+            res_tok = self._res_token(x)
         i2 = 6 if self.use_dropout else 5
         # 16-bit mode: every tensor that faces one of these convolutions (input, output, both gradients)
         # lives in HBM in 16 bits only, as under apex O1; without a last norm the caller (the PATBlock
@@ -403,11 +415,12 @@ class _Net(nn.Module):
         # the block's last norm (no ReLU / dropout; feeds the gate or the residual add): its backward apply pass
         # inside conv 2's backward transform, as for the first norm
         fuse_last = 3 if (last_norm and torch.is_tensor(x) and self._norm_bwd_fusion(blk[i2], x)) else 0
-        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2)
+        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2, res_tok=res_tok)
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
         y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm, g_defer=fuse_last == 3)
         if last_norm:
-            y = self.normact(blk, i2 + 1, y, False, residual=residual, defer=fuse_last)
+            y = self.normact(blk, i2 + 1, y, False, residual=residual, defer=fuse_last,
+                             res_tok=res_tok if residual is not None else None)
         return y
 
 
@@ -543,12 +556,14 @@ class Generator(_Net):
         for b in range(self.n_blocks):
             blk = m["att"][b]
             p = f"model.att.{b}.conv_block_stream"
+            tok = None
             if packing(self):
                 s1, s2, s3 = two_conv_blocks_lockstep(
                     [dict(net=self, blk=blk[f"conv_block_stream{s}"], x=x, site=p + str(s), last_norm=s == 1)
                      for s, x in zip((1, 2, 3), (x1, x2, x3))])
             else:
-                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True)
+                tok = self._res_token(x1)       # x1 feeds the stream-1 conv AND the gate's residual add
+                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True, res_tok=tok)
                 s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
                 s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)
@@ -559,10 +574,10 @@ class Generator(_Net):
                 (s2, a), (s3, b_) = s2, s3
                 s16 = (a, b_)
             if cat_lp:      # the cats feed only the next block's 16-bit convs: written in 16 bits
-                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp, *s16)
+                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp, *s16, tok)
                 x2, x3 = (p2, c2), (p3, c3)
             else:
-                x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more, 0, *s16)
+                x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more, 0, *s16, tok)
         up = m["stream1_up"]
         y = x1
         for i in range(self.n_down):

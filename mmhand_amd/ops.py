@@ -530,10 +530,29 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     return dx
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None, out16=False):
+def _add_into(dx, addend):
+    if addend is None:
+        return dx
+    _chk(addend, "addend")
+    return dx.add_(addend)
+
+
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None, out16=False, addend=None):
     """dx_channels > 0: only the first dx_channels input channels need a gradient (the caller
     ignores the rest, which may come back as zeros).  dy16: an existing 16-bit twin of dy (dy itself
-    may then be None); out16: return dx in 16 bits (conv_lp16 path only)."""
+    may then be None); out16: return dx in 16 bits (conv_lp16 path only).  addend (fp32, dx's shape): returns
+    dx + addend - in the halo kernel's epilogue where that kernel runs, else by one in-place add."""
+    if addend is not None:
+        assert not out16 and not dx_channels
+        _chk(addend, "addend")
+        B_, H_, W__, Cin_ = x_shape
+        k_, _, _, Cout_ = w.shape
+        d_ = conv_desc(B_, H_, W__, Cin_, Cout_, k_, stride, pad, reflect)
+        d_.dtype = _dt(bf16)
+        fused = (bool(bf16) and lp16_v2_ok(Cin_, Cout_, k_, stride, pad, 1) and not _wino_tile(B_, H_, W__, Cin_, Cout_, k_, stride, pad, bf16, "dgrad")
+                 and bool(L.load().mmh_conv3x3_lp16_dgrad_add_supported(C.byref(d_))))
+        if not fused:
+            return _add_into(raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16, 0, dy16, False), addend)
     _chk(w, "w")
     B, H, W_, Cin = x_shape
     if dy is None or out16:
@@ -558,8 +577,8 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
         d.dtype = _dt(bf16)
         if reflect and USE_LP16_FOLD and L.load().mmh_conv3x3_lp16_fold_supported(C.byref(d)):
             # H, W multiples of 16: the halo kernel folds the pad ring's gradient in itself (mode 2), no border call
-            return raw_conv3x3_lp16(dy16, w, None, True, L.ACT_NONE, bf16, 2, out16=out16)
-        dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16)
+            return raw_conv3x3_lp16(dy16, w, None, True, L.ACT_NONE, bf16, 2, out16=out16, addend=addend)
+        dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16, addend=addend)
         if reflect:
             ws = torch.empty(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)) // 4 + 4, dtype=torch.float32,
                              device=dx.device)
@@ -672,6 +691,35 @@ def lp16_twin(x, bf16=True):
     return out
 
 
+# A tensor with two consumers - the block input x that both the first conv of a two-conv block and the residual add
+# read (PATBlock: out = x1 + s1 * gates, models/Generator.py:115-130; ResnetBlock: out = x + conv_block(x),
+# models/Discriminator.py:50) - gets two gradients, which autograd adds in a pass of its own (35 launches, 1.7 ms per
+# 16-bit step).  With a ResidualToken shared by the two consumers the residual side's backward (which always runs first:
+# the conv's gradient depends on it) parks its gradient in the token instead of returning it, and the conv's dgrad adds it
+# in its epilogue (mmh_conv3x3_lp16_dgrad_add) or, on any other path, with one in-place add.
+USE_RESIDUAL_TOKENS = os.environ.get("MMH_RESIDUAL_TOKENS", "1") != "0"
+
+
+class ResidualToken:
+    __slots__ = ("armed", "addend")
+
+    def __init__(self):
+        self.armed = False      # set by the conv's forward: it will compute an input gradient
+        self.addend = None      # parked by the residual side's backward, taken by the conv's backward
+
+    def park(self, g):
+        """residual side: True = the gradient is parked (return None to autograd)"""
+        if not self.armed or g is None:
+            return False
+        assert self.addend is None, "ResidualToken: a gradient is already parked (backward ran twice?)"
+        self.addend = g
+        return True
+
+    def take(self):
+        g, self.addend = self.addend, None
+        return g
+
+
 # dgrad of the reflect-padded 3x3 convs: border terms inside the halo kernel (mmh_conv3x3_lp16 mode 2) where it applies
 USE_LP16_FOLD = os.environ.get("MMH_LP16_FOLD", "1") != "0"
 
@@ -682,7 +730,7 @@ def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
     return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 64 == 0 and Cout % 64 == 0 and n % 256 == 0
 
 
-def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_stats=False):
+def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_stats=False, addend=None):
     """mode 0: y = conv(x16, w) (+bias, act); mode 1: dx = zero-pad correlation of x16 (= dy) with the
     flipped filter (the caller adds the reflect border terms); mode 2: the complete dgrad of a
     ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight."""
@@ -703,6 +751,10 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_s
                _ptr(zero_page(x16.device)), _stream())
         _pending_stats.clear()
         _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+    elif addend is not None:        # dgrad: dx = dgrad(dy) + addend in the epilogue
+        assert mode != 0 and not out16 and bias is None and act == L.ACT_NONE and tuple(addend.shape) == tuple(y.shape)
+        L.call("mmh_conv3x3_lp16_dgrad_add", C.byref(d), mode, _ptr(x16), _ptr(wp), _ptr(addend), _ptr(y),
+               _ptr(zero_page(x16.device)), _stream())
     else:
         L.call("mmh_conv3x3_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
                int(out16), act, _ptr(zero_page(x16.device)), _stream())
@@ -1111,17 +1163,30 @@ def raw_act_bwd(g, y, act):
     return dx
 
 
+def _tok_add(dx, addend):
+    """Conv2dFn.backward: the residual side's parked gradient that no kernel epilogue took, added in place"""
+    if addend is None:
+        return dx
+    assert dx is not None and dx.dtype == torch.float32, "a parked residual gradient needs an fp32 input gradient to join"
+    return dx.add_(addend)
+
+
 class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d (+ReflectionPad2d, +bias, +ReLU/Tanh epilogue) on the implicit-GEMM kernels."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False,
-                null_bias_grad=False, pro=None, g_defer=False):
+                null_bias_grad=False, pro=None, g_defer=False, res_tok=None):
         """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
         the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
         GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
         ctx.set_materialize_grads(False)    # no full-size zero "gradient" for the non-differentiable 16-bit output
+        # res_tok (ResidualToken): x has a second consumer whose gradient this conv's backward adds to its own
+        ctx.res_tok = res_tok
+        if res_tok is not None:
+            assert x16 is None and pro is None, "a residual token belongs to an fp32 block input"
+            res_tok.armed = bool(ctx.needs_input_grad[0])
         # pro (NormDefer): x is the proxy of a normalised activation that was never written; the norm-apply runs
         # inside this conv's input transform.  g_defer: the norm behind this conv sends its input gradient
         # as a NormBwdDefer (see USE_NORM_FUSION)
@@ -1207,6 +1272,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g16=None):
+        addend = ctx.res_tok.take() if ctx.res_tok is not None else None    # the residual side's gradient of x, if parked
         x, w, y = ctx.saved_tensors
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
@@ -1233,19 +1299,22 @@ class Conv2dFn(torch.autograd.Function):
                                                                      out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:
+                fuse = addend is not None and not ctx.x_lp and not ctx.dx_channels
                 dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16,
-                                    out16=ctx.x_lp)
+                                    out16=ctx.x_lp, addend=addend if fuse else None)
+                if fuse:
+                    addend = None       # added by the dgrad itself
                 if ctx.x_lp:
                     dx = lp_grad_out(dx)
             if ctx.needs_input_grad[1]:
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         fused_bwd = (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0]
                      and ctx.needs_input_grad[1]
                      and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6)
@@ -1265,7 +1334,7 @@ class Conv2dFn(torch.autograd.Function):
             dw = _finish_param_grad(dw, wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
@@ -1277,7 +1346,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -1287,7 +1356,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
         if want_db:
             db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
@@ -1656,7 +1725,7 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
-                seed, mask, sync_group, out_lp=0, x16=None, defer=0):
+                seed, mask, sync_group, out_lp=0, x16=None, defer=0, res_tok=None):
         """out_lp (True bf16 | 2 fp16): the output is written in that 16-bit type only - it feeds a
         16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass.
         x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
@@ -1664,6 +1733,7 @@ class NormActFn(torch.autograd.Function):
         batch_norm in fp32 on fp16 conv outputs).
         Returns out | (proxy, out16) with out_lp | (proxy, scale, shift, drows) with defer 1 / 2."""
         ctx.set_materialize_grads(False)
+        ctx.res_tok = res_tok if residual is not None else None    # `residual` is also a conv's input (ResidualToken)
         st = _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16)
         synced = None
         if mode == "batch" and sync_group is not None and st[2] is None:
@@ -1675,14 +1745,16 @@ class NormActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g16=None, _a=None, _b=None):
         if g is None:
-            return (None,) * 15
+            return (None,) * 16
         sync_group = ctx.cfg[5]
         g, s1l, s2l = _norm_bwd_local(ctx, g)
         s1, s2 = s1l, s2l
         if sync_group is not None:
             (s1, s2), = _sync_bwd_sums_multi([(s1l, s2l)], sync_group)
         dx, dgamma, dbeta, dres = _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        if ctx.res_tok is not None and ctx.res_tok.park(dres):
+            dres = None         # joins the block input's gradient inside its first conv's dgrad
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 NORM_SITE_ARGS = 14     # per site: x, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask, out_lp, x16, defer, _
@@ -1785,12 +1857,13 @@ class GateFn(torch.autograd.Function):
     x2n = cat(s3, out), x3n = cat(s2, out) — the concat is written by the same kernel."""
 
     @staticmethod
-    def forward(ctx, x1, s1, s2, s3, want_cat, cat_lp=0, s2_16=None, s3_16=None):
+    def forward(ctx, x1, s1, s2, s3, want_cat, cat_lp=0, s2_16=None, s3_16=None, res_tok=None):
         """cat_lp (True bf16 | 2 fp16): cat(s3,out) / cat(s2,out) are written in that 16-bit type only
         (they feed the next block's 16-bit convolutions and nothing else); `out` stays fp32.
         s2_16 / s3_16: s2 and s3 were written in 16 bits only by their convolutions (Conv2dFn y_lp);
         s2 / s3 are then the proxies on the autograd edges and the gradients go back in 16 bits."""
         ctx.set_materialize_grads(False)
+        ctx.res_tok = res_tok       # x1 is also the input of this block's first stream-1 conv (ResidualToken)
         ctx.s_lp = s2_16 is not None
         ctx.cat_lp = bool(want_cat and cat_lp)
         if ctx.s_lp:
@@ -1833,7 +1906,9 @@ class GateFn(torch.autograd.Function):
                L.F32 if g_x2n is None else _tdt(g_x2n), _tdt(s2), _tdt(gs2), _stream())
         if ctx.s_lp:
             gs2, gs3 = lp_grad_out(gs2), lp_grad_out(gs3)
-        return gx1, gs1, gs2, gs3, None, None, None, None
+        if ctx.res_tok is not None and ctx.res_tok.park(gx1):
+            gx1 = None          # joins the gradient of x1 inside the stream-1 conv's dgrad
+        return gx1, gs1, gs2, gs3, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- losses

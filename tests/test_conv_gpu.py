@@ -714,3 +714,37 @@ def test_thin_dgrad_every_dy_type(case, lp, dev, monkeypatch):
     dx = ops.raw_conv_dgrad_thin(dyi, w, (B, H, W, Cin), True)
     _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), w.cpu(), None, rb(dy), 1, 3, True)
     assert R.rel_l1(dx[..., :3], dxr[..., :3]) < 5e-6, R.rel_l1(dx[..., :3], dxr[..., :3])
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 256, 64, True), (1, 32, 48, 256, 256, True), (2, 17, 33, 256, 128, True),
+                                  (1, 16, 32, 512, 256, False), (2, 9, 11, 256, 256, True)])
+def test_conv3x3_lp16_dgrad_with_addend(case, lp, dev):
+    """ops.raw_conv_dgrad(addend=...): dx = dgrad(dy) + addend with the addition in the halo kernel's epilogue
+    (mmh_conv3x3_lp16_dgrad_add; reflect with the ring folded, reflect with border launches on ragged shapes, zero
+    padding) == the dgrad followed by a separate add, bit for bit where nothing else is reordered; images smaller than
+    a tile take the in-place add.  models/Generator.py:115-130 (x1 feeds conv and residual), models/Discriminator.py:50."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout, refl = case
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    dy16 = ops.lp16_twin(_mk((B, H, W, Cout), 4, dev), lp)
+    addend = _mk((B, H, W, Cin), 7, dev)
+    ops.bump_weights_epoch()
+    ref = ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, refl, bf16=lp, dy16=dy16)
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dx = ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, refl, bf16=lp, dy16=dy16, addend=addend)
+    finally:
+        lib.call = orig
+    fused = H >= 16 and W >= 16
+    assert (calls.get("mmh_conv3x3_lp16_dgrad_add", 0) == 1) == fused, calls
+    want = ref + addend
+    if "mmh_conv2d_dgrad_border" in calls:      # (main + addend) + border against (main + border) + addend
+        assert float((dx - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    else:
+        assert torch.equal(dx, want), float((dx - want).abs().max())

@@ -123,3 +123,45 @@ def test_optimize_parameters_16bit_vs_fp64_oracle(level, loss_tol, grad_tol, img
     assert calls["mmh_conv_lp16"] >= 2 * 10 and calls["mmh_conv_lp16_flat"] >= 2 * 5, calls
     assert calls["mmh_wgrad_lp16_flat"] >= 2 * 4, calls
     assert calls["mmh_wino_gemm"] == 0, calls            # no Winograd in 16-bit mode on these shapes
+
+
+def test_residual_tokens_change_nothing(dev, monkeypatch):
+    """ops.ResidualToken: the gradient a block input receives from its residual consumer (the PATBlock gate, the
+    ResnetBlock add) is parked and added inside the first conv's dgrad (mmh_conv3x3_lp16_dgrad_add) instead of by
+    autograd's add.  One full-width 16-bit Generator + both Discriminator backward passes with and without tokens: every
+    parameter gradient and the losses bit-identical (the fused add is the same fp32 addition; at 16x16 feature maps
+    the reflect dgrad is the one-launch fold kernel, so no other term is reordered), the fused entry point engaged once
+    per PATBlock and per ResnetBlock pass, and no token left holding a gradient."""
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_RESIDUAL_TOKENS", on)
+        calls = Counter()
+        real = lib.call
+
+        def spy(name, *a, _c=calls, _r=real):
+            _c[name] += 1
+            return _r(name, *a)
+        monkeypatch.setattr(lib, "call", spy)
+        torch.manual_seed(5)
+        random.seed(5)
+        ops.set_dropout_seed(777)
+        model = MMHandModel(_opt("O1"))
+        model.set_input(O.synthetic_batch(2, SIZE, SIZE, seed=11))
+        model.forward()
+        for o in model.optimizers:
+            o.zero_grad()
+        model.backward_G()
+        gG = model.netG.flat_grad.clone()
+        model.backward_D_PP()
+        model.backward_D_PB()
+        outs[on] = (gG, model.netD_PB.flat_grad.clone(), model.netD_PP.flat_grad.clone(),
+                    [float(v) for v in model.get_current_errors().values()], calls)
+        monkeypatch.setattr(lib, "call", real)
+        del model
+    a, b = outs[True], outs[False]
+    assert a[4]["mmh_conv3x3_lp16_dgrad_add"] >= NB and b[4]["mmh_conv3x3_lp16_dgrad_add"] == 0, (a[4], b[4])
+    assert a[3] == b[3], (a[3], b[3])
+    for x, y in zip(a[:3], b[:3]):
+        assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
