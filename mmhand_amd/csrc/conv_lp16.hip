@@ -968,11 +968,12 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         // lanes.  Host side guarantees H, W multiples of 16 (no ragged tiles), no activation.
         const int chunks = TX * TY * 2;
         float* sp = p.stats + ((size_t)(b * chunks + (ty * TX + tx) * 2 + wr) * 3) * p.N + n0 + wc * 64 + 4 * g4;
+        float mu[16], m2[16];               // channel c = 4 j + r of this lane's 16: mean and M2 of its 8 rows
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v[8], mean = 0.f, m2 = 0.f;
+                float v[8], mean = 0.f, q = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float t = acc[i][j][r] + bv[j][r];
@@ -981,26 +982,33 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
                 }
                 mean *= 0.125f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) m2 = fmaf(v[i] - mean, v[i] - mean, m2);
-                // xor 1, 2, 4, 8 inside the 16 pixel lanes: ds_swizzle bit mode (and 0x1f, or 0, xor s)
-#define MMH_SWZ(val, s) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, val), 0x1f | ((s) << 10)))
-                {
-                    float mo = MMH_SWZ(mean, 1), qo = MMH_SWZ(m2, 1), dl = mo - mean;
-                    m2 = m2 + qo + dl * dl * 4.f; mean = 0.5f * (mean + mo);
-                    mo = MMH_SWZ(mean, 2); qo = MMH_SWZ(m2, 2); dl = mo - mean;
-                    m2 = m2 + qo + dl * dl * 8.f; mean = 0.5f * (mean + mo);
-                    mo = MMH_SWZ(mean, 4); qo = MMH_SWZ(m2, 4); dl = mo - mean;
-                    m2 = m2 + qo + dl * dl * 16.f; mean = 0.5f * (mean + mo);
-                    mo = MMH_SWZ(mean, 8); qo = MMH_SWZ(m2, 8); dl = mo - mean;
-                    m2 = m2 + qo + dl * dl * 32.f; mean = 0.5f * (mean + mo);
-                }
-#undef MMH_SWZ
-                if (l15 == 0) {
-                    sp[j * 16 + r] = 128.f;
-                    sp[p.N + j * 16 + r] = mean;
-                    sp[2 * p.N + j * 16 + r] = m2;
-                }
+                for (int i = 0; i < 8; ++i) q = fmaf(v[i] - mean, v[i] - mean, q);
+                mu[4 * j + r] = mean; m2[4 * j + r] = q;
             }
+        // Four equal-count Chan merges across the 16 pixel lanes as a reduce-scatter: at the step with lane distance s the
+        // lane keeps the half of its channels whose index bit matches its own lane bit and hands the other half to its
+        // partner (ds_swizzle bit mode: and 0x1f, or 0, xor s) - 8 + 4 + 2 + 1 merges instead of 4 x 16, and lane l15 ends
+        // up with channel l15 of the 16.
+#define MMH_SWZ(val, s) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, val), 0x1f | ((s) << 10)))
+#define MMH_RS_STEP(NOUT, S, BIT, W, MI, QI, MO, QO)                                            \
+    _Pragma("unroll") for (int c = 0; c < NOUT; ++c) {                                         \
+        const float km = BIT ? MI[NOUT + c] : MI[c], sm = BIT ? MI[c] : MI[NOUT + c];           \
+        const float kq = BIT ? QI[NOUT + c] : QI[c], sq = BIT ? QI[c] : QI[NOUT + c];           \
+        const float om = MMH_SWZ(sm, S), oq = MMH_SWZ(sq, S), dl = om - km;                     \
+        QO[c] = kq + oq + dl * dl * W; MO[c] = 0.5f * (km + om);                                \
+    }
+        const bool b3 = (l15 & 8) != 0, b2 = (l15 & 4) != 0, b1 = (l15 & 2) != 0, b0 = (l15 & 1) != 0;
+        float ma[8], qa[8], mb[4], qb[4], mc[2], qc[2], md[1], qd[1];
+        MMH_RS_STEP(8, 8, b3, 4.f, mu, m2, ma, qa)
+        MMH_RS_STEP(4, 4, b2, 8.f, ma, qa, mb, qb)
+        MMH_RS_STEP(2, 2, b1, 16.f, mb, qb, mc, qc)
+        MMH_RS_STEP(1, 1, b0, 32.f, mc, qc, md, qd)
+#undef MMH_RS_STEP
+#undef MMH_SWZ
+        const int co = (l15 >> 2) * 16 + (l15 & 3);     // channel 4 j + r = l15 of the lane's 16 -> j * 16 + r of the 64
+        sp[co] = 128.f;
+        sp[p.N + co] = md[0];
+        sp[2 * p.N + co] = qd[0];
     }
 }
 
