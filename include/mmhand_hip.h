@@ -64,9 +64,13 @@ typedef struct mmh_conv_desc {
 
 const char* mmh_last_error(void);
 int mmh_version(void);
-/* Tuning knobs for A/B measurements inside one process (results never change):
- * "conv_dbuf" 0|1 (LDS double buffering of the 128-wide conv tile), "wgrad_slots" n
- * (resident-workgroup count the split-K factor is rounded to).               */
+/* Tuning knobs for A/B measurements inside one process: kernel variants ("lp16_shape" 16 | 17 |
+ * 18 | 19 = the builds of the 16-bit 3x3 kernel, "lp16_wgrad_ring" 0 | 1 | 2, "conv_dbuf",
+ * "wino_gemm_levels", ...) and work-list parameters ("wgrad_slots", "conv_xcd", ...): the results
+ * stay within the kernels' documented tolerances.  Two keys are NOT such knobs: "conv_dbg" and
+ * "lp16_dbg" switch parts of a kernel OFF for timing ablations (tools/ablate*.py,
+ * tools/bench_lp16_fold.py) and make its results wrong; they default to 0 and nothing in
+ * mmhand_amd/ sets them.  Unknown keys are an error.                                     */
 int mmh_set_option(const char* key, int value);
 
 /* ---- convolutions: nn.Conv2d / nn.ReflectionPad2d / nn.ConvTranspose2d ----
