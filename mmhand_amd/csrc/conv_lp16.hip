@@ -1047,6 +1047,12 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
     constexpr int NB = BNT / 64;               // B-operand DMA instructions per wave and k-step
     constexpr int NJ = BNT / 64;               // 16-column MFMA tiles per wave (wave tile 128 x TBN/4)
     constexpr int GSTAGE = (TBM + BNT) * ROWB;
+    // Stages: these convs have short contractions (64 -> 128 stride 2: nine k-steps of 0.2 us of MFMA work each), so a
+    // work-group lives on what it keeps in flight: with two stages ONE k-step's 48 KB travels while the other is
+    // multiplied - 48 KB per L2 round trip, ~19 GB/s per CU, measured 207 us where HBM alone would need 80.  The
+    // 128-column tile (48 KB stages) takes a third stage: two k-steps in flight, counted vmcnt.  (64 columns: two
+    // work-groups per CU already; 256 columns: 64 KB stages, no room.)
+    constexpr int NST = BNT == 128 ? 3 : 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1141,11 +1147,26 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
     const unsigned b_base = (unsigned)(TBM + wc * (BNT / 4) + l15) * ROWB;
 
     if (nk > 0) issue(0, 0);
+    if (NST == 3 && nk > 1) issue(1, 1);
+    int stg = 0;                                    // ks % NST
     for (int ks = 0; ks < nk; ++ks) {
-        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0): the LDS-DMA of the previous iteration
-        __syncthreads();
-        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
-        const char* st = smem + (ks & 1) * GSTAGE;
+        // k-step ks has landed; with three stages the 4 + NB loads of k-step ks + 1 (every wave issues exactly that
+        // many) may stay in flight.  The barrier also frees the stage multiplied in the previous iteration.
+        if (NST == 3 && ks + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0070 | (4 + NB));
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        if (NST == 3) {
+            // the bare barrier: __syncthreads() carries a fence in front of which hipcc drains every pending LDS-DMA
+            // (s_waitcnt vmcnt(0)) - the second k-step in flight would never be.  The waits above order this wave's DMA
+            // and LDS reads (lgkmcnt(0)) against the barrier themselves.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        if (ks + NST - 1 < nk) issue(ks + NST - 1, stg == 0 ? NST - 1 : stg - 1);
+        const char* st = smem + stg * GSTAGE;
+        stg = stg + 1 == NST ? 0 : stg + 1;
 #pragma unroll
         for (int s32 = 0; s32 < 2; ++s32) {
             const unsigned sw = ((unsigned)(4 * s32 + g4) ^ key) << 4;
@@ -1369,7 +1390,7 @@ __global__ void prep_weights_flat8_kernel(const float* __restrict__ w, int taps,
         conv_lp16g_body<H16, TBNV>(p);                                                                          \
     }                                                                                                           \
     int launch_lp16g_##TBNV(const LpGConvKP& p, bool h16, dim3 grid, hipStream_t st) {                          \
-        constexpr int lds = 2 * (TBM + TBNV) * ROWB;                                                            \
+        constexpr int lds = (TBNV == 128 ? 3 : 2) * (TBM + TBNV) * ROWB;                                        \
         static int ready = -1;                                                                                  \
         if (ready != 0) {                                                                                       \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lp16g##TBNV##_kernel<false>), \
