@@ -197,10 +197,11 @@ def _json_only_stdout():
 class StackMeter:
     """HIP-event brackets around every C-ABI call of the 3x3 / stride-1 stack with 256 / 512 channels (SURVEY.md
     §2.3 K4: the PATBlocks' and the Discriminators' residual convs) in 16-bit mode - fprop (mmh_conv3x3_lp16,
-    mmh_conv3x3_lp16_fprop_stats), dgrad (mmh_conv3x3_lp16 mode 2, or mode 1 + the border terms of
+    mmh_conv3x3_lp16_fprop_stats), dgrad (mmh_conv3x3_lp16 / mmh_conv3x3_lp16_dgrad_add mode 2, or mode 1 + the border terms of
     mmh_conv2d_dgrad_border where the fold does not apply) and the wgrad (mmh_wgrad3x3_lp16) - during a few steps.  stack fraction = sum(algorithmic FLOPs 2.B.H.W.Cin.Cout.9 of every
     pass) / sum(bracketed time) / peak: the north_star's ">= 40 % MFMA on the 3x3 generator conv stack" as measured."""
-    NAMES = ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_fprop_stats", "mmh_wgrad3x3_lp16", "mmh_conv2d_dgrad_border")
+    NAMES = ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_fprop_stats", "mmh_conv3x3_lp16_dgrad_add", "mmh_wgrad3x3_lp16",
+             "mmh_conv2d_dgrad_border")
 
     def __init__(self):
         self.rec = []
@@ -225,6 +226,8 @@ class StackMeter:
                 kind = "wgrad"
             elif name.endswith("fprop_stats"):
                 kind = "fprop"
+            elif name.endswith("dgrad_add"):
+                kind = "dgrad"
             else:       # mmh_conv3x3_lp16 mode: 0 fprop, 1 zero-pad dgrad (+ border call), 2 the complete reflect dgrad
                 kind = "fprop" if int(args[1]) == 0 else "dgrad"
             flop = 0.0 if kind == "border" else 2.0 * d.B * d.H * d.W * d.Cin * d.Cout * 9

@@ -193,4 +193,7 @@ def test_bench_bf16_side_run_with_stack_meter(dev):
     for k in ("fprop_256x256", "dgrad_256x256", "wgrad_256x256", "fprop_512x512", "dgrad_512x512", "wgrad_512x512"):
         assert per[k]["launches"] > 0 and per[k]["tflops"] > 0, (k, per)
     assert not any(k.startswith("border") for k in per), per
+    # every 256/512-channel 3x3 conv is counted once per pass whichever entry point ran it (plain, with the statistics
+    # epilogue, with the residual gradient added): fprop launches == dgrad launches == wgrad launches + frozen-D passes
+    assert per["fprop_256x256"]["launches"] == per["dgrad_256x256"]["launches"], per
     assert out["roofline"]["frac"] > 0

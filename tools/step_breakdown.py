@@ -23,7 +23,7 @@ def describe(name, args):
         d = getattr(a, "_obj", None)
         if isinstance(d, L.ConvDesc):
             mode = ""
-            if name == "mmh_conv3x3_lp16":
+            if name in ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_dgrad_add"):
                 mode = " mode%d" % args[1]
             return "B%d %dx%d %d->%d k%d s%d%s" % (d.B, d.H, d.W, d.Cin, d.Cout, d.kh, d.stride, mode)
     ints = [str(a) for a in args if isinstance(a, int) and not isinstance(a, bool) and 0 < a < 10 ** 9]
