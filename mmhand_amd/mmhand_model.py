@@ -79,7 +79,7 @@ class FlatAdam(torch.optim.Optimizer):
         ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
                       g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
                       self.grad_scale, skip_flag, loss_scale)
-        ops.bump_weights_epoch()
+        ops.bump_weights_epoch(within=self.net.flat_param)     # this network's derived weight copies only
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

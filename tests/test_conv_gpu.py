@@ -748,3 +748,27 @@ def test_conv3x3_lp16_dgrad_with_addend(case, lp, dev):
         assert float((dx - want).abs().max()) <= 2e-6 * float(want.abs().max())
     else:
         assert torch.equal(dx, want), float((dx - want).abs().max())
+
+
+def test_weight_copies_are_dropped_per_network(dev):
+    """ops.bump_weights_epoch(within=flat): an optimizer step drops the derived copies (16-bit twins, Winograd filters)
+    of the weights inside ITS network's flat buffer only - the other networks' copies stay valid (the Discriminators'
+    twins made during the Generator step serve their own step) - and a changed weight gets a fresh copy."""
+    from mmhand_amd import ops
+    ops.bump_weights_epoch()
+    flat_a = torch.randn(2 * 9 * 64 * 64, device=dev)
+    flat_b = torch.randn(9 * 64 * 64, device=dev)
+    wa0, wa1 = flat_a[:9 * 64 * 64].view(3, 3, 64, 64), flat_a[9 * 64 * 64:].view(3, 3, 64, 64)
+    wb = flat_b.view(3, 3, 64, 64)
+    ta0, ta1, tb = ops.bf16_weights(wa0, True), ops.bf16_weights(wa1, True), ops.bf16_weights(wb, True)
+    ua = ops.wino_weights(wa0, 6)
+    assert ops.bf16_weights(wa0, True)[0] is ta0[0] and ops.wino_weights(wa0, 6) is ua      # cached
+    flat_a.mul_(2.0)                                    # "optimizer step" on network a
+    ops.bump_weights_epoch(within=flat_a)
+    assert ops.bf16_weights(wb, True)[0] is tb[0]       # network b untouched
+    na0 = ops.bf16_weights(wa0, True)
+    assert na0[0] is not ta0[0] and torch.equal(na0[0].float(), wa0.bfloat16().float())
+    assert ops.bf16_weights(wa1, True)[0] is not ta1[0]
+    assert ops.wino_weights(wa0, 6) is not ua
+    ops.bump_weights_epoch()                            # global: everything goes
+    assert ops.bf16_weights(wb, True)[0] is not tb[0]
