@@ -486,6 +486,8 @@ int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, 
  *         models/MMHandModel.py:238-243): x16 = dy16 [B,H,W,y_cs >= 64], w the stem's fp32 weight [7][7][Cin][64],
  *         y = dx fp32 [B,H,W,x_cs]: channels [0,4) written, the others left alone (as mmh_conv7_thin_dgrad).  With
  *         MMH_PAD_REFLECT the kernel runs over the padded domain into ws and the pad ring is folded back.
+ *         Also 3x3 / pad 1 / zero padding with Cin == 4: VGG19 conv1_1 seen from the perceptual loss
+ *         (losses/L1_plus_perceptualLoss.py:22-27,60-67).
  * ws (mmh_conv7_n4_lp16_ws_bytes): the 16-bit filter twin, built by the call, + the padded-domain gradient.        */
 int mmh_conv7_n4_lp16_supported(const mmh_conv_desc* d, int mode);
 size_t mmh_conv7_n4_lp16_ws_bytes(const mmh_conv_desc* d, int mode);

@@ -3,7 +3,9 @@
 //   mode 0  the Generator head  ReflectionPad2d(3) + Conv2d(64, 3 -> 4, 7) + Tanh   (models/Generator.py:254-259)
 //   mode 1  the gradient of a Discriminator stem  ReflectionPad2d(3) + Conv2d(Cin, 64, 7)  towards the first four
 //           input channels - the generated image inside cat(img, pose) / cat(img, img)
-//           (models/Discriminator.py:60-64 seen from models/MMHandModel.py:238-243)
+//           (models/Discriminator.py:60-64 seen from models/MMHandModel.py:238-243); with KS = 3 the same for VGG19's
+//           conv1_1, Conv2d(3, 64, 3, padding=1): the perceptual loss's gradient towards the generated image
+//           (losses/L1_plus_perceptualLoss.py:22-27,60-67)
 //
 // conv_thin.hip computes these on the vector ALU (a 32-wide MFMA tile wastes 7/8 of the matrix core on 4 columns):
 // ~1.0 ms each at 256x256, B=32 - 50 TFLOP/s on a machine whose 16-bit MFMA sustains 2000.  Here the 16-column MFMA
@@ -32,14 +34,16 @@ typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
 __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>(addr); }
 
 constexpr int TW = 16, TH = 8;                  // output tile
-constexpr int HPW = TW + 6, HPH = TH + 6;       // halo 22 x 14
-constexpr int HROWS = HPW * HPH;                // 308 LDS rows of 128 bytes
-constexpr int HRD = (HROWS + 31) / 32;          // 10 DMA rounds of 32 rows (256 threads x 16 bytes)
-constexpr int WROWS = 49 * 4;                   // filter rows [tap][channel]
-constexpr int WRD = (WROWS + 31) / 32;          // 7
-constexpr int HALO_B = HRD * 32 * 128;          // 40960 (the rounds' footprint)
-constexpr int W_B = WRD * 32 * 128;             // 28672
-constexpr int LDS_B = HALO_B + W_B;             // 69632
+template <int KS> struct Geo {                  // KS x KS taps (7: head / stems; 3: VGG conv1_1's image gradient)
+    static constexpr int HPW = TW + KS - 1, HPH = TH + KS - 1;     // halo 22 x 14 | 18 x 10
+    static constexpr int HROWS = HPW * HPH;                        // LDS rows of 128 bytes
+    static constexpr int HRD = (HROWS + 31) / 32;                  // DMA rounds of 32 rows (256 threads x 16 bytes)
+    static constexpr int WROWS = KS * KS * 4;                      // filter rows [tap][channel]
+    static constexpr int WRD = (WROWS + 31) / 32;
+    static constexpr int HALO_B = HRD * 32 * 128;                  // the rounds' footprint: 40960 | 24576
+    static constexpr int W_B = WRD * 32 * 128;                     // 28672 | 8192
+    static constexpr int LDS_B = HALO_B + W_B;                     // 69632 | 32768
+};
 
 struct C7KP {
     const char* x;          // 16-bit [B][SH][SW][cs], channels 0..63
@@ -60,8 +64,10 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool H16>
+template <bool H16, int KS>
 __global__ void __launch_bounds__(256, 2) conv7_n4_kernel(const C7KP p) {
+    typedef Geo<KS> G_;
+    constexpr int HPW = G_::HPW, HROWS = G_::HROWS, HRD = G_::HRD, WROWS = G_::WROWS, WRD = G_::WRD, HALO_B = G_::HALO_B;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,9 +113,9 @@ __global__ void __launch_bounds__(256, 2) conv7_n4_kernel(const C7KP p) {
 
     const unsigned lds0 = mmh::lds_addr_of(smem);
     // lane constants: the pixel fragment of tap column kw, k-half h, at this wave's first output row; the filter fragment
-    unsigned aB[7][2], wB[2];
+    unsigned aB[KS][2], wB[2];
 #pragma unroll
-    for (int kw = 0; kw < 7; ++kw)
+    for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned hx = (unsigned)(kw + l15);
@@ -123,12 +129,12 @@ __global__ void __launch_bounds__(256, 2) conv7_n4_kernel(const C7KP p) {
     __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0): this wave's DMA has landed
     __syncthreads();
 #pragma unroll
-    for (int kh = 0; kh < 7; ++kh)
+    for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 7; ++kw)
+        for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const bf16x8 wf = lds_frag(wB[h] + (unsigned)((kh * 7 + kw) * 512));
+                const bf16x8 wf = lds_frag(wB[h] + (unsigned)((kh * KS + kw) * 512));
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const bf16x8 af = lds_frag(aB[kw][h] + (unsigned)((i + kh) * HPW * 128));
@@ -159,13 +165,14 @@ __global__ void __launch_bounds__(256, 2) conv7_n4_kernel(const C7KP p) {
 
 // the 16-bit filter [49][4][64]: mode 0 from the head's w [7][7][64][Cout] (channels n < min(4, Cout)), mode 1 the
 // flipped filter of the stem's w [7][7][Cin][64] restricted to input channels n < 4
-__global__ void prep_w7n4_kernel(const float* __restrict__ w, int Cin, int Cout, int mode, int h16, unsigned short* __restrict__ out) {
+__global__ void prep_w7n4_kernel(const float* __restrict__ w, int taps, int Cin, int Cout, int mode, int h16,
+                                 unsigned short* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 49 * 4 * 64) return;
+    if (i >= taps * 4 * 64) return;
     const int c = i & 63, n = (i >> 6) & 3, t = i >> 8;
     float v;
     if (mode == 0) v = n < Cout ? w[((size_t)t * Cin + c) * Cout + n] : 0.f;
-    else v = n < Cin ? w[((size_t)(48 - t) * Cin + n) * Cout + c] : 0.f;
+    else v = n < Cin ? w[((size_t)(taps - 1 - t) * Cin + n) * Cout + c] : 0.f;
     if (h16) out[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
     else out[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
 }
@@ -194,7 +201,10 @@ __global__ void fold7_kernel(const float* __restrict__ dxp, float* __restrict__ 
 
 
 bool supported(const mmh_conv_desc* d, int mode) {
-    if (!d || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (!d || d->kh != d->kw || (d->kh != 7 && d->kh != 3) || d->stride != 1 || d->pad != d->kh / 2 || d->Ho != d->H ||
+        d->Wo != d->W)
+        return false;
+    if (d->kh == 3 && (mode != 1 || d->pad_mode != MMH_PAD_ZERO)) return false;     // 3x3: VGG conv1_1's image gradient only
     if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
     if (d->H < 8 || d->W < 8) return false;             // single mirror per side; the fold's index lists
     if (mode == 0) return d->Cin == 64 && d->Cout >= 1 && d->Cout <= 4 && d->x_cs >= 64 && d->x_cs % 8 == 0 && d->y_cs % 4 == 0;
@@ -216,7 +226,8 @@ size_t mmh_conv7_n4_lp16_ws_bytes(const mmh_conv_desc* d, int mode) {
 int mmh_conv7_n4_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w, const void* bias, void* y,
                       int act, void* ws, size_t ws_bytes, const void* zeros, mmh_stream_t s) {
     MMH_REQUIRE(supported(d, mode) && x16 && w && y && ws && zeros,
-                "mmh_conv7_n4_lp16: 7x7 / stride 1 / pad 3, 16-bit dtype; mode 0: Cin == 64, Cout <= 4; mode 1: Cout == 64");
+                "mmh_conv7_n4_lp16: 7x7 / stride 1 / pad 3 (mode 1 also 3x3 / pad 1, zero padding), 16-bit dtype; mode 0: "
+                "Cin == 64, Cout <= 4; mode 1: Cout == 64");
     MMH_REQUIRE(ws_bytes >= mmh_conv7_n4_lp16_ws_bytes(d, mode), "mmh_conv7_n4_lp16: workspace too small");
     MMH_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                 "mmh_conv7_n4_lp16: y and ws must be 16-byte aligned");
@@ -225,8 +236,9 @@ int mmh_conv7_n4_lp16(const mmh_conv_desc* d, int mode, const void* x16, const v
     const bool refl = d->pad_mode == MMH_PAD_REFLECT;
     char* w16 = static_cast<char*>(ws);
     float* dxp = reinterpret_cast<float*>(w16 + 25600);
-    hipLaunchKernelGGL(prep_w7n4_kernel, dim3((49 * 4 * 64 + 255) / 256), dim3(256), 0, st, static_cast<const float*>(w),
-                       d->Cin, d->Cout, mode, h16 ? 1 : 0, reinterpret_cast<unsigned short*>(w16));
+    const int taps = d->kh * d->kw;
+    hipLaunchKernelGGL(prep_w7n4_kernel, dim3((taps * 4 * 64 + 255) / 256), dim3(256), 0, st, static_cast<const float*>(w),
+                       taps, d->Cin, d->Cout, mode, h16 ? 1 : 0, reinterpret_cast<unsigned short*>(w16));
     C7KP p{};
     p.x = static_cast<const char*>(x16);
     p.w = w16;
@@ -235,30 +247,35 @@ int mmh_conv7_n4_lp16(const mmh_conv_desc* d, int mode, const void* x16, const v
     if (mode == 0) {
         p.bias = static_cast<const float*>(bias);
         p.y = static_cast<float*>(y);
-        p.cs = d->x_cs; p.OH = d->H; p.OW = d->W; p.ycs = d->y_cs; p.pad = 3; p.reflect = refl ? 1 : 0; p.act = act;
+        p.cs = d->x_cs; p.OH = d->H; p.OW = d->W; p.ycs = d->y_cs; p.pad = d->pad; p.reflect = refl ? 1 : 0; p.act = act;
     } else if (refl) {          // padded domain: dxp[pp] = sum_k wflip[k] dy[pp + k - 6], zero outside
         p.y = dxp;
         p.cs = d->y_cs; p.OH = d->H + 6; p.OW = d->W + 6; p.ycs = 4; p.pad = 6; p.reflect = 0; p.act = MMH_ACT_NONE;
     } else {
         p.y = static_cast<float*>(y);
-        p.cs = d->y_cs; p.OH = d->H; p.OW = d->W; p.ycs = d->x_cs; p.pad = 3; p.reflect = 0; p.act = MMH_ACT_NONE;
+        p.cs = d->y_cs; p.OH = d->H; p.OW = d->W; p.ycs = d->x_cs; p.pad = d->pad; p.reflect = 0; p.act = MMH_ACT_NONE;
     }
     MMH_REQUIRE((long long)p.B * p.SH * p.SW * p.cs < (1ll << 31) && (long long)p.B * p.OH * p.OW * p.ycs < (1ll << 31),
                 "mmh_conv7_n4_lp16: tensor too large");
     p.TX = (p.OW + TW - 1) / TW; p.TY = (p.OH + TH - 1) / TH; p.tiles = p.B * p.TX * p.TY;
     static int ready = -1;
     if (ready != 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_n4_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_n4_kernel<false, 7>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Geo<7>::LDS_B);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_n4_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv7_n4_kernel<true, 7>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Geo<7>::LDS_B);
         ready = e == hipSuccess ? 0 : mmh::fail("conv7_n4_kernel: %s", hipGetErrorString(e));
     }
     if (ready != 0) return ready;
     const dim3 grid(8 * ((p.tiles + 7) / 8));
-    if (h16) hipLaunchKernelGGL(conv7_n4_kernel<true>, grid, dim3(256), LDS_B, st, p);
-    else hipLaunchKernelGGL(conv7_n4_kernel<false>, grid, dim3(256), LDS_B, st, p);
+    if (d->kh == 3) {
+        if (h16) hipLaunchKernelGGL((conv7_n4_kernel<true, 3>), grid, dim3(256), Geo<3>::LDS_B, st, p);
+        else hipLaunchKernelGGL((conv7_n4_kernel<false, 3>), grid, dim3(256), Geo<3>::LDS_B, st, p);
+    } else {
+        if (h16) hipLaunchKernelGGL((conv7_n4_kernel<true, 7>), grid, dim3(256), Geo<7>::LDS_B, st, p);
+        else hipLaunchKernelGGL((conv7_n4_kernel<false, 7>), grid, dim3(256), Geo<7>::LDS_B, st, p);
+    }
     if (mode == 1 && refl) {
         const int64_t n = (int64_t)d->B * d->H * d->W;
         hipLaunchKernelGGL(fold7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxp, static_cast<float*>(y),

@@ -519,7 +519,7 @@ def raw_conv7_n4(d, mode, x16, w, bias, y, act, lp):
     L.call("mmh_conv7_n4_lp16", C.byref(d), mode, _ptr(x16), _ptr(w), _ptr(bias), _ptr(y), act, _ptr(ws), ws.numel() * 4,
            _ptr(zero_page(x16.device)), _stream())
     d.dtype = keep
-    _count("mfma", 2.0 * d.B * d.H * d.W * 49 * 64 * 16)       # executed: 16 columns, 4 of them meaningful
+    _count("mfma", 2.0 * d.B * d.H * d.W * d.kh * d.kw * 64 * 16)      # executed: 16 columns, 4 of them meaningful
     return y
 
 
@@ -579,6 +579,11 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     if wt:
         return raw_conv_dgrad_wino(dy, w, x_shape, reflect, wt, bf16=bf16)
     d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if bf16 and k == 3 and Cin == 4 and not out16 and conv7_n4_ok(d, 1, bf16):
+        # VGG19 conv1_1 (3 -> 64, zero padding) seen from the perceptual loss: four gradient columns - the 16-column MFMA
+        # kernel of the 7x7 stems with nine taps (the generic kernel ran this at 7 TFLOP/s)
+        dx = torch.empty((B, H, W_, Cin), dtype=torch.float32, device=w.device)
+        return raw_conv7_n4(d, 1, dy16 if dy16 is not None else lp16_twin(dy, bf16), w, None, dx, L.ACT_NONE, bf16)
     if bf16 and lp16_v2_ok(Cin, Cout, k, stride, pad, 1):
         # main term (zero-padded correlation with the flipped filter) on the v2 kernel; reflect padding
         # adds the eight border terms (small 16-bit GEMMs + border_add) exactly as the other paths do

@@ -772,3 +772,29 @@ def test_weight_copies_are_dropped_per_network(dev):
     assert ops.wino_weights(wa0, 6) is not ua
     ops.bump_weights_epoch()                            # global: everything goes
     assert ops.bf16_weights(wb, True)[0] is not tb[0]
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16), (1, 20, 70), (2, 37, 66), (1, 8, 8), (1, 64, 64)])
+def test_conv7_n4_vgg_conv1_dgrad(case, lp, dev):
+    """The perceptual loss's gradient towards the generated image through VGG19 conv1_1 (Conv2d(3 -> 4, 64, 3, padding=1),
+    losses/L1_plus_perceptualLoss.py:22-27): mmh_conv7_n4_lp16 mode 1 with nine taps and zero padding, through
+    ops.raw_conv_dgrad as the model calls it, against the fp64 oracle on operands rounded to the storage type."""
+    from mmhand_amd import lib, ops
+    B, H, W = case
+    w = _mk((3, 3, 4, 64), 2, dev) * 0.1
+    dy = _mk((B, H, W, 64), 4, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dx = ops.raw_conv_dgrad(dy, w, (B, H, W, 4), 1, 1, False, bf16=lp)
+    finally:
+        lib.call = orig
+    assert calls.get("mmh_conv7_n4_lp16") == 1 and "mmh_conv2d_dgrad_folded" not in calls, calls
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, 4), rb(w), None, rb(dy), 1, 1, False)
+    assert R.rel_l1(dx, dxr) < 5e-6, R.rel_l1(dx, dxr)
