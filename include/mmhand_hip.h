@@ -406,6 +406,12 @@ int mmh_wino_input_dy_normbwd(const void* g, const void* x, int B, int H, int W,
 /* dx = g * act'(y): relu -> (y>0), tanh -> 1-y^2 (Generator.py:259 head).   */
 int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
                 mmh_stream_t s);
+/* the same product written in 16 bits only (dtype MMH_BF16 | MMH_FP16; n % 8 == 0): the activation
+ * backward of a conv whose dgrad is a 16-bit kernel and whose weights are frozen (VGG19 conv1_1 /
+ * conv1_2 + ReLU, losses/L1_plus_perceptualLoss.py:22-27) - one pass instead of mmh_act_bwd +
+ * mmh_cvt_lp16.                                                                               */
+int mmh_act_bwd_lp16(const void* g, const void* y, int64_t n, int act, int dtype, void* out16,
+                     mmh_stream_t s);
 
 /* ---- PATBlock gate + concat (models/Generator.py:115-130) -----------------
  * out = x1 + s1*sigmoid(s2)*sigmoid(s3);  x2n = cat(s3,out); x3n = cat(s2,out)

@@ -937,6 +937,24 @@ __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restr
     }
 }
 
+// dx16 = 16-bit(g * act'(y)): the activation backward of a conv epilogue fused with the conversion its 16-bit dgrad
+// needs (VGG conv1_1 / conv1_2 + ReLU under the perceptual loss: frozen weights, so nobody else reads the fp32 product)
+__global__ void act_bwd_lp16_kernel(const float* __restrict__ g, const float* __restrict__ y, void* __restrict__ out,
+                                    int64_t n8, int act, int h16) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        const float4 g0 = ld4(g, 2 * i), g1 = ld4(g, 2 * i + 1), y0 = ld4(y, 2 * i), y1 = ld4(y, 2 * i + 1);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        f8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            r.v[e] = act == MMH_ACT_RELU ? (yv[e] > 0.f ? gv[e] : 0.f) : gv[e] * (1.f - yv[e] * yv[e]);
+        st8<true>(out, i, r, h16 != 0);
+    }
+}
+
 // ------------------------------------------------------------------ PATBlock gate
 __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ s1,
                                 const void* __restrict__ s2, const void* __restrict__ s3,
@@ -1750,6 +1768,16 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act, mmh_
                        static_cast<const float*>(g), static_cast<const float*>(y),
                        static_cast<float*>(dx), n / 4, act);
     return mmh::check_launch("act_bwd");
+}
+
+int mmh_act_bwd_lp16(const void* g, const void* y, int64_t n, int act, int dtype, void* out16, mmh_stream_t s) {
+    MMH_REQUIRE(g && y && out16 && n > 0 && n % 8 == 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_act_bwd_lp16: bad arguments (n %% 8 == 0, dtype MMH_BF16 | MMH_FP16)");
+    MMH_REQUIRE(act == MMH_ACT_RELU || act == MMH_ACT_TANH, "mmh_act_bwd_lp16: act must be relu or tanh");
+    hipLaunchKernelGGL(act_bwd_lp16_kernel, dim3(grid_for(n / 8)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const float*>(g), static_cast<const float*>(y), out16, n / 8, act,
+                       dtype == MMH_FP16 ? 1 : 0);
+    return mmh::check_launch("act_bwd_lp16");
 }
 
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2, const void* s3, void* out,

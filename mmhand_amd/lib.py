@@ -114,6 +114,7 @@ SIGNATURES = {
     "mmh_wino_input_dy_normbwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp,
                                        _vp, _i, _i, _f, _vp]),
     "mmh_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "mmh_act_bwd_lp16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_reduce_ws_bytes": (_sz, [_i64]),

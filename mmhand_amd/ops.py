@@ -540,6 +540,15 @@ def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     return dx
 
 
+def _dgrad_takes_dy16(B, H, W_, Cin, Cout, k, stride, pad, reflect, bf16):
+    """raw_conv_dgrad reads only the 16-bit dy for this conv (halo / general 16-bit kernels, the four-column kernel)"""
+    if not bf16 or _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, "dgrad"):
+        return False
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    return bool(lp16_v2_ok(Cin, Cout, k, stride, pad, 1) or (not reflect and lp16g_ok(d, 1, bf16))
+                or (k == 3 and Cin == 4 and conv7_n4_ok(d, 1, bf16)))
+
+
 def _add_into(dx, addend):
     if addend is None:
         return dx
@@ -566,9 +575,8 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
     _chk(w, "w")
     B, H, W_, Cin = x_shape
     if dy is None or out16:
-        assert bf16 and (dy16 is not None or dy is not None) and (
-            lp16_v2_ok(Cin, w.shape[3], w.shape[0], stride, pad, 1)
-            or (not reflect and lp16g_ok(conv_desc(B, H, W_, Cin, w.shape[3], w.shape[0], stride, pad, reflect), 1, bf16)))
+        assert bf16 and (dy16 is not None or dy is not None) and _dgrad_takes_dy16(B, H, W_, Cin, w.shape[3], w.shape[0],
+                                                                                  stride, pad, reflect, bf16)
     if dy is not None:
         _chk(dy, "dy")
     k, _, _, Cout = w.shape
@@ -1171,6 +1179,14 @@ def raw_colsum(x2d_rows, Ccols, x, out=None):
     return out
 
 
+def raw_act_bwd_lp16(g, y, act, lp):
+    """16-bit(g * act'(y)) in one pass (mmh_act_bwd_lp16)"""
+    _chk(g, "g"); _chk(y, "y")
+    out = torch.empty(g.shape, dtype=_wd(lp), device=g.device)
+    L.call("mmh_act_bwd_lp16", _ptr(g), _ptr(y), g.numel(), act, _dt(lp), _ptr(out), _stream())
+    return out
+
+
 def raw_act_bwd(g, y, act):
     g = g.contiguous()
     dx = torch.empty_like(g)
@@ -1292,7 +1308,7 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
         if g is None:
-            return (None,) * 14
+            return (None,) * 15
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
         bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
         want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
@@ -1300,6 +1316,14 @@ class Conv2dFn(torch.autograd.Function):
             # exact zero.  Returned as a tensor unless gradients are accumulated in place (then there is
             # nothing to add): under data parallelism the bucket hooks count one AccumulateGrad per parameter
             db = torch.zeros_like(ctx.bias_p)
+        if (act != L.ACT_NONE and bf16 and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1] and not want_db
+                and not ctx.g_defer and not ctx.y_lp and not ctx.x_lp and not ctx.dx_channels
+                and _dgrad_takes_dy16(*ctx.x_shape, w.shape[3], w.shape[0], stride, pad, reflect, bf16)):
+            # frozen weights behind an activation epilogue (VGG19 conv1_1 / conv1_2 + ReLU under the perceptual loss):
+            # nothing but the 16-bit dgrad reads g * act'(y) - one pass writes it in 16 bits
+            g16 = raw_act_bwd_lp16(g.contiguous(), y, act, bf16)
+            dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, 0, dy16=g16)
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.stem16:      # x is the stem's padded 16-bit input [B,H,W,C8] saved by the forward pass
             g16 = lp_grad_in(g, "Conv2dFn (stem)")
             if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)

@@ -284,3 +284,18 @@ def test_decode_inputs_bit_exact(dev):
         assert np.array_equal(got[..., :42] > 0, ref > 0)
         assert np.abs(got[..., :42].view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max() <= 1
         assert float(np.abs(got[..., 42:]).sum()) == 0
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("act", [1, 2], ids=["relu", "tanh"])
+def test_act_bwd_lp16(act, lp, dev):
+    """mmh_act_bwd_lp16 == mmh_act_bwd followed by mmh_cvt_lp16, bit for bit (the activation backward of VGG19's
+    conv + ReLU epilogues fused with the conversion their 16-bit dgrad needs)."""
+    from mmhand_amd import ops
+    g = torch.randn(3, 9, 11, 64, device=dev)
+    y = torch.randn(3, 9, 11, 64, device=dev)
+    if act == 2:
+        y = torch.tanh(y)
+    want = ops.lp16_twin(ops.raw_act_bwd(g, y, act), lp)
+    got = ops.raw_act_bwd_lp16(g, y, act, lp)
+    assert got.dtype == want.dtype and torch.equal(got, want)
