@@ -820,7 +820,8 @@ _flat8_cache = {}
 
 
 def lp16_flat_ok(d, bf16):
-    if not (bf16 and USE_LP16_V2 and USE_LP16_FLAT) or d.Cin > 64 or d.kh < 5:
+    # 7x7 / 5x5 stems, and 3x3 with <= 8 input channels (VGG19 conv1_1: nine taps x 8 padded channels = 72 -> 128 deep)
+    if not (bf16 and USE_LP16_V2 and USE_LP16_FLAT) or d.Cin > 64 or (d.kh < 5 and not (d.kh == 3 and d.Cin <= 8)):
         return False
     old = d.dtype
     d.dtype = _dt(bf16)
