@@ -798,3 +798,52 @@ def test_conv7_n4_vgg_conv1_dgrad(case, lp, dev):
     assert calls.get("mmh_conv7_n4_lp16") == 1 and "mmh_conv2d_dgrad_folded" not in calls, calls
     _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, 4), rb(w), None, rb(dy), 1, 1, False)
     assert R.rel_l1(dx, dxr) < 5e-6, R.rel_l1(dx, dxr)
+
+
+def test_round3_kernels_random_shapes(dev):
+    """A seeded sweep of shapes nobody picked by hand for the round-3 kernels: the reflect fold (mode 2), the dgrad with an
+    addend, the fprop statistics epilogue and the four-column 7x7 / 3x3 kernels, each against the fp64 oracle (or the
+    path it replaces) on operands rounded to bf16."""
+    import random as _r
+    from mmhand_amd import ops
+    rng = _r.Random(20260310)
+    rb = lambda t: t.cpu().bfloat16().float()       # noqa: E731
+    for it in range(6):
+        B = rng.randint(1, 3)
+        H, W = 16 * rng.randint(1, 4), 16 * rng.randint(1, 4)
+        Cin, Cout = rng.choice([256, 512]), rng.choice([64, 128, 256])
+        w = _mk((3, 3, Cin, Cout), 100 + it, dev) * 0.1
+        dy = _mk((B, H, W, Cout), 200 + it, dev)
+        addend = _mk((B, H, W, Cin), 300 + it, dev)
+        ops.bump_weights_epoch()
+        dy16 = ops.lp16_twin(dy, True)
+        dx = ops.raw_conv_dgrad(None, w, (B, H, W, Cin), 1, 1, True, bf16=True, dy16=dy16, addend=addend)
+        _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), rb(w), None, rb(dy), 1, 1, True)
+        assert R.rel_l1(dx, dxr + addend.cpu()) < 5e-6, ("fold + addend", B, H, W, Cin, Cout)
+        if Cout % 256 == 0:
+            x16 = ops.lp16_twin(_mk((B, H, W, Cin), 400 + it, dev), True)
+            bias = _mk((Cout,), 500 + it, dev)
+            y = ops.raw_conv3x3_lp16(x16, w, bias, True, 0, True, 0, out16=True, want_stats=True)
+            mean, m2, rows = ops.raw_norm_stats(y, B)
+            yd = y.double().cpu().reshape(B, H * W, Cout)
+            assert float((mean.double().cpu() - yd.mean(1)).abs().max()) < 2e-6 * float(yd.abs().max())
+            m2r = ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
+            assert float(((m2.double().cpu() - m2r).abs() / m2r).max()) < 2e-5
+    for it in range(6):
+        B, H, W = rng.randint(1, 2), rng.randint(8, 70), rng.randint(8, 70)
+        refl = rng.random() < 0.7
+        x = _mk((B, H, W, 64), 600 + it, dev)
+        wh = _mk((7, 7, 64, 4), 700 + it, dev) * 0.05
+        bias = _mk((4,), 800 + it, dev)
+        y = ops.raw_conv_fprop(x, wh, bias, 1, 3, refl, 2, bf16=True)
+        assert R.rel_l1(y, R.conv2d(rb(x), rb(wh), bias.cpu(), 1, 3, refl, 2)) < 5e-6, ("head", B, H, W, refl)
+        Cin = rng.choice([4, 8, 24])
+        ws = _mk((7, 7, Cin, 64), 900 + it, dev) * 0.05
+        dy = _mk((B, H, W, 64), 1000 + it, dev)
+        dxs = ops.raw_conv_dgrad_thin(ops.lp16_twin(dy, True), ws, (B, H, W, Cin), refl)
+        _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, Cin), rb(ws), None, rb(dy), 1, 3, refl)
+        assert R.rel_l1(dxs[..., :4], dxr[..., :4]) < 5e-6, ("stem image gradient", B, H, W, Cin, refl)
+        w3 = _mk((3, 3, 4, 64), 1100 + it, dev) * 0.1
+        dx3 = ops.raw_conv_dgrad(dy, w3, (B, H, W, 4), 1, 1, False, bf16=True)
+        _, dx3r, _, _ = R.conv2d_grads(torch.zeros(B, H, W, 4), rb(w3), None, rb(dy), 1, 1, False)
+        assert R.rel_l1(dx3, dx3r) < 5e-6, ("vgg conv1_1 image gradient", B, H, W)
