@@ -311,6 +311,14 @@ int mmh_norm_stats(const void* x, int groups, int64_t rows_per_group, int C,
 int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, void* mean,
                          void* m2, mmh_stream_t s);
 
+/* The same merge for ONE group over many chunks in two levels (BatchNorm statistics from conv-epilogue
+ * partials, models/network_utils.py:74-84 with --norm batch: B * chunks-per-image partials per channel):
+ * `sub` blocks of chunks (chunks % sub == 0) are merged in parallel into [sub][3][C] floats in ws, which
+ * a single-group merge finishes.                                                                      */
+size_t mmh_norm_stats_merge2_ws_bytes(int sub, int C);
+int mmh_norm_stats_merge2(const void* partials, int chunks, int C, int sub, void* ws,
+                          size_t ws_bytes, void* mean, void* m2, mmh_stream_t s);
+
 /* mmh_norm_stats_merge + mmh_norm_finalize of a norm without affine parameters and running statistics
  * (nn.InstanceNorm2d) in one launch: the same fp32 mean / M2 / scale / shift / invstd as the two calls.   */
 int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, int C, double count,

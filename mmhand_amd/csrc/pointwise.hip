@@ -130,10 +130,13 @@ __global__ void norm_stats_partial(const void* __restrict__ x, int xlp, int64_t 
 
 // scale != NULL: also the finalize step of a norm without affine parameters (InstanceNorm) - scale = invstd,
 // shift = -mean * invstd, exactly as norm_finalize_kernel computes them from the fp32 mean / M2 written here
+// cnt != NULL (first level of a two-level merge): the merged count goes to cnt and the three outputs of group g are
+// written at g * ostride + c - with cnt, mean, m2 one C apart and ostride = 3 C that is a coarser partial array.
 __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C, int chunks,
                                  float* __restrict__ mean, float* __restrict__ m2, double count = 0.0,
                                  float eps = 0.f, float* __restrict__ scale = nullptr,
-                                 float* __restrict__ shift = nullptr, float* __restrict__ invstd = nullptr) {
+                                 float* __restrict__ shift = nullptr, float* __restrict__ invstd = nullptr,
+                                 float* __restrict__ cnt = nullptr, int ostride = 0) {
     // 32 channels x 8 chunk-lanes per block: each lane merges its chunks (Chan), then the 8
     // lanes are merged in a fixed order.
     __shared__ double sh[3][8][32];
@@ -193,8 +196,10 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
             }
         }
         const float meanf = (float)ma, m2f = (float)qa;
-        mean[i] = meanf;
-        m2[i] = m2f;
+        const int64_t oi = ostride ? (int64_t)grp * ostride + c : i;
+        mean[oi] = meanf;
+        m2[oi] = m2f;
+        if (cnt) cnt[oi] = (float)na;
         if (scale) {
             const float var = (float)((double)m2f / count);
             const float is = 1.f / sqrtf(var + eps);
@@ -1494,6 +1499,25 @@ int mmh_norm_stats_merge(const void* partials, int groups, int chunks, int C, vo
                        static_cast<const float*>(partials), groups, C, chunks, static_cast<float*>(mean),
                        static_cast<float*>(m2));
     return mmh::check_launch("norm_stats_merge");
+}
+
+// Two-level merge for ONE group over many chunks (BatchNorm statistics from conv-epilogue partials: 1024 chunks per
+// channel after a 16-bit 3x3 conv, 3872 after a Winograd one): `sub` blocks of chunks are merged in parallel into a coarser
+// partial array in ws ([sub][3][C] floats), which the single-group merge then finishes.  chunks % sub == 0.
+size_t mmh_norm_stats_merge2_ws_bytes(int sub, int C) { return sub > 0 && C > 0 ? (size_t)sub * 3 * C * sizeof(float) : 0; }
+
+int mmh_norm_stats_merge2(const void* partials, int chunks, int C, int sub, void* ws, size_t ws_bytes, void* mean,
+                          void* m2, mmh_stream_t s) {
+    MMH_REQUIRE(partials && mean && m2 && ws && chunks > 0 && C > 0 && sub > 0 && chunks % sub == 0,
+                "mmh_norm_stats_merge2: bad arguments (chunks %% sub == 0)");
+    MMH_REQUIRE(ws_bytes >= mmh_norm_stats_merge2_ws_bytes(sub, C), "mmh_norm_stats_merge2: workspace too small");
+    float* t = static_cast<float*>(ws);
+    hipStream_t st = mmh::as_stream(s);
+    hipLaunchKernelGGL(norm_stats_final, dim3((sub * C + 31) / 32), dim3(TPB), 0, st, static_cast<const float*>(partials),
+                       sub, C, chunks / sub, t + C, t + 2 * C, 0.0, 0.f, nullptr, nullptr, nullptr, t, 3 * C);
+    hipLaunchKernelGGL(norm_stats_final, dim3((C + 31) / 32), dim3(TPB), 0, st, static_cast<const float*>(t), 1, C, sub,
+                       static_cast<float*>(mean), static_cast<float*>(m2));
+    return mmh::check_launch("norm_stats_merge2");
 }
 
 int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, int C, double count, float eps,

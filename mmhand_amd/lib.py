@@ -50,6 +50,8 @@ SIGNATURES = {
     "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mmh_norm_stats_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mmh_norm_stats_merge2_ws_bytes": (_sz, [_i, _i]),
+    "mmh_norm_stats_merge2": (_i, [_vp, _i, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "mmh_norm_stats_merge_finalize": (_i, [_vp, _i, _i, _i, _d, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_wino_wgrad_gemm_ws_bytes": (_sz, [_i64, _i, _i, _i]),
     "mmh_wino_wgrad_gemm": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),

@@ -271,7 +271,9 @@ class _Net(nn.Module):
                                       False, bool(to_norm and self.norm == "instance" and self.training), x16, g_defer)
         # to_norm: the output goes straight into this net's norm layer; under InstanceNorm the conv bias then
         # has an identically zero gradient (ops.EXACT_NULL_BIAS_GRAD)
-        nb = bool(to_norm and self.norm == "instance" and self.training)
+        # ... and the conv's epilogue leaves partial statistics of its output for that norm (ops.FUSE_NORM_STATS); a
+        # bias-free conv in front of a BatchNorm gets them too (its statistics are merged over the whole batch)
+        nb = bool(to_norm and self.training and (self.norm == "instance" or cp.bias is None))
         if x16 is not None:
             res_tok = None      # tokens belong to fp32 block inputs (ops.ResidualToken)
         if y_lp:

@@ -92,6 +92,7 @@ def bump_weights_epoch(within=None):
     within (a tensor, e.g. one network's flat parameter buffer): only the copies of weights that live inside it are
     dropped - an optimizer step changes one network, and the Discriminators' copies made during the Generator step
     serve their own step too (96 -> 78 weight conversions per 16-bit iteration)."""
+    _pending_stats.clear()
     if within is not None:
         lo = within.data_ptr()
         hi = lo + within.numel() * within.element_size()
@@ -270,6 +271,17 @@ FUSE_NORM_STATS = os.environ.get("MMH_FUSE_NORM_STATS", "1") != "0"
 _pending_stats = {}
 
 
+def _park_stats(y, stats):
+    """Partial statistics of a conv output y, left for the norm that reads y next (raw_norm_stats[_finalize_pending]).
+    A conv asks for them only when its output goes straight into a norm (to_norm), so an entry lives until that norm
+    takes it - the three generator streams run conv, conv, conv, norm, norm, norm under SyncBN packing - and every
+    optimizer step / epoch bump empties the table, so no entry outlives its iteration.  The key is the output's address
+    and shape; the table is kept tiny (a conv whose norm never came would otherwise leave an entry behind)."""
+    if len(_pending_stats) >= 8:
+        _pending_stats.clear()
+    _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+
+
 def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False,
                fold=False, pro=None):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
@@ -312,8 +324,7 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
     if timed:
         o1.record()
     if stats is not None:
-        _pending_stats.clear()              # only the most recent conv output can be the norm's input
-        _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+        _park_stats(y, stats)
     return (y, V) if keep_V else y
 
 
@@ -481,8 +492,7 @@ def raw_conv_fprop(x, w, bias, stride, pad, reflect, act=L.ACT_NONE, bf16=False,
         if chunks > 0:
             stats = _empty((B, chunks // B, 3, Cout), x)
             L.call("mmh_conv2d_fprop_stats", C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(stats), _stream())
-            _pending_stats.clear()
-            _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+            _park_stats(y, stats)
             return y
     if fprop_timer is not None and fprop_timer.want(d):
         e0, e1 = fprop_timer.bracket()      # HIP events on the launch stream (bench.py roofline)
@@ -772,8 +782,7 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_s
         stats = torch.empty((B, chunks, 3, N), dtype=torch.float32, device=x16.device)
         L.call("mmh_conv3x3_lp16_fprop_stats", C.byref(d), _ptr(x16), _ptr(wt), _ptr(bias), _ptr(y), _ptr(stats),
                _ptr(zero_page(x16.device)), _stream())
-        _pending_stats.clear()
-        _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+        _park_stats(y, stats)
     elif addend is not None:        # dgrad: dx = dgrad(dy) + addend in the epilogue
         assert mode != 0 and not out16 and bias is None and act == L.ACT_NONE and tuple(addend.shape) == tuple(y.shape)
         L.call("mmh_conv3x3_lp16_dgrad_add", C.byref(d), mode, _ptr(x16), _ptr(wp), _ptr(addend), _ptr(y),
@@ -1480,12 +1489,18 @@ def raw_norm_stats(x, groups):
     B, H, W_, Cc = x.shape
     rows = (B // groups) * H * W_
     pend = _pending_stats.pop(x.data_ptr(), None)
-    _pending_stats.clear()      # an entry is only ever valid for the norm call right after its conv
-    if pend is not None and groups == B and pend[1] == tuple(x.shape):
-        stats = pend[0]
-        mean = _empty((groups, Cc), x)
-        m2 = _empty((groups, Cc), x)
-        L.call("mmh_norm_stats_merge", _ptr(stats), groups, stats.shape[1], Cc, _ptr(mean), _ptr(m2), _stream())
+    if pend is not None and groups in (B, 1) and pend[1] == tuple(x.shape):
+        stats = pend[0]         # [B][chunks][3][C]; BatchNorm (groups == 1): the same array as one group of B * chunks
+        mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+        m2 = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+        chunks = stats.shape[1] * (B // groups)
+        if groups == 1 and B > 1 and chunks >= 128:
+            # one group, B * chunks-per-image partials per channel: merge per image in parallel, then the B results
+            ws = torch.empty(B * 3 * Cc, dtype=torch.float32, device=x.device)
+            L.call("mmh_norm_stats_merge2", _ptr(stats), chunks, Cc, B, _ptr(ws), ws.numel() * 4, _ptr(mean), _ptr(m2),
+                   _stream())
+        else:
+            L.call("mmh_norm_stats_merge", _ptr(stats), groups, chunks, Cc, _ptr(mean), _ptr(m2), _stream())
         return mean, m2, rows
     ws = torch.empty(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc) // 4 + 4, dtype=torch.float32, device=x.device)
     mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
@@ -1503,7 +1518,7 @@ def raw_norm_stats_finalize_pending(x, groups):
     pend = _pending_stats.get(x.data_ptr())
     if pend is None or groups != B or pend[1] != tuple(x.shape):
         return None
-    _pending_stats.clear()
+    del _pending_stats[x.data_ptr()]
     stats = pend[0]
     rows = H * W_
     mean = _empty((groups, Cc), x); m2 = _empty((groups, Cc), x)

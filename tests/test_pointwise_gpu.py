@@ -299,3 +299,29 @@ def test_act_bwd_lp16(act, lp, dev):
     want = ops.lp16_twin(ops.raw_act_bwd(g, y, act), lp)
     got = ops.raw_act_bwd_lp16(g, y, act, lp)
     assert got.dtype == want.dtype and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", [(4, 32, 256), (32, 121, 64), (3, 50, 512)])
+def test_norm_stats_two_level_merge(case, dev):
+    """mmh_norm_stats_merge2 (one group over B * chunks partials, per-image blocks first) == the one-level merge of
+    the same partials == the statistics of the tensor they describe (BatchNorm from conv-epilogue partials)."""
+    from mmhand_amd import lib, ops
+    B, chunks, C = case
+    torch.manual_seed(B * 1000 + chunks)
+    n = torch.randint(1, 40, (B, chunks, 1, C), device=dev).float()
+    mean = torch.randn(B, chunks, 1, C, device=dev) * 2 + 0.7
+    m2 = torch.rand(B, chunks, 1, C, device=dev) * n
+    part = torch.cat((n, mean, m2), 2).contiguous()
+    m1 = torch.empty(1, C, device=dev); q1 = torch.empty(1, C, device=dev)
+    lib.call("mmh_norm_stats_merge", ops._ptr(part), 1, B * chunks, C, ops._ptr(m1), ops._ptr(q1), ops._stream())
+    mb = torch.empty(1, C, device=dev); qb = torch.empty(1, C, device=dev)
+    ws = torch.empty(B * 3 * C, device=dev)
+    lib.call("mmh_norm_stats_merge2", ops._ptr(part), B * chunks, C, B, ops._ptr(ws), ws.numel() * 4, ops._ptr(mb),
+             ops._ptr(qb), ops._stream())
+    nd, md, qd = n.double().reshape(-1, C), mean.double().reshape(-1, C), m2.double().reshape(-1, C)
+    tot = nd.sum(0)
+    gm = (nd * md).sum(0) / tot
+    gq = (qd + nd * (md - gm) ** 2).sum(0)
+    for a, b in ((m1, q1), (mb, qb)):
+        assert float((a.double().reshape(-1) - gm).abs().max()) < 1e-6
+        assert float(((b.double().reshape(-1) - gq).abs() / gq).max()) < 1e-6
