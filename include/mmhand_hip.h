@@ -280,6 +280,19 @@ int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_c
                         void* dw, void* ws, size_t ws_bytes, int accumulate, const void* zeros,
                         mmh_stream_t s);
 
+/* 16-bit wgrad of the 7x7 / stride 1 / pad 3 stems with 64 output channels (models/Generator.py:158-164,
+ * models/Discriminator.py:60-64): x16p [B,H,W,C8] = the stem's 16-bit input with its channels padded
+ * to C8 (mmh_lp16_pad_cvt; C8 % 8 == 0, 8..48), dy16 [B,H,W,y_cs >= 64].  The filter's column taps are
+ * flattened into the operand (a row of the NHWC input is one contiguous array: the window of pixel
+ * ow starts at element ow * C8), the contraction runs over the pixels of a row, both MFMA operands
+ * are read transposed from an LDS halo staged once per 4 x 16 pixel block for all 49 taps; split-K
+ * slabs in ws, summed in a fixed order.  dw [7][7][Cin][64] fp32 (+)= ...                          */
+int mmh_wgrad_stem_lp16_supported(const mmh_conv_desc* d, int C8);
+size_t mmh_wgrad_stem_lp16_ws_bytes(const mmh_conv_desc* d, int C8);
+int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const void* dy16, void* dw,
+                        void* ws, size_t ws_bytes, int accumulate, const void* zeros,
+                        mmh_stream_t s);
+
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,

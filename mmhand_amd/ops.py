@@ -894,6 +894,35 @@ def raw_wgrad_lp16_flat(d, x16, c8, dy16, bf16, out=None):
     return dw
 
 
+USE_STEM_WGRAD16 = os.environ.get("MMH_STEM_WGRAD16", "1") != "0"
+
+
+def stem_wgrad16_ok(d, c8, bf16):
+    if not (USE_STEM_WGRAD16 and bf16):
+        return False
+    keep = d.dtype
+    d.dtype = _dt(bf16)
+    ok = bool(L.load().mmh_wgrad_stem_lp16_supported(C.byref(d), c8))
+    d.dtype = keep
+    return ok
+
+
+def raw_wgrad_stem_lp16(d, x16p, dy16, bf16, out=None):
+    """wgrad of a 7x7 stem on wgrad_stem.hip; x16p [B,H,W,C8] the stem's padded 16-bit input, dy16 [B,H,W,64]"""
+    c8 = x16p.shape[3]
+    assert x16p.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and x16p.is_contiguous() and dy16.is_contiguous()
+    keep = d.dtype
+    d.dtype = _dt(bf16)
+    nbytes = L.load().mmh_wgrad_stem_lp16_ws_bytes(C.byref(d), c8)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x16p.device)
+    dw = out if out is not None else torch.empty((7, 7, d.Cin, d.Cout), dtype=torch.float32, device=x16p.device)
+    L.call("mmh_wgrad_stem_lp16", C.byref(d), _ptr(x16p), c8, _ptr(dy16), _ptr(dw), _ptr(ws), ws.numel() * 4,
+           int(out is not None), _ptr(zero_page(x16p.device)), _stream())
+    d.dtype = keep
+    _count_desc("mfma", d)
+    return dw
+
+
 def raw_conv_wgrad_lp16_gen1(x16, dy16, Cin, k, stride, pad, reflect, bf16, out=None):
     """first-generation 16-bit wgrad kernel on 16-bit tensors; x16 [B,H,W,x_cs >= Cin] (a stem's padded input)"""
     B, H, W_, xcs = x16.shape
@@ -1341,7 +1370,9 @@ class Conv2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 Bx, Hx, Wx, Cx = ctx.x_shape
                 dd = conv_desc(Bx, Hx, Wx, Cx, w.shape[3], w.shape[0], stride, pad, reflect)
-                if lp16_flat_wgrad_ok(dd, x.shape[3], bf16):
+                if stem_wgrad16_ok(dd, x.shape[3], bf16) and g16.is_contiguous():
+                    dw = _finish_param_grad(raw_wgrad_stem_lp16(dd, x, g16, bf16, out=wt_), wt_)
+                elif lp16_flat_wgrad_ok(dd, x.shape[3], bf16):
                     dw = _finish_param_grad(raw_wgrad_lp16_flat(dd, x, x.shape[3], g16, bf16, out=wt_), wt_)
                 else:       # small Cin: the first-generation kernel, reading the padded 16-bit input in place
                     dw = _finish_param_grad(raw_conv_wgrad_lp16_gen1(x, g16, Cx, w.shape[0], stride, pad, reflect, bf16,

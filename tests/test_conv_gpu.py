@@ -847,3 +847,30 @@ def test_round3_kernels_random_shapes(dev):
         dx3 = ops.raw_conv_dgrad(dy, w3, (B, H, W, 4), 1, 1, False, bf16=True)
         _, dx3r, _, _ = R.conv2d_grads(torch.zeros(B, H, W, 4), rb(w3), None, rb(dy), 1, 1, False)
         assert R.rel_l1(dx3, dx3r) < 5e-6, ("vgg conv1_1 image gradient", B, H, W)
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 8, True), (1, 20, 70, 24, True), (2, 9, 33, 44, True), (1, 12, 12, 3, False),
+                                  (2, 32, 48, 6, True), (1, 7, 5, 24, True), (3, 64, 64, 42, True), (1, 16, 32, 30, False)])
+def test_wgrad_stem_lp16(case, lp, dev):
+    """mmh_wgrad_stem_lp16 (wgrad_stem.hip): the 7x7 stems' weight gradient with the filter's column taps flattened into
+    the transposed-read operand - 3 .. 44 input channels (padded to 8 .. 48; 44 -> 48 takes the two work-group kinds),
+    ragged 4 x 16 pixel blocks, images smaller than a block, reflect and zero padding - against the fp64 oracle on
+    operands rounded to the storage type, with and without accumulation into dw."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    dy = _mk((B, H, W, 64), 4, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    x16p = ops.lp16_pad8(x, lp)
+    dy16 = ops.lp16_twin(dy, lp)
+    d = ops.conv_desc(B, H, W, Cin, 64, 7, 1, 3, refl)
+    assert ops.stem_wgrad16_ok(d, x16p.shape[3], lp)
+    dw = ops.raw_wgrad_stem_lp16(d, x16p, dy16, lp)
+    _, _, dwr, _ = R.conv2d_grads(rb(x), torch.zeros(7, 7, Cin, 64), None, rb(dy), 1, 3, refl)
+    assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
+    acc = torch.ones_like(dw)
+    ops.raw_wgrad_stem_lp16(d, x16p, dy16, lp, out=acc)
+    assert R.rel_l1(acc - 1.0, dwr) < 2e-5
+    dw2 = ops.raw_wgrad_stem_lp16(d, x16p, dy16, lp)
+    assert torch.equal(dw, dw2)                         # split-K slabs summed in a fixed order
