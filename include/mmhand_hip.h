@@ -280,6 +280,19 @@ int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_c
                         void* dw, void* ws, size_t ws_bytes, int accumulate, const void* zeros,
                         mmh_stream_t s);
 
+/* 16-bit fprop of the same stems with the 22 x 22 pixel input halo of a 16 x 16 pixel tile resident in LDS and
+ * the filter's column taps flattened into the contraction (conv_stem16.hip): the pixel fragment is read
+ * straight from the flat halo row at pixel pitch C8, no im2col tile is staged (mmh_conv_lp16_flat moves 40 KB
+ * per 64-deep k-step).  x16p [B,H,W,C8] as above; w_stem16 from mmh_prep_weights_stem16 (the stem's fp32
+ * weight [7][7][Cin][64] as 16-bit [7][64][32 ceil(7 C8 / 32) + 8], mmh_conv_stem16_weights_bytes(C8) bytes);
+ * y fp32 or 16-bit (y_is16) [B,H,W,y_cs], +bias, activation.                                         */
+int mmh_conv_stem16_supported(const mmh_conv_desc* d, int C8);
+size_t mmh_conv_stem16_weights_bytes(int C8);
+int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out, mmh_stream_t s);
+int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16,
+                    const void* bias, void* y, int y_is16, int act, const void* zeros,
+                    mmh_stream_t s);
+
 /* 16-bit wgrad of the 7x7 / stride 1 / pad 3 stems with 64 output channels (models/Generator.py:158-164,
  * models/Discriminator.py:60-64): x16p [B,H,W,C8] = the stem's 16-bit input with its channels padded
  * to C8 (mmh_lp16_pad_cvt; C8 % 8 == 0, 8..48), dy16 [B,H,W,y_cs >= 64].  The filter's column taps are

@@ -1,0 +1,273 @@
+// 16-bit fprop of the 7x7 / stride-1 / pad-3 stems (3 .. 48 input channels padded to C8, 64 output channels) with the
+// input halo resident in LDS and the filter's COLUMN taps flattened into the contraction
+// (models/Generator.py:158-164, models/Discriminator.py:60-64; the generation path runs three of them per batch).
+//
+// conv_lp16f_kernel (conv_lp16.hip) stages, per 64-deep k-step, a [256 pixels][64] im2col tile gathered tap by tap:
+// 40 KB of LDS-DMA per 2.1 MFLOP - it lives on DMA latency (585 TFLOP/s at 24 channels).  In NHWC a row of the input is
+// one contiguous array and the window of output pixel ow under filter row kh - 7 x C8 values - starts at element
+// ow * C8 of it (wgrad_stem.hip uses the same fact), so per filter row
+//
+//   y[ow][n] += sum_j  R_kh[ow * C8 + j] * Wf[kh][n][j],      j = kw * C8 + c  (zero-padded to JP = 32 * Jt)
+//
+// is a GEMM whose pixel operand is read straight from the flat halo row: the fragment of lane (pixel, k slice) is 16
+// contiguous bytes at pixel pitch C8 * 2 (overlapping windows; conflict-free for C8 = 8, 24, two-way for 48).  No im2col.
+//
+// Work-group = 256 threads = 4 waves, output tile 16 rows x 16 pixels x 64 channels (wave: 4 rows).  Its 22 x 22 pixel
+// halo (22 flat rows, <= 46 KiB; reflect / zero padding folded into the DMA's source addresses) is staged once; the
+// filter is streamed one filter ROW at a time - [64 n][JP + 8] 16-bit, 8 - 45 KiB, two stages (the +8 element pitch makes
+// the sixteen weight rows of a fragment land on distinct banks; the padded layout is prepared in global memory so the
+// linear LDS-DMA reproduces it).  MFMA 16x16x32 with the weight fragment first: D[row = channel][column = pixel], so a
+// lane stores four consecutive channels of a pixel (store4's layout).  72 KiB of LDS at 24 channels: two work-groups
+// per CU.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
+__device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>((size_t)addr); }
+
+constexpr int TS = 16;                      // output tile 16 x 16
+constexpr int HS = TS + 6;                  // halo 22 x 22
+
+struct Stem16KP {
+    const char* x;          // 16-bit [B][H][W][C8]
+    const char* w;          // 16-bit [7][64][wpitch / 2]
+    const char* zeros;
+    const float* bias;
+    float* y;               // fp32 [B][H][W][y_cs] ...
+    char* y16;              // ... or 16-bit
+    int B, H, W, C8, y_cs, reflect, act;
+    int Jt;                 // k-steps of 32 per filter row
+    int rp;                 // bytes per halo row = 22 * C8 * 2
+    int wpitch;             // bytes per weight row = (32 * Jt + 8) * 2
+    int halo_b, wst_b;      // LDS bytes of the halo region / of one weight stage (whole DMA rounds)
+    int TX, TY, tiles;
+};
+
+template <bool H16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (H16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0,
+                                                      0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// RW = output rows per wave: 4 (256 threads; two work-groups per CU where LDS allows) or 2 (512 threads: the 40-48 channel
+// stems, whose 144 KiB of LDS admit one work-group per CU - eight waves instead of four to hide the fragment reads)
+template <bool H16, int RW>
+__global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const Stem16KP p) {
+    constexpr int NT = 64 * (TS / RW);          // threads
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int per_xcd = (p.tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= p.tiles) return;
+    const int b = tile / (p.TX * p.TY);
+    const int trem = tile - b * (p.TX * p.TY);
+    const int ty = trem / p.TX, tx = trem - ty * p.TX;
+    const int oh0 = ty * TS, ow0 = tx * TS;
+    const unsigned lds0 = mmh::lds_addr_of(smem);
+    const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+
+    // filter row kh -> weight stage kh & 1 (linear copy of the padded [64][wpitch] image)
+    const int w_units = 64 * p.wpitch / 16;
+    auto issue_w = [&](int kh) {
+        const char* src = p.w + (size_t)kh * 64 * p.wpitch;
+        const unsigned dst = wdst + (unsigned)p.halo_b + (unsigned)((kh & 1) * p.wst_b);
+        for (int r = 0; r * NT < w_units; ++r) {
+            const int u = r * NT + tid;
+            mmh::lds_dma16(u < w_units ? src + (size_t)u * 16 : p.zeros + (lane & 7) * 16, dst + (unsigned)(r * NT * 16));
+        }
+    };
+    // halo: unit u of the flat image (22 rows x upr units): row u / upr, pixel (u % upr) / c8u, chunk (u % upr) % c8u;
+    // units past the image (the rounds' tail) are zero-filled: the last pixels' padded k columns read into them
+    {
+        const int c8u = p.C8 / 8, upr = HS * c8u, units = HS * upr;
+        for (int r = 0; r * NT * 16 < p.halo_b; ++r) {
+            const int u = r * NT + tid;
+            const int row = u / upr, ur = u - row * upr;
+            const int hx = ur / c8u, ck = ur - hx * c8u;
+            int ih = oh0 + row - 3, iw = ow0 + hx - 3;
+            if (p.reflect) {
+                ih = ih < 0 ? -ih : ih;
+                iw = iw < 0 ? -iw : iw;
+                ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
+                iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
+            }
+            const bool ok = u < units && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const char* g = ok ? p.x + (size_t)((b * p.H + ih) * p.W + iw) * (size_t)(p.C8 * 2) + (unsigned)ck * 16u
+                               : p.zeros + (lane & 7) * 16;
+            mmh::lds_dma16(g, wdst + (unsigned)(r * NT * 16));
+        }
+    }
+    issue_w(0);
+
+    f32x4 acc[RW][4];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane constants: pixel fragment (row 4 wave, pixel l15, k slice g4), weight fragment (row l15 of an n tile, k slice g4)
+    const unsigned x_lane = lds0 + (unsigned)(RW * wave) * (unsigned)p.rp + (unsigned)(l15 * p.C8 + 8 * g4) * 2u;
+    const unsigned w_lane = lds0 + (unsigned)p.halo_b + (unsigned)l15 * (unsigned)p.wpitch + (unsigned)(8 * g4) * 2u;
+    const unsigned w_nt = 16u * (unsigned)p.wpitch;        // bytes between n tiles
+
+    for (int kh = 0; kh < 7; ++kh) {
+        __builtin_amdgcn_s_waitcnt(0x0070);                 // this thread's DMA (halo, filter row kh) has landed
+        __syncthreads();                                    // ... everybody's; filter row kh - 1 is no longer read
+        if (kh + 1 < 7) issue_w(kh + 1);
+        const unsigned wb = w_lane + (unsigned)((kh & 1) * p.wst_b);
+        const unsigned xb = x_lane + (unsigned)kh * (unsigned)p.rp;
+        for (int ks = 0; ks < p.Jt; ++ks) {
+            bf16x8 wf[4], xf[RW];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = lds_frag(wb + (unsigned)j * w_nt + (unsigned)ks * 64u);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) xf[i] = lds_frag(xb + (unsigned)i * (unsigned)p.rp + (unsigned)ks * 64u);
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<H16>(wf[j], xf[i], acc[i][j]);
+        }
+    }
+
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[j * 16 + 4 * g4 + r] : 0.f;
+    const int ow = ow0 + l15;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oh = oh0 + RW * wave + i;
+        if (oh >= p.H || ow >= p.W) continue;
+        const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = v[r] + bv[j][r];
+                v[r] = p.act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (p.act == MMH_ACT_TANH ? tanhf(t) : t);
+            }
+            const size_t elem = m * p.y_cs + (j * 16 + 4 * g4);
+            if (p.y16) {
+                if (H16) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<h4*>(p.y16 + elem * 2) = o;
+                } else {
+                    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                    b4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<b4*>(p.y16 + elem * 2) = o;
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(p.y + elem) = v;
+            }
+        }
+    }
+}
+
+// w fp32 [7][7][Cin][64] -> 16-bit [7][64][pitch], k = kw * C8 + c, zero padded (pitch = 32 * Jt + 8 elements)
+__global__ void prep_stem16_w_kernel(const float* __restrict__ w, int Cin, int C8, int pitch, int h16,
+                                     unsigned short* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 7 * 64 * pitch) return;
+    const int j = i % pitch, n = (i / pitch) & 63, kh = i / (pitch * 64);
+    const int kw = j / C8, c = j - kw * C8;
+    const float v = (kw < 7 && c < Cin) ? w[((size_t)(kh * 7 + kw) * Cin + c) * 64 + n] : 0.f;
+    out[i] = h16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+struct Plan { int Jt, pitch, rp, halo_b, wst_b, lds, rw; };
+
+bool plan(const mmh_conv_desc* d, int C8, Plan& q) {
+    if (!d || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->Cout != 64 || d->y_cs < 64 || d->y_cs % 4 || C8 % 8 || C8 < 8 || C8 > 48 || d->Cin > C8 || d->Cin < 1) return false;
+    if (d->pad_mode == MMH_PAD_REFLECT && (d->H < 4 || d->W < 4)) return false;
+    q.Jt = (7 * C8 + 31) / 32;
+    q.pitch = 32 * q.Jt + 8;
+    q.rp = HS * C8 * 2;
+    // regions in whole DMA rounds (threads x 16 bytes): 4 KiB for the four-wave kernel; where two of its work-groups do
+    // not fit a CU anyway, the eight-wave kernel (8 KiB rounds)
+    for (q.rw = 4; q.rw >= 2; q.rw -= 2) {
+        const int rb = q.rw == 4 ? 4096 : 8192;
+        q.halo_b = (HS * q.rp + 256 + rb - 1) / rb * rb;       // + the last pixels' padded k columns
+        q.wst_b = (64 * q.pitch * 2 + rb - 1) / rb * rb;
+        q.lds = q.halo_b + 2 * q.wst_b;
+        if (q.rw == 4 && q.lds <= 80 * 1024) return true;
+    }
+    q.rw = 2;
+    return q.lds <= 160 * 1024;
+}
+
+}  // namespace
+
+int mmh_conv_stem16_supported(const mmh_conv_desc* d, int C8) {
+    Plan q;
+    return plan(d, C8, q) ? 1 : 0;
+}
+
+size_t mmh_conv_stem16_weights_bytes(int C8) {
+    if (C8 % 8 || C8 < 8 || C8 > 48) return 0;
+    return (size_t)7 * 64 * (32 * ((7 * C8 + 31) / 32) + 8) * 2;
+}
+
+int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out, mmh_stream_t s) {
+    MMH_REQUIRE(w && out && mmh_conv_stem16_weights_bytes(C8) > 0 && Cin >= 1 && Cin <= C8 &&
+                    (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_prep_weights_stem16: bad arguments (C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype)");
+    const int pitch = 32 * ((7 * C8 + 31) / 32) + 8;
+    const int n = 7 * 64 * pitch;
+    hipLaunchKernelGGL(prep_stem16_w_kernel, dim3((n + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(w), Cin, C8, pitch, dtype == MMH_FP16 ? 1 : 0,
+                       static_cast<unsigned short*>(out));
+    return mmh::check_launch("prep_stem16_w_kernel");
+}
+
+int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y,
+                    int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    Plan q;
+    MMH_REQUIRE(plan(d, C8, q) && x16p && w_stem16 && y && zeros,
+                "mmh_conv_stem16: 7x7 / stride 1 / pad 3, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype");
+    MMH_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (long long)d->B * d->H * d->W * std::max(C8, d->y_cs) < (1ll << 31),
+                "mmh_conv_stem16: y must be 16-byte aligned; tensor too large");
+    Stem16KP p{};
+    p.x = static_cast<const char*>(x16p); p.w = static_cast<const char*>(w_stem16); p.zeros = static_cast<const char*>(zeros);
+    p.bias = static_cast<const float*>(bias);
+    if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.y_cs = d->y_cs; p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.act = act; p.Jt = q.Jt; p.rp = q.rp; p.wpitch = q.pitch * 2; p.halo_b = q.halo_b; p.wst_b = q.wst_b;
+    p.TX = (d->W + TS - 1) / TS; p.TY = (d->H + TS - 1) / TS; p.tiles = d->B * p.TX * p.TY;
+    static int ready = -1;
+    if (ready != 0) {
+        hipError_t e = hipSuccess;
+        const void* fs[4] = {reinterpret_cast<const void*>(conv_stem16_kernel<false, 4>),
+                             reinterpret_cast<const void*>(conv_stem16_kernel<true, 4>),
+                             reinterpret_cast<const void*>(conv_stem16_kernel<false, 2>),
+                             reinterpret_cast<const void*>(conv_stem16_kernel<true, 2>)};
+        for (const void* f : fs)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        ready = e == hipSuccess ? 0 : mmh::fail("conv_stem16_kernel: %s", hipGetErrorString(e));
+    }
+    if (ready != 0) return ready;
+    const dim3 grid(8 * ((p.tiles + 7) / 8));
+    hipStream_t st = mmh::as_stream(s);
+    const bool h16 = d->dtype == MMH_FP16;
+    if (q.rw == 2) {                // one work-group per CU anyway: eight waves
+        if (h16) hipLaunchKernelGGL((conv_stem16_kernel<true, 2>), grid, dim3(512), q.lds, st, p);
+        else hipLaunchKernelGGL((conv_stem16_kernel<false, 2>), grid, dim3(512), q.lds, st, p);
+    } else {
+        if (h16) hipLaunchKernelGGL((conv_stem16_kernel<true, 4>), grid, dim3(256), q.lds, st, p);
+        else hipLaunchKernelGGL((conv_stem16_kernel<false, 4>), grid, dim3(256), q.lds, st, p);
+    }
+    return mmh::check_launch("conv_stem16_kernel");
+}

@@ -83,6 +83,10 @@ SIGNATURES = {
     "mmh_prep_weights_lp16_flat8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mmh_conv_lp16_flat_supported": (_i, [_DP, _i]),
     "mmh_conv_lp16_flat": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "mmh_conv_stem16_supported": (_i, [_DP, _i]),
+    "mmh_conv_stem16_weights_bytes": (_sz, [_i]),
+    "mmh_prep_weights_stem16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mmh_conv_stem16": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_wgrad_stem_lp16_supported": (_i, [_DP, _i]),
     "mmh_wgrad_stem_lp16_ws_bytes": (_sz, [_DP, _i]),
     "mmh_wgrad_stem_lp16": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _vp]),

@@ -113,7 +113,7 @@ def derived_weights_snapshot():
 
 
 def _DERIVED_CACHES():
-    return (_bf16_cache, _flat8_cache, _wino_cache)
+    return (_bf16_cache, _flat8_cache, _wino_cache, _stem16_cache)
 
 
 def _cache_get(cache, key, w):
@@ -937,14 +937,37 @@ def raw_conv_wgrad_lp16_gen1(x16, dy16, Cin, k, stride, pad, reflect, bf16, out=
     return dw
 
 
+USE_STEM_FPROP16 = os.environ.get("MMH_STEM_FPROP16", "1") != "0"
+_stem16_cache = {}
+
+
+def stem16_weights(w, bf16):
+    """the 7x7 stem's weight for conv_stem16.hip: 16-bit [7][64][32 ceil(7 C8 / 32) + 8] (mmh_prep_weights_stem16)"""
+    key = (w.data_ptr(), tuple(w.shape), _lp(bf16))
+    ent = _cache_get(_stem16_cache, key, w)
+    if ent is None:
+        cin = w.shape[2]
+        c8 = (cin + 7) // 8 * 8
+        out = torch.empty(L.load().mmh_conv_stem16_weights_bytes(c8) // 2, dtype=_wd(bf16), device=w.device)
+        L.call("mmh_prep_weights_stem16", _ptr(w), cin, c8, _dt(bf16), _ptr(out), _stream())
+        ent = _cache_put(_stem16_cache, key, w, out)
+    return ent
+
+
 def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None):
     """fprop of a small-Cin 'same' conv on the flat-K 16-bit kernel; x: fp32 NHWC [B,H,W,Cin] (or its padded
-    16-bit copy x16p = lp16_pad8(x))"""
+    16-bit copy x16p = lp16_pad8(x)).  The 7x7 stems with 64 output channels take conv_stem16.hip (input halo resident
+    in LDS, column taps flattened into the contraction) instead."""
     c8 = (d.Cin + 7) // 8 * 8
     if x16p is None:
         x16p = lp16_pad8(x, bf16)
     d.dtype = _dt(bf16)
     y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x16p.device)
+    if USE_STEM_FPROP16 and d.kh == 7 and L.load().mmh_conv_stem16_supported(C.byref(d), c8):
+        L.call("mmh_conv_stem16", C.byref(d), _ptr(x16p), c8, _ptr(stem16_weights(w, bf16)), _ptr(bias), _ptr(y),
+               int(out16), act, _ptr(zero_page(x16p.device)), _stream())
+        _count_desc("mfma", d)
+        return y
     L.call("mmh_conv_lp16_flat", C.byref(d), _ptr(x16p), c8, _ptr(flat8_weights(w, bf16)), _ptr(bias), _ptr(y),
            int(out16), act, _ptr(zero_page(x16p.device)), _stream())
     _count_desc("mfma", d)

@@ -874,3 +874,43 @@ def test_wgrad_stem_lp16(case, lp, dev):
     assert R.rel_l1(acc - 1.0, dwr) < 2e-5
     dw2 = ops.raw_wgrad_stem_lp16(d, x16p, dy16, lp)
     assert torch.equal(dw, dw2)                         # split-K slabs summed in a fixed order
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 16, 8, True), (1, 20, 70, 24, True), (2, 9, 33, 44, True), (1, 12, 12, 3, False),
+                                  (2, 32, 48, 6, True), (1, 7, 5, 24, True), (2, 64, 64, 42, True), (1, 16, 32, 30, False)])
+def test_conv_stem16(case, act, lp, dev):
+    """mmh_conv_stem16 (conv_stem16.hip): the 7x7 stems' fprop from the LDS-resident halo with the column taps flattened
+    into the contraction - 3 .. 44 input channels (padded to 8 .. 48), ragged 16 x 16 tiles, images smaller than a tile,
+    reflect and zero padding, fp32 and 16-bit outputs - against the fp64 oracle on operands rounded to the storage type
+    and against the flat-K kernel it replaces; through ops.raw_conv_fprop as the model and the generation path call it."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((7, 7, Cin, 64), 2, dev) * 0.1
+    bias = _mk((64,), 3, dev)
+    ops.bump_weights_epoch()
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        y = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, act, lp)
+    finally:
+        lib.call = orig
+    assert calls.get("mmh_conv_stem16") == 1 and "mmh_conv_lp16_flat" not in calls, calls
+    yr = R.conv2d(rb(x), rb(w), bias.cpu(), 1, 3, refl, act)
+    assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+    d = ops.conv_desc(B, H, W, Cin, 64, 7, 1, 3, refl)
+    y16 = ops.raw_conv_lp16_flat(d, x, w, bias, act, lp, out16=True)
+    assert R.rel_l1(y16.float(), yr) < (2e-3 if lp == 2 else 8e-3)
+    ops.USE_STEM_FPROP16 = False
+    try:
+        y_old = ops.raw_conv_lp16_flat(ops.conv_desc(B, H, W, Cin, 64, 7, 1, 3, refl), x, w, bias, act, lp)
+    finally:
+        ops.USE_STEM_FPROP16 = True
+    assert float((y - y_old).abs().max()) < 2e-5 * max(1.0, float(y_old.abs().max()))
