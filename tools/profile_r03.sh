@@ -12,6 +12,8 @@ python tools/bench_lp16h.py > $O/bench_lp16h.txt 2>&1
 python tools/bench_lp16_fold.py > $O/bench_lp16_fold.txt 2>&1
 python tools/ab_lp16_wgrad.py > $O/ab_lp16_wgrad.txt 2>&1
 python tools/bench_conv7_n4.py > $O/bench_conv7_n4.txt 2>&1
+python tools/bench_stem_wgrad.py > $O/bench_stem_wgrad.txt 2>&1
+python tools/bench_stem_fprop.py > $O/bench_stem_fprop.txt 2>&1
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_f32_line.log 2>&1
