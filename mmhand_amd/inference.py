@@ -119,7 +119,12 @@ class InferenceGenerator:
         for blk in range(n.n_blocks):
             ss = []
             for s, x in zip((1, 2, 3), (x1, x2, x3)):
-                x16 = ops.lp16_twin(x, lp) if x.dtype == torch.float32 else x
+                if x.dtype != torch.float32:
+                    x16 = x
+                elif s == 1 and blk > 0 and ops.USE_LP16_CAT_TWIN:
+                    x16 = x2[..., x.shape[3]:]      # the second half of cat(s3, out): out in 16 bits, read in place
+                else:
+                    x16 = ops.lp16_twin(x, lp)
                 w, b = f[("att", blk, s, 0)]
                 y = ops.raw_conv3x3_lp16(x16, w, b, True, L.ACT_RELU, lp, 0, out16=True)
                 w, b = f[("att", blk, s, 1)]

@@ -257,7 +257,7 @@ class _Net(nn.Module):
 
     # -- functional layers
     def conv(self, cp, x, stride=1, pad=0, reflect=False, act=L.ACT_NONE, dx_channels=0, y_lp=False, to_norm=False,
-             g_defer=False, res_tok=None):
+             g_defer=False, res_tok=None, x_twin=None):
         """x: an fp32 NHWC tensor, a (proxy, x16) pair from a producer that wrote it in 16 bits, or a
         (proxy, NormDefer) pair from a norm whose apply pass runs inside this conv (normact(defer)).
         y_lp (see _lp_edge): the consumer (normact / the PATBlock gate) takes the output in 16 bits ->
@@ -278,10 +278,10 @@ class _Net(nn.Module):
             res_tok = None      # tokens belong to fp32 block inputs (ops.ResidualToken)
         if y_lp:
             p, y16 = ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, True, nb,
-                                        None, False, res_tok)
+                                        None, False, res_tok, x_twin)
             return p, y16
         return ops.Conv2dFn.apply(x, cp.weight, cp.bias, stride, pad, reflect, act, self.bf16, dx_channels, x16, False, nb,
-                                  None, g_defer, res_tok)
+                                  None, g_defer, res_tok, x_twin)
 
     def _lp_edge(self, cp, stride=1, reflect=True):
         """16-bit hand-over to the 3x3 / pad 1 conv (or ConvTranspose2d) `cp` (training, 16-bit mode, all
@@ -403,7 +403,7 @@ class _Net(nn.Module):
         return ops.ResidualToken() if (ops.USE_RESIDUAL_TOKENS and self.bf16 and self.training and torch.is_tensor(x)
                                        and x.requires_grad) else None
 
-    def two_conv_block(self, blk, x, site, last_norm, residual=None, res_tok=None):
+    def two_conv_block(self, blk, x, site, last_norm, residual=None, res_tok=None, x_twin=None):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets).
         res_tok: x is also read by the caller's residual add (the PATBlock gate); with residual is x (ResnetBlock)
         the token is made here."""
@@ -417,7 +417,8 @@ class _Net(nn.Module):
         # the block's last norm (no ReLU / dropout; feeds the gate or the residual add): its backward apply pass
         # inside conv 2's backward transform, as for the first norm
         fuse_last = 3 if (last_norm and torch.is_tensor(x) and self._norm_bwd_fusion(blk[i2], x)) else 0
-        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2, res_tok=res_tok)
+        y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2, res_tok=res_tok,
+                      x_twin=x_twin if torch.is_tensor(x) else None)
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
         y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm, g_defer=fuse_last == 3)
         if last_norm:
@@ -559,13 +560,15 @@ class Generator(_Net):
             blk = m["att"][b]
             p = f"model.att.{b}.conv_block_stream"
             tok = None
+            # x1's 16-bit twin: the second half of cat(s3, out) the previous gate wrote in 16 bits (ops.USE_LP16_CAT_TWIN)
+            x1_twin = x2[1][..., x1.shape[3]:] if (b > 0 and isinstance(x2, tuple) and torch.is_tensor(x1)) else None
             if packing(self):
                 s1, s2, s3 = two_conv_blocks_lockstep(
                     [dict(net=self, blk=blk[f"conv_block_stream{s}"], x=x, site=p + str(s), last_norm=s == 1)
                      for s, x in zip((1, 2, 3), (x1, x2, x3))])
             else:
                 tok = self._res_token(x1)       # x1 feeds the stream-1 conv AND the gate's residual add
-                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True, res_tok=tok)
+                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True, res_tok=tok, x_twin=x1_twin)
                 s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
                 s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)

@@ -635,10 +635,16 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
 
 
 def raw_conv_wgrad(x, dy, k, stride, pad, reflect, bf16=False, out=None):
-    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits.  out: add dw into this tensor."""
-    _chk16(x, "x"); _chk16(dy, "dy")
+    """x, dy: fp32, or (16-bit mode) tensors already held in 16 bits.  out: add dw into this tensor.
+    x may be a channel slice of a wider 16-bit tensor (the gate's concat read in place): the nine-tap wgrad takes the
+    pixel stride, every other kernel gets a contiguous copy."""
     B, H, W_, Cin = x.shape
     Cout = dy.shape[3]
+    if not x.is_contiguous() and not (bf16 and x.dtype != torch.float32 and lp16_wgrad_ok(Cin, Cout, k, stride, pad)):
+        x = x.contiguous()
+    if x.is_contiguous():
+        _chk16(x, "x")
+    _chk16(dy, "dy")
     lp_in = x.dtype != torch.float32 or dy.dtype != torch.float32
     assert bf16 or not lp_in
     if bf16 and lp16_wgrad_ok(Cin, Cout, k, stride, pad):
@@ -716,6 +722,21 @@ def zero_page(dev):
     return z
 
 
+def _pix_stride(t):
+    """pixel stride (elements) of an NHWC tensor or of a channel-slice view of one (channels contiguous, pixels `cs`
+    apart, rows and images dense in pixels): what the kernels take as x_cs"""
+    B, H, W_, Cc = t.shape
+    cs = t.stride(2)
+    assert t.stride(3) == 1 and cs >= Cc and t.stride(1) == W_ * cs and t.stride(0) == H * W_ * cs, \
+        f"not an NHWC tensor or channel slice of one: shape {tuple(t.shape)}, strides {t.stride()}"
+    return cs
+
+
+# the 16-bit twin of a PATBlock's stream-1 input is already in memory: the gate wrote cat(s3, out) in 16 bits, and its
+# second half IS out - the halo kernel and the nine-tap wgrad read it in place (pixel stride 2 C) instead of a conversion
+USE_LP16_CAT_TWIN = os.environ.get("MMH_LP16_CAT_TWIN", "1") != "0"
+
+
 def lp16_twin(x, bf16=True):
     """16-bit copy (bf16 / fp16) of an fp32 NHWC tensor."""
     _chk(x, "x")
@@ -769,8 +790,10 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_s
     ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight."""
     B, H, W_, Cx = x16.shape
     _, _, Cin, Cout = w.shape
-    assert x16.dtype == _wd(bf16) and x16.is_contiguous() and Cx == (Cin if mode == 0 else Cout)
-    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    assert x16.dtype == _wd(bf16) and Cx == (Cin if mode == 0 else Cout)
+    xcs = _pix_stride(x16)          # fprop: x16 may be a channel slice of a wider 16-bit tensor
+    assert mode == 0 or xcs == Cx, "a strided 16-bit operand is supported for the fprop input only"
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect, x_cs=xcs if mode == 0 else None)
     d.dtype = _dt(bf16)
     wp, wt = bf16_weights(w, bf16)
     N = Cout if mode == 0 else Cin
@@ -1147,8 +1170,8 @@ def raw_wgrad3x3_lp16(x16, dy16, reflect, bf16, out=None):
     this tensor instead of returning a new one."""
     B, H, W_, Cin = x16.shape
     Cout = dy16.shape[3]
-    assert x16.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and x16.is_contiguous() and dy16.is_contiguous()
-    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect)
+    assert x16.dtype == _wd(bf16) and dy16.dtype == _wd(bf16) and dy16.is_contiguous()
+    d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, reflect, x_cs=_pix_stride(x16))     # x16: possibly a channel slice
     d.dtype = _dt(bf16)
     ws = torch.empty(max(int(L.load().mmh_wgrad3x3_lp16_ws_bytes(C.byref(d))), 16) // 4, dtype=torch.float32,
                      device=x16.device)
@@ -1269,7 +1292,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, reflect, act, bf16=False, dx_channels=0, x16=None, y_lp=False,
-                null_bias_grad=False, pro=None, g_defer=False, res_tok=None):
+                null_bias_grad=False, pro=None, g_defer=False, res_tok=None, x_twin=None):
         """x16: the producer already wrote x in 16 bits (NormActFn out_lp / GateFn cat_lp); x is then
         the zero-stride fp32 proxy that carries the autograd edge (lp_proxy) and is never read.
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
@@ -1334,7 +1357,12 @@ class Conv2dFn(torch.autograd.Function):
             # kept instead of x, the wgrad.  256 / 512-channel stride-1 stack: conv_lp16s_kernel, the other
             # 3x3 convs (stride 2, 64 / 128 columns): conv_lp16g_kernel
             if x16 is None:
-                x16 = lp16_twin(x, bf16)
+                # x_twin: a 16-bit copy of x that already exists (a channel slice of the gate's 16-bit concat)
+                if x_twin is not None and v2 and USE_LP16_CAT_TWIN:
+                    assert x_twin.dtype == _wd(bf16) and tuple(x_twin.shape) == tuple(x.shape)
+                    x16 = x_twin
+                else:
+                    x16 = lp16_twin(x, bf16)
             d = conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect)
             timed = fprop_timer is not None and fprop_timer.want(d)
             if timed:
@@ -1370,7 +1398,7 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
         if g is None:
-            return (None,) * 15
+            return (None,) * 16
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
         bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
         want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
@@ -1385,7 +1413,7 @@ class Conv2dFn(torch.autograd.Function):
             # nothing but the 16-bit dgrad reads g * act'(y) - one pass writes it in 16 bits
             g16 = raw_act_bwd_lp16(g.contiguous(), y, act, bf16)
             dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, 0, dy16=g16)
-            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.stem16:      # x is the stem's padded 16-bit input [B,H,W,C8] saved by the forward pass
             g16 = lp_grad_in(g, "Conv2dFn (stem)")
             if ctx.needs_input_grad[0]:     # only the generated image inside the concat (stem_lp16_ok)
@@ -1402,7 +1430,7 @@ class Conv2dFn(torch.autograd.Function):
                                                                      out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.y_lp:        # 16-bit edge on the output: the gradient arrives in 16 bits, no fp32 copy exists
             g16 = lp_grad_in(g, "Conv2dFn")
             if ctx.needs_input_grad[0]:
@@ -1417,7 +1445,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g16.numel() // g16.shape[3], g16.shape[3], g16, out=bt_), bt_)
-            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         fused_bwd = (FUSE_WINO6_BWD and ctx.wino_V == 6 and not bf16 and ctx.needs_input_grad[0]
                      and ctx.needs_input_grad[1]
                      and _wino_tile(*ctx.x_shape, w.shape[3], 3, stride, pad, bf16, "dgrad") == 6)
@@ -1437,7 +1465,7 @@ class Conv2dFn(torch.autograd.Function):
             dw = _finish_param_grad(dw, wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.lp16:        # x is the 16-bit twin saved by the forward pass; one twin of g serves both passes
             g16 = lp16_twin(g, bf16)
             if ctx.needs_input_grad[0]:
@@ -1449,7 +1477,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g16, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -1459,7 +1487,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = _finish_param_grad(raw_conv_wgrad(x, g, w.shape[0], stride, pad, reflect, bf16, out=wt_), wt_)
         if want_db:
             db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
-        return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None
+        return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):

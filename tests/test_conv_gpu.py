@@ -914,3 +914,28 @@ def test_conv_stem16(case, act, lp, dev):
     finally:
         ops.USE_STEM_FPROP16 = True
     assert float((y - y_old).abs().max()) < 2e-5 * max(1.0, float(y_old.abs().max()))
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 256, 256, True), (1, 20, 40, 256, 512, True), (2, 9, 11, 256, 256, False)])
+def test_conv3x3_lp16_reads_a_channel_slice(case, lp, dev):
+    """The halo kernel's fprop (plain and with the statistics epilogue) and the nine-tap wgrad read their 16-bit input in
+    place from a channel slice of a wider tensor (pixel stride 2 C: the second half of the PATBlock gate's concat is the
+    next block's stream-1 input, models/Generator.py:115-130) - bit-identical to the same call on a contiguous copy."""
+    from mmhand_amd import ops
+    B, H, W, Cin, Cout, refl = case
+    wide = ops.lp16_twin(_mk((B, H, W, 2 * Cin), 1, dev), lp)
+    view = wide[..., Cin:]
+    assert not view.is_contiguous()
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    bias = _mk((Cout,), 3, dev)
+    dy16 = ops.lp16_twin(_mk((B, H, W, Cout), 4, dev), lp)
+    ops.bump_weights_epoch()
+    for kw in (dict(), dict(want_stats=True)):
+        a = ops.raw_conv3x3_lp16(view, w, bias, refl, 0, lp, 0, out16=True, **kw)
+        ops._pending_stats.clear()
+        b = ops.raw_conv3x3_lp16(view.contiguous(), w, bias, refl, 0, lp, 0, out16=True, **kw)
+        ops._pending_stats.clear()
+        assert torch.equal(a, b)
+    if Cout % 128 == 0 and Cin % 64 == 0:
+        assert torch.equal(ops.raw_wgrad3x3_lp16(view, dy16, refl, lp), ops.raw_wgrad3x3_lp16(view.contiguous(), dy16, refl, lp))

@@ -133,7 +133,9 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
     """ops.ResidualToken: the gradient a block input receives from its residual consumer (the PATBlock gate, the
     ResnetBlock add) is parked and added inside the first conv's dgrad (mmh_conv3x3_lp16_dgrad_add) instead of by
     autograd's add.  One full-width 16-bit Generator + both Discriminator backward passes with and without tokens: every
-    parameter gradient and the losses bit-identical (the fused add is the same fp32 addition; at 16x16 feature maps
+    parameter gradient and the losses bit-identical - also with the stream-1 convs reading their 16-bit input in place
+    from the previous gate's concat (ops.USE_LP16_CAT_TWIN: the same rounded values as a conversion pass writes) - (the
+    fused add is the same fp32 addition; at 16x16 feature maps
     the reflect dgrad is the one-launch fold kernel, so no other term is reordered), the fused entry point engaged once
     per PATBlock and per ResnetBlock pass, and no token left holding a gradient."""
     from mmhand_amd import lib, ops
@@ -141,6 +143,7 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
     outs = {}
     for on in (True, False):
         monkeypatch.setattr(ops, "USE_RESIDUAL_TOKENS", on)
+        monkeypatch.setattr(ops, "USE_LP16_CAT_TWIN", on)   # and the stream-1 convs read the gate's 16-bit concat in place
         calls = Counter()
         real = lib.call
 
