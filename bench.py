@@ -305,29 +305,49 @@ def gradient_parity_run(dev, size, norm):
     b = synthetic_batch_gpu(B, size, size, 49, dev)
     g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
     probe = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3)).to(dev)
-    res, old = {}, ops.USE_WINOGRAD
+    res, old, old_tile = {}, ops.USE_WINOGRAD, ops._wino_tile
+    allowed = set()
+
+    def gated(B_, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
+        return old_tile(B_, H, W_, Cin, Cout, k, stride, pad, bf16, op) if op in allowed else 0
+
+    # key -> (passes that run Winograd, factor on the network input)
+    runs = {"direct": ((), 1.0), "winograd": (("fprop", "dgrad", "wgrad"), 1.0),
+            "winograd_bwd_only": (("dgrad", "wgrad"), 1.0), "direct_input_2ulp": ((), 1.0 + 2.0 ** -22)}
     try:
-        for wino in (False, True):
-            ops.USE_WINOGRAD = wino
+        ops.USE_WINOGRAD = True
+        ops._wino_tile = gated
+        for key, (which, scale) in runs.items():
+            allowed.clear()
+            allowed.update(which)
             ops.bump_weights_epoch()
             net = Generator([3, 42, 6], 3, 64, norm, False, 9).init_weights("normal", 49).to(dev).train()
             net.flatten_parameters()
-            out = net(g_in)
+            out = net([t * scale for t in g_in])
             (out * probe).sum().backward()
-            res[wino] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+            res[key] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
             del net, out
     finally:
-        ops.USE_WINOGRAD = old
+        ops.USE_WINOGRAD, ops._wino_tile = old, old_tile
         ops.bump_weights_epoch()
     rel = lambda a, c: float((a.double() - c.double()).abs().sum() / c.double().abs().sum().clamp_min(1e-30))   # noqa: E731
-    errs = sorted(rel(res[True][1][n], g) for n, g in res[False][1].items() if float(g.abs().sum()) > 0)
-    out = {"winograd_vs_direct": {"output_rel_l1": float(f"{rel(res[True][0], res[False][0]):.3e}"),
-                                  "grad_rel_l1_median": float(f"{statistics.median(errs):.3e}"),
-                                  "grad_rel_l1_p90": float(f"{errs[(len(errs) * 9) // 10]:.3e}"),
-                                  "grad_rel_l1_max": float(f"{errs[-1]:.3e}"), "tensors": len(errs)},
+
+    def against_direct(key):
+        errs = sorted(rel(res[key][1][n], g) for n, g in res["direct"][1].items() if float(g.abs().sum()) > 0)
+        return {"output_rel_l1": float(f"{rel(res[key][0], res['direct'][0]):.3e}"),
+                "grad_rel_l1_median": float(f"{statistics.median(errs):.3e}"),
+                "grad_rel_l1_p90": float(f"{errs[(len(errs) * 9) // 10]:.3e}"),
+                "grad_rel_l1_max": float(f"{errs[-1]:.3e}"), "tensors": len(errs)}
+
+    out = {"winograd_vs_direct": against_direct("winograd"),
+           "winograd_dgrad_wgrad_only_vs_direct": against_direct("winograd_bwd_only"),
+           "direct_input_times_1p2e-22_vs_direct": against_direct("direct_input_2ulp"),
            "note": f"full-size Generator (ngf 64, 9 PATBlocks, {size}x{size}, B={B}, --norm {norm}, dropout off), gradients of "
-                   "sum(out * probe) per parameter tensor; the headline path (Winograd) against direct_path's kernels, whose "
-                   "own distance from the fp64 oracle is 1e-6 (tests/test_winograd_step_gpu.py)"}
+                   "sum(out * probe) per parameter tensor against direct_path's kernels (whose own distance from the fp64 "
+                   "oracle is 1e-6: tests/test_winograd_step_gpu.py).  Second key: Winograd dgrad and wgrad kernels with the "
+                   "direct fprop, i.e. what the backward kernels themselves add.  Third key: the direct kernels against "
+                   "themselves with the network input scaled by (1 + 2^-22) - the gradients' conditioning, which the "
+                   "Winograd fprop's 7e-6 output difference excites (ReLU masks within rounding of zero flip)"}
     del res
     gc.collect()
     torch.cuda.empty_cache()
