@@ -90,6 +90,14 @@ int mmh_conv2d_fprop(const mmh_conv_desc* d, const void* x, const void* w,
 int mmh_conv2d_fprop_stats_chunks(const mmh_conv_desc* d);
 int mmh_conv2d_fprop_stats(const mmh_conv_desc* d, const void* x, const void* w, const void* bias,
                            void* y, void* stats, mmh_stream_t s);
+/* 1 when mmh_conv2d_dgrad / mmh_conv2d_dgrad_folded / mmh_convT2d_fprop run conv `d` (fp32, 3x3, stride 2,
+ * zero pad 1, 64 -> 128 channels, dense dy) on the halo-resident kernel of dgrad_s2.hip - the 9 x 17 dy halo of
+ * an 8 x 16 block of dy positions in LDS for all nine taps and all four output parity classes - instead of the
+ * four parity-class implicit GEMMs (mmh_set_option("dgrad_s2_halo", 0) forces those).  Replaces the data
+ * gradient of nn.Conv2d(ngf, 2 ngf, 3, 2, 1), models/Generator.py:192-199, and the forward of
+ * nn.ConvTranspose2d(2 ngf, ngf, 3, 2, 1, output_padding=1), models/Generator.py:212-219.                      */
+int mmh_dgrad_s2_halo_supported(const mmh_conv_desc* d, int dx_cs);
+
 /* Gradient w.r.t. x.  MMH_PAD_ZERO: dx is [B,H,W,Cin] (channel stride
  * dx_cs).  MMH_PAD_REFLECT: dx is the gradient on the padded domain,
  * [B,H+2p,W+2p,Cin]; fold it with mmh_reflect_fold.                        */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mmh_conv_lp16_flat_supported": (_i, [_DP, _i]),
     "mmh_conv_lp16_flat": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_conv_stem16_supported": (_i, [_DP, _i]),
+    "mmh_dgrad_s2_halo_supported": (_i, [_DP, _i]),
     "mmh_conv_stem16_weights_bytes": (_sz, [_i]),
     "mmh_prep_weights_stem16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mmh_conv_stem16": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
