@@ -77,7 +77,7 @@ int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16
 bool dgrad_s2_halo_ok(const mmh_conv_desc* d, int dx_cs);
 int launch_dgrad_s2_halo(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx, int dx_cs,
                          int act, hipStream_t st);
-extern int g_dgrad_s2_halo;
+extern int g_dgrad_s2_halo, g_dgrad_s2_dbg;
 extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;

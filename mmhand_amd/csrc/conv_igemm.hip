@@ -3181,6 +3181,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
+    if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
     if (!strcmp(key, "lp16_dbg")) { mmh::g_lp16_dbg = value; return 0; }
     if (!strcmp(key, "lp16_wgrad_ring")) { mmh::g_lp16_wgrad_ring = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
