@@ -73,8 +73,8 @@ bool wgrad_lp16t_supported(const mmh_conv_desc* d);
 int wgrad_lp16t_splits(const mmh_conv_desc* d);
 int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16, float* slab, const void* zeros,
                        hipStream_t st);
-// fp32 dgrad of the 3x3 stride-2 conv 64 -> 128 with the dy halo resident in LDS (dgrad_s2.hip)
-bool dgrad_s2_halo_ok(const mmh_conv_desc* d, int dx_cs);
+// fp32 dgrad of the 3x3 stride-2 convs 64 -> 128 / 128 -> 256 with the dy halo resident in LDS (dgrad_s2.hip)
+bool dgrad_s2_halo_ok(const mmh_conv_desc* d, int dx_cs, int act);
 int launch_dgrad_s2_halo(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx, int dx_cs,
                          int act, hipStream_t st);
 extern int g_dgrad_s2_halo, g_dgrad_s2_dbg;

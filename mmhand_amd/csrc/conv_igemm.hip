@@ -2425,7 +2425,7 @@ int do_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, const void* 
     const int off = d->pad_mode == MMH_PAD_REFLECT ? d->pad : 0;  // padded-domain origin shift
     const int OH = d->H + 2 * off, OW = d->W + 2 * off;
     MMH_REQUIRE(s == 1 || (OH % 2 == 0 && OW % 2 == 0), "stride-2 dgrad needs even H,W");
-    if (mmh::dgrad_s2_halo_ok(d, dx_cs)) return mmh::launch_dgrad_s2_halo(d, dy, w, bias, dx, dx_cs, act, st);
+    if (mmh::dgrad_s2_halo_ok(d, dx_cs, act)) return mmh::launch_dgrad_s2_halo(d, dy, w, bias, dx, dx_cs, act, st);
     ConvKP classes[4];
     int ncls = 0;
     // one piece per output parity class (1 class for stride 1, 4 for stride 2)

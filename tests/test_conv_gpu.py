@@ -941,47 +941,55 @@ def test_conv3x3_lp16_reads_a_channel_slice(case, lp, dev):
         assert torch.equal(ops.raw_wgrad3x3_lp16(view, dy16, refl, lp), ops.raw_wgrad3x3_lp16(view.contiguous(), dy16, refl, lp))
 
 
+@pytest.mark.parametrize("chans", [(64, 128), (128, 256)])
 @pytest.mark.parametrize("case", [(2, 16, 16), (1, 20, 36), (2, 34, 66), (1, 2, 2), (1, 18, 4)])
-def test_dgrad_s2_halo_64_to_128(case, dev):
-    """fp32 dgrad of the 3x3 / stride-2 / pad-1 conv 64 -> 128 on the halo-resident kernel (dgrad_s2.hip): whole and ragged
-    8 x 16 tiles, one-tile images, against the fp64 oracle and against the generic parity-class kernels; the
-    ConvTranspose2d fprop that shares the arithmetic, with bias."""
+def test_dgrad_s2_halo(case, chans, dev):
+    """fp32 dgrad of the 3x3 / stride-2 / pad-1 convs 64 -> 128 and 128 -> 256 on the halo-resident kernel (dgrad_s2.hip):
+    whole and ragged 8 x 16 tiles, one-tile images, against the fp64 oracle and - bit for bit, the order of summation per
+    output class is the same - against the generic parity-class kernels; the ConvTranspose2d fprop that shares the
+    arithmetic, with bias and with bias + ReLU."""
+    import ctypes
     from mmhand_amd import lib, ops
     B, H, W = case
-    x_shape = (B, H, W, 64)
-    w = _mk((3, 3, 64, 128), 2, dev) * 0.1
-    dy = _mk((B, H // 2, W // 2, 128), 4, dev)
-    import ctypes
-    assert lib.load().mmh_dgrad_s2_halo_supported(ctypes.byref(ops.conv_desc(B, H, W, 64, 128, 3, 2, 1, False)), 64) == 1
-    assert lib.load().mmh_dgrad_s2_halo_supported(ctypes.byref(ops.conv_desc(B, H, W, 128, 256, 3, 2, 1, False)), 128) == 0
+    Cin, Cout = chans
+    x_shape = (B, H, W, Cin)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    dy = _mk((B, H // 2, W // 2, Cout), 4, dev)
+    assert lib.load().mmh_dgrad_s2_halo_supported(ctypes.byref(ops.conv_desc(B, H, W, Cin, Cout, 3, 2, 1, False)), Cin) == 1
+    assert lib.load().mmh_dgrad_s2_halo_supported(ctypes.byref(ops.conv_desc(B, H, W, 32, 64, 3, 2, 1, False)), 32) == 0
     dx = ops.raw_conv_dgrad(dy, w, x_shape, 2, 1, False)
     _, dxr, _, _ = R.conv2d_grads(torch.zeros(x_shape), w.cpu(), None, dy.cpu(), 2, 1, False)
     assert R.rel_l1(dx, dxr) < TOL, R.rel_l1(dx, dxr)
+    bias = _mk((Cin,), 3, dev)
+    y = ops.raw_convT_fprop(dy, w, bias)
+    y_relu = ops.raw_convT_fprop(dy, w, bias, 1)
     lib.call("mmh_set_option", b"dgrad_s2_halo", 0)
     try:
         dx0 = ops.raw_conv_dgrad(dy, w, x_shape, 2, 1, False)
+        y0 = ops.raw_convT_fprop(dy, w, bias)
     finally:
         lib.call("mmh_set_option", b"dgrad_s2_halo", 1)
-    assert R.rel_l1(dx, dx0) < 1e-6
-    bias = _mk((64,), 3, dev)
-    y = ops.raw_convT_fprop(dy, w, bias)
+    assert torch.equal(dx, dx0) and torch.equal(y, y0)
+    assert torch.equal(y_relu, torch.relu(y))
     yr, _, _, _ = R.convT2d_grads(dy.cpu(), w.cpu(), bias.cpu(), torch.zeros(x_shape))
     assert R.rel_l1(y, yr) < TOL, R.rel_l1(y, yr)
 
 
-def test_dgrad_s2_halo_persistent_tiles(dev):
-    """More tiles than work-groups (384 tiles on 256 CUs): the persistent loop's second tile, whose halo is requested under
-    the first tile's stores, equals the generic kernels' result."""
+@pytest.mark.parametrize("chans", [(64, 128), (128, 256)])
+def test_dgrad_s2_halo_persistent_tiles(chans, dev):
+    """More tiles than work-groups (384 tiles on 256 CUs): the persistent loop's second tile, whose halo chunks are requested
+    while the first tile multiplies, equals the generic kernels' result."""
     from mmhand_amd import lib, ops
     B, H, W = 6, 128, 256
-    w = _mk((3, 3, 64, 128), 2, dev) * 0.1
-    dy = _mk((B, H // 2, W // 2, 128), 4, dev)
-    dx = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 2, 1, False)
-    dx2 = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 2, 1, False)
+    Cin, Cout = chans
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.1
+    dy = _mk((B, H // 2, W // 2, Cout), 4, dev)
+    dx = ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), 2, 1, False)
+    dx2 = ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), 2, 1, False)
     assert torch.equal(dx, dx2)
     lib.call("mmh_set_option", b"dgrad_s2_halo", 0)
     try:
-        dx0 = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 2, 1, False)
+        dx0 = ops.raw_conv_dgrad(dy, w, (B, H, W, Cin), 2, 1, False)
     finally:
         lib.call("mmh_set_option", b"dgrad_s2_halo", 1)
-    assert R.rel_l1(dx, dx0) < 1e-6, R.rel_l1(dx, dx0)
+    assert torch.equal(dx, dx0)
