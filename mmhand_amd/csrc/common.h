@@ -78,6 +78,12 @@ bool dgrad_s2_halo_ok(const mmh_conv_desc* d, int dx_cs, int act);
 int launch_dgrad_s2_halo(const mmh_conv_desc* d, const void* dy, const void* w, const void* bias, void* dx, int dx_cs,
                          int act, hipStream_t st);
 extern int g_dgrad_s2_halo, g_dgrad_s2_dbg;
+// fp32 wgrad of the 3x3 stride-2 convs as a stream down a column strip of dy (wgrad_s2.hip)
+bool wgrad_s2_strip_ok(const mmh_conv_desc* d);
+size_t wgrad_s2_strip_ws_bytes(const mmh_conv_desc* d);
+int launch_wgrad_s2_strip(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws, size_t ws_bytes,
+                          int accumulate, hipStream_t st);
+extern int g_wgrad_s2_strip;
 extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;

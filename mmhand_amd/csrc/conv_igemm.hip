@@ -3106,13 +3106,15 @@ int launch_wgrad_grid_t(const WgradKP& p, dim3 grid, hipStream_t st) {
 size_t wgrad_ws(const mmh_conv_desc* d) {
     const int Mrows = d->kh * d->kw * d->Cin;
     const int P = d->B * d->Ho * d->Wo;
-    return (size_t)wgrad_splits(Mrows, d->Cout, P) * Mrows * d->Cout * sizeof(float);
+    const size_t generic = (size_t)wgrad_splits(Mrows, d->Cout, P) * Mrows * d->Cout * sizeof(float);
+    return mmh::wgrad_s2_strip_ok(d) ? std::max(generic, mmh::wgrad_s2_strip_ws_bytes(d)) : generic;
 }
 
 int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws,
              size_t ws_bytes, int accumulate, hipStream_t st, bool x16 = false, bool dy16 = false) {
     MMH_REQUIRE(!(x16 || dy16) || is16(d->dtype), "wgrad: 16-bit operands need a 16-bit dtype");
     MMH_REQUIRE(x16 == dy16, "wgrad: io16 must be 0 (both tensors fp32) or 3 (both 16-bit)");
+    if (!x16 && mmh::wgrad_s2_strip_ok(d)) return mmh::launch_wgrad_s2_strip(d, x, dy, dw, ws, ws_bytes, accumulate, st);
     WgradKP p{};
     p.g = fwd_gather(d, x);
     p.g.chunk_major = 0;
@@ -3181,6 +3183,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
+    if (!strcmp(key, "wgrad_s2_strip")) { mmh::g_wgrad_s2_strip = value; return 0; }
     if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
     if (!strcmp(key, "lp16_dbg")) { mmh::g_lp16_dbg = value; return 0; }
     if (!strcmp(key, "lp16_wgrad_ring")) { mmh::g_lp16_wgrad_ring = value; return 0; }
