@@ -84,6 +84,9 @@ size_t wgrad_s2_strip_ws_bytes(const mmh_conv_desc* d);
 int launch_wgrad_s2_strip(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws, size_t ws_bytes,
                           int accumulate, hipStream_t st);
 extern int g_wgrad_s2_strip;
+// dw[b][i] (+)= sum over a batch's split-K slabs, fixed order (slab_reduce.hip)
+int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
+extern int g_slab_reduce_par;
 extern int g_wino6_vec;
 extern int g_lp16_shape;
 extern int g_lp16_tap_inner;

@@ -2160,26 +2160,6 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_gemm_bf16_kernel(const Wino
     }
 }
 
-// dw[i] (+)= sum_z slab[z][i], fixed order -> deterministic.
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                   int64_t n4_total, int splits, int accumulate, int64_t n4) {
-    // n4 = float4 elements per batch; batch b's slabs are [b*splits .. b*splits+splits)
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n4_total; i += stride) {
-        const int64_t b = i / n4, r = i - b * n4;
-        const float4* base = reinterpret_cast<const float4*>(slab) + b * splits * n4 + r;
-        float4 s = base[0];
-        for (int z = 1; z < splits; ++z) {
-            float4 t = base[(int64_t)z * n4];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        float4* o = reinterpret_cast<float4*>(dw) + i;
-        if (accumulate) { float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-        *o = s;
-    }
-}
-
 // Transpose of ReflectionPad2d: every real pixel sums the padded positions that mirror onto it.
 __global__ void reflect_fold_kernel(const float* __restrict__ dxp, float* __restrict__ dx, int B,
                                     int H, int W, int C4, int p) {
@@ -3149,10 +3129,7 @@ int do_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, vo
     else rc = launch_wgrad_t<32, 4, 1, false>(p, splits, st);
     if (rc) return rc;
     const int64_t n4 = (int64_t)p.Mrows * p.N / 4;
-    int blocks = (int)std::min<int64_t>(mmh::cdiv(n4, 256), 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab,
-                       static_cast<float*>(dw), n4, splits, accumulate, n4);
-    return mmh::check_launch("slab_reduce_kernel");
+    return mmh::launch_slab_reduce(p.slab, static_cast<float*>(dw), n4, splits, accumulate, n4, st);
 }
 
 }  // namespace
@@ -3184,6 +3161,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
     if (!strcmp(key, "wgrad_s2_strip")) { mmh::g_wgrad_s2_strip = value; return 0; }
+    if (!strcmp(key, "slab_reduce_par")) { mmh::g_slab_reduce_par = value; return 0; }
     if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
     if (!strcmp(key, "lp16_dbg")) { mmh::g_lp16_dbg = value; return 0; }
     if (!strcmp(key, "lp16_wgrad_ring")) { mmh::g_lp16_wgrad_ring = value; return 0; }
@@ -3484,9 +3462,7 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
         else hipLaunchKernelGGL(wino_wgrad_gemm_bf16_kernel<false>, dim3(8 * q.nb), dim3(256), lds, st, q);
         if (int rc = mmh::check_launch("wino_wgrad_gemm_bf16_kernel")) return rc;
         const int64_t n4 = (int64_t)Cin * Cout / 4;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
-                           dim3(256), 0, st, q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4);
-        return mmh::check_launch("wino wgrad gemm (bf16)");
+        return mmh::launch_slab_reduce(q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4, st);
     }
     if (g_wino_wgrad_v2 && Cin % BM == 0 && Cout % 128 == 0) {
         WinoWgradKP q{};
@@ -3512,9 +3488,7 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
         }
         if (int rc = mmh::check_launch("wino_wgrad_gemm_kernel")) return rc;
         const int64_t n4 = (int64_t)Cin * Cout / 4;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
-                           dim3(256), 0, st, q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4);
-        return mmh::check_launch("wino wgrad gemm");
+        return mmh::launch_slab_reduce(q.slab, static_cast<float*>(dU), nbatch * n4, q.S, 0, n4, st);
     }
     WgradKP p{};
     Gather& g = p.g;
@@ -3544,9 +3518,7 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
     else rc = launch_wgrad_grid_t<32, 4, 1>(p, grid, st);
     if (rc) return rc;
     const int64_t n4 = (int64_t)Cin * Cout / 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(nbatch * n4, 256), 4096)),
-                       dim3(256), 0, st, p.slab, static_cast<float*>(dU), nbatch * n4, splits, 0, n4);
-    return mmh::check_launch("wino wgrad gemm");
+    return mmh::launch_slab_reduce(p.slab, static_cast<float*>(dU), nbatch * n4, splits, 0, n4, st);
 }
 
 int mmh_wino_dw(const void* dU, int Cin, int Cout, int tile, void* dw, int accumulate, mmh_stream_t s) {

@@ -167,20 +167,6 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const StemWgKP p) {
         }
 }
 
-// dw[7][run][64] (+)= sum over splits, fixed order
-__global__ void stem_slab_reduce_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int n4, int splits,
-                                        int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    float4 s = slab[i];
-    for (int z = 1; z < splits; ++z) {
-        const float4 t = slab[(long long)z * n4 + i];
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-    }
-    if (accumulate) { const float4 t = dw[i]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-    dw[i] = s;
-}
-
 // filter rows per workgroup: as many as fit RBMAX row blocks (44 ch: 1, 24 ch: 2, 8 ch and fewer: 7)
 int stem_khg(int Cin) {
     int k = (RBMAX * 32) / (7 * Cin);
@@ -258,9 +244,7 @@ int mmh_conv7_stem_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, 
 #undef MMH_STEM
     if (int rc = mmh::check_launch("stem_wgrad_kernel")) return rc;
     const int n4 = 49 * Cin * 64 / 4;
-    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(p.slab), static_cast<float4*>(dw), n4, splits, accumulate);
-    return mmh::check_launch("stem_slab_reduce_kernel");
+    return mmh::launch_slab_reduce(p.slab, static_cast<float*>(dw), n4, splits, accumulate, n4, st);
 }
 
 }  // extern "C"

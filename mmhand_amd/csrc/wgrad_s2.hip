@@ -12,7 +12,8 @@
 // strip.  The contraction runs over positions, two per v_mfma_f32_32x32x2_f32: the x operand of lane (ci, k) is ONE float
 // at [pixel 2 (2 ks + k) + kw][ci] - lanes along ci read 128 contiguous bytes, no swizzle, no transposed staging - and
 // one dy read serves the nine taps: 10 ds_read_b32 (immediate offsets) and 9 independent MFMAs per k-step, 8 k-steps and
-// one barrier per row.  Each work-group writes its block of dw once, into its slab; a fixed-order reduction sums the slabs.
+// one barrier per row.  Each work-group writes its block of dw once, into its slab; a fixed-order reduction sums the slabs
+// (slab_reduce.hip).
 #include <algorithm>
 #include "common.h"
 
@@ -147,45 +148,6 @@ __global__ void __launch_bounds__(NT, 1) wgrad_s2_kernel(const WgradS2KP p) {
             sl[(size_t)(tp * p.Cin + (i & 3) + 8 * (i >> 2)) * p.Cout] = acc[tp][i];
 }
 
-// dw[i] (+)= sum_z slab[z][i] in a fixed order: 64 float4 columns x 8 groups of slabs per work-group (group g sums slabs
-// g, g + 8, ... with four loads in flight), then the eight partial sums in order
-constexpr int RZ = 8;
-__global__ void __launch_bounds__(64 * RZ) wgrad_s2_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                  int64_t n4, int Z, int accumulate) {
-    __shared__ float4 part[RZ][64];
-    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + col;
-    float4 s[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4) {
-        const float4* base = reinterpret_cast<const float4*>(slab) + i;
-        int zz = g;
-        for (; zz + 3 * RZ < Z; zz += 4 * RZ) {
-            float4 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = base[(int64_t)(zz + u * RZ) * n4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s[u].x += t[u].x; s[u].y += t[u].y; s[u].z += t[u].z; s[u].w += t[u].w; }
-        }
-        for (; zz < Z; zz += RZ) {
-            const float4 t = base[(int64_t)zz * n4];
-            s[0].x += t.x; s[0].y += t.y; s[0].z += t.z; s[0].w += t.w;
-        }
-    }
-    part[g][col] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
-                               (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
-    __syncthreads();
-    if (g == 0 && i < n4) {
-        float4 r = part[0][col];
-#pragma unroll
-        for (int q = 1; q < RZ; ++q) { const float4 t = part[q][col]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
-        float4* o = reinterpret_cast<float4*>(dw) + i;
-        if (accumulate) { const float4 t = *o; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
-        *o = r;
-    }
-}
-
 struct Plan { int strips, rowsplit, rows_per, Z; };
 Plan plan(const mmh_conv_desc* d) {
     Plan pl;
@@ -237,9 +199,7 @@ int launch_wgrad_s2_strip(const mmh_conv_desc* d, const void* x, const void* dy,
     hipLaunchKernelGGL(wgrad_s2_kernel, dim3(p.blocks), dim3(NT), LDS_B, st, p);
     if (int rc = check_launch("wgrad_s2_kernel")) return rc;
     const int64_t n4 = (int64_t)9 * d->Cin * d->Cout / 4;
-    hipLaunchKernelGGL(wgrad_s2_reduce_kernel, dim3((unsigned)cdiv(n4, 64)), dim3(64 * RZ), 0, st, p.slab,
-                       static_cast<float*>(dw), n4, pl.Z, accumulate);
-    return check_launch("wgrad_s2_reduce_kernel");
+    return launch_slab_reduce(p.slab, static_cast<float*>(dw), n4, pl.Z, accumulate, n4, st);
 }
 
 }  // namespace mmh
