@@ -210,18 +210,33 @@ __global__ void __launch_bounds__(512, 2) wgrad_stem_kernel(const StemWgKP p) {
     }
 }
 
-// dw[kh][kw][c][n] (+)= sum over splits of slab[s][kh][kw * C8 + c][n], c < Cin: fixed order
-__global__ void stem_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int JP, int C8,
-                                        int Cin, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over 49 * Cin * 64
-    if (i >= 49 * Cin * 64) return;
-    const int n = i & 63, t = i >> 6;
+// dw[kh][kw][c][n] (+)= sum over splits of slab[s][kh][kw * C8 + c][n], c < Cin: fixed order (slab group g of 8 sums slabs
+// g, g + 8, ...; then the eight partial sums in order)
+__global__ void __launch_bounds__(512) stem_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                                               int JP, int C8, int Cin, int accumulate) {
+    __shared__ float part[8][64];
+    const int n = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x;                                   // over 49 * Cin
     const int c = t % Cin, tap = t / Cin;
     const int kh = tap / 7, kw = tap - kh * 7;
-    const size_t o = ((size_t)kh * JP + kw * C8 + c) * 64 + n;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += slab[(size_t)s * 7 * JP * 64 + o];
-    dw[i] = accumulate ? dw[i] + a : a;
+    const size_t o = ((size_t)kh * JP + kw * C8 + c) * 64 + n, ss = (size_t)7 * JP * 64;
+    float a0 = 0.f, a1 = 0.f;
+    int s = g;
+    for (; s + 8 < S; s += 16) {
+        const float u = slab[(size_t)s * ss + o], v = slab[(size_t)(s + 8) * ss + o];
+        a0 += u;
+        a1 += v;
+    }
+    if (s < S) a0 += slab[(size_t)s * ss + o];
+    part[g][n] = a0 + a1;
+    __syncthreads();
+    if (g == 0) {
+        float a = part[0][n];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) a += part[q][n];
+        const int i = t * 64 + n;
+        dw[i] = accumulate ? dw[i] + a : a;
+    }
 }
 
 struct Plan { int Jt, JP, KG, S, bps, nblk, TR, TC, rp, xstage, tstage; };
@@ -288,8 +303,7 @@ int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const 
     const int per_xcd = (q.S * q.KG + 7) / 8;
     if (d->dtype == MMH_FP16) hipLaunchKernelGGL(wgrad_stem_kernel<true>, dim3(8 * per_xcd), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(wgrad_stem_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, st, p);
-    const int n = 49 * d->Cin * 64;
-    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws),
+    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3(49 * d->Cin), dim3(512), 0, st, static_cast<const float*>(ws),
                        static_cast<float*>(dw), q.S, q.JP, C8, d->Cin, accumulate);
     return mmh::check_launch("wgrad_stem_kernel");
 }
