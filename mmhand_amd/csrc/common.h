@@ -84,6 +84,12 @@ size_t wgrad_s2_strip_ws_bytes(const mmh_conv_desc* d);
 int launch_wgrad_s2_strip(const mmh_conv_desc* d, const void* x, const void* dy, void* dw, void* ws, size_t ws_bytes,
                           int accumulate, hipStream_t st);
 extern int g_wgrad_s2_strip;
+// fp32 fprop of the 7x7 stems from an LDS-resident input halo (conv_stem_f32.hip)
+bool stem_f32_ok(const mmh_conv_desc* d);
+int stem_f32_stats_chunks(const mmh_conv_desc* d);
+int launch_stem_f32(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y, int act, float* stats,
+                    hipStream_t st);
+extern int g_stem_f32, g_stem_f32_dbg;
 // dw[b][i] (+)= sum over a batch's split-K slabs, fixed order (slab_reduce.hip)
 int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
 extern int g_slab_reduce_par;

@@ -2352,6 +2352,7 @@ Gather fwd_gather(const mmh_conv_desc* d, const void* x) {
 // partial rows the fp32 direct fprop writes when asked for output statistics: (M / 128) row tiles x wave rows of the
 // kernel launch_conv picks for this N; 0 = not available (ragged row tiles, 16-bit, tall tiles)
 int fprop_stats_chunks(const mmh_conv_desc* d) {
+    if (mmh::stem_f32_ok(d)) return mmh::stem_f32_stats_chunks(d);
     const long long M = (long long)d->B * d->Ho * d->Wo;
     if (is16(d->dtype) || M % BM != 0 || d->Cout % 4 != 0) return 0;
     const int waves_m = d->Cout > 32 ? 2 : 4;
@@ -2360,6 +2361,8 @@ int fprop_stats_chunks(const mmh_conv_desc* d) {
 
 int do_fprop(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y,
              int act, hipStream_t st, float* stats = nullptr) {
+    if (mmh::stem_f32_ok(d) && (!stats || mmh::stem_f32_stats_chunks(d) > 0))
+        return mmh::launch_stem_f32(d, x, w, bias, y, act, stats, st);
     ConvKP p{};
     p.stats = stats;
     p.g = fwd_gather(d, x);
@@ -3161,6 +3164,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
     if (!strcmp(key, "wgrad_s2_strip")) { mmh::g_wgrad_s2_strip = value; return 0; }
+    if (!strcmp(key, "stem_f32")) { mmh::g_stem_f32 = value; return 0; }
+    if (!strcmp(key, "stem_f32_dbg")) { mmh::g_stem_f32_dbg = value; return 0; }
     if (!strcmp(key, "slab_reduce_par")) { mmh::g_slab_reduce_par = value; return 0; }
     if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
     if (!strcmp(key, "lp16_dbg")) { mmh::g_lp16_dbg = value; return 0; }

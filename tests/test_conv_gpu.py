@@ -1020,3 +1020,40 @@ def test_wgrad_s2_strip(case, dev):
     assert R.rel_l1(dw, dw0) < 2e-6, R.rel_l1(dw, dw0)
     assert not torch.equal(dw, dw0) or B * H * W <= 8           # a different kernel did run (order of summation differs)
     assert torch.equal(dw, ops.raw_conv_wgrad(x, dy, 3, 2, 1, False))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 24, True), (1, 20, 24, 44, True), (2, 9, 37, 8, True), (1, 24, 32, 48, False),
+                                  (1, 8, 16, 4, True), (3, 32, 48, 12, False), (1, 32, 32, 44, True), (1, 48, 16, 48, True)])
+def test_conv_stem_f32(case, dev):
+    """fp32 fprop of the 7x7 stems from the LDS-resident halo (conv_stem_f32.hip): whole and ragged 16 x 16 tiles, reflect and
+    zero padding, one to four filter phases per filter row, double- and single-buffered halos, bias + ReLU - against the fp64
+    oracle and the generic implicit-GEMM kernel; its statistics partials (where the tiles are whole) against a pass over y."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((7, 7, Cin, 64), 2, dev) * 0.05
+    bias = _mk((64,), 3, dev)
+    y = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, 0)
+    yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), 1, 3, refl, 0)
+    assert R.rel_l1(y, yr) < TOL, R.rel_l1(y, yr)
+    y_relu = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, 1)
+    assert torch.equal(y_relu, torch.relu(y))
+    y_nb = ops.raw_conv_fprop(x, w, None, 1, 3, refl, 0)
+    lib.call("mmh_set_option", b"stem_f32", 0)
+    try:
+        y0 = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, 0)
+    finally:
+        lib.call("mmh_set_option", b"stem_f32", 1)
+    assert R.rel_l1(y, y0) < 2e-6 and R.rel_l1(y_nb + bias, y0) < 2e-6
+    import ctypes
+    if lib.load().mmh_conv2d_fprop_stats_chunks(ctypes.byref(ops.conv_desc(B, H, W, Cin, 64, 7, 1, 3, refl))) > 0:      # whole tiles
+        ops._pending_stats.clear()
+        y2 = ops.raw_conv_fprop(x, w, bias, 1, 3, refl, want_stats=True)
+        assert torch.equal(y2, y)
+        fast = ops.raw_norm_stats_finalize_pending(y2, B)
+        assert fast is not None
+        mean, _, _, invstd, rows = fast
+        yd = y2.double().reshape(B, -1, 64)
+        assert rows == H * W
+        assert torch.allclose(mean.double(), yd.mean(1), atol=2e-6)
+        assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + ops.EPS), rtol=2e-5)
