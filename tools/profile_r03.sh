@@ -14,6 +14,12 @@ python tools/ab_lp16_wgrad.py > $O/ab_lp16_wgrad.txt 2>&1
 python tools/bench_conv7_n4.py > $O/bench_conv7_n4.txt 2>&1
 python tools/bench_stem_wgrad.py > $O/bench_stem_wgrad.txt 2>&1
 python tools/bench_stem_fprop.py > $O/bench_stem_fprop.txt 2>&1
+python tools/bench_dgrad_s2.py > $O/bench_dgrad_s2.txt 2>&1
+python tools/ablate_dgrad_s2.py > $O/ablate_dgrad_s2.txt 2>&1
+python tools/bench_wgrad_s2.py > $O/bench_wgrad_s2.txt 2>&1
+python tools/bench_stem_f32.py > $O/bench_stem_f32.txt 2>&1
+CIN=44 python tools/ablate_stem_f32.py > $O/ablate_stem_f32.txt 2>&1
+python tools/probes/wino_grad_split.py > $O/wino_grad_split.txt 2>&1
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_f32_line.log 2>&1
