@@ -154,6 +154,13 @@ int mmh_wino_input_dy(const void* dy, int B, int H, int W, int C, int tile, int 
                       void* Yh, int fold, mmh_stream_t s);
 int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
                   int nbatch, int dtype, mmh_stream_t s);
+/* The fp32 GEMMs with the summation chosen per call: levels = 2 folds every 32-deep k-step's chain into the
+ * totals (the default of mmh_wino_gemm for 64 planes: the F(6x6,3x3) output transform amplifies the rounding of
+ * one k-ordered chain), levels = 1 is one chain (5-6 % faster).  The package runs the FORWARD GEMMs with 2 and
+ * the dgrad GEMMs with 1: a forward difference of 7e-6 flips ReLU masks and moves the parameter gradients of
+ * this network by 3e-3, a backward one cannot (profiles/r03_wino_grad_split.txt: Winograd dgrad alone 6e-6).  */
+int mmh_wino_gemm_levels(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
+                         int nbatch, int levels, mmh_stream_t s);
 /* stats (tile 6, fp32; may be NULL): [B][tiles per image][3][C] floats = per (image, tile, channel)
  * the count, mean and M2 of the tile's outputs - the partial-statistics layout that
  * mmh_norm_stats_merge reduces, so the InstanceNorm after the conv does not re-read y.

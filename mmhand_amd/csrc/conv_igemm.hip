@@ -2964,7 +2964,7 @@ static int launch_wino_gemm_t(const WinoGemmKP& p, hipStream_t st) {
 }
 
 static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st,
-                        int nbatch) {
+                        int nbatch, int levels) {
     WinoGemmKP p{};
     p.A = V; p.B = U; p.C = Mo;
     p.M = (int)tiles; p.K = K; p.N = N; p.P = nbatch;
@@ -2973,7 +2973,7 @@ static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long til
     p.NT = (N + bn - 1) / bn;
     p.W = nbatch * p.MT * p.NT;
     p.Wx = (p.W + 7) / 8;
-    const bool two = g_wino_gemm_levels == 2 && nbatch == 64 && K > WINO_FOLD * BK;   // nothing to fold below 2 blocks
+    const bool two = (levels ? levels : g_wino_gemm_levels) == 2 && nbatch == 64 && K > WINO_FOLD * BK;   // nothing to fold below 2 blocks
     p.nb = std::min(p.Wx, 32 * g_wino_gemm_occ);       // 32 CUs per XCD
     if (two) return bn == 128 ? launch_wino_gemm_t<128, 2>(p, st) : launch_wino_gemm_t<64, 2>(p, st);
     return bn == 128 ? launch_wino_gemm_t<128, 1>(p, st) : launch_wino_gemm_t<64, 1>(p, st);
@@ -2981,9 +2981,9 @@ static int wino_gemm_v2(const float* V, const float* U, float* Mo, long long til
 
 // 16 x ( [tiles x K] . [K x N] ): V [16][tiles][K], U [16][K][N] -> M [16][tiles][N]
 int wino_gemm(const float* V, const float* U, float* Mo, long long tiles, int K, int N, hipStream_t st,
-              int nbatch = 16) {
+              int nbatch = 16, int levels = 0) {
     MMH_REQUIRE(tiles * (long long)std::max(K, N) < (1ll << 30), "winograd: tensor too large");
-    if (g_wino_gemm_v2 && K % BK == 0 && N >= 64 && N % 32 == 0) return wino_gemm_v2(V, U, Mo, tiles, K, N, st, nbatch);
+    if (g_wino_gemm_v2 && K % BK == 0 && N >= 64 && N % 32 == 0) return wino_gemm_v2(V, U, Mo, tiles, K, N, st, nbatch, levels);
     BatchKP bp{};
     ConvKP& p = bp.p;
     Gather& g = p.g;
@@ -3387,6 +3387,14 @@ int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, i
     if (is16(dtype)) return wino_gemm_bf16(V, U, M, tiles, K, N, nbatch, dtype == MMH_FP16, mmh::as_stream(s));
     return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles,
                      K, N, mmh::as_stream(s), nbatch);
+}
+
+int mmh_wino_gemm_levels(const void* V, const void* U, void* M, int64_t tiles, int K, int N, int nbatch, int levels,
+                         mmh_stream_t s) {
+    MMH_REQUIRE(V && U && M && tiles > 0 && K % 32 == 0 && N % 4 == 0 && nbatch > 0 && (levels == 1 || levels == 2),
+                "mmh_wino_gemm_levels: bad arguments (fp32; levels 1 | 2)");
+    return wino_gemm(static_cast<const float*>(V), static_cast<const float*>(U), static_cast<float*>(M), tiles, K, N,
+                     mmh::as_stream(s), nbatch, levels);
 }
 
 int mmh_wino_output(const void* M, void* y, const void* bias, int B, int H, int W, int C, int act, int tile,

@@ -254,6 +254,11 @@ def wino_weights(w, tile, flip_transpose=False, bf16=False):
 # folds onto share one 6x6 tile - the output transform adds them in registers.  Replaces the eight
 # border GEMMs + border_add per conv (16 ms of a 303 ms step).  MMH_WINO_FOLD=0: border-GEMM path.
 USE_WINO_FOLD = os.environ.get("MMH_WINO_FOLD", "1") != "0"
+# Summation of the fp32 Winograd dgrad GEMMs: 1 = one k-ordered chain (5-6 % faster), 2 = the two-level sum of the forward
+# GEMMs, 0 = the library default.  The two-level sum exists because a forward rounding difference flips ReLU masks and moves
+# this network's gradients by 3e-3; a rounding difference in a BACKWARD GEMM stays what it is (Winograd dgrad alone against
+# the direct kernels: 6e-6 with two levels, profiles/r03_wino_grad_split.txt).
+WINO_DGRAD_LEVELS = int(os.environ.get("MMH_WINO_DGRAD_LEVELS", "1"))
 
 
 def _fold_ok(H, W_):
@@ -283,7 +288,7 @@ def _park_stats(y, stats):
 
 
 def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False,
-               fold=False, pro=None):
+               fold=False, pro=None, levels=0):
     """input transform -> P batched GEMMs (one launch) -> output transform (+bias, activation).
     keep_V also returns the transformed input (the wgrad pass contracts exactly this tensor).
     bf16: V, U, M are bf16 (tile 2), the GEMMs run on the bf16 MFMA; x, y stay fp32.
@@ -312,7 +317,10 @@ def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False
         L.call("mmh_wino_input", _ptr(x), B, H, W_, Cin, 2 if fold else int(bool(reflect)), tile, dt, _ptr(V), _stream())
     if timed:
         e0.record()
-    L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
+    if levels and not bf16:
+        L.call("mmh_wino_gemm_levels", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, levels, _stream())
+    else:
+        L.call("mmh_wino_gemm", _ptr(V), _ptr(U), _ptr(M), tiles, Cin, Cout, P, dt, _stream())
     if timed:
         e1.record()
     _count("mfma", 2.0 * P * tiles * Cin * Cout)
@@ -348,8 +356,9 @@ def raw_conv_dgrad_wino(dy, w, x_shape, reflect, tile=4, bf16=False):
     B, H, W_, Cin = x_shape
     Cout = w.shape[3]
     if reflect and tile == 6 and not bf16 and _fold_ok(H, W_):
-        return _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, fold=True)
-    dx = _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, bf16=bf16)
+        return _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, fold=True,
+                          levels=WINO_DGRAD_LEVELS)
+    dx = _wino_conv(dy, wino_weights(w, tile, True, bf16), None, Cin, False, L.ACT_NONE, tile, bf16=bf16, levels=WINO_DGRAD_LEVELS)
     if reflect:
         d = conv_desc(B, H, W_, Cin, Cout, 3, 1, 1, True)
         wb = w
@@ -420,7 +429,11 @@ def raw_conv_bwd_wino6(dy, w, x_shape, reflect, V, dw_out=None, nbd=None):
     # dgrad: correlation with the flipped filter; reflect padding: folded in the output transform
     # (padded-domain tiles) or, where the size does not allow it, the eight border GEMMs
     M = _empty((P, tiles, Cin), dy)
-    L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
+    if WINO_DGRAD_LEVELS:
+        L.call("mmh_wino_gemm_levels", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, WINO_DGRAD_LEVELS,
+               _stream())
+    else:
+        L.call("mmh_wino_gemm", _ptr(Vd), _ptr(wino_weights(w, tile, True)), _ptr(M), tiles, Cout, Cin, P, L.F32, _stream())
     _count("mfma", 2.0 * 2 * P * tiles * Cin * Cout)       # this GEMM and the wgrad GEMM below
     dx = _empty((B, H, W_, Cin), dy)
     L.call("mmh_wino_output", _ptr(M), _ptr(dx), None, B, H, W_, Cin, L.ACT_NONE, tile, L.F32, None, int(fold),
