@@ -44,7 +44,7 @@ struct StemF32KP {
     const float* w;         // [7][7 Cin][64]
     const float* bias;
     float* y;               // [B][H][W][y_cs]
-    float* stats;           // [tiles * 4 MT][3][64] or null
+    float* stats;           // [tiles * 4][3][64] or null
     int B, H, W, Cin, x_cs, y_cs, reflect, act;
     int J;                  // 7 Cin
     int parts;              // phases per filter row
@@ -215,8 +215,13 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
                 if (oh < p.H && ow < p.W)
                     p.y[((size_t)(b * p.H + oh) * p.W + ow) * (size_t)p.y_cs + n] = act_of(acc[mt][i] + bv, p.act);
             }
-            if (p.stats) {
-                // (count, mean, M2) of these 32 pixels per channel: a lane holds 16 of them, lane ^ 32 the other 16
+        }
+        if (p.stats) {
+            // (count, mean, M2) of this wave's 32 MT pixels per channel: a lane holds 16 of each accumulator tile, lane ^ 32
+            // the other 16; Chan merges of equal counts
+            float mean_w = 0.f, m2_w = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sum += acc[mt][i] + bv;
@@ -229,12 +234,21 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
                 }
                 const float mean_o = __shfl_xor(mean_l, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
                 const float dm = mean_o - mean_l;
-                if (kg == 0) {
-                    float* o = p.stats + ((size_t)((tile * MT + mt) * 4 + pg) * 3) * 64 + n;
-                    o[0] = 32.f;
-                    o[64] = mean_l + 0.5f * dm;
-                    o[128] = m2 + m2_o + dm * dm * 8.f;
+                const float mean_t = mean_l + 0.5f * dm, m2_t = m2 + m2_o + dm * dm * 8.f;      // 32 pixels
+                if (mt == 0) {
+                    mean_w = mean_t;
+                    m2_w = m2_t;
+                } else {
+                    const float d2 = mean_t - mean_w;
+                    mean_w += 0.5f * d2;
+                    m2_w += m2_t + d2 * d2 * 16.f;                                              // 32 * 32 / 64
                 }
+            }
+            if (kg == 0) {
+                float* o = p.stats + ((size_t)(tile * 4 + pg) * 3) * 64 + n;
+                o[0] = 32.f * MT;
+                o[64] = mean_w;
+                o[128] = m2_w;
             }
         }
     }
@@ -284,12 +298,12 @@ bool stem_f32_ok(const mmh_conv_desc* d) {
     return g_stem_f32 && plan(d, q);
 }
 
-// partial rows written for mmh_conv2d_fprop_stats: one per wave row group of a full 8 x 16 tile (32 pixels); 0 = ragged tiles
+// partial rows written for mmh_conv2d_fprop_stats: one per wave row group of a full tile (32 or 64 pixels); 0 = ragged tiles
 int stem_f32_stats_chunks(const mmh_conv_desc* d) {
     Plan q;
     if (!plan(d, q)) return 0;
     const int tr = 8 * q.mt;
-    return (d->H % tr == 0 && d->W % TC == 0) ? d->B * (d->H / tr) * (d->W / TC) * q.mt * 4 : 0;
+    return (d->H % tr == 0 && d->W % TC == 0) ? d->B * (d->H / tr) * (d->W / TC) * 4 : 0;
 }
 
 int launch_stem_f32(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y, int act, float* stats,
