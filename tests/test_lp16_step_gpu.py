@@ -172,3 +172,64 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
     assert a[3] == b[3], (a[3], b[3])
     for x, y in zip(a[:3], b[:3]):
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
+
+
+def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(dev, monkeypatch):
+    """The same problem in fp32 (--opt_level O0), so that the round-3 fp32 kernels sit under a step-level oracle test at the
+    channel counts they are built for: the halo-resident stem fprop (conv_stem_f32.hip: 8 / 24 / 44 -> 64), the stride-2
+    dgrad and wgrad (dgrad_s2.hip / wgrad_s2.hip: 64 -> 128 and 128 -> 256; mmh_dgrad_s2_halo_supported asserted for the
+    step's shapes), the ConvTranspose2d forward on dgrad_s2, the F(6x6,3x3) stack with the forward GEMMs on two summation
+    levels and the dgrad GEMMs on one (mmh_wino_gemm_levels).  Two free-running iterations: the six losses <= 1e-3, the
+    generated image of iteration 1 <= 2e-5, the Generator's parameter gradients per tensor <= 2e-3 and median <= 1e-3
+    relative L1 against fp64 (VERDICT r2 #4's bounds; measured: image 2.7e-6, median 3.5e-4, max 4.8e-4).
+    tests/test_winograd_step_gpu.py's ngf = 32 keeps the stem and 128 -> 256 kernels idle."""
+    import ctypes
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    from tests.golden.make_lp16_cond import SEED, nets
+    calls = Counter()
+    real = lib.call
+
+    def spy(name, *a):
+        calls[name] += 1
+        return real(name, *a)
+    monkeypatch.setattr(lib, "call", spy)
+    model = MMHandModel(_opt("O0"))
+    assert not model.bf16
+    for net, sd in zip((model.netG, model.netD_PB, model.netD_PP, model.vgg), nets()):
+        net.load_state_dict(sd)
+    sds = [OrderedDict((k, v.cpu()) for k, v in n.state_dict().items())
+           for n in (model.netG, model.netD_PB, model.netD_PP)]
+    vgg = OrderedDict((k, v.cpu()) for k, v in model.vgg.state_dict().items())
+    f64 = lambda sd: OrderedDict((k, v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items())  # noqa: E731
+    o64 = O.StepOracle(f64(sds[0]), f64(sds[1]), f64(sds[2]), f64(vgg), "instance", False, False, NB, NLD, pool_size=2,
+                       rng=random.Random(49))
+    random.seed(49)
+    errs = []
+    for it in range(2):
+        batch = O.synthetic_batch(2, SIZE, SIZE, seed=SEED + it)
+        want = list(o64.step({k: v.double() for k, v in batch.items()}).values())
+        model.set_input(batch)
+        model.optimize_parameters()
+        got = [float(v) for v in model.get_current_errors().values()]
+        assert np.allclose(got, want, rtol=1e-3), (it, got, want)
+        if it == 0:
+            e_img = R.rel_l1(model.fake_p2, o64.fake_p2.detach())
+            assert e_img < 2e-5, e_img
+            gg = logical_grads(model.netG)
+            og = dict((k, t.grad) for k, t in o64.G.named_parameters())
+            for k, g in gg.items():
+                if RC.is_null_grad_bias("G", k, "instance") or og.get(k) is None:
+                    continue
+                errs.append((R.rel_l1(g.double(), og[k]), k))
+    errs.sort()
+    med = errs[len(errs) // 2][0]
+    print(f"\n[fp32, ngf 64] image {e_img:.2e}; G gradients vs fp64: median {med:.2e}, max {errs[-1][0]:.2e} ({errs[-1][1]})")
+    assert errs[-1][0] <= 2e-3 and med <= 1e-3, errs[-5:]
+    # the kernels this test is here for did run
+    dsc = lambda *a: ctypes.byref(ops.conv_desc(*a))     # noqa: E731
+    assert lib.load().mmh_dgrad_s2_halo_supported(dsc(2, SIZE, SIZE, 64, 128, 3, 2, 1, False), 64) == 1
+    assert lib.load().mmh_dgrad_s2_halo_supported(dsc(2, SIZE // 2, SIZE // 2, 128, 256, 3, 2, 1, False), 128) == 1
+    assert calls["mmh_conv2d_dgrad_folded"] + calls["mmh_conv2d_dgrad"] >= 2 * 6 and calls["mmh_convT2d_fprop"] >= 2 * 2, calls
+    assert calls["mmh_conv2d_wgrad"] >= 2 * 6 and calls["mmh_conv2d_fprop_stats"] >= 2 * 5, calls
+    assert calls["mmh_wino_gemm"] >= 2 * 6 * NB and calls["mmh_wino_gemm_levels"] >= 2 * 6 * NB, calls
