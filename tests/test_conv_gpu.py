@@ -1057,3 +1057,49 @@ def test_conv_stem_f32(case, dev):
         assert rows == H * W
         assert torch.allclose(mean.double(), yd.mean(1), atol=2e-6)
         assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(yd.var(1, unbiased=False) + ops.EPS), rtol=2e-5)
+
+
+def test_round3_fp32_kernels_on_channel_slices(dev):
+    """The round-3 fp32 kernels on tensors that are channel slices of wider buffers (pixel strides x_cs / y_cs / dx_cs larger
+    than the channel counts, as a concat buffer presents them), straight through the C-ABI: dgrad_s2 writing dx into the
+    second half of a 128-channel buffer, the ConvTranspose2d forward likewise, wgrad_s2 reading x and dy from slices, the
+    stem fprop reading a 24-channel slice and writing a 64-channel slice - each equal to the dense call."""
+    import ctypes as C
+    from mmhand_amd import lib as L, ops
+    P, st = ops._ptr, ops._stream
+    B, H, W = 2, 32, 48
+    w = _mk((3, 3, 64, 128), 2, dev) * 0.1
+    dy_wide = _mk((B, H // 2, W // 2, 160), 4, dev)
+    dy = dy_wide[..., 16:144]                                # 128 channels at pixel stride 160
+    dyc = dy.contiguous()
+    # dgrad into a slice
+    d = ops.conv_desc(B, H, W, 64, 128, 3, 2, 1, False)
+    dense = ops.raw_conv_dgrad(dyc, w, (B, H, W, 64), 2, 1, False)
+    wide = torch.full((B, H, W, 128), 7.0, device=dev)
+    assert L.load().mmh_dgrad_s2_halo_supported(C.byref(d), 128) == 1
+    L.call("mmh_conv2d_dgrad", C.byref(d), P(dyc), P(w), P(wide[..., 64:]), 128, st())
+    assert torch.equal(wide[..., 64:], dense) and bool((wide[..., :64] == 7.0).all())
+    # ConvTranspose2d forward into a slice, bias + ReLU
+    bias = _mk((64,), 3, dev)
+    dense_t = ops.raw_convT_fprop(dyc, w, bias, 1)
+    wide.fill_(7.0)
+    L.call("mmh_convT2d_fprop", C.byref(d), P(dyc), P(w), P(bias), P(wide[..., 64:]), 128, 1, st())
+    assert torch.equal(wide[..., 64:], dense_t) and bool((wide[..., :64] == 7.0).all())
+    # wgrad from slices of x and dy
+    x_wide = _mk((B, H, W, 96), 1, dev)
+    x = x_wide[..., 32:]
+    dense_w = ops.raw_conv_wgrad(x.contiguous(), dyc, 3, 2, 1, False)
+    ds = ops.conv_desc(B, H, W, 64, 128, 3, 2, 1, False, x_cs=96, y_cs=160)
+    ws = torch.empty(L.load().mmh_conv2d_wgrad_ws_bytes(C.byref(ds)) // 4 + 4, device=dev)
+    dw = torch.empty(3, 3, 64, 128, device=dev)
+    L.call("mmh_conv2d_wgrad", C.byref(ds), P(x), P(dy), P(dw), P(ws), ws.numel() * 4, 0, 0, st())
+    assert torch.equal(dw, dense_w)
+    # stem fprop from a 24-channel slice into a 64-channel slice
+    xs_wide = _mk((B, H, W, 40), 5, dev)
+    xs = xs_wide[..., 8:32]
+    w7 = _mk((7, 7, 24, 64), 6, dev) * 0.05
+    dense_y = ops.raw_conv_fprop(xs.contiguous(), w7, bias, 1, 3, True, 0)
+    d7 = ops.conv_desc(B, H, W, 24, 64, 7, 1, 3, True, x_cs=40, y_cs=128)
+    wide.fill_(7.0)
+    L.call("mmh_conv2d_fprop", C.byref(d7), P(xs), P(w7), P(bias), P(wide[..., :64]), 0, st())
+    assert torch.equal(wide[..., :64], dense_y) and bool((wide[..., 64:] == 7.0).all())
