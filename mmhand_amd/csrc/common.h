@@ -90,6 +90,12 @@ int stem_f32_stats_chunks(const mmh_conv_desc* d);
 int launch_stem_f32(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y, int act, float* stats,
                     hipStream_t st);
 extern int g_stem_f32, g_stem_f32_dbg;
+// fp32 Winograd-domain wgrad GEMMs as a three-stage LDS-DMA ring (wino_wgrad_dma.hip)
+bool wino_wgrad_dma_ok(int64_t tiles, int Cin, int Cout, int nbatch);
+size_t wino_wgrad_dma_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);
+int launch_wino_wgrad_dma(const float* V, const float* Yh, int64_t tiles, int Cin, int Cout, int nbatch, float* ws, float* dU,
+                          hipStream_t st);
+extern int g_wino_wgrad_dma;
 // dw[b][i] (+)= sum over a batch's split-K slabs, fixed order (slab_reduce.hip)
 int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
 extern int g_slab_reduce_par;

@@ -3165,6 +3165,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
     if (!strcmp(key, "wgrad_s2_strip")) { mmh::g_wgrad_s2_strip = value; return 0; }
     if (!strcmp(key, "stem_f32")) { mmh::g_stem_f32 = value; return 0; }
+    if (!strcmp(key, "wino_wgrad_dma")) { mmh::g_wino_wgrad_dma = value; return 0; }
     if (!strcmp(key, "stem_f32_dbg")) { mmh::g_stem_f32_dbg = value; return 0; }
     if (!strcmp(key, "slab_reduce_par")) { mmh::g_slab_reduce_par = value; return 0; }
     if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
@@ -3442,7 +3443,9 @@ static int wino_wgrad_splits(int Cin, int Cout, long long tiles, int nbatch) {
 
 size_t mmh_wino_wgrad_gemm_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch) {
     if (tiles <= 0 || Cin <= 0 || Cout <= 0 || nbatch <= 0) return 0;
-    return (size_t)nbatch * wino_wgrad_splits(Cin, Cout, tiles, nbatch) * Cin * Cout * sizeof(float);
+    const size_t generic = (size_t)nbatch * wino_wgrad_splits(Cin, Cout, tiles, nbatch) * Cin * Cout * sizeof(float);
+    return mmh::wino_wgrad_dma_ok(tiles, Cin, Cout, nbatch) ? std::max(generic, mmh::wino_wgrad_dma_ws_bytes(tiles, Cin, Cout, nbatch))
+                                                            : generic;
 }
 
 int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, int Cout, int nbatch, int dtype,
@@ -3454,6 +3457,9 @@ int mmh_wino_wgrad_gemm(const void* V, const void* Yh, int64_t tiles, int Cin, i
                 "mmh_wino_wgrad_gemm: workspace too small");
     MMH_REQUIRE(tiles * (long long)std::max(Cin, Cout) < (1ll << 30), "mmh_wino_wgrad_gemm: tensor too large");
     hipStream_t st = mmh::as_stream(s);
+    if (dtype == MMH_F32 && mmh::wino_wgrad_dma_ok(tiles, Cin, Cout, nbatch))
+        return mmh::launch_wino_wgrad_dma(static_cast<const float*>(V), static_cast<const float*>(Yh), tiles, Cin, Cout, nbatch,
+                                          static_cast<float*>(ws), static_cast<float*>(dU), st);
     const int splits = wino_wgrad_splits(Cin, Cout, tiles, nbatch);
     if (is16(dtype)) {
         MMH_REQUIRE(Cin % BM == 0 && Cout % 128 == 0, "mmh_wino_wgrad_gemm (bf16): needs Cin, Cout %% 128 == 0");

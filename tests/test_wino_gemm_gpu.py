@@ -39,11 +39,13 @@ WGRAD_SHAPES = [(36, 32, 128, 128), (36, 200, 128, 256), (16, 1000, 256, 128), (
                 (36, 37, 128, 128), (4, 8192, 512, 512), (36, 300, 64, 96)]
 
 
-@pytest.mark.parametrize("v2", [0, 1])
-@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+@pytest.mark.parametrize("v2", [0, 1, 2])
+@pytest.mark.parametrize("shape", WGRAD_SHAPES + [(64, 3872, 256, 256), (64, 105, 128, 512), (16, 64, 256, 256)])
 def test_wino_wgrad_gemm_matches_fp64_product(shape, v2):
     """dU[xi] = V[xi]^T . Yh[xi] (contraction over tiles, split-K + fixed-order slab reduction):
-    the persistent TN kernel (v2, channel counts % 128 == 0) and the generic wgrad kernel."""
+    the persistent TN kernel (v2 = 1, channel counts % 128 == 0), the generic wgrad kernel (0) and the LDS-DMA ring kernel
+    (2: wino_wgrad_dma.hip, Cin % 128 == 0, Cout % 256 == 0, >= 32 tiles; other shapes fall through to v2 = 1): whole and
+    ragged last stages, with and without a split tile range."""
     from mmhand_amd import lib
     P, T, Cin, Cout = shape
     dev = torch.device("cuda:0")
@@ -51,7 +53,8 @@ def test_wino_wgrad_gemm_matches_fp64_product(shape, v2):
     V = torch.randn(P, T, Cin, generator=g).to(dev)
     Y = torch.randn(P, T, Cout, generator=g).to(dev)
     L = lib.load()
-    lib.check(L.mmh_set_option(b"wino_wgrad_v2", v2), "mmh_set_option")
+    lib.check(L.mmh_set_option(b"wino_wgrad_v2", min(v2, 1)), "mmh_set_option")
+    lib.check(L.mmh_set_option(b"wino_wgrad_dma", int(v2 == 2)), "mmh_set_option")
     try:
         nws = L.mmh_wino_wgrad_gemm_ws_bytes(T, Cin, Cout, P)
         ws = torch.full((nws // 4 + 4,), float("nan"), device=dev)
