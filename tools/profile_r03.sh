@@ -20,6 +20,7 @@ python tools/bench_wgrad_s2.py > $O/bench_wgrad_s2.txt 2>&1
 python tools/bench_stem_f32.py > $O/bench_stem_f32.txt 2>&1
 CIN=44 python tools/ablate_stem_f32.py > $O/ablate_stem_f32.txt 2>&1
 python tools/probes/wino_grad_split.py > $O/wino_grad_split.txt 2>&1
+python tools/ab_wino_wgrad_dma.py > $O/ab_wino_wgrad_dma.txt 2>&1
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > $O/mfma_peak.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_f32_line.log 2>&1
