@@ -67,10 +67,11 @@ int mmh_version(void);
 /* Tuning knobs for A/B measurements inside one process: kernel variants ("lp16_shape" 16 | 17 |
  * 18 | 19 = the builds of the 16-bit 3x3 kernel, "lp16_wgrad_ring" 0 | 1 | 2, "conv_dbuf",
  * "wino_gemm_levels", ...) and work-list parameters ("wgrad_slots", "conv_xcd", ...): the results
- * stay within the kernels' documented tolerances.  Two keys are NOT such knobs: "conv_dbg" and
- * "lp16_dbg" switch parts of a kernel OFF for timing ablations (tools/ablate*.py,
- * tools/bench_lp16_fold.py) and make its results wrong; they default to 0 and nothing in
- * mmhand_amd/ sets them.  Unknown keys are an error.                                     */
+ * stay within the kernels' documented tolerances.  The "*_dbg" keys are NOT such knobs: "conv_dbg",
+ * "lp16_dbg" (bits 1-16), "dgrad_s2_dbg", "stem_f32_dbg" switch parts of a kernel OFF for timing
+ * ablations (tools/ablate*.py, tools/bench_lp16_fold.py) and make its results wrong ("lp16_dbg" bit 32 only
+ * moves the DMA issue of half the waves, results unchanged: tools/ab_lp16_stagger.py); they default to 0
+ * and nothing in mmhand_amd/ sets them.  Unknown keys are an error.                       */
 int mmh_set_option(const char* key, int value);
 
 /* ---- convolutions: nn.Conv2d / nn.ReflectionPad2d / nn.ConvTranspose2d ----

@@ -860,12 +860,19 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         if (t == 1 && kc + 1 < KC) __builtin_amdgcn_s_waitcnt(0x0070 | (HROUNDS2 - 1));
         else __builtin_amdgcn_s_waitcnt(0x0070);
         __syncthreads();
-        if (ks + 2 < nk && !(p.dbg & 1)) {      // dbg: timing-only ablations (mmh_set_option "lp16_dbg"; results wrong)
-            int kc3 = kc, t3 = t + 2;
-            if (t3 >= 9) { t3 -= 9; ++kc3; }
-            issue_w(kc3, t3);
-        }
-        if (t == 0 && kc + 1 < KC && !(p.dbg & 2)) issue_halo(kc + 1);
+        // The DMA of the next stages: a DMA instruction costs its wave 60-180 cycles of issue time, so the two waves of a SIMD
+        // (wr = 0 / 1) issue theirs at different points of half 1 - one wave's issue runs under the other's multiplies
+        // (wino_wgrad_dma.hip: 1045 -> 906 us from the same change; mmh_set_option("lp16_dbg") bit 32 = everybody here).
+        auto issue_next = [&]() {
+            if (ks + 2 < nk && !(p.dbg & 1)) {      // dbg: timing-only ablations (mmh_set_option "lp16_dbg"; results wrong)
+                int kc3 = kc, t3 = t + 2;
+                if (t3 >= 9) { t3 -= 9; ++kc3; }
+                issue_w(kc3, t3);
+            }
+            if (t == 0 && kc + 1 < KC && !(p.dbg & 2)) issue_halo(kc + 1);
+        };
+        const bool early = wr == 0 || (p.dbg & 32);
+        if (early) issue_next();
         if (FOLD && do_any) {     // the fold fragments of half 1
             axr = lds_frag((a_cur - f_dhb + f_rsel) ^ 64u);
             axc = lds_frag((baseT + f_st + f_dhb) ^ 64u);
@@ -876,13 +883,25 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = lds_frag(bb0n + j * (16 * ROWB));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b1[j], af[i], acc[i][j]);
             af[i] = lds_frag(a0n + i * (HP2 * ROWB));
         }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (!early) issue_next();
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16s<H16>(b1[j], af[i], acc[i][j]);
+            af[i] = lds_frag(a0n + i * (HP2 * ROWB));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
