@@ -162,6 +162,12 @@ int mmh_wino_gemm(const void* V, const void* U, void* M, int64_t tiles, int K, i
  * this network by 3e-3, a backward one cannot (profiles/r03_wino_grad_split.txt: Winograd dgrad alone 6e-6).  */
 int mmh_wino_gemm_levels(const void* V, const void* U, void* M, int64_t tiles, int K, int N,
                          int nbatch, int levels, mmh_stream_t s);
+/* The F(6x6,3x3) filter transform of MANY fp32 filters in one launch (after an optimizer step a network's 74
+ * transforms are 8-25 us launches that cannot fill the chip).  table: n rows of six int64 in device memory -
+ * {w pointer, U pointer, Cin, Cout, flip_transpose, first block} - entry e owning the 256-thread blocks
+ * [first block of e, first block of e + 1), ceil(Cin Cout / 256) of them; total_blocks their sum.  Each entry
+ * gets exactly what mmh_wino_weights(w, Cin, Cout, flip_transpose, 6, MMH_F32, U) writes.                  */
+int mmh_wino_weights_multi(const void* table, int n, int64_t total_blocks, mmh_stream_t s);
 /* stats (tile 6, fp32; may be NULL): [B][tiles per image][3][C] floats = per (image, tile, channel)
  * the count, mean and M2 of the tile's outputs - the partial-statistics layout that
  * mmh_norm_stats_merge reduces, so the InstanceNorm after the conv does not re-read y.

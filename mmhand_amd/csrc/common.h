@@ -54,6 +54,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 // Winograd F(6x6,3x3) transforms (wino6.hip); tiles = B * ceil(H/6) * ceil(W/6), 64 planes
 int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st);
+int wino6_weights_multi(const long long* table, int n, long long total_blocks, hipStream_t st);
 int wino6_input(const float* x, float* V, int B, int H, int W, int C, int reflect, int xcd, hipStream_t st);
 int wino6_output(const float* M, float* y, const float* bias, int B, int H, int W, int C, int act, float* stats,
                  int fold, hipStream_t st);

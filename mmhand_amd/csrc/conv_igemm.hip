@@ -3246,6 +3246,11 @@ int mmh_wino_weights(const void* w, int Cin, int Cout, int flip_transpose, int t
 // Reflect-fold dgrad (padded-domain tiles, in-tile fold): both ring partners must share a tile.
 static bool wino_fold_ok(int H, int W) { return H >= 6 && W >= 6 && (H + 1) % 6 >= 2 && (W + 1) % 6 >= 2; }
 
+int mmh_wino_weights_multi(const void* table, int n, int64_t total_blocks, mmh_stream_t s) {
+    MMH_REQUIRE(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "mmh_wino_weights_multi: bad arguments");
+    return mmh::wino6_weights_multi(static_cast<const long long*>(table), n, total_blocks, mmh::as_stream(s));
+}
+
 int mmh_wino_input(const void* x, int B, int H, int W, int C, int reflect, int tile, int dtype, void* V,
                    mmh_stream_t s) {
     MMH_REQUIRE(x && V && B > 0 && wino_tile_ok(tile) && wino_hw_ok(H, W, tile) && C % 4 == 0 &&

@@ -86,10 +86,9 @@ __device__ __forceinline__ void w6_gt(const T* u, T* w) {
     w[2] = (-2.f / 9.f) * s1 + (2.f / 45.f) * s2 + (8.f / 45.f) * s3 + u[7];
 }
 
-__global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
-                                     int flip_transpose) {
+__device__ __forceinline__ void wino6_weights_body(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                                   int flip_transpose, int i) {
     const int total = Cin * Cout;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     // thread -> (ci, co) with the OUTPUT's fastest index fastest: 64 coalesced plane stores per
     // thread (the 9 filter reads are the strided side when the output is transposed)
@@ -117,6 +116,26 @@ __global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restr
 #pragma unroll
         for (int b = 0; b < 8; ++b) U[(size_t)(a * 8 + b) * plane + o] = o8[b];
     }
+}
+
+__global__ void wino6_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                     int flip_transpose) {
+    wino6_weights_body(w, U, Cin, Cout, flip_transpose, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Many filters in one launch (a network's 3x3 filters after an optimizer step: 74 launches of 8-25 us each, every one
+// too small to fill the chip).  table[e] = {w, U, Cin, Cout, flip_transpose, first block}: entry e owns blocks
+// [first block of e, first block of e + 1) of 256 threads.
+__global__ void __launch_bounds__(256) wino6_weights_multi_kernel(const long long* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {                   // last entry whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* e = table + lo * 6;
+    wino6_weights_body(reinterpret_cast<const float*>(e[0]), reinterpret_cast<float*>(e[1]), (int)e[2], (int)e[3], (int)e[4],
+                       (int)(b - e[5]) * 256 + threadIdx.x);
 }
 
 __device__ __forceinline__ float zero_of(float) { return 0.f; }
@@ -638,6 +657,11 @@ int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpos
     hipLaunchKernelGGL(wino6_weights_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st, w, U, Cin, Cout,
                        flip_transpose);
     return check_launch("wino6_weights_kernel");
+}
+
+int wino6_weights_multi(const long long* table, int n, long long total_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(wino6_weights_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, table, n);
+    return check_launch("wino6_weights_multi_kernel");
 }
 
 int g_wino6_vec = 0x0;   // bit 0 / 1 / 2: input / output / dy transform works on 2 channels per thread

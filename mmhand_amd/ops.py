@@ -99,10 +99,16 @@ def bump_weights_epoch(within=None):
         for c in _DERIVED_CACHES():
             for k in [k for k in c if lo <= k[0] < hi]:
                 del c[k]
+        if USE_WINO_BATCH:
+            b = _wino_batches.get((lo, hi))
+            if b is None:
+                b = _wino_batches[(lo, hi)] = _WinoBatch(lo, hi)
+            b.stale = True
         return
     _weights_epoch[0] += 1
     for c in _DERIVED_CACHES():
         c.clear()
+    _wino_batches.clear()        # load_state_dict / a new model: the batches learn their filters again
 
 
 def derived_weights_snapshot():
@@ -239,6 +245,11 @@ def wino_weights(w, tile, flip_transpose=False, bf16=False):
     U = _cache_get(_wino_cache, key, w)
     if U is None:
         _, _, cin, cout = w.shape
+        batch = _wino_batch_of(w) if (USE_WINO_BATCH and tile == 6 and not bf16) else None
+        if batch is not None:
+            U = batch.fetch(key, w, cin, cout, bool(flip_transpose))
+            if U is not None:
+                return U
         P = (tile + 2) ** 2
         kn = (cout, cin) if flip_transpose else (cin, cout)        # (K, N)
         U = torch.empty((P, kn[1], kn[0]) if bf16 else (P, kn[0], kn[1]),
@@ -246,7 +257,67 @@ def wino_weights(w, tile, flip_transpose=False, bf16=False):
         L.call("mmh_wino_weights", _ptr(w), cin, cout, int(flip_transpose), tile, _dt(bf16),
                _ptr(U), _stream())
         _cache_put(_wino_cache, key, w, U)
+        if batch is not None:
+            batch.learn(key, w, U, cin, cout, bool(flip_transpose))
     return U
+
+
+# One launch for all F(6x6,3x3) filter transforms of a network (mmh_wino_weights_multi).  After an optimizer step every
+# Winograd-domain filter of that network is stale; transforming them one by one as the forward pass reaches them is 74
+# launches of 8-25 us that cannot fill the chip (1.9 ms per fp32 step).  A batch belongs to one parameter buffer (the `within`
+# of bump_weights_epoch): it LEARNS the (weight, flip) pairs the network asks for during one iteration - each still
+# transformed on its own - and from then on the first request after a step transforms all of them, into buffers the batch
+# keeps, with one launch.  MMH_WINO_BATCH=0: every filter on its own.
+USE_WINO_BATCH = os.environ.get("MMH_WINO_BATCH", "1") != "0"
+_wino_batches = {}
+
+
+class _WinoBatch:
+    def __init__(self, lo, hi):
+        self.lo, self.hi = lo, hi
+        self.entries = {}           # key -> [weakref(w), U, cin, cout, flip]
+        self.table = None           # device int64 [n][6], rebuilt when the set of entries changes
+        self.order = []
+        self.blocks = 0
+        self.stale = False          # an optimizer step since the last batched transform
+
+    def learn(self, key, w, U, cin, cout, flip):
+        self.entries[key] = [weakref.ref(w), U, cin, cout, flip]
+        self.table = None
+
+    def fetch(self, key, w, cin, cout, flip):
+        """The Winograd-domain filter of (w, flip) if this batch knows the pair: all of the batch's filters are
+        transformed now if a step has gone by since the last time.  None: not known (the caller transforms it alone)."""
+        ent = self.entries.get(key)
+        if ent is None or ent[0]() is not w or not self.stale:
+            return None
+        live = [(k, e) for k, e in self.entries.items() if e[0]() is not None]
+        if len(live) != len(self.entries):
+            self.entries = dict(live)
+            self.table = None
+        if self.table is None:
+            rows, first = [], 0
+            self.order = list(self.entries)
+            for k in self.order:
+                wr, U, ci, co, fl = self.entries[k]
+                rows.append([wr().data_ptr(), U.data_ptr(), ci, co, int(fl), first])
+                first += (ci * co + 255) // 256
+            self.blocks = first
+            self.table = torch.tensor(rows, dtype=torch.int64).to(w.device)
+        L.call("mmh_wino_weights_multi", _ptr(self.table), len(self.order), self.blocks, _stream())
+        self.stale = False
+        for k in self.order:
+            wr, U, _, _, _ = self.entries[k]
+            _cache_put(_wino_cache, k, wr(), U)
+        return ent[1]
+
+
+def _wino_batch_of(w):
+    a = w.data_ptr()
+    for b in _wino_batches.values():
+        if b.lo <= a < b.hi:
+            return b
+    return None
 
 
 # Reflect-fold dgrad for F(6x6,3x3): the gradient of a ReflectionPad2d(1) conv is taken on the padded

@@ -300,3 +300,37 @@ def test_winograd_backward_kernels_add_no_gradient_noise(dev, monkeypatch):
     print(f"direct path, input * (1 + 2^-22): output {rel(ulp[0], ref[0]):.2e}, gradients median {statistics.median(errs_u):.2e}, max {errs_u[-1]:.2e}")
     assert statistics.median(errs_u) > 5e-4
     ops.bump_weights_epoch()
+
+
+def test_batched_filter_transforms_change_nothing(dev, monkeypatch):
+    """ops._WinoBatch: after an optimizer step a network's F(6x6,3x3) filter transforms run as ONE launch
+    (mmh_wino_weights_multi) at the first request instead of one by one.  Four free-running iterations with and without:
+    the six losses of every iteration and the final weights bit-identical; with batching, from the third iteration on
+    (the second one learns the set) the single-filter entry point is no longer called for the three trained networks."""
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_WINO_BATCH", on)
+        ops.bump_weights_epoch()
+        calls = []
+        real = lib.call
+        monkeypatch.setattr(lib, "call", lambda n, *a, _c=calls, _r=real: (_c.append(n), _r(n, *a))[1])
+        torch.manual_seed(7)
+        random.seed(7)
+        model = MMHandModel(_opt("instance"))
+        losses, per_it = [], []
+        for it in range(4):
+            mark = len(calls)
+            model.set_input(O.synthetic_batch(2, SIZE, SIZE, seed=500 + it))
+            model.optimize_parameters()
+            losses.append([float(v) for v in model.get_current_errors().values()])
+            per_it.append(Counter(calls[mark:]))
+        outs[on] = (losses, [p.detach().clone() for p in model.netG.parameters()], per_it)
+        monkeypatch.setattr(lib, "call", real)
+    assert outs[True][0] == outs[False][0], (outs[True][0], outs[False][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[True][1], outs[False][1]))
+    on_it = outs[True][2]
+    assert on_it[3]["mmh_wino_weights_multi"] == 3 and on_it[3]["mmh_wino_weights"] == 0, on_it[3]
+    assert outs[False][2][3]["mmh_wino_weights_multi"] == 0 and outs[False][2][3]["mmh_wino_weights"] > 10
+    ops.bump_weights_epoch()
