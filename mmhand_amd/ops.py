@@ -102,6 +102,8 @@ def bump_weights_epoch(within=None):
         if USE_WINO_BATCH:
             b = _wino_batches.get((lo, hi))
             if b is None:
+                for k in [k for k in _wino_batches if k[0] < hi and lo < k[1]]:     # a dead model's buffer lived here
+                    del _wino_batches[k]
                 b = _wino_batches[(lo, hi)] = _WinoBatch(lo, hi)
             b.stale = True
         return
