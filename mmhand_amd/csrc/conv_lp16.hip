@@ -2628,7 +2628,7 @@ int mmh_wgrad3x3_lp16(const mmh_conv_desc* d, const void* x16, const void* dy16,
     p.CT = d->Cin / 256; p.NT = d->Cout / 256;
     p.items = p.S * p.CT * p.NT * 9;
     hipStream_t st = mmh::as_stream(s);
-    if (mmh::g_lp16_wgrad_ring == 2 && mmh::wgrad_lp16t_supported(d)) {
+    if (mmh::g_lp16_wgrad_ring >= 2 && mmh::wgrad_lp16t_supported(d)) {
         if (int rc = mmh::launch_wgrad_lp16t(d, x16, dy16, p.slab, zeros, st)) return rc;
         const int64_t n4t = (int64_t)9 * d->Cin * d->Cout / 4;
         hipLaunchKernelGGL(lp16_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4t, 256), 4096)), dim3(256),

@@ -61,6 +61,7 @@ struct LpWgradTP {
     float* slab;            // [S][9][Cin][Cout]
     int B, H, W, Cin, Cout, x_cs, dy_cs;
     int reflect;
+    int stagger;            // the two waves of a SIMD issue their DMA at different points of a block
     int TR, TC;             // blocks per image: rows, columns
     int nblk, bps;          // blocks in all, blocks per split
     int CT, NT, S, items;
@@ -88,9 +89,10 @@ template <bool H16>
 __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int wr = wave >> 2, wc = wave & 3;
+    const bool stagger = p.stagger != 0;
     const int per_xcd = (p.items + 7) / 8;
     int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (item >= p.items) return;
@@ -221,8 +223,12 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
                         // block prefetches from it; every wave is past block s-1, whose slot stage s+3 takes
                         __builtin_amdgcn_s_waitcnt(0x0070 | 4);     // vmcnt(4) lgkmcnt(0)
                         __syncthreads();
-                        issue();
+                        // the two waves of a SIMD (wr = 0 / 1) issue the stage three blocks ahead at different points of the
+                        // last k16-step (mmh_set_option("lp16_wgrad_ring", 3): both here): a DMA instruction costs its wave
+                        // 60-180 cycles of issue time
+                        if (wr == 0 || !stagger) issue();
                     }
+                    if (kk == BR - 1 && kh == 2 && wr != 0 && stagger) issue();
                     // request the next group's fragments
                     if (kh < 2) {
 #pragma unroll
@@ -287,6 +293,7 @@ int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16
     p.slab = slab;
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
     p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.stagger = g_lp16_wgrad_ring != 3;
     p.TR = (d->H + BR - 1) / BR; p.TC = (d->W + BC - 1) / BC;
     p.nblk = d->B * p.TR * p.TC;
     p.S = wgrad_lp16t_splits(d);
