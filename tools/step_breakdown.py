@@ -36,13 +36,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
     ap.add_argument("--set", action="append", default=[], help="mmh_set_option key=value (repeatable)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for kv in a.set:
         k, v = kv.split("=")
         L.check(L.load().mmh_set_option(k.encode(), int(v)), "mmh_set_option")
-    opt = default_train_opt(batchSize=a.batch, norm="instance", name="breakdown", checkpoints_dir="/tmp/mmh_bench",
+    opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="breakdown", checkpoints_dir="/tmp/mmh_bench",
                             opt_level={"f32": "O0", "bf16": "O1", "fp16": "O1_FP16"}[a.dtype])
     model = MMHandModel(opt)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
