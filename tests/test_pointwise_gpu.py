@@ -325,3 +325,25 @@ def test_norm_stats_two_level_merge(case, dev):
     for a, b in ((m1, q1), (mb, qb)):
         assert float((a.double().reshape(-1) - gm).abs().max()) < 1e-6
         assert float(((b.double().reshape(-1) - gq).abs() / gq).max()) < 1e-6
+
+
+@pytest.mark.parametrize("lp", [1, 2])
+@pytest.mark.parametrize("shape", [(9, 256, 512), (1, 64, 64), (9, 128, 64), (4, 192, 320), (9, 24, 64)])
+def test_prep_weights_16bit_copies(shape, lp, dev):
+    """mmh_prep_weights_bf16 / _fp16: the plain 16-bit copy [taps][Cin][Cout] and the transposed one [taps][Cout][Cin] are
+    exactly the rounded fp32 values; either output may be omitted."""
+    from mmhand_amd import lib as L, ops
+    taps, cin, cout = shape
+    wd = torch.bfloat16 if lp == 1 else torch.float16
+    fn = "mmh_prep_weights_" + ("bf16" if lp == 1 else "fp16")
+    w = torch.randn(taps, cin, cout, device=dev)
+    wp = torch.zeros(taps, cin, cout, dtype=wd, device=dev)
+    wt = torch.zeros(taps, cout, cin, dtype=wd, device=dev)
+    L.call(fn, ops._ptr(w), taps, cin, cout, ops._ptr(wp), ops._ptr(wt), ops._stream())
+    assert torch.equal(wp, w.to(wd)) and torch.equal(wt, w.to(wd).transpose(1, 2).contiguous())
+    wt2 = torch.zeros_like(wt)
+    L.call(fn, ops._ptr(w), taps, cin, cout, None, ops._ptr(wt2), ops._stream())
+    assert torch.equal(wt2, wt)
+    wp2 = torch.zeros_like(wp)
+    L.call(fn, ops._ptr(w), taps, cin, cout, ops._ptr(wp2), None, ops._stream())
+    assert torch.equal(wp2, wp)
