@@ -1103,3 +1103,56 @@ def test_round3_fp32_kernels_on_channel_slices(dev):
     wide.fill_(7.0)
     L.call("mmh_conv2d_fprop", C.byref(d7), P(xs), P(w7), P(bias), P(wide[..., :64]), 0, st())
     assert torch.equal(wide[..., :64], dense_y) and bool((wide[..., 64:] == 7.0).all())
+
+
+def test_round3_fp32_kernels_random_shapes(dev):
+    """Seeded random shapes through the round-3 fp32 kernels against the kernels they replaced (the same C-ABI entry points
+    with the mmh_set_option switch off): ragged tiles and strips, odd batch sizes, tile counts around the number of
+    work-groups, split and unsplit row ranges, one to four filter phases."""
+    import random as _r
+    from mmhand_amd import lib, ops
+    rng = _r.Random(2026)
+
+    def both(key, fn):
+        out = fn()
+        lib.call("mmh_set_option", key, 0)
+        try:
+            ref = fn()
+        finally:
+            lib.call("mmh_set_option", key, 1)
+        return out, ref
+
+    for _ in range(10):                                            # stride-2 dgrad / wgrad
+        cin, cout = rng.choice([(64, 128), (128, 256)])
+        B, H, W = rng.randint(1, 5), 2 * rng.randint(1, 40), 2 * rng.randint(1, 40)
+        w = _mk((3, 3, cin, cout), rng.randint(0, 99), dev) * 0.1
+        dy = _mk((B, H // 2, W // 2, cout), rng.randint(0, 99), dev)
+        x = _mk((B, H, W, cin), rng.randint(0, 99), dev)
+        dx, dx0 = both(b"dgrad_s2_halo", lambda: ops.raw_conv_dgrad(dy, w, (B, H, W, cin), 2, 1, False))
+        assert torch.equal(dx, dx0), ("dgrad_s2", B, H, W, cin, cout)
+        dw, dw0 = both(b"wgrad_s2_strip", lambda: ops.raw_conv_wgrad(x, dy, 3, 2, 1, False))
+        assert R.rel_l1(dw, dw0) < 3e-6, ("wgrad_s2", B, H, W, cin, cout, R.rel_l1(dw, dw0))
+    for _ in range(10):                                            # 7x7 stems
+        cin = rng.choice([4, 8, 12, 24, 44, 48])
+        B, H, W, refl = rng.randint(1, 3), rng.randint(4, 50), rng.randint(4, 70), rng.random() < 0.6
+        x = _mk((B, H, W, cin), rng.randint(0, 99), dev)
+        w = _mk((7, 7, cin, 64), rng.randint(0, 99), dev) * 0.05
+        bias = _mk((64,), rng.randint(0, 99), dev)
+        act = rng.choice([0, 1])
+        y, y0 = both(b"stem_f32", lambda: ops.raw_conv_fprop(x, w, bias, 1, 3, refl, act))
+        assert R.rel_l1(y, y0) < 3e-6, ("stem_f32", B, H, W, cin, refl, act, R.rel_l1(y, y0))
+    for _ in range(6):                                             # Winograd-domain wgrad GEMM
+        P, T = rng.choice([4, 16, 36, 64]), rng.randint(32, 700)
+        cin, cout = rng.choice([256, 512]), rng.choice([256, 512])
+        V = _mk((P, T, cin), rng.randint(0, 99), dev)
+        Y = _mk((P, T, cout), rng.randint(0, 99), dev)
+
+        def gemm():
+            nws = lib.load().mmh_wino_wgrad_gemm_ws_bytes(T, cin, cout, P)
+            ws = torch.empty(nws // 4 + 4, device=dev)
+            dU = torch.empty(P, cin, cout, device=dev)
+            lib.call("mmh_wino_wgrad_gemm", V.data_ptr(), Y.data_ptr(), T, cin, cout, P, lib.F32, ws.data_ptr(), nws,
+                     dU.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            return dU
+        dU, dU0 = both(b"wino_wgrad_dma", gemm)
+        assert R.rel_l1(dU, dU0) < 3e-6, ("wino_wgrad_dma", P, T, cin, cout, R.rel_l1(dU, dU0))
