@@ -13,3 +13,6 @@ cp $O/breakdown_f32.txt $P/r03_step_breakdown_f32.txt
 cp $O/breakdown_bf16.txt $P/r03_step_breakdown_bf16.txt
 for f in bench_lp16h bench_conv7_n4 bench_stem_wgrad bench_stem_fprop ab_lp16_wgrad mfma_peak pmc_lp16 bench_dgrad_s2 ablate_dgrad_s2 bench_wgrad_s2 bench_stem_f32 ablate_stem_f32 wino_grad_split ab_wino_wgrad_dma; do grep -v amdgpu.ids $O/$f.txt > $P/r03_$f.txt; done
 grep -v amdgpu.ids $O/bench_lp16_fold.txt > $P/r03_lp16_fold.txt
+
+# r03_traffic_f32.json is written by hand from this listing (FETCH_SIZE doubled, KB -> MB; the MFMA-busy pass is appended to the listing)
+[ -f $O/traffic_f32.txt ] && cp $O/traffic_f32.txt $P/r03_traffic_f32_listing.txt || true

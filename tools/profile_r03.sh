@@ -34,6 +34,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_IN
   rm -rf /tmp/fs; rocprofv3 --pmc $c --output-format csv -d /tmp/fs -- python3 $R/tools/pmc_r03.py >/dev/null 2>&1
   echo "== --pmc $c"; python3 $R/tools/pmc_summary.py /tmp/fs | grep -A3 "lp16\|cvt" | grep -v "^--"
 done > $O/pmc_lp16.txt 2>&1
+bash $R/tools/traffic_r03_f32.sh > $O/traffic_f32.txt 2>&1
 cd $R
 rm -rf $O/prof_f32 $O/prof_bf16
 grep -h "^{" $O/bench_f32_full.log $O/bench_bf16_full.log | cut -c1-200
