@@ -123,25 +123,38 @@ def cpu_baseline_child(H, W, norm, budget_s, threads=CPU_THREADS, max_steps=10):
                       f"{os.cpu_count()} logical CPUs; oracle/mmhand_ref.py StepOracle"}), file=_OUT, flush=True)
 
 
-def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=CPU_THREADS, max_steps=10):
-    """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
-    host's cores on a bounded sample of the same workload, in a child process with a hard timeout."""
+def cpu_baseline_start(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=CPU_THREADS, max_steps=10):
+    """start the CPU-oracle child (never touches the GPU) -> handle for cpu_baseline_collect"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--size", str(H),
            "--norm", norm, "--cpu-budget", str(budget_s), "--cpu-threads", str(threads), "--cpu-max-steps", str(max_steps)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MMH_FORCE_DP", "OMP_NUM_THREADS"):
         env.pop(k, None)
+    return (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env), time.time() + hard_timeout_s,
+            threads, hard_timeout_s)
+
+
+def cpu_baseline_collect(handle):
+    import subprocess
+    proc, deadline, threads, hard_timeout_s = handle
     try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env)
-        for line in reversed(out.stdout.strip().splitlines()):
+        out, err = proc.communicate(timeout=max(1.0, deadline - time.time()))
+        for line in reversed(out.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
-        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
-                "sample": "child failed: " + out.stderr[-300:]}
+        return {"value": None, "unit": "images/s", "cores": threads, "kind": "port", "sample": "child failed: " + err[-300:]}
     except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
         return {"value": None, "unit": "images/s", "cores": threads, "kind": "port",
                 "sample": f"child exceeded the {hard_timeout_s}s hard timeout"}
+
+
+def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=CPU_THREADS, max_steps=10):
+    """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
+    host's cores on a bounded sample of the same workload, in a child process with a hard timeout."""
+    return cpu_baseline_collect(cpu_baseline_start(H, W, norm, budget_s, hard_timeout_s, threads, max_steps))
 
 
 def infer_main(a):
@@ -253,25 +266,56 @@ class StackMeter:
                 "stack_tflop": round(tot_f / 1e12, 3), "stack_ms": round(tot_ms, 2), "per_pass": per}, by
 
 
-def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, **opt_kw):
+def _rank_ms(dt_s, steps, dev):
+    """(max, min) over the ranks of this rank's seconds for `steps` steps, as ms per step"""
+    ms = dt_s / steps * 1e3
+    if not dist.is_initialized():
+        return ms, ms
+    t = torch.tensor([ms, -ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0]), float(-t[1])
+
+
+def _sync(dp):
+    if dp and dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, dp=False, seed=49, **opt_kw):
     """A fresh MMHandModel with option overrides: images/s over `steps` optimize_parameters() calls (inputs resident),
-    measured like the headline region; optionally the 16-bit stack fraction from a separate bracketed pass."""
+    measured like the headline region; optionally the 16-bit stack fraction from a separate bracketed pass.
+    dp: the model is built on the process group (distributed=True): barriers around the timed region, the slowest rank's
+    time counts, images/s is the whole job's, and `comm_exposed_ms` = the step minus the same step with every
+    collective stubbed out (dp.set_no_comm: gradients stay rank-local - measured LAST, the replicas drift apart)."""
     import gc
+    from mmhand_amd import dp as DP
+    from mmhand_amd import ops
     from mmhand_amd.mmhand_model import MMHandModel
     from mmhand_amd.options import default_train_opt
-    kw = dict(batchSize=B, norm="instance", name="bench_side", local_rank=dev.index, checkpoints_dir="/tmp/mmh_bench")
+    world = dist.get_world_size() if (dp and dist.is_initialized()) else 1
+    kw = dict(batchSize=B, norm="instance", name="bench_side", local_rank=dev.index, checkpoints_dir="/tmp/mmh_bench",
+              distributed=bool(dp))
     kw.update(opt_kw)
     model = MMHandModel(default_train_opt(**kw))
-    model.set_input(synthetic_batch_gpu(B, size, size, 49, dev))
+    model.set_input(synthetic_batch_gpu(B, size, size, seed, dev))
     for _ in range(warmup):
         model.optimize_parameters()
-    torch.cuda.synchronize()
+    ops.collective_counter.clear()
+    _sync(dp)
     t0 = time.perf_counter()
     for _ in range(steps):
         model.optimize_parameters()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    out = {"images_per_s": round(B / ms * 1e3, 3), "ms_per_step": round(ms, 2), "steps": steps, "warmup": warmup}
+    _sync(dp)
+    ms, ms_min = _rank_ms(time.perf_counter() - t0, steps, dev)
+    out = {"images_per_s": round(world * B / ms * 1e3, 3), "ms_per_step": round(ms, 2), "steps": steps, "warmup": warmup}
+    if dp:
+        cc = dict(ops.collective_counter)
+        out.update({"n_gpus": world, "global_batch": world * B, "ms_per_step_fastest_rank": round(ms_min, 2),
+                    "bucket_allreduce": "mmh_allreduce_bucket (C-ABI, torch.distributed's RCCL communicator)"
+                    if getattr(model, "dp_native", None) else f"dist.all_reduce ({getattr(model, 'dp_native_why', '-')})",
+                    "inplace_param_grads": bool(getattr(model, "dp_accum", False)),
+                    "syncbn_collectives_per_step": {k: round(v / steps, 1) for k, v in cc.items()} if cc else None})
     if stack:
         with StackMeter() as m:
             for _ in range(stack_steps):
@@ -286,10 +330,31 @@ def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, **
                                "kernel": f"conv_lp16h2_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
                                          f"{c[1] / c[0] / 1e9:.1f} GFLOP/launch, {c[2] / c[0]:.3f} ms avg over {c[0]} launches"}
     out["losses_finite"] = all(torch.isfinite(v).item() for v in model.get_current_errors().values())
+    if dp:
+        out["comm_exposed_ms"] = comm_exposed_ms(model, dev, ms, max(2, min(3, steps)))
     del model
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def comm_exposed_ms(model, dev, ms_with_comm, steps):
+    """ms per step that the collectives cost the data-parallel step: the step as measured minus the same step with every
+    collective stubbed out (gradient buckets and SyncBN exchanges: dp.set_no_comm).  ~0 = the all-reduces are hidden
+    beneath the backward passes.  Run it LAST on a model: without collectives the replicas drift apart."""
+    from mmhand_amd import dp as DP
+    DP.set_no_comm(True)
+    try:
+        model.optimize_parameters()
+        _sync(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.optimize_parameters()
+        _sync(True)
+        ms0, _ = _rank_ms(time.perf_counter() - t0, steps, dev)
+    finally:
+        DP.set_no_comm(False)
+    return {"value": round(ms_with_comm - ms0, 2), "ms_per_step_without_collectives": round(ms0, 2), "steps": steps}
 
 
 def gradient_parity_run(dev, size, norm):
@@ -305,22 +370,13 @@ def gradient_parity_run(dev, size, norm):
     b = synthetic_batch_gpu(B, size, size, 49, dev)
     g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
     probe = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(3)).to(dev)
-    res, old, old_tile = {}, ops.USE_WINOGRAD, ops._wino_tile
-    allowed = set()
-
-    def gated(B_, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
-        return old_tile(B_, H, W_, Cin, Cout, k, stride, pad, bf16, op) if op in allowed else 0
-
-    # key -> (passes that run Winograd, factor on the network input)
-    runs = {"direct": ((), 1.0), "winograd": (("fprop", "dgrad", "wgrad"), 1.0),
-            "winograd_bwd_only": (("dgrad", "wgrad"), 1.0), "direct_input_2ulp": ((), 1.0 + 2.0 ** -22)}
+    res, old_mode = {}, ("off" if not ops.USE_WINOGRAD else "all" if ops.WINOGRAD_FPROP else "bwd")
+    # key -> (ops.set_winograd_mode, factor on the network input)
+    runs = {"direct": ("off", 1.0), "winograd": ("all", 1.0), "winograd_bwd_only": ("bwd", 1.0),
+            "direct_input_2ulp": ("off", 1.0 + 2.0 ** -22)}
     try:
-        ops.USE_WINOGRAD = True
-        ops._wino_tile = gated
-        for key, (which, scale) in runs.items():
-            allowed.clear()
-            allowed.update(which)
-            ops.bump_weights_epoch()
+        for key, (mode, scale) in runs.items():
+            ops.set_winograd_mode(mode)
             net = Generator([3, 42, 6], 3, 64, norm, False, 9).init_weights("normal", 49).to(dev).train()
             net.flatten_parameters()
             out = net([t * scale for t in g_in])
@@ -328,8 +384,7 @@ def gradient_parity_run(dev, size, norm):
             res[key] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
             del net, out
     finally:
-        ops.USE_WINOGRAD, ops._wino_tile = old, old_tile
-        ops.bump_weights_epoch()
+        ops.set_winograd_mode(old_mode)
     rel = lambda a, c: float((a.double() - c.double()).abs().sum() / c.double().abs().sum().clamp_min(1e-30))   # noqa: E731
 
     def against_direct(key):
@@ -344,8 +399,8 @@ def gradient_parity_run(dev, size, norm):
            "direct_input_times_1p2e-22_vs_direct": against_direct("direct_input_2ulp"),
            "note": f"full-size Generator (ngf 64, 9 PATBlocks, {size}x{size}, B={B}, --norm {norm}, dropout off), gradients of "
                    "sum(out * probe) per parameter tensor against direct_path's kernels (whose own distance from the fp64 "
-                   "oracle is 1e-6: tests/test_winograd_step_gpu.py).  Second key: Winograd dgrad and wgrad kernels with the "
-                   "direct fprop, i.e. what the backward kernels themselves add.  Third key: the direct kernels against "
+                   "oracle is 1e-6: tests/test_winograd_step_gpu.py).  Second key: --fp32_exact_grads (ops.set_winograd_mode('bwd'), "
+                   "timed as hybrid_path): direct fprop, Winograd dgrad and wgrad, i.e. what the backward kernels themselves add.  Third key: the direct kernels against "
                    "themselves with the network input scaled by (1 + 2^-22) - the gradients' conditioning, which the "
                    "Winograd fprop's 7e-6 output difference excites (ReLU masks within rounding of zero flip)"}
     del res
@@ -377,7 +432,7 @@ def side_infer_run(dev, B, size, steps, bf16):
     return {"images_per_s": round(B / ms * 1e3, 2), "ms_per_batch": round(ms, 2), "batch": B, "steps": steps}
 
 
-def rccl_child_run(steps, warmup, batch, size, timeout_s=420):
+def rccl_child_run(steps, warmup, batch, size, timeout_s=600):
     """The same step through the data-parallel code path on RCCL with ONE rank, in a child process with a hard timeout:
     init_process_group("nccl"), the parameter broadcast, the bucketed gradient all-reduces on the side stream and the
     deferred optimizer steps (mmhand_amd/dp.py) all run on the real communicator.  A 1-GPU box cannot show scaling; it
@@ -387,7 +442,7 @@ def rccl_child_run(steps, warmup, batch, size, timeout_s=420):
                MASTER_PORT=str(_free_port()))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
-           "--batch", str(batch), "--size", str(size), "--no-side-runs", "--no-cpu-baseline"]
+           "--batch", str(batch), "--size", str(size), "--no-cpu-baseline", "--dp-side-runs"]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     except subprocess.TimeoutExpired:
@@ -396,7 +451,9 @@ def rccl_child_run(steps, warmup, batch, size, timeout_s=420):
         if line.startswith("{"):
             j = json.loads(line)
             return {"images_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": steps,
-                    "rccl_ranks": j.get("rccl_ranks"), "backend": j.get("backend")}
+                    "rccl_ranks": j.get("rccl_ranks"), "backend": j.get("backend"),
+                    **{k: j[k] for k in ("bucket_allreduce", "inplace_param_grads", "comm_exposed_ms", "dp_bf16_path",
+                                         "dp_norm_batch", "dp_size512_bf16_b4") if k in j}}
     return {"error": f"rc {out.returncode}: " + out.stderr[-400:]}
 
 
@@ -409,12 +466,13 @@ def _free_port():
     return port
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, timeout_s=2400.0, share_gpu=False):
     """python bench.py --gpus N without a launcher: start N ranks as child processes of this one (which
     never touches the GPU: torch.cuda.device_count() does not initialise it) and relay rank 0's JSON
-    line.  A rank that fails ends the others (by their own PIDs) and its exit code becomes ours."""
+    line.  A rank that fails ends the others (by their own PIDs) and its exit code becomes ours; ranks still
+    running after timeout_s (a hung collective) are ended the same way and the exit code is 124."""
     import subprocess
-    if "--selftest-ranks" not in argv:
+    if "--selftest-ranks" not in argv and not share_gpu:
         have = torch.cuda.device_count()
         if have < n:
             print(f"bench.py --gpus {n}: this node exposes {have} GPU(s)", file=sys.stderr, flush=True)
@@ -422,16 +480,26 @@ def self_launch(n, argv):
     port = _free_port()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share_gpu else str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this host driver
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // n))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=_OUT if r == 0 else sys.stderr, stderr=sys.stderr))
     rc = 0
     live = list(procs)
+    deadline = time.time() + timeout_s
     while live:
         time.sleep(0.2)
+        if time.time() > deadline:
+            print(f"bench.py --gpus {n}: ranks still running after {timeout_s:.0f}s - ending them", file=sys.stderr, flush=True)
+            for q in live:
+                q.terminate()
+            time.sleep(5)
+            for q in live:
+                if q.poll() is None:
+                    q.kill()
+            return 124
         for p in list(live):
             code = p.poll()
             if code is None:
@@ -503,6 +571,15 @@ def main():
     ap.add_argument("--cpu-all-cores", type=float, default=0.0, metavar="SECONDS",
                     help="also time the CPU oracle with os.cpu_count() threads inside this budget (off by default)")
     ap.add_argument("--selftest-ranks", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-timeout", type=float, default=2400.0,
+                    help="seconds after which a self-started multi-rank run (a hung collective) is ended with exit code 124")
+    ap.add_argument("--dp-side-runs", action="store_true",
+                    help="with MMH_FORCE_DP=1 and one rank: also run the data-parallel side regions of an N-GPU launch")
+    ap.add_argument("--dp-512", action="store_true",
+                    help="N-GPU launch: also time configs[4]'s shape (512x512, per-GPU batch 4, bf16); default only at N = 4")
+    ap.add_argument("--share-gpu-gloo", action="store_true",
+                    help="TEST AID (tests/test_dp_gpu.py): all N ranks on GPU 0 over the gloo backend - exercises every line of "
+                         "the N-GPU bench on a one-GPU box; the throughput it prints means nothing")
     ap.add_argument("--no-side-runs", action="store_true",
                     help="skip the extra driver-visible measurements (direct-kernel steps, set_input in the loop, "
                          "16-bit mode, --norm batch, RCCL world-1, inference, 512x512); profiling runs use this to "
@@ -514,7 +591,7 @@ def main():
         return cpu_baseline_child(a.size, a.size, a.norm, a.cpu_budget, a.cpu_threads, a.cpu_max_steps)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become one.  Nothing has touched the GPU yet (and this process never will).
-        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+        sys.exit(self_launch(a.gpus, sys.argv[1:], a.launch_timeout, a.share_gpu_gloo))
     if a.selftest_ranks:
         return selftest_ranks()
     if a.mode == "infer":
@@ -529,7 +606,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dp = os.environ.get("MMH_FORCE_DP") == "1" and "RANK" in os.environ
-    if world > 1 or force_dp:
+    if a.share_gpu_gloo:
+        dist.init_process_group("gloo", init_method="env://")
+    elif world > 1 or force_dp:
         init_rccl(dev)
 
     from mmhand_amd import ops
@@ -581,10 +660,11 @@ def main():
     timer.enabled = False
     flops = dict(ops.flop_meter)
     ops.flop_meter = None
+    dt_fastest = dt
     if dist.is_initialized():
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt, dt_fastest = float(t[0]), float(-t[1])
     losses = {k: float(v) for k, v in model.get_current_errors().items()}
     peak_gib = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)
 
@@ -607,6 +687,52 @@ def main():
     n_rccl = rccl_ranks(dev)
     side = {}
     side_ok = not a.no_side_runs and world == 1 and not force_dp
+    dp_side = (world > 1 and not a.no_side_runs) or (force_dp and a.dp_side_runs)
+    dp_info = {}
+    cpu_child = None
+    if getattr(model, "dp", False):
+        dp_info = {"bucket_allreduce": "mmh_allreduce_bucket (C-ABI, torch.distributed's RCCL communicator)"
+                   if getattr(model, "dp_native", None) else f"dist.all_reduce ({getattr(model, 'dp_native_why', '-')})",
+                   "inplace_param_grads": bool(getattr(model, "dp_accum", False)),
+                   "ms_per_step_fastest_rank": round(dt_fastest / a.steps * 1e3, 2)}
+    if world > 1 and rank == 0 and not a.no_cpu_baseline:
+        # N-GPU launch: the CPU oracle runs on rank 0's host cores WHILE the side regions below run on the GPUs (16 of the
+        # host's threads; every rank's own host work is one thread), collected before the line is printed
+        cpu_child = cpu_baseline_start(H, W, a.norm)
+    if dp_side:
+        # the N-GPU launch measures every multi-GPU configuration of BASELINE.json in this one process group: the headline's
+        # exposed communication, then - fresh models - configs[2] (bf16, per-GPU batch 32), the reference's default
+        # --norm batch (SyncBN: packed collectives counted) and configs[4]'s shape (512x512, per-GPU batch 4; at N = 4)
+        n_side = max(2, min(5, a.steps))
+        dp_info["comm_exposed_ms"] = comm_exposed_ms(model, dev, dt / a.steps * 1e3, max(2, min(3, a.steps)))
+
+        def guarded_dp(key, fn):
+            try:
+                side[key] = fn()
+            except Exception as e:      # noqa: BLE001 - every rank raises alike (same code, same shapes): no rank is left behind
+                side[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
+        ops.fprop_timer = None
+        vgg_source = getattr(model, "vgg_source", "n/a")
+        del model
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+        model = None
+        if a.dtype == "f32":
+            guarded_dp("dp_bf16_path", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, dp=True, seed=49 + rank,
+                                                                   opt_level="O1", norm=a.norm),
+                                                    note="BASELINE.json configs[2]: --opt_level O1 (bf16), per-GPU batch "
+                                                         f"{a.batch}, global batch {world * a.batch}, RCCL gradient all-reduce"))
+        guarded_dp("dp_norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, dp=True, seed=49 + rank, norm="batch",
+                                                                opt_level="O1" if a.dtype == "bf16" else "O0"),
+                                                 note="the reference's script default --norm batch under data parallelism = "
+                                                      "SyncBN (apex convert_syncbn_model): statistics over the global batch, "
+                                                      "collectives of independent norm sites packed"))
+        if world == 4 or a.dp_512:
+            guarded_dp("dp_size512_bf16_b4", lambda: dict(side_train_run(dev, 4, 512, n_side, dp=True, seed=49 + rank, opt_level="O1"),
+                                                          note="BASELINE.json configs[4]: 512x512, per-GPU batch 4 (global 16 at "
+                                                               "4 GPUs), bf16"))
     if side_ok:
         # (1) the reference's set_input inside the loop: the batch comes from pinned HOST memory every
         # step (H2D over PCIe + the NHWC pack), as train.py:35 does per iteration
@@ -630,7 +756,8 @@ def main():
                                    "implicit-GEMM MFMA kernels (bench.py --no-winograd)"}
             ops.USE_WINOGRAD = True
             ops.bump_weights_epoch()
-    vgg_source = getattr(model, "vgg_source", "n/a")
+    if model is not None:
+        vgg_source = getattr(model, "vgg_source", "n/a")
     ops.fprop_timer = None
     if side_ok:
         # (3)... fresh models: the 16-bit mode, the reference's default --norm batch, RCCL with one rank, the other
@@ -656,6 +783,23 @@ def main():
                                                    "three passes incl. reflect border terms, algorithmic FLOPs / kernel time / 2500 TF"))
         if a.dtype == "f32" and not a.no_winograd:
             guarded("gradient_parity", lambda: gradient_parity_run(dev, a.size, a.norm))
+
+            def hybrid():
+                try:
+                    r = side_train_run(dev, a.batch, a.size, n_side, norm=a.norm, fp32_exact_grads=True)
+                finally:
+                    ops.set_winograd_mode("all")
+                gp = side.get("gradient_parity", {}).get("winograd_dgrad_wgrad_only_vs_direct", {})
+                r.update({"grad_rel_l1_median_vs_direct": gp.get("grad_rel_l1_median"),
+                          "grad_rel_l1_max_vs_direct": gp.get("grad_rel_l1_max"),
+                          "direct_bound_images_per_s": round(PEAK_F32_MFMA_TF * 1e3 / (GFLOP_PER_IMAGE_STEP * (a.size * a.size / 65536.0)), 1),
+                          "note": "--fp32_exact_grads: forward 3x3 convs on the direct implicit-GEMM kernels (identical activations "
+                                  "and ReLU masks to direct_path), dgrad + wgrad on Winograd F(6x6,3x3) - every gradient tensor "
+                                  "within 1e-3 (tests/test_lp16_step_gpu.py::..._fp32_full_width[bwd] vs fp64; this line: vs "
+                                  "direct_path's kernels at full size), against BASELINE.md's <= 64 img/s bound for an all-direct "
+                                  "fp32 step at 100 % MFMA"})
+                return r
+            guarded("hybrid_path", hybrid)
         guarded("norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch",
                                                           opt_level="O1" if a.dtype == "bf16" else "O0"),
                                            note="the reference's script default --norm batch (BatchNorm2d affine, conv bias off)"))
@@ -684,7 +828,7 @@ def main():
                        "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
                        "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
-        tname = "r03_traffic_bf16.json" if a.dtype == "bf16" else ("r02_traffic.json" if wino else "r01_traffic.json")
+        tname = "r03_traffic_bf16.json" if a.dtype == "bf16" else ("r04_traffic.json" if wino else "r01_traffic.json")
         tj = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tj) and a.batch == 32 and a.size == 256:
             tjd = json.load(open(tj))
@@ -732,18 +876,22 @@ def main():
             # process group.  N > 1: gradients of G / D_PB / D_PP all-reduced over RCCL (mmhand_amd/dp.py)
             "rccl_ranks": n_rccl, "backend": ("nccl(RCCL)" if dist.is_initialized() else None),
         }
+        line.update(dp_info)
         line.update(side)
+        if cpu_child is not None:
+            line["cpu_baseline"] = cpu_baseline_collect(cpu_child)
         if world == 1 and not force_dp and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
             # SURVEY.md §8(d) asks for os.cpu_count() threads.  On the GPU box's 256 logical CPUs oneDNN is far slower
-            # at 128+ threads than at 16 (tools/cpu_probe.py; one B=2 step did not finish in 240 s): opt-in, measured
-            # once and kept in profiles/r03_cpu_all_cores.json, not paid by every default run
+            # at 128+ threads than at 16 (tools/cpu_probe.py; one B=2 step did not finish in 240 s): opt-in
+            # (--cpu-all-cores SECONDS; the round-4 measurement is profiles/r04_cpu_all_cores.json), not paid by every default run
             if a.cpu_all_cores and (os.cpu_count() or 0) > CPU_THREADS:
                 allc = cpu_baseline(H, W, a.norm, budget_s=a.cpu_all_cores, hard_timeout_s=int(a.cpu_all_cores * 2 + 60),
                                     threads=os.cpu_count(), max_steps=2)
                 line["cpu_baseline"]["all_cores"] = {k: allc.get(k) for k in ("value", "cores", "sample")}
         print(json.dumps(line), file=_OUT, flush=True)
     if dist.is_initialized():
+        dist.barrier()          # the other ranks wait here while rank 0 collects the CPU baseline and prints
         dist.destroy_process_group()
 
 

@@ -28,6 +28,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared between this push and
+ * the pop at the end of the header are its ONLY exported symbols (tests/test_host_cpu.py checks
+ * `nm -D` against this header in both directions). */
+#pragma GCC visibility push(default)
 
 typedef void* mmh_stream_t; /* a hipStream_t */
 
@@ -640,6 +644,22 @@ int mmh_decode_inputs(const void* img1, const void* img2, const void* dep1,
                       int B, int H, int W, double sigma, void* x_h1, void* x_h2,
                       void* x_p, void* x_d, mmh_stream_t s);
 
+/* ---- data-parallel gradient all-reduce (apex DistributedDataParallel behind
+ * models/MMHandModel.py:109-116; reduce_tensor :381-384) -------------------------
+ * The training process already holds ONE RCCL communicator per GPU (torch.distributed's "nccl"
+ * backend is RCCL on ROCm).  mmh_rccl_bind resolves ncclAllReduce from the RCCL image that
+ * communicator lives in (the path of the librccl the process has loaded; no link-time
+ * dependency, no second RCCL).  mmh_allreduce_bucket enqueues the in-place SUM all-reduce of
+ * `count` elements of type `dtype` (MMH_F32 | MMH_BF16 | MMH_FP16) at `buf` - a contiguous
+ * bucket of a network's flat gradient buffer - on communicator `comm` (an ncclComm_t) and
+ * stream `s`; the 1/world factor is folded into mmh_adam_step.  Every rank must issue its
+ * buckets in the same order (mmhand_amd/dp.py cuts them in reverse layer order).
+ * mmh_rccl_comm_ranks: the communicator's rank count, -1 if unbound / invalid.              */
+int mmh_rccl_bind(const char* librccl_path);
+int mmh_rccl_comm_ranks(void* comm);
+int mmh_allreduce_bucket(void* comm, void* buf, int64_t count, int dtype, mmh_stream_t s);
+
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,9 @@ SIGNATURES = {
     "mmh_pose_heatmaps": (_i, [_vp, _i, _i, _i, _d, _vp, _vp]),
     "mmh_map_to_cord": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mmh_decode_inputs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "mmh_rccl_bind": (_i, [C.c_char_p]),
+    "mmh_rccl_comm_ranks": (_i, [_vp]),
+    "mmh_allreduce_bucket": (_i, [_vp, _vp, _i64, _i, _vp]),
 }
 
 _lib = None

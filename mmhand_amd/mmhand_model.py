@@ -189,6 +189,8 @@ class MMHandModel(torch.nn.Module):
         self.overflow = False
         self.world = dist.get_world_size() if (getattr(opt, "distributed", False)
                                                and dist.is_initialized()) else 1
+        if getattr(opt, "fp32_exact_grads", False):
+            ops.set_winograd_mode("bwd")     # process-wide, like MMH_WINOGRAD=bwd (one model family per process)
         seed = getattr(opt, "seed", 49)
         # dropout masks: an independent stream per rank, as each reference rank has its own RNG
         # (the weights are seeded identically on every rank and broadcast from rank 0).  ImagePool
@@ -322,16 +324,26 @@ class MMHandModel(torch.nn.Module):
         global _LAST_BUCKET_LOG
         _LAST_BUCKET_LOG = self._bucket_log
         # SyncBN's small all-gathers / all-reduces are issued from inside the forward and backward passes; on the WORLD
-        # communicator they would queue behind whatever 32 MB gradient bucket is in flight.  The buckets therefore get a
-        # communicator of their own when any net runs SyncBN (MMH_DP_BUCKET_GROUP=0: everything on WORLD).
+        # communicator they queue behind whatever 32 MB gradient bucket is in flight.  MMH_DP_BUCKET_GROUP=1 gives the
+        # buckets a communicator of their own.  OFF by default: two RCCL communicators running concurrently from one
+        # process can deadlock unless both kernels are co-resident on every rank, and that has never run on more than
+        # one rank of this hardware - one communicator, one issue order, is correct by construction.
         self._bucket_group = None
         if (any(n.norm == "batch" for n in (self.netG, self.netD_PB, self.netD_PP))
-                and os.environ.get("MMH_DP_BUCKET_GROUP", "1") != "0"):
+                and os.environ.get("MMH_DP_BUCKET_GROUP", "0") == "1"):
             self._bucket_group = dist.new_group()
+        # on RCCL the buckets' collectives are issued through the C-ABI (mmh_allreduce_bucket) on torch.distributed's own
+        # communicator; any other backend (gloo in the tests), MMH_DP_NATIVE=0 or a separate bucket group: dist.all_reduce
+        from .dp import native_comm
+        self.dp_native, self.dp_native_why = (None, "separate bucket communicator") if self._bucket_group is not None \
+            else native_comm(None)
         self._buckets = {o: GradBuckets(list(o.net.parameters()), o.net.flat_grad, comm_stream=self.comm_stream,
-                                        log=self._bucket_log, name=n, group=self._bucket_group)
+                                        log=self._bucket_log, name=n, group=self._bucket_group,
+                                        flat_param=o.net.flat_param, native=self.dp_native)
                          for n, o in (("G", self.optimizer_G), ("D_PB", self.optimizer_D_PB),
                                       ("D_PP", self.optimizer_D_PP))}
+        # in-place parameter gradients under data parallelism too (the shims report to the buckets: dp.param_use / _done)
+        self.dp_accum = os.environ.get("MMH_DP_ACCUM", "1") != "0"
 
     # ------------------------------------------------------------------ input
     def set_input(self, input):
@@ -571,23 +583,28 @@ class MMHandModel(torch.nn.Module):
                 self._guarded_step(o, k, lid)
             pending.clear()
 
-        def backward_of(o, fn, k, lid):
+        def backward_of(o, fn, k, lid, pre=None):
             if any(q[1] is o for q in pending):
                 flush()                         # its previous step must land before its next forward
             bk = self._buckets[o]
             o.zero_grad()
-            bk.begin()
+            bk.begin()                          # armed BEFORE the forward pass: the conv shims report their parameter uses
+            if pre is not None:
+                pre()
             fn()
             bk.launch_remaining()
             pending.append((bk, o, k, lid))
 
-        self.forward()
-        backward_of(self.optimizer_G, self.backward_G, 0, 0)
-        for i in range(r):
-            backward_of(self.optimizer_D_PP, self.backward_D_PP, 1 + i, 2)
-        for i in range(r):
-            backward_of(self.optimizer_D_PB, self.backward_D_PB, 1 + r + i, 1)
-        flush()
+        prev, ops.ACCUM_PARAM_GRADS = ops.ACCUM_PARAM_GRADS, self.dp_accum
+        try:
+            backward_of(self.optimizer_G, self.backward_G, 0, 0, pre=self.forward)
+            for i in range(r):
+                backward_of(self.optimizer_D_PP, self.backward_D_PP, 1 + i, 2)
+            for i in range(r):
+                backward_of(self.optimizer_D_PB, self.backward_D_PB, 1 + r + i, 1)
+            flush()
+        finally:
+            ops.ACCUM_PARAM_GRADS = prev
 
     # ------------------------------------------------------------------ reporting / io
     def get_current_errors(self):

@@ -191,6 +191,22 @@ def conv_desc(B, H, W, Cin, Cout, k, stride, pad, reflect, x_cs=None, y_cs=None)
 # MMH_WINOGRAD=0 or ops.USE_WINOGRAD = False selects the direct kernels everywhere;
 # MMH_WINOGRAD_TILE / ops.WINOGRAD_TILE = 4 | 2 caps the tile size.
 USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
+# MMH_WINOGRAD=bwd (ops.set_winograd_mode("bwd"), train option --fp32_exact_grads): the gradient-exact fp32 hybrid.
+# The FORWARD 3x3 convs run on the direct implicit-GEMM kernels, so activations - and with them every ReLU mask - are
+# those of the direct path; dgrad and wgrad stay on F(6x6,3x3), whose rounding differences stay what they are (1e-5 on
+# the gradients, profiles/r03_wino_grad_split.txt) instead of being amplified into mask flips (3e-3).  The backward
+# computes the transformed input V itself (one extra input transform per conv) and runs the fused dy pass.
+WINOGRAD_FPROP = os.environ.get("MMH_WINOGRAD", "1") != "bwd"
+
+
+def set_winograd_mode(mode):
+    """"all" (default: every pass of the eligible fp32 3x3 convs on Winograd), "bwd" (direct fprop, Winograd dgrad + wgrad:
+    gradients within 1e-3 of fp64 on every tensor), "off" (direct kernels everywhere)"""
+    global USE_WINOGRAD, WINOGRAD_FPROP
+    if mode not in ("all", "bwd", "off"):
+        raise ValueError(f"winograd mode {mode!r}: expected all | bwd | off")
+    USE_WINOGRAD, WINOGRAD_FPROP = mode != "off", mode != "bwd"
+    bump_weights_epoch()
 WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "6"))
 WINO6_MIN = 128 * 128      # F(6x6,3x3) from this Cin*Cout up (64 planes of filter transform per conv)
 # keep the forward pass's transformed input for the wgrad pass (1.78x the activation's bytes per
@@ -217,6 +233,8 @@ WINO_BF16_MIN = {"fprop": 512 * 256, "dgrad": 512 * 512, "wgrad": 0}
 def _wino_tile(B, H, W_, Cin, Cout, k, stride, pad, bf16, op="fprop"):
     """0 = direct kernel, else the Winograd output-tile size (2, 4 or 6)."""
     if not (USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and Cin % 32 == 0 and Cout % 32 == 0):
+        return 0
+    if op == "fprop" and not WINOGRAD_FPROP and not bf16:
         return 0
     if bf16:
         # fprop / dgrad of the 256- and 512-channel stack: the second-generation direct kernel
@@ -357,7 +375,22 @@ def _park_stats(y, stats):
     and shape; the table is kept tiny (a conv whose norm never came would otherwise leave an entry behind)."""
     if len(_pending_stats) >= 8:
         _pending_stats.clear()
-    _pending_stats[y.data_ptr()] = (stats, tuple(y.shape))
+    _pending_stats[y.data_ptr()] = (stats, tuple(y.shape), weakref.ref(y), y._version)
+
+
+def _take_stats(x, peek=False):
+    """the partials parked for the tensor that still lives at x's address (not for a dead conv output whose address the
+    caching allocator handed to a new tensor: the producing conv's norm may never have run), else None"""
+    pend = _pending_stats.get(x.data_ptr())
+    if pend is None:
+        return None
+    y = pend[2]()
+    if pend[1] != tuple(x.shape) or y is None or y._version != pend[3] or x._version != pend[3]:
+        del _pending_stats[x.data_ptr()]
+        return None
+    if not peek:
+        del _pending_stats[x.data_ptr()]
+    return pend
 
 
 def _wino_conv(x, U, bias, Cout, reflect, act, tile, time_it=False, keep_V=False, bf16=False, want_stats=False,
@@ -841,15 +874,17 @@ USE_RESIDUAL_TOKENS = os.environ.get("MMH_RESIDUAL_TOKENS", "1") != "0"
 
 
 class ResidualToken:
-    __slots__ = ("armed", "addend")
+    __slots__ = ("armed", "addend", "taken")
 
     def __init__(self):
         self.armed = False      # set by the conv's forward: it will compute an input gradient
         self.addend = None      # parked by the residual side's backward, taken by the conv's backward
+        self.taken = False      # the conv's backward has run: a later park() must go through autograd instead
 
     def park(self, g):
-        """residual side: True = the gradient is parked (return None to autograd)"""
-        if not self.armed or g is None:
+        """residual side: True = the gradient is parked (return None to autograd).  False once the conv's backward has
+        already taken what there was (the residual side ran late): autograd then accumulates the two gradients itself."""
+        if not self.armed or g is None or self.taken:
             return False
         assert self.addend is None, "ResidualToken: a gradient is already parked (backward ran twice?)"
         self.addend = g
@@ -857,6 +892,7 @@ class ResidualToken:
 
     def take(self):
         g, self.addend = self.addend, None
+        self.taken = True
         return g
 
 
@@ -1234,6 +1270,31 @@ def _grad_target(p):
     return None
 
 
+# Data parallelism with in-place parameter gradients: the bucket all-reduce of dp.GradBuckets has to know when a
+# parameter's gradient is complete, and an in-place accumulate never reaches autograd's AccumulateGrad (whose hook tells
+# it otherwise).  The conv shims therefore report every use of a trainable parameter in their forward and every finished
+# contribution - added in place, or none to add - in their backward.  No GradBuckets object alive: two list tests per conv.
+def _dp_use(ctx_needs, w, bias):
+    from . import dp
+    if dp.tracking():
+        if ctx_needs[1]:
+            dp.param_use(w)
+        if bias is not None and ctx_needs[2]:
+            dp.param_use(bias)
+
+
+def _dp_done(ctx_needs, w, bias, dw, db):
+    from . import dp
+    if dp.tracking():
+        if ctx_needs[1] and dw is None:
+            dp.param_done(w)
+        if bias is not None and ctx_needs[2] and db is None:
+            dp.param_done(bias)
+
+
+DP_NO_COMM = os.environ.get("MMH_DP_NO_COMM") == "1"       # see dp.NO_COMM: collectives stubbed out (timing aid only)
+
+
 def _finish_param_grad(g, target):
     """what a backward returns for a parameter whose gradient was added into `target` in place"""
     return None if target is not None else g
@@ -1384,11 +1445,13 @@ class Conv2dFn(torch.autograd.Function):
         y_lp: hand the output over in 16 bits only -> returns (proxy, y16); the consumer (NormActFn /
         GateFn) sends the gradient back in 16 bits too (lp_grad_out)."""
         ctx.set_materialize_grads(False)    # no full-size zero "gradient" for the non-differentiable 16-bit output
+        _dp_use(ctx.needs_input_grad, w, bias)
         # res_tok (ResidualToken): x has a second consumer whose gradient this conv's backward adds to its own
         ctx.res_tok = res_tok
         if res_tok is not None:
             assert x16 is None and pro is None, "a residual token belongs to an fp32 block input"
             res_tok.armed = bool(ctx.needs_input_grad[0])
+            res_tok.taken = False
         # pro (NormDefer): x is the proxy of a normalised activation that was never written; the norm-apply runs
         # inside this conv's input transform.  g_defer: the norm behind this conv sends its input gradient
         # as a NormBwdDefer (see USE_NORM_FUSION)
@@ -1479,12 +1542,18 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g16=None):
+        out = Conv2dFn._backward(ctx, g, _g16)
+        _dp_done(ctx.needs_input_grad, ctx.saved_tensors[1], ctx.bias_p, out[1], out[2])
+        return out
+
+    @staticmethod
+    def _backward(ctx, g, _g16=None):
         addend = ctx.res_tok.take() if ctx.res_tok is not None else None    # the residual side's gradient of x, if parked
         x, w, y = ctx.saved_tensors
         stride, pad, reflect, act, has_bias, bf16 = ctx.cfg
         dx = dw = db = None
-        if g is None:
-            return (None,) * 16
+        if g is None:       # no gradient reaches the conv: what the residual side parked IS the gradient of x
+            return (addend,) + (None,) * 15
         wt_ = _grad_target(w) if ctx.needs_input_grad[1] else None                       # in-place targets
         bt_ = _grad_target(ctx.bias_p) if (has_bias and ctx.needs_input_grad[2]) else None
         want_db = has_bias and ctx.needs_input_grad[2] and not ctx.skip_db
@@ -1564,6 +1633,19 @@ class Conv2dFn(torch.autograd.Function):
             if want_db:
                 db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
             return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
+        if (not WINOGRAD_FPROP and FUSE_WINO6_BWD and not bf16 and not ctx.wino_V and not ctx.dx_channels
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and x is not None and x.dtype == torch.float32
+                and _wino_tile(*ctx.x_shape, w.shape[3], w.shape[0], stride, pad, bf16, "dgrad") == 6
+                and _wino_tile(*ctx.x_shape, w.shape[3], w.shape[0], stride, pad, bf16, "wgrad") == 6):
+            # gradient-exact hybrid: the forward ran on the direct kernel and kept x; its transform is made here
+            Bx, Hx, Wx, Cx = ctx.x_shape
+            V = _empty((64, Bx * (-(-Hx // 6)) * (-(-Wx // 6)), Cx), x)
+            L.call("mmh_wino_input", _ptr(x), Bx, Hx, Wx, Cx, int(bool(reflect)), 6, L.F32, _ptr(V), _stream())
+            dx, dw = raw_conv_bwd_wino6(g, w, ctx.x_shape, reflect, V, dw_out=wt_)
+            dw = _finish_param_grad(dw, wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels)
         if ctx.needs_input_grad[1]:
@@ -1583,6 +1665,7 @@ class ConvT2dFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, bf16=False, x16=None, y_lp=False, null_bias_grad=False):
         """x16 / y_lp: 16-bit edges as in Conv2dFn (convT_lp16_ok); null_bias_grad as there."""
         ctx.set_materialize_grads(False)
+        _dp_use(ctx.needs_input_grad, w, bias)
         ctx.skip_db = bool(null_bias_grad and EXACT_NULL_BIAS_GRAD)
         ctx.bias_p = bias
         ctx.has_bias = bias is not None
@@ -1610,6 +1693,12 @@ class ConvT2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g16=None):
+        out = ConvT2dFn._backward(ctx, g, _g16)
+        _dp_done(ctx.needs_input_grad, ctx.saved_tensors[1], ctx.bias_p, out[1], out[2])
+        return out
+
+    @staticmethod
+    def _backward(ctx, g, _g16=None):
         x, w = ctx.saved_tensors
         dx = dw = db = None
         if g is None:
@@ -1656,8 +1745,8 @@ def raw_norm_stats(x, groups):
     merged instead of reading x again."""
     B, H, W_, Cc = x.shape
     rows = (B // groups) * H * W_
-    pend = _pending_stats.pop(x.data_ptr(), None)
-    if pend is not None and groups in (B, 1) and pend[1] == tuple(x.shape):
+    pend = _take_stats(x) if groups in (B, 1) else None
+    if pend is not None:
         stats = pend[0]         # [B][chunks][3][C]; BatchNorm (groups == 1): the same array as one group of B * chunks
         mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
         m2 = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
@@ -1683,10 +1772,9 @@ def raw_norm_stats_finalize_pending(x, groups):
     finalise (scale = invstd, shift = -mean * invstd) in one launch -> (mean, scale, shift, invstd, rows), or None
     when no partials are pending for x"""
     B, H, W_, Cc = x.shape
-    pend = _pending_stats.get(x.data_ptr())
-    if pend is None or groups != B or pend[1] != tuple(x.shape):
+    pend = _take_stats(x) if groups == B else None
+    if pend is None:
         return None
-    del _pending_stats[x.data_ptr()]
     stats = pend[0]
     rows = H * W_
     mean = _empty((groups, Cc), x); m2 = _empty((groups, Cc), x)
@@ -1725,6 +1813,8 @@ def _sync_stats(mean, m2, rows, group):
     [groups=1][chunks=world][3][C] that mmh_norm_stats_merge reduces: one launch, no torch glue."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if DP_NO_COMM:      # timing aid: this rank's statistics stand in for the global ones
+        return mean, m2, rows
     collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
     if mean.is_cuda:
         packed = torch.cat([torch.full_like(mean, float(rows)), mean, m2], 0)          # [3, C]
@@ -1756,6 +1846,8 @@ def _sync_stats_multi(items, group):
     import torch.distributed as dist
     if len(items) == 1:
         return [_sync_stats(*items[0], group)]
+    if DP_NO_COMM:
+        return [(m, m2, rows) for m, m2, rows in items]
     world = dist.get_world_size(group)
     collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
     collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(items)
@@ -1786,6 +1878,8 @@ def _sync_stats_multi(items, group):
 def _sync_bwd_sums_multi(pairs, group):
     """the backward sums (s1, s2) of several norm sites all-reduced as ONE message; pairs = [(s1, s2), ...]"""
     import torch.distributed as dist
+    if DP_NO_COMM:
+        return list(pairs)
     collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
     if len(pairs) > 1:
         collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(pairs)
@@ -2010,7 +2104,7 @@ class NormActMultiFn(torch.autograd.Function):
         synced = [None] * n
         if sync_group is not None:
             synced = _sync_stats_multi([(st[3], st[4], st[5]) for st in states], sync_group)
-        outs, saved, counts = [], [], []
+        outs, saved, counts, nondiff = [], [], [], []
         for sc, st, sy, a in zip(sites, states, synced, args):
             x, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, out_lp, x16, defer, _ = a
             o = _norm_fwd_finish(sc, st, sy, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, sync_group,
@@ -2018,9 +2112,10 @@ class NormActMultiFn(torch.autograd.Function):
             outs += list(o) + [None] * (NORM_SITE_OUTS - len(o))
             saved += list(sc.saved_tensors)
             counts.append(len(sc.saved_tensors))
-            if sc.nondiff:
-                ctx.mark_non_differentiable(*sc.nondiff)
+            nondiff += sc.nondiff
             sc.saved_tensors = ()
+        if nondiff:     # ONE call: mark_non_differentiable replaces, it does not append
+            ctx.mark_non_differentiable(*nondiff)
         ctx.save_for_backward(*saved)
         ctx.sites, ctx.counts, ctx.sync_group = sites, counts, sync_group
         return tuple(outs)

@@ -13,6 +13,7 @@ Differences, all deliberate:
     numerics); BF16 = the bf16 compute without a scaler;
   * conv biases that feed an InstanceNorm get their exact (zero) gradient by default instead of the reference's
     rounding noise (ops.EXACT_NULL_BIAS_GRAD; MMH_NULL_BIAS_GRAD=compute restores it; INTEGRATION.md §2b);
+  * --fp32_exact_grads (addition): the gradient-exact fp32 hybrid, see ops.set_winograd_mode;
   * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline) and
     --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
@@ -68,6 +69,10 @@ _BASE = [
     ("--vgg_random_init", dict(action="store_true",
                                help="perceptual loss on seeded RANDOM VGG weights (benchmarks / tests; "
                                     "not the reference's objective)")),
+    ("--fp32_exact_grads", dict(action="store_true",
+                                help="fp32 only: forward 3x3 convs on the direct implicit-GEMM kernels, dgrad / wgrad on "
+                                     "Winograd F(6x6,3x3) - every gradient within 1e-3 of fp64 (the all-Winograd default "
+                                     "reaches 3e-3 on this network's ill-conditioned gradients); = MMH_WINOGRAD=bwd")),
 ]
 _TRAIN = [
     ("--display_freq", dict(type=int, default=100)),

@@ -148,6 +148,84 @@ def _w_grad_buckets(rank, world, port):
     dist.destroy_process_group()
 
 
+def _w_grad_buckets_inplace(rank, world, port):
+    """The second way a parameter gradient completes (dp.param_use / dp.param_done): a shim that adds its weight gradient
+    into the flat buffer ITSELF and returns None to autograd - what the conv shims do under ops.ACCUM_PARAM_GRADS - beside
+    parameters that still go through AccumulateGrad (the biases here).  Each layer is used TWICE in one pass (as a
+    discriminator on its real and its fake batch): a weight is complete after its second contribution only, and the
+    buckets still go out in reverse layer order, before the early layers are reached, with the sum over ranks in them."""
+    _init(rank, world, port)
+    from mmhand_amd import dp
+    from mmhand_amd.dp import GradBuckets
+
+    class InplaceLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            dp.param_use(w)
+            ctx.save_for_backward(x, w)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            w.grad.add_(g.t() @ x)          # in place, into the view of the flat gradient buffer
+            dp.param_done(w)
+            return g @ w, None, g.sum(0)    # the bias gradient still travels through AccumulateGrad
+
+    torch.manual_seed(5)
+    n_layers, width = 4, 8
+    per = width * width + width
+    flat, gflat = torch.zeros(n_layers * per), torch.zeros(n_layers * per)
+    ws, bs, ps, off = [], [], [], 0
+    for _ in range(n_layers):
+        for shape, lst in (((width, width), ws), ((width,), bs)):
+            k = 1
+            for d in shape:
+                k *= d
+            flat[off:off + k] = torch.randn(k) * 0.3
+            p = torch.nn.Parameter(torch.zeros(shape))
+            p.data = flat[off:off + k].view(shape)
+            p.grad = gflat[off:off + k].view(shape)
+            lst.append(p); ps.append(p)
+            off += k
+    log = []
+    bk = GradBuckets(ps, gflat, bucket_bytes=per * 4, log=log, flat_param=flat)     # one layer per bucket
+    assert len(bk.buckets) == n_layers
+
+    def net(x):
+        for w, b in zip(ws, bs):
+            x = torch.tanh(InplaceLinear.apply(x, w, b))
+        return x
+
+    xa = torch.randn(6, width, generator=torch.Generator().manual_seed(20 + rank))
+    xb = torch.randn(6, width, generator=torch.Generator().manual_seed(40 + rank))
+    gflat.zero_()
+    bk.begin()
+    (net(xa).square().mean() + net(xb).square().mean()).backward()      # every parameter used twice
+    bk.launch_remaining()
+    bk.wait()
+    # reference: ordinary autograd on plain tensors, summed over ranks
+    rw = [w.detach().clone().requires_grad_() for w in ws]
+    rb = [b.detach().clone().requires_grad_() for b in bs]
+
+    def ref_net(x):
+        for w, b in zip(rw, rb):
+            x = torch.tanh(x @ w.t() + b)
+        return x
+    (ref_net(xa).square().mean() + ref_net(xb).square().mean()).backward()
+    ref = torch.cat([t.grad.reshape(-1) for pair in zip(rw, rb) for t in pair])
+    dist.all_reduce(ref)
+    assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7), (gflat - ref).abs().max()
+    assert [e for e in log if e[0] == "bucket"] == [("bucket", i) for i in range(n_layers)], log
+    # the last layer's bucket went out before the first layer's weight (parameter 0) was complete, and no weight was
+    # reported complete twice
+    assert log.index(("bucket", 0)) < log.index(("param", 0))
+    assert len([e for e in log if e[0] == "param"]) == 2 * n_layers
+    bk.remove()
+    assert not dp.tracking()
+    dist.destroy_process_group()
+
+
 def _w_options(rank, world, port):
     _init(rank, world, port)
     from mmhand_amd.options import TrainOptions
@@ -159,6 +237,7 @@ def _w_options(rank, world, port):
 
 
 @pytest.mark.parametrize("worker,port", [(_w_sync_stats, 29611), (_w_grad_average, 29612),
-                                          (_w_options, 29613), (_w_grad_buckets, 29614), (_w_sync_stats_packed, 29615)])
+                                          (_w_options, 29613), (_w_grad_buckets, 29614), (_w_sync_stats_packed, 29615),
+                                          (_w_grad_buckets_inplace, 29616)])
 def test_world2_gloo(worker, port):
     mp.spawn(worker, args=(2, port), nprocs=2, join=True)

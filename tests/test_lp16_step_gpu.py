@@ -174,8 +174,12 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
 
 
-def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(dev, monkeypatch):
-    """The same problem in fp32 (--opt_level O0), so that the round-3 fp32 kernels sit under a step-level oracle test at the
+@pytest.mark.parametrize("mode", ["all", "bwd"])
+def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypatch):
+    """mode "bwd" = --fp32_exact_grads (ops.set_winograd_mode("bwd")): direct fprop, F(6x6,3x3) dgrad and
+    wgrad with the transformed input made in the backward - EVERY Generator gradient tensor within 1e-3 of fp64 (north_star's
+    bar), the forward Winograd GEMM entry point never called.  mode "all":
+    The same problem in fp32 (--opt_level O0), so that the round-3 fp32 kernels sit under a step-level oracle test at the
     channel counts they are built for: the halo-resident stem fprop (conv_stem_f32.hip: 8 / 24 / 44 -> 64), the stride-2
     dgrad and wgrad (dgrad_s2.hip / wgrad_s2.hip: 64 -> 128 and 128 -> 256; mmh_dgrad_s2_halo_supported asserted for the
     step's shapes), the ConvTranspose2d forward on dgrad_s2, the F(6x6,3x3) stack with the forward GEMMs on two summation
@@ -194,8 +198,9 @@ def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(dev, monkeypatch):
         calls[name] += 1
         return real(name, *a)
     monkeypatch.setattr(lib, "call", spy)
-    model = MMHandModel(_opt("O0"))
-    assert not model.bf16
+    monkeypatch.setattr(ops, "WINOGRAD_FPROP", ops.WINOGRAD_FPROP)     # restored after the test (the option sets it)
+    model = MMHandModel(_opt("O0", fp32_exact_grads=mode == "bwd"))
+    assert not model.bf16 and ops.WINOGRAD_FPROP == (mode == "all") and ops.USE_WINOGRAD
     for net, sd in zip((model.netG, model.netD_PB, model.netD_PP, model.vgg), nets()):
         net.load_state_dict(sd)
     sds = [OrderedDict((k, v.cpu()) for k, v in n.state_dict().items())
@@ -224,7 +229,13 @@ def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(dev, monkeypatch):
                 errs.append((R.rel_l1(g.double(), og[k]), k))
     errs.sort()
     med = errs[len(errs) // 2][0]
-    print(f"\n[fp32, ngf 64] image {e_img:.2e}; G gradients vs fp64: median {med:.2e}, max {errs[-1][0]:.2e} ({errs[-1][1]})")
+    print(f"\n[fp32, ngf 64, winograd {mode}] image {e_img:.2e}; G gradients vs fp64: median {med:.2e}, max {errs[-1][0]:.2e} ({errs[-1][1]})")
+    if mode == "bwd":
+        assert errs[-1][0] <= 1e-3, errs[-5:]
+        assert calls["mmh_wino_gemm"] == 0 and calls["mmh_wino_input_normact"] == 0, calls
+        assert calls["mmh_wino_gemm_levels"] >= 2 * 6 * NB and calls["mmh_wino_wgrad_gemm"] >= 2 * 6 * NB, calls
+        assert calls["mmh_wino_input_dy"] >= 2 * 6 * NB, calls        # the fused dy pass ran (V made in the backward)
+        return
     assert errs[-1][0] <= 2e-3 and med <= 1e-3, errs[-5:]
     # the kernels this test is here for did run
     dsc = lambda *a: ctypes.byref(ops.conv_desc(*a))     # noqa: E731
