@@ -399,6 +399,15 @@ int mmh_scale_shift_act(const void* x, const void* scale, const void* shift,
                         int64_t rows_per_group, int C, int relu, float drop_p,
                         uint64_t seed, const void* mask, void* keep_bits,
                         int x_dtype, int out_dtype, mmh_stream_t s);
+/* The same pass writing `out` AND the same values in 16 bits to `twin` (twin_dtype MMH_BF16 | MMH_FP16): a norm output with
+ * two consumers - the residual stream of a ResnetBlock (models/Discriminator.py:50), a PATBlock's first stream-1 input -
+ * stays fp32 for the residual add, and the 3x3 conv that reads it takes the twin instead of a conversion pass of its
+ * own (mmh_cvt_lp16: 6 B per element against 2).  Needs C / 8 a power of two <= 256.                                      */
+int mmh_scale_shift_act_twin(const void* x, const void* scale, const void* shift,
+                             const void* residual, void* out, int groups,
+                             int64_t rows_per_group, int C, int relu, float drop_p,
+                             uint64_t seed, const void* mask, void* keep_bits,
+                             int x_dtype, int out_dtype, void* twin, int twin_dtype, mmh_stream_t s);
 
 /* Backward of norm+relu+dropout.  dz = g * (relu||drop ? (out>0)/(1-p) : 1).
  * masked: 0 = no ReLU / dropout (`out` unused), 1 = `out` is the fp32 forward output,
@@ -417,6 +426,16 @@ int mmh_norm_bwd_apply(const void* g, const void* out, const void* x,
                        double count, int groups, int64_t rows_per_group,
                        int C, int masked, float drop_p, void* dx,
                        int g_dtype, int x_dtype, int dx_dtype, mmh_stream_t s);
+
+/* The same backward in ONE pass for small planes (InstanceNorm at 64x64 and below; 16-bit x): a workgroup holds the whole
+ * (group, 8-16 channels) plane in registers - g, x and the keep bits are read once, s1 / s2 summed on chip (and written
+ * out: the affine parameters' gradients need them), dx applied.  Same per-element arithmetic as the two entry points
+ * above, different (fixed) order of the plane sums.  Not for SyncBN (its sums cross ranks between the two passes).
+ * mmh_norm_bwd_fused_supported: 1 when (groups, rows, C, masked, types) fit - rows <= 8192 / 8-channel lane groups.  */
+int mmh_norm_bwd_fused_supported(int groups, int64_t rows, int C, int masked, int g_dtype, int x_dtype);
+int mmh_norm_bwd_fused(const void* g, const void* out, const void* x, const void* mean, const void* invstd,
+                       const void* gamma, double count, int groups, int64_t rows, int C, int masked, float drop_p,
+                       void* s1, void* s2, void* dx, int g_dtype, int x_dtype, int dx_dtype, mmh_stream_t s);
 
 /* ---- norm-apply fused into the consuming convolution (fp32, Winograd F(6x6,3x3) stack) ----
  * The reference runs conv -> Norm -> ReLU -> Dropout -> ReflectionPad -> conv as separate modules

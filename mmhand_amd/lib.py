@@ -114,9 +114,12 @@ SIGNATURES = {
     "mmh_norm_stats": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_norm_finalize": (_i, [_vp, _vp, _d, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "mmh_scale_shift_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _i, _vp]),
+    "mmh_scale_shift_act_twin": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "mmh_norm_bwd_ws_bytes": (_sz, [_i, _i64, _i]),
     "mmh_norm_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "mmh_norm_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _i, _i, _i, _vp]),
+    "mmh_norm_bwd_fused_supported": (_i, [_i, _i64, _i, _i, _i, _i]),
+    "mmh_norm_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mmh_dropout_bits": (_i, [_i64, _f, _u64, _vp, _vp, _vp]),
     "mmh_dropout_bits_rows": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "mmh_dropout_bits_both": (_i, [_i64, _i, _i, _f, _u64, _vp, _vp, _vp, _vp]),

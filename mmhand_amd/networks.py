@@ -318,7 +318,7 @@ class _Net(nn.Module):
             return p, y16
         return ops.ConvT2dFn.apply(x, cp.weight, cp.bias, self.bf16, x16, False, nb)
 
-    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0, defer=0, res_tok=None):
+    def normact(self, bag, idx, x, relu, drop=False, site=None, residual=None, out_lp=0, defer=0, res_tok=None, want_twin=0):
         """out_lp: hand the result to the next conv in 16 bits -> returns a (proxy, x16) pair.
         x may itself be a (proxy, x16) pair from a 16-bit convolution (conv(y_lp=True)).
         defer (1 | 2, training fp32): only the statistics are finalised here; returns a (proxy, NormDefer)
@@ -355,15 +355,17 @@ class _Net(nn.Module):
                 sync = self.sync_group
             p, scale, shift, drows = ops.NormActFn.apply(x, *args, relu, drop_p, seed, mask, sync, 0, None, defer)
             return p, ops.NormDefer(x.detach(), scale, shift, groups, relu, drop_p, drows)
+        # want_twin: the fp32 output has a second, 16-bit consumer (the next 3x3 conv) -> returns (out, twin16 | None)
+        want_twin = want_twin if (self.training and not out_lp) else 0
         if self.norm == "instance":
             return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", relu,
-                                       drop_p, seed, mask, None, out_lp, x16, 0, res_tok)
+                                       drop_p, seed, mask, None, out_lp, x16, 0, res_tok, want_twin)
         np_ = bag[idx]
         if self.training:
             np_.num_batches_tracked += 1
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean,
                                        np_.running_var, "batch", relu, drop_p, seed, mask,
-                                       self.sync_group, out_lp, x16, 0, res_tok)
+                                       self.sync_group, out_lp, x16, 0, res_tok, want_twin)
         scale = np_.weight / torch.sqrt(np_.running_var + ops.EPS)
         shift = np_.bias - np_.running_mean * scale
         y = ops.AffineActFn.apply(x, scale, shift, relu)
@@ -403,7 +405,14 @@ class _Net(nn.Module):
         return ops.ResidualToken() if (ops.USE_RESIDUAL_TOKENS and self.bf16 and self.training and torch.is_tensor(x)
                                        and x.requires_grad) else None
 
-    def two_conv_block(self, blk, x, site, last_norm, residual=None, res_tok=None, x_twin=None):
+    def _twin_for(self, cp):
+        """the operand type of the 16-bit twin that the 3x3 / stride 1 conv `cp` would read in place of its fp32 input, else 0"""
+        if not (self.bf16 and self.training and cp is not None and cp.k == 3 and not cp.transposed):
+            return 0
+        ws = cp.weight.shape
+        return self.bf16 if (ops.lp16_v2_ok(ws[2], ws[3], 3, 1, 1, 0) and ops.norm_twin_ok(ws[2])) else 0
+
+    def two_conv_block(self, blk, x, site, last_norm, residual=None, res_tok=None, x_twin=None, want_twin=0):
         """RP1-conv-norm-ReLU-(Dropout)-RP1-conv-(norm) (build_conv_block in both reference nets).
         res_tok: x is also read by the caller's residual add (the PATBlock gate); with residual is x (ResnetBlock)
         the token is made here."""
@@ -422,8 +431,9 @@ class _Net(nn.Module):
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
         y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm, g_defer=fuse_last == 3)
         if last_norm:
+            # want_twin: the block's output also feeds the next block's first conv -> (out, twin16 | None)
             y = self.normact(blk, i2 + 1, y, False, residual=residual, defer=fuse_last,
-                             res_tok=res_tok if residual is not None else None)
+                             res_tok=res_tok if residual is not None else None, want_twin=want_twin if not fuse_last else 0)
         return y
 
 
@@ -533,6 +543,7 @@ class Generator(_Net):
         """x1,x2,x3: NHWC (channels zero-padded to 4) -> NHWC [B,H,W,pad4(output_nc)]."""
         m = self.model
         xs = []
+        x1_twin0 = None
         if packing(self):       # SyncBN: the three streams side by side, one packed collective per depth
             x1, x2, x3 = self._down_lockstep(x1, x2, x3)
         # 16-bit mode: the tensors between the 3x3 convs and their norms travel in 16 bits (see two_conv_block);
@@ -551,8 +562,14 @@ class Generator(_Net):
                     out_lp = self._lp_edge(m["att"][0][f"conv_block_stream{s}"][1])
                 else:
                     out_lp = 0
+                # stream 1 stays fp32 (it is the gate's residual input too): its 16-bit twin for block 0's first conv comes
+                # out of the same norm pass (ops.USE_NORM_TWIN)
+                wt = (self._twin_for(m["att"][0]["conv_block_stream1"][1])
+                      if (s == 1 and i + 1 == self.n_down and self.n_blocks > 0 and not out_lp) else 0)
                 x = self.normact(d, 5 + 3 * i, self.conv(cp, x, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True), True,
-                                 out_lp=out_lp)
+                                 out_lp=out_lp, want_twin=wt)
+                if wt:
+                    x, x1_twin0 = x
             xs.append(x)
         if not packing(self):
             x1, x2, x3 = xs
@@ -562,6 +579,8 @@ class Generator(_Net):
             tok = None
             # x1's 16-bit twin: the second half of cat(s3, out) the previous gate wrote in 16 bits (ops.USE_LP16_CAT_TWIN)
             x1_twin = x2[1][..., x1.shape[3]:] if (b > 0 and isinstance(x2, tuple) and torch.is_tensor(x1)) else None
+            if b == 0 and torch.is_tensor(x1):
+                x1_twin = x1_twin0
             if packing(self):
                 s1, s2, s3 = two_conv_blocks_lockstep(
                     [dict(net=self, blk=blk[f"conv_block_stream{s}"], x=x, site=p + str(s), last_norm=s == 1)
@@ -643,15 +662,23 @@ class Discriminator(_Net):
         y = self.normact(m, 2, self.conv(m[1], x, 1, 3, True, dx_channels=dx_channels, to_norm=True,
                                          y_lp=self._lp_out_stem(m[1], Bx, Hx, Wx, x.requires_grad, dx_channels)), True,
                          out_lp=self._lp_edge(first, 2, False))
+        base = 4 + 3 * self.n_down
+        twin = None         # 16-bit twin of the residual stream, written by the norm that produced it (ops.USE_NORM_TWIN)
         for i in range(self.n_down):
             cp = m[4 + 3 * i]
             out_lp = self._lp_edge(m[4 + 3 * (i + 1)], 2, False) if i + 1 < self.n_down else 0
+            wt = self._twin_for(m[base]["conv_block"][1]) if (i + 1 == self.n_down and self.n_blocks > 0) else 0
             y = self.normact(m, 5 + 3 * i, self.conv(cp, y, 2, 1, False, y_lp=self._lp_out(cp, 2, False), to_norm=True), True,
-                             out_lp=out_lp)
-        base = 4 + 3 * self.n_down
+                             out_lp=out_lp, want_twin=wt)
+            if wt and not out_lp:
+                y, twin = y
         for b in range(self.n_blocks):
+            wt = self._twin_for(m[base + b + 1]["conv_block"][1]) if b + 1 < self.n_blocks else 0
             y = self.two_conv_block(m[base + b]["conv_block"], y, f"model.{base + b}.conv_block",
-                                    True, residual=y)
+                                    True, residual=y, x_twin=twin, want_twin=wt)
+            twin = None
+            if wt:
+                y, twin = y
         return y
 
     def forward(self, input):

@@ -1793,14 +1793,22 @@ def raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var, m
     return scale, shift, invstd
 
 
-def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=False, out_lp=0):
+def raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=False, out_lp=0, twin_lp=0):
     """keep_bits: also return the uint8 [B,H,W,C/4] array of surviving-lane bits (4 per byte), the
-    only thing the norm backward needs of `out`.  out_lp: 0 fp32 | True bf16 | 2 fp16 output."""
+    only thing the norm backward needs of `out`.  out_lp: 0 fp32 | True bf16 | 2 fp16 output.
+    twin_lp (True bf16 | 2 fp16): also return the same values as a 16-bit tensor, written by the same pass
+    (mmh_scale_shift_act_twin) -> out [, keep bits] [, twin]."""
     B, H, W_, Cc = x.shape
     groups = scale.shape[0]
     rows = (B // groups) * H * W_
     out = torch.empty(x.shape, dtype=_wd(out_lp), device=x.device)
     kb = torch.empty((B, H, W_, Cc // 4), dtype=torch.uint8, device=x.device) if keep_bits else None
+    if twin_lp:
+        twin = torch.empty(x.shape, dtype=_wd(twin_lp), device=x.device)
+        L.call("mmh_scale_shift_act_twin", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+               groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _tdt(x), _dt(out_lp), _ptr(twin),
+               _dt(twin_lp), _stream())
+        return (out, kb, twin) if keep_bits else (out, twin)
     L.call("mmh_scale_shift_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
            groups, rows, Cc, int(relu), float(drop_p), seed, _ptr(mask), _ptr(kb), _tdt(x), _dt(out_lp), _stream())
     return (out, kb) if keep_bits else out
@@ -1929,8 +1937,18 @@ def _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16):
     return x, groups, None, mean, m2, rows
 
 
+# A norm output that stays fp32 for a non-conv consumer (a residual add) AND feeds a 16-bit 3x3 conv: the apply pass writes the
+# conv's 16-bit operand beside the fp32 tensor (mmh_scale_shift_act_twin) instead of leaving a conversion pass to the conv.
+USE_NORM_TWIN = os.environ.get("MMH_NORM_TWIN", "1") != "0"
+
+
+def norm_twin_ok(C):
+    c8 = C // 8
+    return USE_NORM_TWIN and USE_LP16_CAT_TWIN and C % 8 == 0 and 1 <= c8 <= 256 and (c8 & (c8 - 1)) == 0
+
+
 def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask,
-                     sync_group, out_lp, x16, defer):
+                     sync_group, out_lp, x16, defer, want_twin=0):
     x, groups, fast, mean, m2, rows = st
     if fast is not None:
         mean, scale, shift, invstd, rows = fast
@@ -1963,14 +1981,18 @@ def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, runni
             ctx.mark_non_differentiable(drows)
         return lp_proxy(x.shape, x.device), scale, shift, drows
     masked = bool(relu or drop_p > 0)
-    if masked:      # the backward needs only which lanes survived: 4 bits per float4, not `out`
-        out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=True,
-                                      out_lp=out_lp)
-    else:
-        out, kb = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, out_lp=out_lp), None
+    twin_lp = want_twin if (want_twin and not out_lp and norm_twin_ok(x.shape[3])) else 0
+    r = raw_scale_shift_act(x, scale, shift, residual, relu, drop_p, seed, mask, keep_bits=masked, out_lp=out_lp,
+                            twin_lp=twin_lp)        # masked: the backward needs only which lanes survived (4 bits per float4)
+    r = r if isinstance(r, tuple) else (r,)
+    out, kb, twin = r[0], (r[1] if masked else None), (r[-1] if twin_lp else None)
     ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
                residual is not None)
     ctx.save_for_backward(x, kb, mean, invstd, gamma)
+    if want_twin and not out_lp:        # (out, twin | None): the caller asked for the pair
+        if twin is not None:
+            ctx.mark_non_differentiable(twin)
+        return out, twin
     if out_lp:
         if residual is not None:
             raise RuntimeError("NormActFn: a 16-bit output together with a residual is not supported")
@@ -1979,9 +2001,17 @@ def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, runni
     return (out,)
 
 
+# InstanceNorm backward in ONE pass where a (sample, channel) plane fits a workgroup (mmh_norm_bwd_fused: 16-bit x, rows <=
+# 8192 / 8-channel lane groups - the 64x64 feature maps of the 256x256 configurations): g, x and the keep bits are read once
+# instead of twice, the reduce launch is gone.  Not under SyncBN (the sums cross ranks between the passes).
+# MMH_NORM_BWD_PLANE=0: always reduce + apply.
+USE_NORM_BWD_PLANE = os.environ.get("MMH_NORM_BWD_PLANE", "0") == "1"
+
+
 def _norm_bwd_local(ctx, g):
     """this rank's sums (s1 = sum dz, s2 = sum dz * xhat per plane) -> (g, s1, s2)"""
     groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
+    ctx.fused_dx = None
     if ctx.defer:
         x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
         g = g.contiguous()
@@ -1998,8 +2028,15 @@ def _norm_bwd_local(ctx, g):
     g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
     Cc = x.shape[3]
     masked = 2 if (relu or drop_p > 0) else 0
-    ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
     s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+    if (USE_NORM_BWD_PLANE and sync_group is None and x.dtype != torch.float32 and g.dtype in (torch.float32, x.dtype)
+            and L.load().mmh_norm_bwd_fused_supported(groups, rows, Cc, masked, _tdt(g), _tdt(x))):
+        dx = torch.empty_like(x)
+        L.call("mmh_norm_bwd_fused", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), float(count),
+               groups, rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
+        ctx.fused_dx = dx
+        return g, s1, s2
+    ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
     L.call("mmh_norm_bwd_reduce", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd), groups,
            rows, Cc, masked, drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _tdt(g), _tdt(x), _stream())
     return g, s1, s2
@@ -2024,10 +2061,13 @@ def _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2):
     x, out, mean, invstd, gamma = ctx.saved_tensors
     Cc = x.shape[3]
     masked = 2 if (relu or drop_p > 0) else 0
-    dx = torch.empty_like(x)        # a 16-bit x came from a 16-bit convolution: its gradient goes back in 16 bits
-    L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
-           _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
-           _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
+    dx = getattr(ctx, "fused_dx", None)
+    ctx.fused_dx = None
+    if dx is None:
+        dx = torch.empty_like(x)        # a 16-bit x came from a 16-bit convolution: its gradient goes back in 16 bits
+        L.call("mmh_norm_bwd_apply", _ptr(g), _ptr(out), _ptr(x), _ptr(mean), _ptr(invstd),
+               _ptr(gamma), _ptr(s1), _ptr(s2), float(count), groups, rows, Cc, masked, drop_p,
+               _ptr(dx), _tdt(g), _tdt(x), _tdt(dx), _stream())
     dres = g if has_res else None
     if ctx.in_lp:
         dx = lp_grad_out(dx)
@@ -2042,12 +2082,13 @@ class NormActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, mode, relu, drop_p,
-                seed, mask, sync_group, out_lp=0, x16=None, defer=0, res_tok=None):
+                seed, mask, sync_group, out_lp=0, x16=None, defer=0, res_tok=None, want_twin=0):
         """out_lp (True bf16 | 2 fp16): the output is written in that 16-bit type only - it feeds a
         16-bit convolution (conv_lp16.hip) and nothing else, so no fp32 copy and no conversion pass.
         x16: the producing convolution wrote x in 16 bits only (Conv2dFn y_lp); x is then the proxy on
         the autograd edge.  Statistics and all arithmetic are fp32 either way (apex O1 keeps
         batch_norm in fp32 on fp16 conv outputs).
+        want_twin (True bf16 | 2 fp16): the fp32 output also feeds a 16-bit conv - returns (out, twin16 | None).
         Returns out | (proxy, out16) with out_lp | (proxy, scale, shift, drows) with defer 1 / 2."""
         ctx.set_materialize_grads(False)
         ctx.res_tok = res_tok if residual is not None else None    # `residual` is also a conv's input (ResidualToken)
@@ -2056,13 +2097,15 @@ class NormActFn(torch.autograd.Function):
         if mode == "batch" and sync_group is not None and st[2] is None:
             synced = _sync_stats(st[3], st[4], st[5], sync_group)
         outs = _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed,
-                                mask, sync_group, out_lp, x16, defer)
+                                mask, sync_group, out_lp, x16, defer, want_twin if not defer else 0)
+        if want_twin and not defer and not out_lp and outs[1] is None:
+            return outs[0], None        # (a None output is not a tensor: autograd passes it through)
         return outs[0] if len(outs) == 1 else outs
 
     @staticmethod
     def backward(ctx, g, _g16=None, _a=None, _b=None):
         if g is None:
-            return (None,) * 16
+            return (None,) * 17
         sync_group = ctx.cfg[5]
         g, s1l, s2l = _norm_bwd_local(ctx, g)
         s1, s2 = s1l, s2l
@@ -2071,7 +2114,7 @@ class NormActFn(torch.autograd.Function):
         dx, dgamma, dbeta, dres = _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2)
         if ctx.res_tok is not None and ctx.res_tok.park(dres):
             dres = None         # joins the block input's gradient inside its first conv's dgrad
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 NORM_SITE_ARGS = 14     # per site: x, gamma, beta, residual, running_mean, running_var, relu, drop_p, seed, mask, out_lp, x16, defer, _

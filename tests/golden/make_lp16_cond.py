@@ -6,7 +6,8 @@ what apex O1 does to the reference (models/MMHandModel.py:99-108) - against the 
     python tests/golden/make_lp16_cond.py        (CPU, about a minute: fp16 convolutions are slow on the host)
 
 Writes tests/golden/lp16_cond.npz: per Generator parameter the relative L1 distance of its iteration-1 gradient from
-float64 (`bf16/<key>`, `fp16/<key>`), the generated image's (`bf16/image`, ...) and the six fp64 losses.  The GPU test
+float64 (`bf16/<key>`, `fp16/<key>`, and `fp32/<key>` = the oracle in plain float32), the generated image's
+(`bf16/image`, ...) and the six fp64 losses.  The GPU test
 holds the HIP 16-bit path to these figures (x 1.2): no 16-bit implementation of this network can be closer to float64
 than the arithmetic allows - bf16: median 1.7e-1 per tensor, fp16: 5e-2."""
 import os
@@ -60,7 +61,8 @@ def main():
     o64 = run(torch.float64, None)
     ref = dict((k, t.grad) for k, t in o64.G.named_parameters())
     out = {"losses64": np.array(list(o64.losses.values()))}
-    for tag, ac in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+    # "fp32": PyTorch's own fp32 run of the same step (no autocast) - the conditioning yardstick of the fp32 HIP paths
+    for tag, ac in (("bf16", torch.bfloat16), ("fp16", torch.float16), ("fp32", None)):
         o = run(torch.float32, ac)
         out[f"{tag}/image"] = np.float64(R.rel_l1(o.fake_p2.detach().double(), o64.fake_p2.detach()))
         errs = []

@@ -1,13 +1,16 @@
 """Per-shape launch durations of one kernel from a rocprofv3 --kernel-trace CSV: shows that the
 HIP-event average bench.py reports for its roofline kernel agrees with the profiler.
-usage: python tools/roofline_from_trace.py <dir with *_kernel_trace.csv> [kernel substring]"""
+usage: python tools/roofline_from_trace.py <dir with *_kernel_trace.csv> [kernel substring]
+The substring is matched with all blanks removed on both sides, so give the FULL template argument list of the kernel you
+mean - "wino_gemm_kernel<128,2>" (the two-level forward GEMMs bench.py times) is not "wino_gemm_kernel<128,1>" (the
+one-level dgrad twin, 5 % faster): a prefix that matches both mixes them."""
 import collections, csv, glob, statistics, sys
 d = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else "conv_igemm_kernel<128, 2, 2, false, false>"
 f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if pat in r["Kernel_Name"]:
+    if pat.replace(" ", "") in r["Kernel_Name"].replace(" ", ""):
         wg = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
         acc[wg].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(f"kernel: {pat}\ntrace:  {f.split('/')[-1]}")
