@@ -25,6 +25,7 @@ from .networks import Discriminator, Generator, VGGHead, discriminators_lockstep
 from .ops import pad4
 
 
+MERGE_D_PASSES = os.environ.get("MMH_MERGE_D", "1") != "0"
 _LAST_BUCKET_LOG = None      # MMH_DP_LOG=1: the event log of the last data-parallel model (tests)
 
 
@@ -460,7 +461,21 @@ class MMHandModel(torch.nn.Module):
         return float(self._scaler[loss_id, 0])
 
     def backward_D_basic(self, netD, real, fake, loss_id=0):
+        """real: a [2B,H,W,C] buffer whose first half holds the real batch (backward_D_PB / _PP pack it there) when the two
+        passes run as one, else the [B,H,W,C] real batch."""
         o = self.opt
+        if real.shape[0] == 2 * fake.shape[0]:
+            # --norm instance: every sample is normalised on its own, so netD(real) and netD(fake) (two passes,
+            # models/MMHandModel.py:263-274) ARE netD(cat(real, fake)) sample by sample - one pass over 2B images: half the
+            # launches of a discriminator step and fuller tail rounds in every kernel.  (BatchNorm keeps the two passes: each
+            # has its own batch statistics.)  MMH_MERGE_D=0: two passes.
+            B = fake.shape[0]
+            real[B:].copy_(fake.detach())
+            pred = netD.forward_nhwc(real)
+            loss_D_real, loss_D_fake = ops.BCEWithLogitsHalvesFn.apply(pred, 1.0)
+            loss_D = (loss_D_real * o.lambda_GAN + loss_D_fake * o.lambda_GAN) * 0.5
+            self.loss_backward(loss_D, loss_id)
+            return loss_D
         # the real and the fake batch keep their own batch statistics (two passes, models/MMHandModel.py:263-274);
         # under SyncBN they run side by side and share each depth's collective
         pred_real, pred_fake = discriminators_lockstep([(netD, real, 0), (netD, fake.detach(), 0)])
@@ -470,11 +485,18 @@ class MMHandModel(torch.nn.Module):
         self.loss_backward(loss_D, loss_id)
         return loss_D
 
+    def _real_buffer(self, netD, B, H, W, Cd):
+        """[2B,H,W,Cd] when the discriminator step runs its real and fake batch as ONE pass (InstanceNorm; see
+        backward_D_basic), else [B,H,W,Cd]; the real batch is packed into the first B images"""
+        merged = netD.norm == "instance" and MERGE_D_PASSES
+        return torch.empty(((2 if merged else 1) * B, H, W, Cd), dtype=torch.float32, device=self.device)
+
     def backward_D_PB(self):
         o = self.opt
         B, _, H, W = self.input_H2.shape
-        real_PB = ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_P2, True, o.P_input_nc)],
-                               B, H, W, pad4(o.H_input_nc + o.P_input_nc), self.device)
+        real_PB = self._real_buffer(self.netD_PB, B, H, W, pad4(o.H_input_nc + o.P_input_nc))
+        ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_P2, True, o.P_input_nc)],
+                     B, H, W, pad4(o.H_input_nc + o.P_input_nc), self.device, out=real_PB[:B])
         with torch.no_grad():
             fake_now = self._cat_PB(self.fake_nhwc.detach(), True)
         fake_PB = self.fake_PB_pool.query(fake_now)
@@ -483,8 +505,9 @@ class MMHandModel(torch.nn.Module):
     def backward_D_PP(self):
         o = self.opt
         B, _, H, W = self.input_H2.shape
-        real_PP = ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_H1, True, o.H_input_nc)],
-                               B, H, W, pad4(2 * o.H_input_nc), self.device)
+        real_PP = self._real_buffer(self.netD_PP, B, H, W, pad4(2 * o.H_input_nc))
+        ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_H1, True, o.H_input_nc)],
+                     B, H, W, pad4(2 * o.H_input_nc), self.device, out=real_PP[:B])
         with torch.no_grad():
             fake_now = self._cat_PP(self.fake_nhwc.detach())
         fake_PP = self.fake_PP_pool.query(fake_now)

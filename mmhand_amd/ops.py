@@ -2300,6 +2300,41 @@ class BCEWithLogitsConstFn(torch.autograd.Function):
         return dx, None, None
 
 
+class BCEWithLogitsHalvesFn(torch.autograd.Function):
+    """GANLoss of a discriminator that ran ONCE on cat(real batch, fake batch) (MMHandModel.backward_D_basic under
+    InstanceNorm): (weight * mean BCE(x[:B], 1), weight * mean BCE(x[B:], 0)) straight from the two halves of the logits
+    and, backward, both halves of dx written in place - no slice views, so no zero-fill / copy / add passes of autograd's
+    slice backward over the [2B, H/4, W/4, 256] map."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _chk(x, "x")
+        assert x.shape[0] % 2 == 0
+        n = x.numel() // 2
+        ws = _ws(L.load().mmh_reduce_ws_bytes(n), x)
+        out = torch.empty((2,), dtype=torch.float32, device=x.device)
+        for h, target in ((0, 1.0), (1, 0.0)):
+            L.call("mmh_bce_logits_fwd", C.c_void_p(x.data_ptr() + 4 * n * h), n, target, float(weight), float(n),
+                   C.c_void_p(out.data_ptr() + 4 * h), _ptr(ws), ws.numel() * 4, _stream())
+        ctx.weight = float(weight)
+        ctx.save_for_backward(x)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_real, g_fake):
+        (x,) = ctx.saved_tensors
+        n = x.numel() // 2
+        dx = torch.empty_like(x)
+        for h, (target, g) in enumerate(((1.0, g_real), (0.0, g_fake))):
+            if g is None:
+                dx[h * (x.shape[0] // 2):(h + 1) * (x.shape[0] // 2)].zero_()
+                continue
+            g = g.contiguous().float()
+            L.call("mmh_bce_logits_bwd", C.c_void_p(x.data_ptr() + 4 * n * h), n, target, ctx.weight, float(n), _ptr(g),
+                   C.c_void_p(dx.data_ptr() + 4 * n * h), _stream())
+        return dx, None
+
+
 def _pair_loss_fwd(kind, ctx, a, b, weight, denom):
     _chk(a, "a"); _chk(b, "b")
     n = a.numel()
@@ -2381,15 +2416,19 @@ def _plane(t, nchw):
     return L.PlaneSrc(t.data_ptr(), Cc, sb, sc, sh, sw)
 
 
-def raw_pack(srcs, B, H, W_, Cd, device):
-    """srcs: list of (tensor, is_nchw, n_channels).  Returns NHWC [B,H,W,Cd] (zero padded)."""
+def raw_pack(srcs, B, H, W_, Cd, device, out=None):
+    """srcs: list of (tensor, is_nchw, n_channels).  Returns NHWC [B,H,W,Cd] (zero padded); out: write into this
+    contiguous [B,H,W,Cd] tensor (e.g. one half of a two-batch buffer) instead of a new one."""
     arr = (L.PlaneSrc * len(srcs))()
     for i, (t, nchw, nch) in enumerate(srcs):
         assert t.dtype == torch.float32 and t.is_cuda
         p = _plane(t, nchw)
         p.C = nch
         arr[i] = p
-    out = torch.empty((B, H, W_, Cd), dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty((B, H, W_, Cd), dtype=torch.float32, device=device)
+    else:
+        assert tuple(out.shape) == (B, H, W_, Cd) and out.is_contiguous() and out.dtype == torch.float32
     L.call("mmh_pack_nhwc", arr, len(srcs), _ptr(out), B, H, W_, Cd, 0, _stream())
     return out
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-4 evidence run (one MI355X).  Outputs under gpurun_out/r04prof/ (copied into profiles/r04_* by tools/collect_r04.sh).
+#   part A: configs[3] and configs[4] - kernel stats of the hipGraph inference run, per-entry-point breakdown
+#                           of the 512x512 B=4 bf16 step, the host-enqueue table
+#   part B               : the headline fp32 step and the bf16 step - kernel stats, traces, roofline from the trace, traffic
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04prof; mkdir -p $O
+cd $R
+python tools/host_overhead.py > $O/host_overhead.txt 2>&1
+python tools/step_breakdown.py --dtype bf16 --size 512 --batch 4 --top 60 > $O/breakdown_bf16_512.txt 2>&1
+python tools/step_breakdown.py --dtype bf16 > $O/breakdown_bf16.txt 2>&1
+python tools/step_breakdown.py --dtype f32 > $O/breakdown_f32.txt 2>&1
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -- python3 $R/bench.py --mode infer --dtype bf16 --steps 10 --warmup 3 > $O/infer_bf16_line.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_512 -- python3 $R/tools/run_512.py > $O/run_512.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_f32_line.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_bf16_line.log 2>&1
+cd $R
+python tools/roofline_from_trace.py $O/prof_f32 "wino_gemm_kernel<128, 2>" > $O/roofline_f32_trace.txt 2>&1
+python tools/roofline_from_trace.py $O/prof_bf16 conv_lp16h2_kernel > $O/roofline_bf16_trace.txt 2>&1
+for f in prof_infer prof_512 prof_f32 prof_bf16; do find $O/$f -name "*kernel_stats.csv" -exec cp {} $O/$f.kernel_stats.csv \; ; rm -rf $O/$f; done
+bash $R/tools/traffic_r04.sh $O/r04_traffic.json > $O/traffic.log 2>&1
+ls -la $O
