@@ -99,6 +99,11 @@ int launch_wino_wgrad_dma(const float* V, const float* Yh, int64_t tiles, int Ci
 extern int g_wino_wgrad_dma;
 // dw[b][i] (+)= sum over a batch's split-K slabs, fixed order (slab_reduce.hip)
 int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
+// 16-bit fprop of the 3x3 stride-2 convs with register-resident weights and an LDS-resident input halo (conv_s2_lp16.hip)
+bool conv_s2f_ok(const mmh_conv_desc* d, int mode);
+int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16, int act,
+                    const void* zeros, hipStream_t st);
+extern int g_lp16_s2f;
 extern int g_slab_reduce_par;
 extern int g_wino6_vec;
 extern int g_lp16_shape;

@@ -1,0 +1,72 @@
+"""conv_s2_lp16.hip - the 16-bit fprop of the 3x3 / stride-2 / zero-pad-1 convs (nn.Conv2d(c, 2c, 3, 2, 1), models/Generator.py
+:166-180, models/Discriminator.py:86-92) with register-resident weights and a de-interleaved LDS halo - behind
+mmh_conv_lp16 (mode 0).  Against the general 16-bit kernel it replaces (mmh_set_option("lp16_s2f", 0)): bit-identical at 64
+input channels (same order of summation), 2e-6 at 128 (chunk-outer instead of tap-outer order); and against the fp64
+convolution of the same 16-bit operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 64, 64, 64, 128), (1, 32, 64, 128, 256), (3, 16, 32, 64, 128),
+                                            (2, 16, 96, 128, 256), (5, 48, 32, 64, 256)])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("out16,bias,act", [(True, False, 0), (False, True, 1), (True, True, 0)])
+def test_stride2_fprop_vs_general_kernel_and_fp64(B, H, W, Cin, Cout, lp, out16, bias, act, dev):
+    import ctypes as C
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(H * 7 + Cin)
+    x = torch.randn((B, H, W, Cin), generator=gen, device=dev)
+    w = torch.randn((3, 3, Cin, Cout), generator=gen, device=dev) * 0.05
+    b = torch.randn((Cout,), generator=gen, device=dev) if bias else None
+    x16 = ops.lp16_twin(x, lp)
+    d = ops.conv_desc(B, H, W, Cin, Cout, 3, 2, 1, False)
+    assert ops.lp16g_ok(d, 0, lp)
+    outs = {}
+    for on in (1, 0):
+        L.check(L.load().mmh_set_option(b"lp16_s2f", 2 * on), "set_option")     # 2: the new kernel also at 128 input channels
+        try:
+            outs[on] = ops.raw_conv_lp16g(ops.conv_desc(B, H, W, Cin, Cout, 3, 2, 1, False), 0, x16, w, b, act, lp, out16=out16)
+        finally:
+            L.check(L.load().mmh_set_option(b"lp16_s2f", 1), "set_option")
+    torch.cuda.synchronize()
+    new, old = outs[1], outs[0]
+    assert new.dtype == (ops._wd(lp) if out16 else torch.float32) and bool(torch.isfinite(new.float()).all())
+    if Cin == 64:
+        assert torch.equal(new, old)
+    else:
+        assert _rel(new, old) <= (2e-6 if not out16 else 1e-3)
+    # fp64 convolution of the SAME 16-bit operands
+    wp, wt = ops.bf16_weights(w, lp)        # wt: [3,3,Cout,Cin] 16-bit
+    xr = x16.double().permute(0, 3, 1, 2)
+    wr = wt.double().permute(2, 3, 0, 1)    # OIHW
+    ref = F.conv2d(xr.cpu(), wr.cpu(), None if b is None else b.double().cpu(), stride=2, padding=1)
+    if act == 1:
+        ref = ref.relu()
+    ref = ref.permute(0, 2, 3, 1)
+    tol = 2e-5 if not out16 else (3e-3 if lp is True else 4e-4)
+    assert _rel(new.cpu(), ref) <= tol, _rel(new.cpu(), ref)
+
+
+def test_stride2_fprop_kernel_declines_other_shapes(dev):
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    import ctypes as C
+    l = L.load()
+    d64 = ops.conv_desc(32, 256, 256, 64, 128, 3, 2, 1, False)
+    d64.dtype = L.BF16
+    assert l.mmh_conv_lp16_supported(C.byref(d64), 0) == 1
+    # 20 x 20 outputs: not a multiple of the 8 x 16 tile -> the general kernel (same entry point, same result contract)
+    x = torch.randn((1, 40, 40, 64), device=dev)
+    w = torch.randn((3, 3, 64, 128), device=dev) * 0.05
+    y = ops.raw_conv_lp16g(ops.conv_desc(1, 40, 40, 64, 128, 3, 2, 1, False), 0, ops.lp16_twin(x, True), w, None, 0, True)
+    ref = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2).cpu(), w.bfloat16().double().permute(3, 2, 0, 1).cpu(), stride=2, padding=1)
+    assert _rel(y.cpu(), ref.permute(0, 2, 3, 1)) <= 2e-5

@@ -1,0 +1,16 @@
+#!/bin/bash
+# copy the outputs of tools/profile_r04.sh (gpurun_out/r04prof/, merged back from the GPU box) into profiles/r04_*
+R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/r04prof; P=$R/profiles
+grep -h "^{" $O/prof_f32_line.log > $P/r04_bench_f32_line.json
+grep -h "^{" $O/prof_bf16_line.log > $P/r04_bench_bf16_line.json
+grep -h "^{" $O/infer_bf16_line.log > $P/r04_infer_b64_bf16_line.json
+cp $O/prof_f32.kernel_stats.csv $P/r04_bench_f32_kernel_stats.csv
+cp $O/prof_bf16.kernel_stats.csv $P/r04_bench_bf16_kernel_stats.csv
+cp $O/prof_infer.kernel_stats.csv $P/r04_infer_b64_bf16_kernel_stats.csv
+cp $O/prof_512.kernel_stats.csv $P/r04_size512_bf16_b4_kernel_stats.csv
+cp $O/roofline_f32_trace.txt $P/r04_roofline_winograd_kernel_trace.txt
+cp $O/roofline_bf16_trace.txt $P/r04_roofline_lp16_kernel_trace.txt
+for f in breakdown_f32 breakdown_bf16 host_overhead; do grep -v "amdgpu.ids\|^WARNING" $O/$f.txt > $P/r04_${f/breakdown/step_breakdown}.txt; done
+grep -v "amdgpu.ids\|^WARNING" $O/breakdown_bf16_512.txt > $P/r04_step_breakdown_bf16_512.txt
+cp $O/r04_traffic.json $P/r04_traffic.json
+grep -v "amdgpu.ids\|^WARNING" $O/run_512.log > $P/r04_size512_bf16_b4_run.txt
