@@ -104,6 +104,7 @@ bool conv_s2f_ok(const mmh_conv_desc* d, int mode);
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16, int act,
                     const void* zeros, hipStream_t st);
 extern int g_lp16_s2f;
+extern int g_lp16_persist;
 extern int g_slab_reduce_par;
 extern int g_wino6_vec;
 extern int g_lp16_shape;

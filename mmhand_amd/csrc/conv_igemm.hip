@@ -3161,6 +3161,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "wino6_vec")) { mmh::g_wino6_vec = value; return 0; }
     if (!strcmp(key, "lp16_shape")) { mmh::g_lp16_shape = value; return 0; }
     if (!strcmp(key, "lp16_s2f")) { mmh::g_lp16_s2f = value; return 0; }
+    if (!strcmp(key, "lp16_persist")) { mmh::g_lp16_persist = value; return 0; }
     if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
