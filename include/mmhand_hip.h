@@ -508,6 +508,25 @@ int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n,
                           void* g_s3, int64_t rows, int C, int gcat_dtype, int s23_dtype,
                           int gs23_dtype, mmh_stream_t s);
 
+/* The gate with the block's LAST InstanceNorm inside (16-bit mode; models/Generator.py:66-77 + 115-130): s1 is not
+ * materialised - the gate reads the stream-1 conv output y2 (16-bit, [groups * rows][C]) and scale / shift [groups][C] and
+ * evaluates s1 = fma(y2, scale, shift) itself.  Backward: besides the gate's four gradients (g_s1 = the gradient of the
+ * norm's output, fp32) the same launch leaves the norm backward's sums sum1[g][c] = sum g_s1, sum2[g][c] = sum g_s1 * xhat
+ * (xhat = (y2 - mean) * invstd), taken in mmh_norm_bwd_reduce's chunks and order: follow it with mmh_norm_bwd_apply
+ * (masked 0).  Bit-identical to mmh_scale_shift_act + mmh_patblock_gate_fwd and to mmh_patblock_gate_bwd +
+ * mmh_norm_bwd_reduce.  ws: mmh_norm_bwd_ws_bytes(groups, rows, C).  x2n / x3n as in mmh_patblock_gate_fwd.   */
+int mmh_patblock_gate_norm_supported(int groups, int64_t rows_per_group, int C);
+int mmh_patblock_gate_norm_fwd(const void* x1, const void* y2, const void* scale, const void* shift,
+                               const void* s2, const void* s3, void* out, void* x2n, void* x3n, int groups,
+                               int64_t rows_per_group, int C, int y_dtype, int cat_dtype, int s23_dtype,
+                               mmh_stream_t s);
+int mmh_patblock_gate_norm_bwd(const void* g_out, const void* g_x2n, const void* g_x3n, const void* y2,
+                               const void* scale, const void* shift, const void* mean, const void* invstd,
+                               const void* s2, const void* s3, void* g_x1, void* g_s1, void* g_s2, void* g_s3,
+                               void* sum1, void* sum2, void* ws, size_t ws_bytes, int groups,
+                               int64_t rows_per_group, int C, int y_dtype, int gcat_dtype, int s23_dtype,
+                               mmh_stream_t s);
+
 /* ---- losses ----------------------------------------------------------------
  * GANLoss = BCEWithLogits vs a constant target, mean (network_utils.py:129-163)
  * L1 mean (L1_plus_perceptualLoss.py:37,66-67).  `out` is one device float:

@@ -1280,6 +1280,144 @@ __global__ void gate_bwd_kernel(const float* __restrict__ g_out, const void* __r
     }
 }
 
+// ------------------------------------------------------------------ PATBlock gate with the block's last norm inside (16-bit mode)
+// A PATBlock's stream-1 branch ends conv2 -> InstanceNorm -> (gate) (models/Generator.py:66-77,115-130): the norm's output s1
+// has ONE reader, the gate.  Here the gate reads the conv output y2 (16 bits) and applies scale / shift itself
+// (s1 = fma(y2, scale, shift): the expression mmh_scale_shift_act evaluates), so s1 is never written or read (the apply pass
+// and 2 B per element of gate input are gone); backward, the gate's kernel - which recomputes s1 and produces the gradient
+// gs1 of the norm's output anyway - also leaves the norm backward's plane sums (sum gs1, sum gs1 * xhat) in the partial layout
+// and summation order of col_reduce_partial_v2<1>, so mmh_norm_bwd_reduce's pass over gs1 and y2 is gone as well.  Same
+// arithmetic, same order: bit-identical to the unfused sequence (tests/test_pointwise_gpu.py).
+// Geometry as the other second-generation row kernels: block = (256 / C8 rows) x C8 lanes of 8 channels, grid (chunks, groups).
+template <bool SW>      // SW: s2 / s3 are 16-bit
+__global__ void __launch_bounds__(TPB) gate_norm_fwd_kernel(
+        const float* __restrict__ x1, const void* __restrict__ y2, bool yh16, const float* __restrict__ scale,
+        const float* __restrict__ shift, const void* __restrict__ s2, const void* __restrict__ s3, bool sh16,
+        float* __restrict__ out, void* __restrict__ x2n, void* __restrict__ x3n, int cat_lp, int64_t rows, RowGeom rg) {
+    const int q = threadIdx.x & (rg.c8 - 1), rsub = threadIdx.x / rg.c8;
+    const int grp = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rg.rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rg.rows_per_chunk);
+    const f8 sc = ld8<false>(scale, (int64_t)grp * rg.c8 + q, false);
+    const f8 sf = ld8<false>(shift, (int64_t)grp * rg.c8 + q, false);
+    const int64_t gbase = (int64_t)grp * rows;
+    constexpr int U = 2;
+    for (int64_t r = r0 + rsub; r < r1; r += (int64_t)rg.rpi * U) {
+        Raw8<false> xa[U];
+        Raw8<true> ya[U];
+        Raw8<SW> ca[U], da[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr < r1) {
+                const int64_t i8 = (gbase + rr) * rg.c8 + q;
+                ldraw(xa[u], x1, i8); ldraw(ya[u], y2, i8); ldraw(ca[u], s2, i8); ldraw(da[u], s3, i8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r + (int64_t)u * rg.rpi;
+            if (rr >= r1) continue;
+            const int64_t row = gbase + rr;
+            const f8 a = widen(xa[u], false), y = widen(ya[u], yh16), c = widen(ca[u], sh16), d = widen(da[u], sh16);
+            f8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float b = __builtin_fmaf(y.v[e], sc.v[e], sf.v[e]);
+                o.v[e] = a.v[e] + b * sigmoidf_(c.v[e]) * sigmoidf_(d.v[e]);
+            }
+            st8<false>(out, row * rg.c8 + q, o, false);
+            if (x2n) {      // cat(s3, out) / cat(s2, out): rows of 2 C channels
+                const int64_t j8 = row * 2 * rg.c8 + q;
+                if (cat_lp) {
+                    st8<true>(x2n, j8, d, cat_lp == 2); st8<true>(x2n, j8 + rg.c8, o, cat_lp == 2);
+                    st8<true>(x3n, j8, c, cat_lp == 2); st8<true>(x3n, j8 + rg.c8, o, cat_lp == 2);
+                } else {
+                    st8<false>(x2n, j8, d, false); st8<false>(x2n, j8 + rg.c8, o, false);
+                    st8<false>(x3n, j8, c, false); st8<false>(x3n, j8 + rg.c8, o, false);
+                }
+            }
+        }
+    }
+}
+
+template <bool GCW, bool SW>    // GCW: the concat gradients are 16-bit; SW: s2 / s3 (and their gradients) are 16-bit
+__global__ void __launch_bounds__(TPB) gate_norm_bwd_kernel(
+        const float* __restrict__ g_out, const void* __restrict__ g_x2n, const void* __restrict__ g_x3n, bool gch16,
+        const void* __restrict__ y2, bool yh16, const float* __restrict__ scale, const float* __restrict__ shift,
+        const float* __restrict__ mean, const float* __restrict__ invstd, const void* __restrict__ s2,
+        const void* __restrict__ s3, bool sh16, float* __restrict__ g_x1, float* __restrict__ g_s1,
+        void* __restrict__ g_s2, void* __restrict__ g_s3, int64_t rows, int C, int c8, int rpi, int chunks,
+        int64_t rows_per_chunk, float* __restrict__ ws) {
+    __shared__ float sh[2][TPB * 8];
+    const int tid = threadIdx.x;
+    const int q = tid & (c8 - 1), rsub = tid / c8;
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rows_per_chunk);
+    const int64_t gbase = (int64_t)grp * rows;
+    const int64_t gi = (int64_t)grp * c8 + q;
+    const f8 sc = ld8<false>(scale, gi, false), sf = ld8<false>(shift, gi, false);
+    const f8 mu = ld8<false>(mean, gi, false), is = ld8<false>(invstd, gi, false);
+    float s1[8], s2a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2a[e] = 0.f; }
+    for (int64_t r = r0 + rsub; r < r1; r += rpi) {      // one row per pass: ascending rows, the order of col_reduce_partial_v2
+        const int64_t row = gbase + r;
+        const int64_t i8 = row * c8 + q, j8 = row * 2 * c8 + q;
+        Raw8<false> Gr; Raw8<GCW> t2, e3r, t3, e2r; Raw8<true> yr; Raw8<SW> cr, dr;
+        if (g_out) ldraw(Gr, g_out, i8);
+        if (g_x2n) { ldraw(e3r, g_x2n, j8); ldraw(t2, g_x2n, j8 + c8); }
+        if (g_x3n) { ldraw(e2r, g_x3n, j8); ldraw(t3, g_x3n, j8 + c8); }
+        ldraw(yr, y2, i8); ldraw(cr, s2, i8); ldraw(dr, s3, i8);
+        f8 G, e2, e3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { G.v[e] = 0.f; e2.v[e] = 0.f; e3.v[e] = 0.f; }
+        if (g_out) G = widen(Gr, false);
+        if (g_x2n) {
+            const f8 t = widen(t2, gch16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) G.v[e] += t.v[e];
+            e3 = widen(e3r, gch16);
+        }
+        if (g_x3n) {
+            const f8 t = widen(t3, gch16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) G.v[e] += t.v[e];
+            e2 = widen(e2r, gch16);
+        }
+        const f8 y = widen(yr, yh16), c = widen(cr, sh16), d = widen(dr, sh16);
+        f8 o1, o2, o3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float b = __builtin_fmaf(y.v[e], sc.v[e], sf.v[e]);
+            const float a2 = sigmoidf_(c.v[e]), a3 = sigmoidf_(d.v[e]);
+            o1.v[e] = G.v[e] * a2 * a3;
+            o2.v[e] = G.v[e] * b * a3 * a2 * (1.f - a2) + e2.v[e];
+            o3.v[e] = G.v[e] * b * a2 * a3 * (1.f - a3) + e3.v[e];
+            const float gg = o1.v[e];
+            s2a[e] += gg * ((y.v[e] - mu.v[e]) * is.v[e]);
+            s1[e] += gg;
+        }
+        st8<false>(g_x1, i8, G, false);
+        st8<false>(g_s1, i8, o1, false);
+        st8<SW>(g_s2, i8, o2, sh16);
+        st8<SW>(g_s3, i8, o3, sh16);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[0][tid * 8 + e] = s1[e]; sh[1][tid * 8 + e] = s2a[e]; }
+    __syncthreads();
+    for (int t = tid; t < 8 * c8; t += TPB) {
+        const int qq = t >> 3, e = t & 7;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float acc = sh[o][qq * 8 + e];
+            for (int j = 1; j < rpi; ++j) acc += sh[o][(j * c8 + qq) * 8 + e];
+            ws[((int64_t)(grp * chunks + chunk) * 2 + o) * C + qq * 8 + e] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ scalar losses
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
@@ -2157,6 +2295,64 @@ int mmh_patblock_gate_bwd(const void* g_out, const void* g_x2n, const void* g_x3
                        s2, s3, static_cast<float*>(g_x1), static_cast<float*>(g_s1), g_s2, g_s3, n4,
                        C / 4, gcat_dtype, s23_dtype, gs23_dtype);
     return mmh::check_launch("gate_bwd");
+}
+
+int mmh_patblock_gate_norm_supported(int groups, int64_t rows, int C) {
+    return (mmh::g_pw_v2 && groups > 0 && rows > 0 && row_geom_ok(C)) ? 1 : 0;
+}
+
+int mmh_patblock_gate_norm_fwd(const void* x1, const void* y2, const void* scale, const void* shift, const void* s2,
+                               const void* s3, void* out, void* x2n, void* x3n, int groups, int64_t rows, int C,
+                               int y_dtype, int cat_dtype, int s23_dtype, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_patblock_gate_norm_fwd", C)) return rc;
+    MMH_REQUIRE(mmh_patblock_gate_norm_supported(groups, rows, C) && is_dtype(cat_dtype) && is_dtype(s23_dtype) &&
+                    (y_dtype == MMH_BF16 || y_dtype == MMH_FP16),
+                "mmh_patblock_gate_norm_fwd: C / 8 a power of two <= 256, a 16-bit y2");
+    MMH_REQUIRE(x1 && y2 && scale && shift && s2 && s3 && out && ((x2n == nullptr) == (x3n == nullptr)),
+                "mmh_patblock_gate_norm_fwd: bad arguments");
+    const RowGeom rg = row_geom(groups, rows, C);
+    const dim3 grid(rg.chunks, groups);
+#define MMH_GNF(SW)                                                                                                  \
+    hipLaunchKernelGGL((gate_norm_fwd_kernel<SW>), grid, dim3(TPB), 0, mmh::as_stream(s), static_cast<const float*>(x1), \
+                       y2, y_dtype == MMH_FP16, static_cast<const float*>(scale), static_cast<const float*>(shift), s2, \
+                       s3, s23_dtype == MMH_FP16, static_cast<float*>(out), x2n, x3n, cat_dtype, rows, rg)
+    if (s23_dtype != MMH_F32) MMH_GNF(true); else MMH_GNF(false);
+#undef MMH_GNF
+    return mmh::check_launch("gate_norm_fwd");
+}
+
+int mmh_patblock_gate_norm_bwd(const void* g_out, const void* g_x2n, const void* g_x3n, const void* y2, const void* scale,
+                               const void* shift, const void* mean, const void* invstd, const void* s2, const void* s3,
+                               void* g_x1, void* g_s1, void* g_s2, void* g_s3, void* sum1, void* sum2, void* ws,
+                               size_t ws_bytes, int groups, int64_t rows, int C, int y_dtype, int gcat_dtype,
+                               int s23_dtype, mmh_stream_t s) {
+    if (int rc = check_cols("mmh_patblock_gate_norm_bwd", C)) return rc;
+    MMH_REQUIRE(mmh_patblock_gate_norm_supported(groups, rows, C) && is_dtype(gcat_dtype) && is_dtype(s23_dtype) &&
+                    (y_dtype == MMH_BF16 || y_dtype == MMH_FP16),
+                "mmh_patblock_gate_norm_bwd: C / 8 a power of two <= 256, a 16-bit y2");
+    MMH_REQUIRE(y2 && scale && shift && mean && invstd && s2 && s3 && g_x1 && g_s1 && g_s2 && g_s3 && sum1 && sum2 && ws,
+                "mmh_patblock_gate_norm_bwd: bad arguments");
+    MMH_REQUIRE(ws_bytes >= mmh_norm_bwd_ws_bytes(groups, rows, C), "mmh_patblock_gate_norm_bwd: workspace too small");
+    const ColGeom cg = col_geom(groups, rows, C);       // the chunks of mmh_norm_bwd_reduce: the same partial sums
+    const int c8 = C / 8;
+    hipStream_t st = mmh::as_stream(s);
+    const dim3 grid(cg.chunks, groups);
+#define MMH_GNB(GCW, SW)                                                                                             \
+    hipLaunchKernelGGL((gate_norm_bwd_kernel<GCW, SW>), grid, dim3(TPB), 0, st, static_cast<const float*>(g_out), g_x2n, \
+                       g_x3n, gcat_dtype == MMH_FP16, y2, y_dtype == MMH_FP16, static_cast<const float*>(scale),     \
+                       static_cast<const float*>(shift), static_cast<const float*>(mean),                           \
+                       static_cast<const float*>(invstd), s2, s3, s23_dtype == MMH_FP16, static_cast<float*>(g_x1),  \
+                       static_cast<float*>(g_s1), g_s2, g_s3, rows, C, c8, TPB / c8, cg.chunks, cg.rows_per_chunk,   \
+                       static_cast<float*>(ws))
+    const bool gcw = gcat_dtype != MMH_F32, sw = s23_dtype != MMH_F32;
+    if (gcw && sw) MMH_GNB(true, true);
+    else if (gcw) MMH_GNB(true, false);
+    else if (sw) MMH_GNB(false, true);
+    else MMH_GNB(false, false);
+#undef MMH_GNB
+    MMH_COL_FINAL(groups * C, cg.chunks, st, static_cast<const float*>(ws), groups, C, cg.chunks, 2,
+                  static_cast<float*>(sum1), static_cast<float*>(sum2), 0);
+    return mmh::check_launch("gate_norm_bwd");
 }
 
 size_t mmh_reduce_ws_bytes(int64_t n) { return (size_t)grid_for(n / 4, 4096) * sizeof(float); }

@@ -132,6 +132,10 @@ SIGNATURES = {
     "mmh_act_bwd_lp16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "mmh_patblock_gate_norm_supported": (_i, [_i, _i64, _i]),
+    "mmh_patblock_gate_norm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "mmh_patblock_gate_norm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                        _i, _i64, _i, _i, _i, _i, _vp]),
     "mmh_reduce_ws_bytes": (_sz, [_i64]),
     "mmh_bce_logits_fwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_bce_logits_bwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _vp]),

@@ -425,11 +425,13 @@ class _Net(nn.Module):
         fuse = self._norm_fusion(blk[1], blk[i2], x)
         # the block's last norm (no ReLU / dropout; feeds the gate or the residual add): its backward apply pass
         # inside conv 2's backward transform, as for the first norm
-        fuse_last = 3 if (last_norm and torch.is_tensor(x) and self._norm_bwd_fusion(blk[i2], x)) else 0
+        fuse_last = 3 if (last_norm and last_norm != "gate" and torch.is_tensor(x) and self._norm_bwd_fusion(blk[i2], x)) else 0
         y = self.conv(blk[1], x, 1, 1, True, y_lp=self._lp_out(blk[1]), to_norm=True, g_defer=fuse == 2, res_tok=res_tok,
                       x_twin=x_twin if torch.is_tensor(x) else None)
         y = self.normact(blk, 2, y, True, self.use_dropout, site, out_lp=self._lp_edge(blk[i2]), defer=fuse)
-        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=last_norm, g_defer=fuse_last == 3)
+        y = self.conv(blk[i2], y, 1, 1, True, y_lp=self._lp_out(blk[i2]), to_norm=bool(last_norm), g_defer=fuse_last == 3)
+        if last_norm == "gate":     # the caller's gate applies this norm itself (ops.GateNormFn): the (proxy, y16) pair
+            return y
         if last_norm:
             # want_twin: the block's output also feeds the next block's first conv -> (out, twin16 | None)
             y = self.normact(blk, i2 + 1, y, False, residual=residual, defer=fuse_last,
@@ -587,7 +589,13 @@ class Generator(_Net):
                      for s, x in zip((1, 2, 3), (x1, x2, x3))])
             else:
                 tok = self._res_token(x1)       # x1 feeds the stream-1 conv AND the gate's residual add
-                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", True, res_tok=tok, x_twin=x1_twin)
+                # 16-bit mode, InstanceNorm: the block's last norm runs inside the gate (ops.GateNormFn)
+                i2 = 6 if self.use_dropout else 5
+                gate_norm = bool(self.norm == "instance" and self.training and self.bf16 and torch.is_tensor(x1)
+                                 and self._lp_out(blk["conv_block_stream1"][i2])
+                                 and ops.gate_norm_ok(x1.shape[0], x1.shape[1] * x1.shape[2], x1.shape[3]))
+                s1 = self.two_conv_block(blk["conv_block_stream1"], x1, p + "1", "gate" if gate_norm else True, res_tok=tok,
+                                         x_twin=x1_twin)
                 s2 = self.two_conv_block(blk["conv_block_stream2"], x2, p + "2", False)
                 s3 = self.two_conv_block(blk["conv_block_stream3"], x3, p + "3", False)
             # (out, cat(s3,out), cat(s2,out)): the reference's stream swap (Generator.py:130 vs :278)
@@ -597,9 +605,15 @@ class Generator(_Net):
             if isinstance(s2, tuple):       # stream 2 / 3 end in a 16-bit convolution
                 (s2, a), (s3, b_) = s2, s3
                 s16 = (a, b_)
+            gate_norm = isinstance(s1, tuple)       # (proxy, y16) of the stream-1 conv: its norm runs inside the gate
             if cat_lp:      # the cats feed only the next block's 16-bit convs: written in 16 bits
-                x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp, *s16, tok)
+                if gate_norm:
+                    x1, p2, p3, c2, c3 = ops.GateNormFn.apply(x1, s1[0], s2, s3, True, cat_lp, s1[1], *s16, tok)
+                else:
+                    x1, p2, p3, c2, c3 = ops.GateFn.apply(x1, s1, s2, s3, True, cat_lp, *s16, tok)
                 x2, x3 = (p2, c2), (p3, c3)
+            elif gate_norm:
+                x1, x2, x3 = ops.GateNormFn.apply(x1, s1[0], s2, s3, more, 0, s1[1], *s16, tok)
             else:
                 x1, x2, x3 = ops.GateFn.apply(x1, s1, s2, s3, more, 0, *s16, tok)
         up = m["stream1_up"]

@@ -2272,6 +2272,85 @@ class GateFn(torch.autograd.Function):
         return gx1, gs1, gs2, gs3, None, None, None, None, None
 
 
+# The PATBlock gate with the block's last InstanceNorm inside (16-bit mode): the norm's output s1 has one reader, the gate,
+# so it is never written - the gate applies scale / shift to the conv output itself, and its backward kernel leaves the norm
+# backward's plane sums (mmh_patblock_gate_norm_fwd / _bwd: bit-identical to the separate launches).  MMH_GATE_NORM=0: off.
+USE_GATE_NORM = os.environ.get("MMH_GATE_NORM", "1") != "0"
+
+
+def gate_norm_ok(B, rows, C):
+    return bool(USE_GATE_NORM and L.load().mmh_patblock_gate_norm_supported(B, rows, C))
+
+
+class GateNormFn(torch.autograd.Function):
+    """GateFn with s1 = InstanceNorm(y2) computed inside: y2 is the proxy of the stream-1 conv output that exists in 16 bits
+    only (y2_16, Conv2dFn y_lp).  Same outputs and conventions as GateFn."""
+
+    @staticmethod
+    def forward(ctx, x1, y2, s2, s3, want_cat, cat_lp, y2_16, s2_16, s3_16, res_tok):
+        ctx.set_materialize_grads(False)
+        ctx.res_tok = res_tok
+        ctx.s_lp = s2_16 is not None
+        ctx.cat_lp = bool(want_cat and cat_lp)
+        if ctx.s_lp:
+            assert s3_16 is not None and s2_16.dtype == s3_16.dtype and s2_16.is_contiguous() and s3_16.is_contiguous()
+            s2, s3 = s2_16, s3_16
+        _chk(x1, "x1")
+        assert y2_16.dtype != torch.float32 and y2_16.is_contiguous() and tuple(y2_16.shape) == tuple(x1.shape)
+        B, H, W_, Cc = x1.shape
+        rows = H * W_
+        fast = raw_norm_stats_finalize_pending(y2_16, B)
+        if fast is not None:
+            mean, scale, shift, invstd, _ = fast
+        else:
+            mean, m2, _ = raw_norm_stats(y2_16, B)
+            scale, shift, invstd = raw_norm_finalize(mean, m2, rows, None, None, None, None)
+        out = torch.empty_like(x1)
+        x2n = x3n = None
+        if want_cat:
+            x2n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
+            x3n = torch.empty((B, H, W_, 2 * Cc), dtype=_wd(cat_lp), device=x1.device)
+        L.call("mmh_patblock_gate_norm_fwd", _ptr(x1), _ptr(y2_16), _ptr(scale), _ptr(shift), _ptr(s2), _ptr(s3), _ptr(out),
+               _ptr(x2n), _ptr(x3n), B, rows, Cc, _tdt(y2_16), _dt(cat_lp), _tdt(s2), _stream())
+        ctx.save_for_backward(y2_16, mean, invstd, scale, shift, s2, s3)
+        ctx.want_cat = want_cat
+        if want_cat and cat_lp:
+            ctx.mark_non_differentiable(x2n, x3n)
+            return out, lp_proxy(x2n.shape, x1.device), lp_proxy(x3n.shape, x1.device), x2n, x3n
+        if want_cat:
+            return out, x2n, x3n
+        return out, None, None
+
+    @staticmethod
+    def backward(ctx, g_out, g_x2n, g_x3n, _a=None, _b=None):
+        y2, mean, invstd, scale, shift, s2, s3 = ctx.saved_tensors
+        B, H, W_, Cc = y2.shape
+        rows = H * W_
+        g_out = None if g_out is None else g_out.contiguous()
+        if ctx.cat_lp:
+            g_x2n = lp_grad_in(g_x2n, "GateNormFn (cat(s3,out))")
+            g_x3n = lp_grad_in(g_x3n, "GateNormFn (cat(s2,out))")
+        else:
+            g_x2n = None if g_x2n is None else g_x2n.contiguous()
+            g_x3n = None if g_x3n is None else g_x3n.contiguous()
+        gx1 = torch.empty((B, H, W_, Cc), dtype=torch.float32, device=y2.device)
+        gs1 = torch.empty_like(gx1)
+        gs2 = torch.empty_like(s2); gs3 = torch.empty_like(s3)
+        sum1 = _empty((B, Cc), gx1); sum2 = _empty((B, Cc), gx1)
+        ws = _ws(L.load().mmh_norm_bwd_ws_bytes(B, rows, Cc), gx1)
+        L.call("mmh_patblock_gate_norm_bwd", _ptr(g_out), _ptr(g_x2n), _ptr(g_x3n), _ptr(y2), _ptr(scale), _ptr(shift),
+               _ptr(mean), _ptr(invstd), _ptr(s2), _ptr(s3), _ptr(gx1), _ptr(gs1), _ptr(gs2), _ptr(gs3), _ptr(sum1), _ptr(sum2),
+               _ptr(ws), ws.numel() * 4, B, rows, Cc, _tdt(y2), L.F32 if g_x2n is None else _tdt(g_x2n), _tdt(s2), _stream())
+        dy2 = torch.empty_like(y2)      # the norm backward's apply pass: the gradient of the conv output, in 16 bits
+        L.call("mmh_norm_bwd_apply", _ptr(gs1), None, _ptr(y2), _ptr(mean), _ptr(invstd), None, _ptr(sum1), _ptr(sum2),
+               float(rows), B, rows, Cc, 0, 0.0, _ptr(dy2), L.F32, _tdt(y2), _tdt(dy2), _stream())
+        if ctx.s_lp:
+            gs2, gs3 = lp_grad_out(gs2), lp_grad_out(gs3)
+        if ctx.res_tok is not None and ctx.res_tok.park(gx1):
+            gx1 = None
+        return gx1, lp_grad_out(dy2), gs2, gs3, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- losses
 class BCEWithLogitsConstFn(torch.autograd.Function):
     """weight * mean(BCEWithLogits(x, target)) for a constant target (GANLoss,

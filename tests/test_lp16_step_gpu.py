@@ -181,6 +181,50 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
 
 
+def test_gate_norm_fusion_changes_nothing(dev, monkeypatch):
+    """ops.GateNormFn: the last InstanceNorm of a PATBlock's stream-1 branch applied inside the gate (forward) and its backward
+    sums taken by the gate's backward kernel (mmh_patblock_gate_norm_fwd / _bwd) against the separate launches
+    (mmh_scale_shift_act + mmh_patblock_gate_fwd; mmh_patblock_gate_bwd + mmh_norm_bwd_reduce): same arithmetic in the same
+    order - losses, the generated image and every parameter gradient of one full-width 16-bit iteration bit-identical, NB
+    apply passes and NB reduce passes fewer."""
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_GATE_NORM", on)
+        calls = Counter()
+        real = lib.call
+
+        def spy(name, *a, _c=calls, _r=real):
+            _c[name] += 1
+            return _r(name, *a)
+        monkeypatch.setattr(lib, "call", spy)
+        torch.manual_seed(5)
+        random.seed(5)
+        ops.set_dropout_seed(777)
+        model = MMHandModel(_opt("O1"))
+        model.set_input(O.synthetic_batch(2, SIZE, SIZE, seed=11))
+        model.forward()
+        for o in model.optimizers:
+            o.zero_grad()
+        model.backward_G()
+        gG = model.netG.flat_grad.clone()
+        model.backward_D_PP()
+        model.backward_D_PB()
+        outs[on] = (gG, model.netD_PB.flat_grad.clone(), model.netD_PP.flat_grad.clone(), model.fake_nhwc.detach().clone(),
+                    [float(v) for v in model.get_current_errors().values()], calls)
+        monkeypatch.setattr(lib, "call", real)
+        del model
+    a, b = outs[True], outs[False]
+    assert a[5]["mmh_patblock_gate_norm_fwd"] == NB == a[5]["mmh_patblock_gate_norm_bwd"] and a[5]["mmh_patblock_gate_fwd"] == 0
+    assert b[5]["mmh_patblock_gate_norm_fwd"] == 0 and b[5]["mmh_patblock_gate_fwd"] == NB == b[5]["mmh_patblock_gate_bwd"]
+    assert b[5]["mmh_norm_bwd_reduce"] - a[5]["mmh_norm_bwd_reduce"] == NB, (a[5]["mmh_norm_bwd_reduce"], b[5]["mmh_norm_bwd_reduce"])
+    assert (b[5]["mmh_scale_shift_act"] + b[5]["mmh_scale_shift_act_twin"]) - (a[5]["mmh_scale_shift_act"] + a[5]["mmh_scale_shift_act_twin"]) == NB
+    assert a[4] == b[4], (a[4], b[4])
+    for x, y in zip(a[:4], b[:4]):
+        assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
+
+
 @pytest.mark.parametrize("mode", ["all", "bwd"])
 def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypatch):
     """mode "bwd" = --fp32_exact_grads (ops.set_winograd_mode("bwd")): direct fprop, F(6x6,3x3) dgrad and
