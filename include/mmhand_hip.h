@@ -282,6 +282,13 @@ int mmh_conv_lp16_supported(const mmh_conv_desc* d, int mode);
 int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void* w16,
                   const void* bias, void* y, int y_is16, int act, const void* zeros,
                   mmh_stream_t s);
+/* fprop (mode 0) with a 16-bit output AND the partial statistics of that output for the InstanceNorm behind the conv,
+ * where the stride-2 kernel of conv_s2_lp16.hip takes the shape (3x3 / stride 2 / zero pad 1, Cin 64, Cout %% 128 == 0,
+ * Ho %% 8 == 0, Wo %% 16 == 0): stats [B][chunks][3][Cout], chunks = mmh_conv_lp16_stats_chunks(d) (0: use
+ * mmh_conv_lp16 and mmh_norm_stats).                                                                                  */
+int mmh_conv_lp16_stats_chunks(const mmh_conv_desc* d);
+int mmh_conv_lp16_fprop_stats(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y16,
+                              void* stats, const void* zeros, mmh_stream_t s);
 
 /* Flat-K 16-bit fprop for the 7x7 stems (Cin = 3..42: models/Generator.py:158-164,
  * models/Discriminator.py:79-84): contraction index k = tap * C8 + c over the channels padded to C8
@@ -318,6 +325,13 @@ int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out
 int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16,
                     const void* bias, void* y, int y_is16, int act, const void* zeros,
                     mmh_stream_t s);
+/* The same launch also leaving the partial statistics of its 16-bit output for the InstanceNorm behind the stem
+ * (H, W multiples of 16; no activation): stats [B][chunks][3][64] (n, mean, M2 per wave tile and channel) in the layout
+ * mmh_norm_stats_merge_finalize reduces - the norm does not read y for statistics.  chunks = mmh_conv_stem16_stats_chunks
+ * (0: not available for this shape).                                                                                  */
+int mmh_conv_stem16_stats_chunks(const mmh_conv_desc* d, int C8);
+int mmh_conv_stem16_stats(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias,
+                          void* y16, void* stats, const void* zeros, mmh_stream_t s);
 
 /* 16-bit wgrad of the 7x7 / stride 1 / pad 3 stems with 64 output channels (models/Generator.py:158-164,
  * models/Discriminator.py:60-64): x16p [B,H,W,C8] = the stem's 16-bit input with its channels padded

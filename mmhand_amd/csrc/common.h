@@ -52,6 +52,70 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// Partial InstanceNorm statistics of a conv output tile from the epilogue of an MFMA 16x16x32 kernel whose FIRST operand is the
+// weight fragment (lane (l15 = pixel, g4): channels 4 g4 + r, r < 4, of each of its NJ 16-channel column tiles, NV pixel
+// rows per lane): count / mean / M2 of the wave's 16 NV pixels per channel, in the partial layout mmh_norm_stats_merge
+// [_finalize] reduces ([.][3][N]: n, mean, M2).  val(i, j, r) = the value AS STORED (bias added, rounded to 16 bits) of row i,
+// column tile j, register r.  Per lane two passes over its NV values per channel slot (4 j + r), then four equal-count Chan
+// merges across the 16 pixel lanes as a reduce-scatter (ds_swizzle, xor 8 / 4 / 2 / 1): while a lane still holds more than
+// one slot it keeps the half whose index bit matches its lane bit and hands the other half over; with one slot left the two
+// partners merge and both keep the result (the lane whose remaining low bits are 0 writes).  sp: the partial's `n` row at
+// this wave's first channel + 4 g4.  conv_lp16h2_kernel carries the NV = 8, NJ = 4 instance of the same scheme inline.
+#define MMH_SWZ_(val, s) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, val), 0x1f | ((s) << 10)))
+template <int NS, int S>
+__device__ __forceinline__ void wave_stats_step(float* m, float* q, int& ns, bool bit, float w) {
+    if (ns > 1) {
+        const int h = ns / 2;
+#pragma unroll
+        for (int c = 0; c < NS / 2; ++c) {
+            if (c < h) {
+                const float km = bit ? m[h + c] : m[c], sm = bit ? m[c] : m[h + c];
+                const float kq = bit ? q[h + c] : q[c], sq = bit ? q[c] : q[h + c];
+                const float om = MMH_SWZ_(sm, S), oq = MMH_SWZ_(sq, S), dl = om - km;
+                q[c] = kq + oq + dl * dl * w;
+                m[c] = 0.5f * (km + om);
+            }
+        }
+        ns = h;
+    } else {
+        const float om = MMH_SWZ_(m[0], S), oq = MMH_SWZ_(q[0], S), dl = om - m[0];
+        q[0] = q[0] + oq + dl * dl * w;
+        m[0] = 0.5f * (m[0] + om);
+    }
+}
+template <int NV, int NJ, typename F>
+__device__ __forceinline__ void wave_tile_stats(F val, int l15, float* sp, int N) {
+    constexpr int NS = 4 * NJ;
+    float m[NS], q[NS];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[NV], mean = 0.f, qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { v[i] = val(i, j, r); mean += v[i]; }
+            mean *= 1.f / NV;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) qq = __builtin_fmaf(v[i] - mean, v[i] - mean, qq);
+            m[4 * j + r] = mean; q[4 * j + r] = qq;
+        }
+    int ns = NS;
+    wave_stats_step<NS, 8>(m, q, ns, (l15 & 8) != 0, 0.5f * NV);
+    wave_stats_step<NS, 4>(m, q, ns, (l15 & 4) != 0, 1.0f * NV);
+    wave_stats_step<NS, 2>(m, q, ns, (l15 & 2) != 0, 2.0f * NV);
+    wave_stats_step<NS, 1>(m, q, ns, (l15 & 1) != 0, 4.0f * NV);
+    // the slot this lane ends with: its lane bits, high to low, over the steps that still split (log2 NS of them)
+    constexpr int SPLITS = NS >= 16 ? 4 : (NS >= 8 ? 3 : (NS >= 4 ? 2 : 1));
+    const int slot = l15 >> (4 - SPLITS);
+    const bool writer = (l15 & ((1 << (4 - SPLITS)) - 1)) == 0;
+    if (writer) {
+        const int co = (slot >> 2) * 16 + (slot & 3);
+        sp[co] = 16.f * NV;
+        sp[N + co] = m[0];
+        sp[2 * N + co] = q[0];
+    }
+}
+
 // Winograd F(6x6,3x3) transforms (wino6.hip); tiles = B * ceil(H/6) * ceil(W/6), 64 planes
 int wino6_weights(const float* w, float* U, int Cin, int Cout, int flip_transpose, hipStream_t st);
 int wino6_weights_multi(const long long* table, int n, long long total_blocks, hipStream_t st);
@@ -101,8 +165,9 @@ extern int g_wino_wgrad_dma;
 int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
 // 16-bit fprop of the 3x3 stride-2 convs with register-resident weights and an LDS-resident input halo (conv_s2_lp16.hip)
 bool conv_s2f_ok(const mmh_conv_desc* d, int mode);
+int conv_s2f_stats_chunks(const mmh_conv_desc* d);
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16, int act,
-                    const void* zeros, hipStream_t st);
+                    const void* zeros, hipStream_t st, float* stats = nullptr);
 extern int g_lp16_s2f;
 extern int g_lp16_persist;
 extern int g_slab_reduce_par;

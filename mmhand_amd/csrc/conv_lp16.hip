@@ -2464,6 +2464,17 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
 }
 
 
+int mmh_conv_lp16_stats_chunks(const mmh_conv_desc* d) { return d ? mmh::conv_s2f_stats_chunks(d) : 0; }
+
+int mmh_conv_lp16_fprop_stats(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y16,
+                              void* stats, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(d && mmh::conv_s2f_stats_chunks(d) > 0 && x16 && w16 && y16 && stats && zeros && d->y_cs % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(y16) & 15) == 0,
+                "mmh_conv_lp16_fprop_stats: shapes with mmh_conv_lp16_stats_chunks(d) > 0 only (the stride-2 kernel of "
+                "conv_s2_lp16.hip)");
+    return mmh::launch_conv_s2f(d, x16, w16, bias, y16, 1, MMH_ACT_NONE, zeros, mmh::as_stream(s), static_cast<float*>(stats));
+}
+
 // ---- flat-K 16-bit fprop for the 7x7 stems (models/Generator.py:158-164, Discriminator.py:79-84) ----
 int mmh_lp16_pad_cvt(const void* x, int64_t rows, int C, int C8, int dtype, void* out, mmh_stream_t s) {
     MMH_REQUIRE(x && out && rows > 0 && C > 0 && C8 >= C && C8 % 8 == 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),

@@ -55,6 +55,7 @@ struct S2KP {
     int TX, TY, tiles;      // tiles = B * TY * TX
     int nsplit;             // N / 128
     int lists;              // tile lists = workgroups / nsplit
+    float* stats;           // per (image, tile, row half, channel) count / mean / M2 of the stored outputs, [B][chunks][3][N], or null
     int dbg;                // timing-only ablations (mmh_set_option "lp16_dbg"; results wrong): 1 no halo DMA after the first, 2 no MFMAs
 };
 
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         for (int kc = 0; kc < KC; ++kc) {
             // item q has landed: the queue retires in order, so everything but the MI * NJ stores of the epilogue just
             // behind the DMA is enough after a tile boundary
-            if (after_store) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
+            if (after_store && p.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ + 3) : "memory");
+            else if (after_store) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             after_store = false;
             __builtin_amdgcn_s_barrier();
@@ -237,6 +239,14 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
                     store4<H16>(p.y, p.y16, pix * p.y_cs + (n0 + 16 * j + 4 * g4), acc[i][j], bv[j], p.act);
             }
         }
+        if (p.stats) {      // the InstanceNorm behind this conv merges these partials instead of reading y (common.h)
+            const int chunks = p.TX * p.TY * MW;
+            float* sp = p.stats + ((size_t)(b * chunks + (ty * p.TX + tx) * MW + wm) * 3) * p.N + n0 + 4 * g4;
+            mmh::wave_tile_stats<MI, NJ>([&](int i, int j, int r) {
+                const float t = acc[i][j][r] + bv[j][r];
+                return H16 ? (float)(_Float16)t : (float)(__bf16)t;
+            }, l15, sp, p.N);
+        }
         after_store = true;
     }
 }
@@ -261,8 +271,13 @@ bool conv_s2f_ok(const mmh_conv_desc* d, int mode) {
     return true;
 }
 
+int conv_s2f_stats_chunks(const mmh_conv_desc* d) {        // partials per image, 0 = no statistics from this kernel
+    if (!conv_s2f_ok(d, 0)) return 0;
+    return (d->Ho / TH) * (d->Wo / TW) * (d->Cin == 64 ? 2 : 1);
+}
+
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16,
-                    int act, const void* zeros, hipStream_t st) {
+                    int act, const void* zeros, hipStream_t st, float* stats) {
     S2KP p{};
     p.x = static_cast<const char*>(x16);
     p.w = static_cast<const char*>(w16);
@@ -274,6 +289,7 @@ int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, co
     p.TX = p.Wo / TW; p.TY = p.Ho / TH; p.tiles = p.B * p.TX * p.TY;
     p.nsplit = p.N / 128;
     p.dbg = g_lp16_dbg;
+    p.stats = stats;
     if (!g_cus) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)

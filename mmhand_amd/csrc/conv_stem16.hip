@@ -46,6 +46,7 @@ struct Stem16KP {
     int wpitch;             // bytes per weight row = (32 * Jt + 8) * 2
     int halo_b, wst_b;      // LDS bytes of the halo region / of one weight stage (whole DMA rounds)
     int TX, TY, tiles;
+    float* stats;           // per (image, tile, wave, channel) count / mean / M2 of the stored outputs, [B][chunks][3][64], or null
 };
 
 template <bool H16>
@@ -173,6 +174,14 @@ __global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const St
             }
         }
     }
+    if (p.stats) {      // full tiles, 16-bit output, no activation (host side): the norm behind the stem merges these partials
+        constexpr int WPT = TS / RW;        // waves (= partials) per tile
+        float* sp = p.stats + ((size_t)(b * (p.TX * p.TY * WPT) + (ty * p.TX + tx) * WPT + wave) * 3) * 64 + 4 * g4;
+        mmh::wave_tile_stats<RW, 4>([&](int i, int j, int r) {
+            const float t = acc[i][j][r] + bv[j][r];
+            return H16 ? (float)(_Float16)t : (float)(__bf16)t;
+        }, l15, sp, 64);
+    }
 }
 
 // w fp32 [7][7][Cin][64] -> 16-bit [7][64][pitch], k = kw * C8 + c, zero padded (pitch = 32 * Jt + 8 elements)
@@ -233,8 +242,28 @@ int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out
     return mmh::check_launch("prep_stem16_w_kernel");
 }
 
+static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y,
+                           int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s);
+
 int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y,
                     int y_is16, int act, const void* zeros, mmh_stream_t s) {
+    return conv_stem16_impl(d, x16p, C8, w_stem16, bias, y, y_is16, act, zeros, nullptr, s);
+}
+
+int mmh_conv_stem16_stats_chunks(const mmh_conv_desc* d, int C8) {
+    Plan q;
+    if (!d || !plan(d, C8, q) || d->H % TS || d->W % TS) return 0;
+    return (d->H / TS) * (d->W / TS) * (TS / q.rw);
+}
+
+int mmh_conv_stem16_stats(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y16,
+                          void* stats, const void* zeros, mmh_stream_t s) {
+    MMH_REQUIRE(mmh_conv_stem16_stats_chunks(d, C8) > 0 && stats, "mmh_conv_stem16_stats: H, W multiples of 16 and a stats buffer");
+    return conv_stem16_impl(d, x16p, C8, w_stem16, bias, y16, 1, MMH_ACT_NONE, zeros, stats, s);
+}
+
+static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y,
+                           int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s) {
     Plan q;
     MMH_REQUIRE(plan(d, C8, q) && x16p && w_stem16 && y && zeros,
                 "mmh_conv_stem16: 7x7 / stride 1 / pad 3, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype");
@@ -245,6 +274,7 @@ int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void
     p.bias = static_cast<const float*>(bias);
     if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
     p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.y_cs = d->y_cs; p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
+    p.stats = static_cast<float*>(stats);
     p.act = act; p.Jt = q.Jt; p.rp = q.rp; p.wpitch = q.pitch * 2; p.halo_b = q.halo_b; p.wst_b = q.wst_b;
     p.TX = (d->W + TS - 1) / TS; p.TY = (d->H + TS - 1) / TS; p.tiles = d->B * p.TX * p.TY;
     static int ready = -1;

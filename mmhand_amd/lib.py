@@ -81,6 +81,10 @@ SIGNATURES = {
     "mmh_cvt_lp16": (_i, [_vp, _i64, _i, _vp, _vp]),
     "mmh_conv_lp16_supported": (_i, [_DP, _i]),
     "mmh_conv_lp16": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "mmh_conv_lp16_stats_chunks": (_i, [_DP]),
+    "mmh_conv_lp16_fprop_stats": (_i, [_DP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mmh_conv_stem16_stats_chunks": (_i, [_DP, _i]),
+    "mmh_conv_stem16_stats": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_lp16_pad_cvt": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "mmh_prep_weights_lp16_flat8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mmh_conv_lp16_flat_supported": (_i, [_DP, _i]),

@@ -364,6 +364,11 @@ def _fold_same_grid(H, W_):
 # Per-tile output statistics of the last Winograd F(6x6,3x3) conv outputs, keyed by the output's
 # data pointer: NormActFn (instance norm) picks them up instead of re-reading the conv output.
 FUSE_NORM_STATS = os.environ.get("MMH_FUSE_NORM_STATS", "1") != "0"
+# ... also from the epilogues of the 16-bit 7x7 stems (conv_stem16.hip) and of the stride-2 kernel (conv_s2_lp16.hip): built,
+# tested (tests/test_conv_s2_lp16_gpu.py) and measured - the 16-bit step runs 101.5 ms with them against 101.0 without
+# (tools/ab_step.py ops:FUSE_NORM_STATS_NARROW): at 64 / 128 channels the statistics pass they save (33-59 us) costs less
+# than the epilogue arithmetic on kernels that hold one or two workgroups per CU.  Off by default.
+FUSE_NORM_STATS_NARROW = os.environ.get("MMH_FUSE_NORM_STATS_NARROW", "0") == "1"
 _pending_stats = {}
 
 
@@ -954,14 +959,24 @@ def lp16g_ok(d, mode, bf16):
     return ok
 
 
-def raw_conv_lp16g(d, mode, x16, w, bias, act, bf16, out16=False):
+def raw_conv_lp16g(d, mode, x16, w, bias, act, bf16, out16=False, want_stats=False):
     """pass `mode` of conv d on the general 16-bit kernel; x16: the 16-bit input (mode 0) / output
-    gradient (mode 1); w: the fp32 physical weight [3,3,Cin,Cout]."""
+    gradient (mode 1); w: the fp32 physical weight [3,3,Cin,Cout].  want_stats (fprop, 16-bit output, no activation):
+    where the stride-2 kernel takes the shape its epilogue leaves the partial statistics for the norm behind the conv."""
     assert x16.dtype == _wd(bf16) and x16.is_contiguous()
     d.dtype = _dt(bf16)
     wp, wt = bf16_weights(w, bf16)
     shape = (d.B, d.Ho, d.Wo, d.Cout) if mode == 0 else (d.B, d.H, d.W, d.Cin)
     y = torch.empty(shape, dtype=_wd(bf16) if out16 else torch.float32, device=x16.device)
+    if want_stats and FUSE_NORM_STATS and FUSE_NORM_STATS_NARROW and mode == 0 and out16 and act == L.ACT_NONE:
+        chunks = L.load().mmh_conv_lp16_stats_chunks(C.byref(d))
+        if chunks > 0:
+            stats = torch.empty((d.B, chunks, 3, d.Cout), dtype=torch.float32, device=x16.device)
+            L.call("mmh_conv_lp16_fprop_stats", C.byref(d), _ptr(x16), _ptr(wt), _ptr(bias), _ptr(y), _ptr(stats),
+                   _ptr(zero_page(x16.device)), _stream())
+            _park_stats(y, stats)
+            _count_desc("mfma", d)
+            return y
     L.call("mmh_conv_lp16", C.byref(d), mode, _ptr(x16), _ptr(wt if mode == 0 else wp), _ptr(bias), _ptr(y),
            int(out16), act, _ptr(zero_page(x16.device)), _stream())
     _count_desc("mfma", d)
@@ -1099,7 +1114,7 @@ def stem16_weights(w, bf16):
     return ent
 
 
-def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None):
+def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None, want_stats=False):
     """fprop of a small-Cin 'same' conv on the flat-K 16-bit kernel; x: fp32 NHWC [B,H,W,Cin] (or its padded
     16-bit copy x16p = lp16_pad8(x)).  The 7x7 stems with 64 output channels take conv_stem16.hip (input halo resident
     in LDS, column taps flattened into the contraction) instead."""
@@ -1109,6 +1124,15 @@ def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None):
     d.dtype = _dt(bf16)
     y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x16p.device)
     if USE_STEM_FPROP16 and d.kh == 7 and L.load().mmh_conv_stem16_supported(C.byref(d), c8):
+        chunks = (L.load().mmh_conv_stem16_stats_chunks(C.byref(d), c8)
+                  if (want_stats and FUSE_NORM_STATS and FUSE_NORM_STATS_NARROW and out16 and act == L.ACT_NONE) else 0)
+        if chunks > 0:      # the InstanceNorm behind the stem merges these partials instead of reading y
+            stats = torch.empty((d.B, chunks, 3, d.Cout), dtype=torch.float32, device=x16p.device)
+            L.call("mmh_conv_stem16_stats", C.byref(d), _ptr(x16p), c8, _ptr(stem16_weights(w, bf16)), _ptr(bias), _ptr(y),
+                   _ptr(stats), _ptr(zero_page(x16p.device)), _stream())
+            _park_stats(y, stats)
+            _count_desc("mfma", d)
+            return y
         L.call("mmh_conv_stem16", C.byref(d), _ptr(x16p), c8, _ptr(stem16_weights(w, bf16)), _ptr(bias), _ptr(y),
                int(out16), act, _ptr(zero_page(x16p.device)), _stream())
         _count_desc("mfma", d)
@@ -1493,7 +1517,7 @@ class Conv2dFn(torch.autograd.Function):
             assert bf16 and act == L.ACT_NONE and x16 is None and stem_lp16_ok(d, bf16, dx_channels), \
                 "a 16-bit output needs 16-bit kernels for all passes and no activation"
             x16p = lp16_pad8(x, bf16)
-            y = raw_conv_lp16_flat(d, None, w, bias, act, bf16, out16=True, x16p=x16p)
+            y = raw_conv_lp16_flat(d, None, w, bias, act, bf16, out16=True, x16p=x16p, want_stats=bool(null_bias_grad))
             ctx.stem16 = True
             ctx.save_for_backward(x16p, w, None)        # the padded 16-bit input serves the wgrad too
             ctx.mark_non_differentiable(y)
@@ -1521,7 +1545,7 @@ class Conv2dFn(torch.autograd.Function):
                 y = raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, 0, out16=bool(y_lp),
                                      want_stats=bool(null_bias_grad and y_lp))
             else:
-                y = raw_conv_lp16g(d, 0, x16, w, bias, act, bf16, out16=bool(y_lp))
+                y = raw_conv_lp16g(d, 0, x16, w, bias, act, bf16, out16=bool(y_lp), want_stats=bool(null_bias_grad and y_lp))
             if timed:
                 e1.record()
             ctx.lp16 = chain or lp16_wgrad_ok(Cin, w.shape[3], k, stride, pad)

@@ -70,3 +70,39 @@ def test_stride2_fprop_kernel_declines_other_shapes(dev):
     y = ops.raw_conv_lp16g(ops.conv_desc(1, 40, 40, 64, 128, 3, 2, 1, False), 0, ops.lp16_twin(x, True), w, None, 0, True)
     ref = F.conv2d(x.bfloat16().double().permute(0, 3, 1, 2).cpu(), w.bfloat16().double().permute(3, 2, 0, 1).cpu(), stride=2, padding=1)
     assert _rel(y.cpu(), ref.permute(0, 2, 3, 1)) <= 2e-5
+
+
+@pytest.mark.parametrize("kind,B,H,W,Cin", [("s2", 2, 64, 64, 64), ("s2", 3, 32, 96, 64), ("stem", 2, 64, 64, 24), ("stem", 1, 32, 48, 44),
+                                            ("stem", 2, 32, 32, 8)])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_epilogue_statistics_match_the_stored_output(kind, B, H, W, Cin, lp, dev):
+    """The partial statistics the stride-2 kernel (conv_s2_lp16.hip) and the 7x7 stem kernel (conv_stem16.hip) leave for the
+    InstanceNorm behind them (common.h: wave_tile_stats; mmh_conv_lp16_fprop_stats / mmh_conv_stem16_stats), merged by
+    mmh_norm_stats_merge: mean and M2 per (image, channel) of the 16-bit output AS STORED, against float64 over that output."""
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(H + Cin)
+    Cout = 128 if kind == "s2" else 64
+    k, stride, pad = (3, 2, 1) if kind == "s2" else (7, 1, 3)
+    x = torch.randn((B, H, W, ops.pad4(Cin)), generator=gen, device=dev) * 1.3 + 0.2
+    w = torch.randn((k, k, ops.pad4(Cin), Cout), generator=gen, device=dev) * 0.05
+    bias = torch.randn((Cout,), generator=gen, device=dev)
+    ops._pending_stats.clear()
+    ops.FUSE_NORM_STATS_NARROW, keep = True, ops.FUSE_NORM_STATS_NARROW      # (off by default: measured slower at step level)
+    d = ops.conv_desc(B, H, W, ops.pad4(Cin), Cout, k, stride, pad, kind == "stem")
+    if kind == "s2":
+        y = ops.raw_conv_lp16g(d, 0, ops.lp16_twin(x, lp), w, bias, 0, lp, out16=True, want_stats=True)
+    else:
+        y = ops.raw_conv_lp16_flat(d, x, w, bias, 0, lp, out16=True, want_stats=True)
+    ops.FUSE_NORM_STATS_NARROW = keep
+    pend = ops._pending_stats.get(y.data_ptr())
+    assert pend is not None, "the kernel left no partial statistics"
+    stats = pend[0]
+    assert stats.shape[0] == B and stats.shape[2] == 3 and stats.shape[3] == Cout
+    mean, m2, rows = ops.raw_norm_stats(y, B)           # takes the parked partials (merge), does not read y
+    torch.cuda.synchronize()
+    assert rows == y.shape[1] * y.shape[2] and float(stats[:, :, 0].sum(1).min()) == float(stats[:, :, 0].sum(1).max()) == rows
+    yd = y.double().view(B, -1, Cout)
+    rm, rq = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float((mean.double() - rm).abs().max()) <= 2e-6 * float(yd.abs().max()), float((mean.double() - rm).abs().max())
+    assert float(((m2.double() - rq).abs() / rq).max()) <= 2e-5, float(((m2.double() - rq).abs() / rq).max())
