@@ -168,6 +168,9 @@ bool conv_s2f_ok(const mmh_conv_desc* d, int mode);
 int conv_s2f_stats_chunks(const mmh_conv_desc* d);
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16, int act,
                     const void* zeros, hipStream_t st, float* stats = nullptr);
+bool conv_s2d_ok(const mmh_conv_desc* d, int mode);
+int launch_conv_s2d(const mmh_conv_desc* d, const void* g16, const void* w16, const void* bias, void* dx, int dx_is16, int act,
+                    const void* zeros, hipStream_t st);
 extern int g_lp16_s2f;
 extern int g_lp16_persist;
 extern int g_slab_reduce_par;

@@ -92,7 +92,7 @@ typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
 __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>(addr); }
 
 // KC = C / 64 chunks; MW waves along the rows (MI = 8 / MW rows each), NJ column tiles per wave
-template <bool H16, int KC, int MW, int NJ>
+template <bool H16, int KC, int MW, int NJ, bool STATS>
 __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
     constexpr int MI = TH / MW;             // output rows (16-pixel MFMA column tiles) per wave
     constexpr int NG = 8 / MW;              // column groups
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         for (int kc = 0; kc < KC; ++kc) {
             // item q has landed: the queue retires in order, so everything but the MI * NJ stores of the epilogue just
             // behind the DMA is enough after a tile boundary
-            if (after_store && p.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ + 3) : "memory");
+            if (after_store && STATS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ + 3) : "memory");
             else if (after_store) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             after_store = false;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
                     store4<H16>(p.y, p.y16, pix * p.y_cs + (n0 + 16 * j + 4 * g4), acc[i][j], bv[j], p.act);
             }
         }
-        if (p.stats) {      // the InstanceNorm behind this conv merges these partials instead of reading y (common.h)
+        if (STATS) {        // the InstanceNorm behind this conv merges these partials instead of reading y (common.h)
             const int chunks = p.TX * p.TY * MW;
             float* sp = p.stats + ((size_t)(b * chunks + (ty * p.TX + tx) * MW + wm) * 3) * p.N + n0 + 4 * g4;
             mmh::wave_tile_stats<MI, NJ>([&](int i, int j, int r) {
@@ -247,6 +247,153 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
                 return H16 ? (float)(_Float16)t : (float)(__bf16)t;
             }, l15, sp, p.N);
         }
+        after_store = true;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The input gradient of the same convolution (and the forward of the decoder's ConvTranspose2d(2c, c, 3, 2, 1, 1)): dx[2p + a]
+// [2q + b] = sum over the taps of parity class (a, b) of dy[p + dh][q + dw] . w[kh][kw], dh = (kh == 0), dw = (kw == 0) - one
+// tap for class (0,0), two for (0,1) and (1,0), four for (1,1).  The general kernel runs the four classes as four GEMMs that
+// each re-stage dy and their taps' weights; here a tile of 8 x 16 dy positions brings its 9 x 17 halo of dy (128 channels:
+// 41 KB) in ONCE for all nine taps and all four classes, and the weights are register-resident as in the fprop kernel: a wave
+// owns one 16-channel column tile of dx (64 channels = 4 column tiles) and four of the tile's eight rows, all nine taps (144
+// VGPRs) and all four classes (64 accumulator VGPRs).  Per (row, k-step) FOUR pixel fragments - (dh, dw) in {0,1}^2 - feed the
+// nine MFMAs.  Only for 128 -> 64 channels (the dgrad of the 64 -> 128 down-sampling conv, the ConvTranspose2d 128 -> 64).
+constexpr int DH = TH + 1, DW = TW + 1;            // halo 9 x 17 positions of dy
+constexpr int DPITCH = 18;
+constexpr int DROWS = DH * DPITCH;                 // 162 LDS rows per 64-channel chunk image
+constexpr int DCHUNK_B = DROWS * 128;              // 20736 B
+constexpr int DROUNDS = (DROWS + 63) / 64;         // 3 DMA instructions per wave and chunk
+constexpr int DBUF_B = 2 * DCHUNK_B;               // both chunks of a tile
+constexpr int DLDS_B = 2 * DBUF_B;                 // two tiles: 82944 B
+
+struct S2DKP {
+    const char* g;          // 16-bit dy [B][Ho][Wo][cs], 128 channels
+    const char* w;          // 16-bit [tap][N = 64][K = 128]
+    const char* zeros;
+    float* y;               // dx fp32 [B][2 Ho][2 Wo][y_cs] ...
+    char* y16;              // ... or 16-bit
+    const float* bias;
+    int B, Ho, Wo, cs, y_cs, act;
+    int TX, TY, tiles, lists;
+};
+
+template <bool H16>
+__global__ void __launch_bounds__(512) conv_s2d_kernel(const S2DKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int nj = wave & 3, rh = wave >> 2;        // column tile of dx, row half of the tile
+    const int xcd = blockIdx.x & 7, lst = blockIdx.x >> 3;
+    const int per_xcd = (p.tiles + 7) / 8, lists_x = p.lists / 8;
+    const int per_list = (per_xcd + lists_x - 1) / lists_x;
+    const int t_begin = xcd * per_xcd + lst * per_list;
+    const int t_end = min(min(t_begin + per_list, (xcd + 1) * per_xcd), p.tiles);
+    if (t_begin >= t_end) return;
+    const int n0 = nj * 16;
+
+    bf16x8 wf[9][4];        // (tap, k32 step): rows n0 + l15 of [tap][64][128], K-values 32 s + 8 g4 .. + 7
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            wf[t][k] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)(t * 64 + n0 + l15) * 128 + 32 * k + 8 * g4) * 2);
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[n0 + 4 * g4 + r] : 0.f;
+
+    const unsigned lds0 = mmh::lds_addr_of(smem);
+    auto issue_tile = [&](int tile, int buf) {      // both 64-channel chunks of the tile's dy halo
+        const int b = tile / (p.TX * p.TY);
+        const int rem = tile - b * (p.TX * p.TY);
+        const int ty = rem / p.TX, tx = rem - ty * p.TX;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const unsigned dst = lds0 + (unsigned)buf * DBUF_B + (unsigned)kc * DCHUNK_B + (unsigned)wave * 1024u;
+#pragma unroll
+            for (int rd = 0; rd < DROUNDS; ++rd) {
+                const int r = rd * 64 + wave * 8 + (lane >> 3);
+                const int hy = r / DPITCH, sl = r - hy * DPITCH;
+                const int ph = ty * TH + hy, qw = tx * TW + sl;
+                const bool row = r < DROWS && sl < DW;
+                const bool ok = row && ph < p.Ho && qw < p.Wo;
+                const unsigned q8 = (unsigned)((lane & 7) ^ (sl & 6));
+                if (row) {
+                    const char* gsrc = ok ? p.g + ((size_t)((unsigned)((b * p.Ho + ph) * p.Wo + qw) * (unsigned)p.cs * 2u) + kc * 128 + q8 * 16u)
+                                          : p.zeros + (lane & 7) * 16;
+                    mmh::lds_dma16(gsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)rd * 8192u)));
+                }
+            }
+        }
+    };
+    // pixel fragment of tile row rh * 4 + i, shift (dh, dw), k32 step (kc, hf): LDS row (rh 4 + i + dh) * DPITCH + dw + l15
+    unsigned aL[2][2];
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+        const unsigned sl = (unsigned)(dw + l15);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            aL[dw][hf] = lds0 + ((unsigned)(rh * 4) * DPITCH + sl) * 128u + ((((unsigned)(4 * hf + g4)) ^ (sl & 6u)) << 4);
+    }
+
+    f32x4 acc[4][4];        // [class 2 a + b][row]
+    int nt = 0;
+    issue_tile(t_begin, 0);
+    bool after_store = false;
+    for (int tile = t_begin; tile < t_end; ++tile, ++nt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (after_store) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // all but the 16 stores behind the halo DMA
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tile + 1 < t_end) issue_tile(tile + 1, (nt + 1) & 1);
+        const unsigned boff = (unsigned)(nt & 1) * DBUF_B;
+        // 16 blocks (k32 step, row): four fragments, nine MFMAs; the fragments of block n + 1 requested before block n multiplies
+        auto frag = [&](int blk, int d) -> bf16x8 {
+            const int k = blk >> 2, i = blk & 3, kc = k >> 1, hf = k & 1, dh = d >> 1, dw = d & 1;
+            return lds_frag(aL[dw][hf] + boff + (unsigned)kc * DCHUNK_B + (unsigned)((i + dh) * DPITCH) * 128u);
+        };
+        bf16x8 af[2][4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) af[0][d] = frag(0, d);
+#pragma unroll
+        for (int blk = 0; blk < 16; ++blk) {
+            const int k = blk >> 2, i = blk & 3;
+            if (blk + 1 < 16) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) af[(blk + 1) & 1][d] = frag(blk + 1, d);
+            }
+            const bf16x8 f00 = af[blk & 1][0], f01 = af[blk & 1][1], f10 = af[blk & 1][2], f11 = af[blk & 1][3];
+            // tap (kh, kw) = wf[3 kh + kw]; shift dh = (kh == 0), dw = (kw == 0); class a = (kh != 1), b = (kw != 1)
+            acc[0][i] = mfma<H16>(wf[4][k], f00, acc[0][i]);        // (1,1)
+            acc[1][i] = mfma<H16>(wf[3][k], f01, acc[1][i]);        // (1,0)
+            acc[1][i] = mfma<H16>(wf[5][k], f00, acc[1][i]);        // (1,2)
+            acc[2][i] = mfma<H16>(wf[1][k], f10, acc[2][i]);        // (0,1)
+            acc[2][i] = mfma<H16>(wf[7][k], f00, acc[2][i]);        // (2,1)
+            acc[3][i] = mfma<H16>(wf[0][k], f11, acc[3][i]);        // (0,0)
+            acc[3][i] = mfma<H16>(wf[2][k], f10, acc[3][i]);        // (0,2)
+            acc[3][i] = mfma<H16>(wf[6][k], f01, acc[3][i]);        // (2,0)
+            acc[3][i] = mfma<H16>(wf[8][k], f00, acc[3][i]);        // (2,2)
+            if (blk + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        }
+        // epilogue: class (a, b), row i -> dx pixel (2 (ty 8 + rh 4 + i) + a, 2 (tx 16 + l15) + b), channels n0 + 4 g4 .. + 3
+        const int b = tile / (p.TX * p.TY);
+        const int rem = tile - b * (p.TX * p.TY);
+        const int ty = rem / p.TX, tx = rem - ty * p.TX;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oh = 2 * (ty * TH + rh * 4 + i) + (c >> 1), ow = 2 * (tx * TW + l15) + (c & 1);
+                const size_t pix = ((size_t)b * (2 * p.Ho) + oh) * (2 * p.Wo) + ow;
+                store4<H16>(p.y, p.y16, pix * p.y_cs + (n0 + 4 * g4), acc[c][i], bv, p.act);
+            }
         after_store = true;
     }
 }
@@ -276,6 +423,51 @@ int conv_s2f_stats_chunks(const mmh_conv_desc* d) {        // partials per image
     return (d->Ho / TH) * (d->Wo / TW) * (d->Cin == 64 ? 2 : 1);
 }
 
+bool conv_s2d_ok(const mmh_conv_desc* d, int mode) {
+    if (!g_lp16_s2f || mode != 1 || !d) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 2 || d->pad != 1 || d->pad_mode != MMH_PAD_ZERO) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->Cin != 64 || d->Cout != 128) return false;
+    if (d->H % 2 || d->W % 2 || d->Ho != d->H / 2 || d->Wo != d->W / 2 || d->Ho % TH || d->Wo % TW) return false;
+    if ((long long)d->B * d->H * d->W >= (1ll << 31) || (long long)d->B * d->Ho * d->Wo * d->y_cs >= (1ll << 31)) return false;
+    return true;
+}
+
+int launch_conv_s2d(const mmh_conv_desc* d, const void* g16, const void* w16, const void* bias, void* dx, int dx_is16,
+                    int act, const void* zeros, hipStream_t st) {
+    S2DKP p{};
+    p.g = static_cast<const char*>(g16);
+    p.w = static_cast<const char*>(w16);
+    p.zeros = static_cast<const char*>(zeros);
+    if (dx_is16) p.y16 = static_cast<char*>(dx); else p.y = static_cast<float*>(dx);
+    p.bias = static_cast<const float*>(bias);
+    p.B = d->B; p.Ho = d->Ho; p.Wo = d->Wo; p.cs = d->y_cs; p.y_cs = d->x_cs; p.act = act;
+    p.TX = p.Wo / TW; p.TY = p.Ho / TH; p.tiles = p.B * p.TX * p.TY;
+    if (!g_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_cus = n;
+    }
+    const int per_xcd = (p.tiles + 7) / 8;
+    p.lists = 8 * std::max(1, std::min(g_cus / 8, per_xcd));
+    const dim3 grid(p.lists);
+    const bool h16 = d->dtype == MMH_FP16;
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DLDS_B);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2d_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, DLDS_B);
+        if (e != hipSuccess) return fail("hipFuncSetAttribute(conv_s2d): %s", hipGetErrorString(e));
+        ready = true;
+    }
+    if (h16) hipLaunchKernelGGL(conv_s2d_kernel<true>, grid, dim3(512), DLDS_B, st, p);
+    else hipLaunchKernelGGL(conv_s2d_kernel<false>, grid, dim3(512), DLDS_B, st, p);
+    return check_launch("conv_s2d_kernel");
+}
+
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16,
                     int act, const void* zeros, hipStream_t st, float* stats) {
     S2KP p{};
@@ -302,9 +494,10 @@ int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, co
     p.lists = 8 * lists_x;
     const dim3 grid(p.lists * p.nsplit);
     const bool h16 = d->dtype == MMH_FP16;
-#define MMH_S2F(H16, KC, MW, NJ)                                                                                   \
+#define MMH_S2F(H16, KC, MW, NJ) { if (stats) MMH_S2F_(H16, KC, MW, NJ, true) else MMH_S2F_(H16, KC, MW, NJ, false) }
+#define MMH_S2F_(H16, KC, MW, NJ, ST)                                                                              \
     {                                                                                                              \
-        auto kfn = conv_s2f_kernel<H16, KC, MW, NJ>;                                                               \
+        auto kfn = conv_s2f_kernel<H16, KC, MW, NJ, ST>;                                                           \
         static bool ready = false;                                                                                 \
         if (!ready) {                                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
@@ -317,6 +510,7 @@ int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, co
     if (p.C == 64) { if (h16) MMH_S2F(true, 1, 2, 2) else MMH_S2F(false, 1, 2, 2) }
     else { if (h16) MMH_S2F(true, 2, 1, 1) else MMH_S2F(false, 2, 1, 1) }
 #undef MMH_S2F
+#undef MMH_S2F_
     return check_launch("conv_s2f_kernel");
 }
 

@@ -106,3 +106,36 @@ def test_epilogue_statistics_match_the_stored_output(kind, B, H, W, Cin, lp, dev
     rm, rq = yd.mean(1), ((yd - yd.mean(1, keepdim=True)) ** 2).sum(1)
     assert float((mean.double() - rm).abs().max()) <= 2e-6 * float(yd.abs().max()), float((mean.double() - rm).abs().max())
     assert float(((m2.double() - rq).abs() / rq).max()) <= 2e-5, float(((m2.double() - rq).abs() / rq).max())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 32, 96), (3, 16, 32)])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("out16,bias", [(True, False), (False, True)])
+def test_stride2_dgrad_vs_general_kernel_and_fp64(B, H, W, lp, out16, bias, dev):
+    """conv_s2d_kernel (mmh_conv_lp16 mode 1 at 64 -> 128 channels: the input gradient of the stride-2 conv = the forward of
+    ConvTranspose2d(128, 64, 3, 2, 1, 1), models/Generator.py:225-243): against the general per-class kernel (2e-6 fp32 output;
+    the k order differs) and against the fp64 transposed convolution of the same 16-bit operands."""
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    Cin, Cout = 64, 128
+    gen = torch.Generator(device=dev).manual_seed(H * 3 + W)
+    dy = torch.randn((B, H // 2, W // 2, Cout), generator=gen, device=dev)
+    w = torch.randn((3, 3, Cin, Cout), generator=gen, device=dev) * 0.05
+    b = torch.randn((Cin,), generator=gen, device=dev) if bias else None
+    dy16 = ops.lp16_twin(dy, lp)
+    outs = {}
+    for on in (1, 0):
+        L.check(L.load().mmh_set_option(b"lp16_s2f", on), "set_option")
+        try:
+            outs[on] = ops.raw_conv_lp16g(ops.conv_desc(B, H, W, Cin, Cout, 3, 2, 1, False), 1, dy16, w, b, 0, lp, out16=out16)
+        finally:
+            L.check(L.load().mmh_set_option(b"lp16_s2f", 1), "set_option")
+    torch.cuda.synchronize()
+    new, old = outs[1], outs[0]
+    assert tuple(new.shape) == (B, H, W, Cin) and bool(torch.isfinite(new.float()).all())
+    assert _rel(new, old) <= (2e-6 if not out16 else 1e-3), _rel(new, old)
+    wp, _ = ops.bf16_weights(w, lp)         # [3,3,Cin,Cout] 16-bit
+    ref = F.conv_transpose2d(dy16.double().permute(0, 3, 1, 2).cpu(), wp.double().permute(3, 2, 0, 1).cpu(),
+                             None if b is None else b.double().cpu(), stride=2, padding=1, output_padding=1)
+    tol = 2e-5 if not out16 else (3e-3 if lp is True else 4e-4)
+    assert _rel(new.cpu(), ref.permute(0, 2, 3, 1)) <= tol, _rel(new.cpu(), ref.permute(0, 2, 3, 1))

@@ -27,3 +27,16 @@ for B, H, Cin, Cout in ((32, 256, 64, 128), (32, 128, 128, 256), (4, 512, 64, 12
     L.check(L.load().mmh_set_option(b"lp16_dbg", 0), "opt")
     L.check(L.load().mmh_set_option(b"lp16_s2f", 1), "opt")
     print(f"B={B} {H}x{H} {Cin}->{Cout} stride 2 fprop, 16-bit out: " + "; ".join(res))
+
+for B, H in ((32, 256), (64, 256), (4, 512)):
+    Cin, Cout = 64, 128
+    dy16 = torch.randn(B, H // 2, H // 2, Cout, device=dev).bfloat16(); w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
+    d = lambda: ops.conv_desc(B, H, H, Cin, Cout, 3, 2, 1, False)
+    fl = 2.0 * B * (H // 2) ** 2 * Cin * Cout * 9
+    res = []
+    for on in (0, 1):
+        L.check(L.load().mmh_set_option(b"lp16_s2f", on), "opt")
+        us = t(lambda: ops.raw_conv_lp16g(d(), 1, dy16, w, None, 0, True, out16=True))
+        res.append(f"{'s2d' if on else 'general'} {us:.1f} us = {fl / us / 1e6:.0f} TF ({fl / us / 1e6 / 2500:.3f})")
+    L.check(L.load().mmh_set_option(b"lp16_s2f", 1), "opt")
+    print(f"B={B} {H}x{H} {Cin}->{Cout} stride 2 DGRAD, 16-bit out: " + "; ".join(res))
