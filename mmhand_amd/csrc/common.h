@@ -52,6 +52,41 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// Epilogue of the MFMA 16x16x32 kernels whose first operand is the weight fragment, 16-bit output: lane (l15 = pixel, g4) holds
+// channels 4 g4 .. + 3 of each 16-channel column tile.  The lanes g4 and g4 ^ 1 (16 apart) trade one accumulator of a column
+// tile PAIR (v_permlane16_swap: one instruction per register) - afterwards a lane holds EIGHT consecutive channels of its
+// pixel, tile `even` from the even lane's side, tile `odd` from the odd lane's - and stores 16 bytes: half the store
+// instructions, 64 contiguous bytes per pixel and instruction instead of 32 (the store shapes alone: 3.7 against 5.5 TB/s,
+// tools/probes/store_pattern.hip).  v[0..7] on return: the lane's 8 channels, first channel = (g4 odd ? 16 : 0) + 4 (g4 & 2)
+// of the 32-channel pair.  Every lane of the wave must call this (the swap is a cross-lane operation).
+// (Inline asm: through __builtin_amdgcn_permlane16_swap hipcc 7.2 loses the instruction's second output in unrolled code.)
+typedef float mmh_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pair_swap8(const mmh_f32x4& even, const mmh_f32x4& odd, float* v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float lo = even[r], hi = odd[r];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+        v[r] = lo;
+        v[4 + r] = hi;
+    }
+}
+template <bool H16>
+__device__ __forceinline__ void store8_lp16(char* dst, const float* v) {
+    if (H16) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        *reinterpret_cast<h8*>(dst) = o;
+    } else {
+        typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+        b8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<b8*>(dst) = o;
+    }
+}
+
 // Partial InstanceNorm statistics of a conv output tile from the epilogue of an MFMA 16x16x32 kernel whose FIRST operand is the
 // weight fragment (lane (l15 = pixel, g4): channels 4 g4 + r, r < 4, of each of its NJ 16-channel column tiles, NV pixel
 // rows per lane): count / mean / M2 of the wave's 16 NV pixels per channel, in the partial layout mmh_norm_stats_merge

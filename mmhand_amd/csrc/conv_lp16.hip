@@ -974,6 +974,36 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + 4 * g4 + r] : 0.f;
     const int ow = ow0 + l15;
+    if (p.y16 && !(p.dbg & 128)) {
+        // 16-bit output: 16-byte stores after the lane-pair trade (common.h: pair_swap8) - 16 store instructions per tile
+        // instead of 32; 256 -> 256 fprop 150 -> 134 us, the 16-bit step 102.5 -> 100.8 ms (tools/ab_lp16_stores.py;
+        // mmh_set_option("lp16_dbg", 128) = 8-byte stores)
+        const bool odd = (g4 & 1) != 0;
+        const int cb0 = (odd ? 16 : 0) + 4 * (g4 & 2);      // this lane's 8 channels within a 32-channel tile pair
+        float bo[2][8];
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bo[jp][e] = p.bias ? p.bias[n0 + wc * 64 + jp * 32 + cb0 + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int oh = oh0 + wr * 8 + i;
+            const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float v[8];
+                mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] + bo[jp][e];
+                    v[e] = p.act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (p.act == MMH_ACT_TANH ? tanhf(t) : t);
+                }
+                if (oh < p.H && ow < p.W) {
+                    mmh::store8_lp16<H16>(p.y16 + (m * p.y_cs + (n0 + wc * 64 + jp * 32 + cb0)) * 2, v);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int oh = oh0 + wr * 8 + i;
@@ -985,6 +1015,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             if (SIGN < 0 && p.addend) acc[i][j] += *reinterpret_cast<const f32x4*>(p.addend + elem);
             store4<H16>(p.y, p.y16, elem, acc[i][j], bv[j], p.act);
         }
+    }
     }
     if (SIGN > 0 && !FOLD && p.stats) {
         // The InstanceNorm behind this conv (models/Generator.py:66-77) wants mean and M2 per (image, channel): each wave
@@ -1221,6 +1252,30 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * (BNT / 4) + j * 16 + 4 * g4 + r] : 0.f;
+    if (p.y16 && NJ % 2 == 0) {      // 16-byte stores after the lane-pair trade (common.h: pair_swap8)
+        const int cb0 = ((g4 & 1) ? 16 : 0) + 4 * (g4 & 2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + l15;
+            const int mc = m < M ? m : M - 1;
+            const int b = mc / (p.MH * p.MW);
+            const int rem = mc - b * (p.MH * p.MW);
+            const int mh = rem / p.MW, mw = rem - mh * p.MW;
+            const size_t opix = ((size_t)b * p.OH + (mh * p.os + oh0)) * p.OW + (mw * p.os + ow0);
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                float v[8];
+                mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + (NJ > 1 ? 1 : 0)], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] + (p.bias ? p.bias[n0 + wc * (BNT / 4) + jp * 32 + cb0 + e] : 0.f);
+                    v[e] = p.act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (p.act == MMH_ACT_TANH ? tanhf(t) : t);
+                }
+                if (m < M) mmh::store8_lp16<H16>(p.y16 + (opix * p.y_cs + (n0 + wc * (BNT / 4) + jp * 32 + cb0)) * 2, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + l15;

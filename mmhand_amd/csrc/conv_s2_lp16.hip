@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         }
         // epilogue: lane (l15, g4) holds channels 4 g4 .. + 3 of pixel l15 of each of its rows, in each of its NJ column tiles
         // (tried: the lanes g4 / g4 ^ 1 trading one accumulator each so that a lane stores 16 bytes - half the store
-        // instructions - ran 152 us against 116: tools/bench_s2f.py)
+        // instructions, what gives conv_lp16h2_kernel 11 % at 256 -> 256 (common.h: pair_swap8) - ran 152 us (__shfl_xor) and
+        // 163 us (v_permlane16_swap) against 116: tools/bench_s2f.py)
         const int b = tile / (p.TX * p.TY);
         const int rem = tile - b * (p.TX * p.TY);
         const int ty = rem / p.TX, tx = rem - ty * p.TX;

@@ -145,6 +145,26 @@ __global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const St
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[j * 16 + 4 * g4 + r] : 0.f;
     const int ow = ow0 + l15;
+    // (16-byte stores after the lane-pair trade of common.h's pair_swap8: 24 -> 64 396 us against 348 with 8-byte stores - off)
+    if (p.y16 && false) {
+        const int cb0 = ((g4 & 1) ? 16 : 0) + 4 * (g4 & 2);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int oh = oh0 + RW * wave + i;
+            const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                float v[8];
+                mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] + (p.bias ? p.bias[jp * 32 + cb0 + e] : 0.f);
+                    v[e] = p.act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (p.act == MMH_ACT_TANH ? tanhf(t) : t);
+                }
+                if (oh < p.H && ow < p.W) mmh::store8_lp16<H16>(p.y16 + (m * p.y_cs + (jp * 32 + cb0)) * 2, v);
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int oh = oh0 + RW * wave + i;
