@@ -663,6 +663,8 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     // own prologue: 3-8 % faster from 512 tiles up (no second wave of workgroup launches behind the first, no ragged last
     // round).  Prefetching the next tile's first stages during the last k-steps was built as well and added nothing to that
     // (145 against 143 us at 256 -> 256), while its live state spilled the reflect-fold variant (148 -> 201 us): not kept.
+    // (The reflect-fold variant walks tile lists as well since it has one fold accumulator per wave and its halo offsets in
+    // LDS: 250 registers, nothing in scratch; mmh_set_option("lp16_persist", 2) = every variant but that one.)
     const int per_xcd = (p.MT * p.NT + 7) / 8;
     const int wpx = (int)(gridDim.x >> 3);
     const int tile_end = min(((int)(blockIdx.x & 7) + 1) * per_xcd, p.MT * p.NT);
@@ -675,11 +677,10 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     const int ty = trem / TX, tx = trem - ty * TX;
     const int oh0 = ty * HT, ow0 = tx * HT;
 
-    // halo DMA roles: round rd covers LDS rows rd*64 .. +63 (row = hy * 20 + hx); wave w rows rd*64 + w*8 + lane/8
-    unsigned a_off[HROUNDS2];
-#pragma unroll
-    for (int rd = 0; rd < HROUNDS2; ++rd) {
-        const int r = rd * 64 + wave * 8 + (lane >> 3);
+    // halo DMA roles: round rd covers LDS rows rd*64 .. +63 (row = hy * 20 + hx); wave w rows rd*64 + w*8 + lane/8.
+    // Source offset of LDS row r with the row's swizzle key in the free low bits (the offset is a multiple of 128 bytes):
+    // a lane XORs its own chunk (lane & 7) * 16 into it.  0xfffffffe: zero page, 0xffffffff: no such row.
+    auto halo_row_off = [&](int r) -> unsigned {
         const int hy = r / HP2, hx = r - hy * HP2;
         int ih = oh0 + hy - 1, iw = ow0 + hx - 1;
         const bool row = r < HROWS2 && hx < HW_;
@@ -690,9 +691,24 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             iw = iw >= p.W ? 2 * (p.W - 1) - iw : iw;
         }
         const bool ok = row && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        const unsigned q = (unsigned)((lane & 7) ^ (hx & 6));
-        a_off[rd] = ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + q * 16u
-                       : (row ? 0xfffffffeu : 0xffffffffu);        // ...fe: zero page, ...ff: no row
+        return ok ? (unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.cs * 2u + (unsigned)(hx & 6) * 16u
+                  : (row ? 0xfffffffeu : 0xffffffffu);
+    };
+    // The plain variants hold their six offsets in registers.  The reflect-fold variant is six registers short of keeping
+    // its fold accumulators out of scratch (a scratch reload in the k-loop is followed by s_waitcnt vmcnt(0): a drain of the
+    // whole LDS-DMA ring in every fold k-step), so it parks the 384 row offsets in LDS behind the stages (1.5 of the 6 KiB
+    // the stages leave) and fetches its six per chunk.
+    unsigned a_off[FOLD ? 1 : HROUNDS2];
+    unsigned* const sOff = reinterpret_cast<unsigned*>(smem + 2 * HSTAGE_A2 + 2 * HSTAGE_B);
+    if (FOLD) {
+        if (tid < HROUNDS2 * 64) sOff[tid] = halo_row_off(tid);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int rd = 0; rd < HROUNDS2; ++rd) {
+            const unsigned ro = halo_row_off(rd * 64 + wave * 8 + (lane >> 3));
+            a_off[rd] = ro >= 0xfffffffeu ? ro : ro ^ ((unsigned)(lane & 7) * 16u);
+        }
     }
     // weight DMA: wave w, round j moves rows (w * 4 + j) * 8 + lane / 8 of the [256][64] tile.  The swizzle key (r >> 1) & 7
     // = (4 j + lane / 16) & 7 splits into a lane part and bit 0 of j: ONE lane offset, ^ 64 (chunk ^ 4) for odd j; the row
@@ -708,8 +724,16 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         const char* xb = p.x + (size_t)kc * (TBK * 2);
 #pragma unroll
         for (int rd = 0; rd < HROUNDS2; ++rd) {
-            if (a_off[rd] != 0xffffffffu) {
-                const char* g = a_off[rd] != 0xfffffffeu ? xb + a_off[rd] : p.zeros + (lane & 7) * 16;
+            unsigned ao;
+            if (FOLD) {         // one offset at a time (the asm keeps the six reads from being gathered in front)
+                ao = sOff[rd * 64 + wave * 8 + (lane >> 3)];
+                asm volatile("" : "+v"(ao) :: "memory");
+                ao = ao >= 0xfffffffeu ? ao : ao ^ ((unsigned)(lane & 7) * 16u);
+            } else {
+                ao = a_off[FOLD ? 0 : rd];
+            }
+            if (ao != 0xffffffffu) {
+                const char* g = ao != 0xfffffffeu ? xb + ao : p.zeros + (lane & 7) * 16;
                 __builtin_amdgcn_global_load_lds(g, (lds_vp)(sA + (rd * 8 + wave) * 1024), 16, 0, 0);
             }
         }
@@ -761,26 +785,38 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     };
     const int nk = 9 * KC;
 
-    // FOLD (dgrad of a ReflectionPad2d(1) conv; H, W multiples of 16): the gradient of the pad ring, folded back onto
-    // rows 1 / H-2 and columns 1 / W-2, is computed HERE with the weight fragments the k-step holds anyway - instead of
-    // eight border GEMMs + an add kernel per conv (mmh_conv2d_dgrad_border: 46-70 us, 90 times per step).
-    //   ring row -1 -> row 1 (top tiles, taps kh = 0): one extra A fragment (halo row of dy row 0) into acc[1], by the
-    //       waves that own tile rows 0-7; ring row H -> row H-2 (bottom tiles, kh = 2) into acc[6] likewise;
+    // FOLD (dgrad of a ReflectionPad2d(1) conv; H, W multiples of 16, at least two tiles each way): the gradient of the pad
+    // ring, folded back onto rows 1 / H-2 and columns 1 / W-2, is computed HERE with the weight fragments the k-step holds
+    // anyway - instead of eight border GEMMs + an add kernel per conv (mmh_conv2d_dgrad_border: 46-70 us, 90 times per step).
+    //   ring row -1 -> row 1 (top tiles, taps kh = 0): one extra A fragment (halo row of dy row 0), accumulated by the
+    //       waves that own tile rows 0-7 and added to acc[1] after the loop; ring row H -> row H-2 (bottom tiles, kh = 2)
+    //       likewise by the waves of rows 8-15 into acc[6];
     //   ring column -1 -> column 1 (left tiles, taps kw = 0): the ring values of the tile's 16 ROWS form one MFMA
-    //       column block (lane <-> tile row, its fragment read down the halo column of dy column 0) accumulated in DT
-    //       by waves wr = 0; ring column W -> column W-2 (right tiles, kw = 2) by waves wr = 1; after the loop DT goes
-    //       through LDS to the lanes that hold pixel column 1 / 14;
-    //   the four ring corners (one tap each) are single-lane fragments into acc[1] / acc[6].
-    // Cost: 8 MFMAs on 64 in a third of the k-steps of edge tiles.
+    //       column block (lane <-> tile row, its fragment read down the halo column of dy column 0); ring column W ->
+    //       column W-2 (right tiles, kw = 2) likewise; after the loop the block goes through LDS to the lanes that hold
+    //       pixel column 1 / 14;
+    //   the four ring corners (one tap each) are single-lane fragments of the row term.
+    // A tile has at most one row term and one column term (two tiles each way), and a workgroup two wave rows: ONE fold
+    // accumulator FA per wave - the row term on its own wave row, the column term on the other one (on wr = 0 / 1 for left /
+    // right when the tile has no row term).  One accumulator, one fragment, one multiply site per half k-step: the earlier
+    // build (row term into acc[1] | acc[6] in place, a second accumulator for the column term) made the register allocator
+    // copy acc[6] through temporaries in every fold k-step and spill part of the column accumulator - whose reload was
+    // followed by s_waitcnt vmcnt(0), a drain of the LDS-DMA ring - and left no room for the tile loop (534 -> 482 us at
+    // 512 -> 512, plain dgrad 441: tools/bench_lp16_fold.py).  Cost: 4 MFMAs on 64 in a third of the k-steps of edge tiles.
     const bool fold_on = FOLD && !(p.dbg & 4);
-    const bool f_top = fold_on && !(p.dbg & 16) && ty == 0 && wr == 0, f_bot = fold_on && !(p.dbg & 16) && ty == TY - 1 && wr == 1;
+    const bool t_top = fold_on && !(p.dbg & 16) && ty == 0, t_bot = fold_on && !(p.dbg & 16) && ty == TY - 1;
     const bool f_left = fold_on && !(p.dbg & 8) && tx == 0, f_right = fold_on && !(p.dbg & 8) && tx == TX - 1;
-    const bool f_col = (f_left && wr == 0) || (f_right && wr == 1);
-    f32x4 DT[4];
+    const bool my_row = (t_top && wr == 0) || (t_bot && wr == 1);
+    const int col_wr = t_top ? 1 : (t_bot ? 0 : (f_left ? 0 : 1));
+    const bool my_col = (f_left || f_right) && wr == col_wr;
+    const int fold_kh = t_top ? 0 : 2, fold_kw = f_left ? 0 : 2;    // the taps of this wave's term
+    f32x4 FA[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) DT[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // lane <-> tile row l15: halo row (l15 + dh) * 20 + hx, hx = 1 (left) or 16 (right): both have key hx & 6 == 0
-    const unsigned baseT = lds0 + (unsigned)l15 * (HP2 * ROWB) + (unsigned)(wr == 0 ? 1 : 16) * ROWB + ((unsigned)g4 << 4);
+    for (int j = 0; j < 4; ++j) FA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // column term: lane <-> tile row l15: halo row (l15 + dh) * 20 + hx, hx = 1 (left) or 16 (right): both have key hx & 6 == 0
+    const unsigned baseT = lds0 + (unsigned)l15 * (HP2 * ROWB) + (unsigned)(f_left ? 1 : 16) * ROWB + ((unsigned)g4 << 4);
+    // row term: the tap's halo row 1 (top) / 16 (bottom) at this lane's column: a_cur without its dh rows and wave rows
+    const unsigned f_rsel = (unsigned)(((t_top ? 1 : 16) - wr * 8) * (HP2 * ROWB));
 
     bf16x8 af[8], b0[4], b1[4];
     issue_halo(0);
@@ -805,22 +841,18 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         if (t2 == 9) { t2 = 0; kh2 = 0; ++kc2; }
         const unsigned a0n = a_half0(SIGN > 0 ? kh2 : 2 - kh2, SIGN > 0 ? kw2 : 2 - kw2, kc2 & 1);
         const unsigned bb0n = aB[0] + (HSTAGE_B - sb);
-        // fold roles of this k-step (wave-uniform): row fold (top: kh = 0, waves wr = 0 -> acc[1]; bottom: kh = 2, wr = 1
-        // -> acc[6]), column fold (-> DT), corner (a row-fold k-step of a left / right tile with kw = 0 / 2).  Their
-        // fragments are fetched BEFORE the MFMA block of each half so that the LDS latency hides behind it.
-        const bool do_row = FOLD && ((f_top && kh == 0) || (f_bot && kh == 2));
-        const bool do_col = FOLD && f_col && kw == (wr == 0 ? 0 : 2);
-        const bool do_cnr = do_row && ((kw == 0 && f_left) || (kw == 2 && f_right));
-        const bool do_any = do_row || do_col;
-        // fragment addresses of the fold terms (half 0; half 1 is ^ 64): the tap's halo row 1 (top) / 16 (bottom) at this
-        // lane's column; the halo column 1 / 16 at this lane's row; lane 1 / 14 of the dw = 0 / 2 variant for the corner
+        // fold role of this k-step (wave-uniform): this wave's row term (its kh) or column term (its kw); corner = a row
+        // k-step of a left / right tile with kw = 0 / 2.  The fragment is fetched BEFORE the MFMA block of each half so
+        // that the LDS latency hides behind it: the tap's halo row 1 / 16 at this lane's column, or the halo column 1 / 16
+        // at this lane's row; lane 1 / 14 of the dw = 0 / 2 variant for the corner.
+        const bool do_row = FOLD && my_row && kh == fold_kh;
+        const bool do_fold = do_row || (FOLD && my_col && kw == fold_kw);
+        const bool do_cnr = do_row && ((kw == 0 && f_left) || (kw == 2 && f_right)) && !(p.dbg & 1024);
         const unsigned f_dhb = (unsigned)((2 - kh) * (HP2 * ROWB)), f_st = (unsigned)((kc & 1) * HSTAGE_A2);
-        const unsigned f_rsel = (unsigned)((wr == 0 ? 1 : 8) * (HP2 * ROWB));
-        bf16x8 axr, axc;
-        if (FOLD && do_any) {
-            axr = lds_frag(a_cur - f_dhb + f_rsel);
-            axc = lds_frag(baseT + f_st + f_dhb);
-        }
+        const unsigned f_addr = my_row ? a_cur - f_dhb + f_rsel
+                                       : ((p.dbg & 64) ? a_cur : baseT + f_st + f_dhb);    // dbg 64: timing only
+        bf16x8 axf;
+        if (FOLD && do_fold) axf = lds_frag(f_addr);
         // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = lds_frag(bb1 + j * (16 * ROWB));
@@ -835,29 +867,14 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if (FOLD && do_any) {     // the fold terms of this half (b0 = this tap's weights); fragments fetched above
-            if (do_row) {
-                if (wr == 0) {
+        if (FOLD && do_fold) {    // the fold term of this half (b0 = this tap's weights); fragment fetched above
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b0[j], axr, acc[1][j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b0[j], axr, acc[6][j]);
-                }
-            }
-            if (do_col)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) DT[j] = mfma16s<H16>(b0[j], axc, DT[j]);
+            for (int j = 0; j < 4; ++j) FA[j] = mfma16s<H16>(b0[j], axf, FA[j]);
             if (do_cnr) {         // once per chunk in the four corner tiles: not worth registers for a prefetch
-                axr = lds_frag((kw == 0 ? aA00 : aA20) + f_st + f_rsel);
-                if (l15 != (kw == 0 ? 1 : 14)) axr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (wr == 0) {
+                axf = lds_frag((kw == 0 ? aA00 : aA20) + f_st + f_rsel);
+                if (l15 != (kw == 0 ? 1 : 14) || (p.dbg & 2048)) axf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b0[j], axr, acc[1][j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b0[j], axr, acc[6][j]);
-                }
+                for (int j = 0; j < 4; ++j) FA[j] = mfma16s<H16>(b0[j], axf, FA[j]);
             }
         }
         // ---- middle of the k-step: the weight stage ks is read; stage ks+1 (issued one k-step ago) must have
@@ -880,10 +897,7 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         };
         const bool early = wr == 0 || (p.dbg & 32);
         if (early) issue_next();
-        if (FOLD && do_any) {     // the fold fragments of half 1
-            axr = lds_frag((a_cur - f_dhb + f_rsel) ^ 64u);
-            axc = lds_frag((baseT + f_st + f_dhb) ^ 64u);
-        }
+        if (FOLD && do_fold) axf = lds_frag(f_addr ^ 64u);      // the fold fragment of half 1
         // ---- half 1: multiply (ks, 1) while the fragments of (ks+1, 0) stream in
         // (after the last k-step these reads fetch fragments nobody uses, from addresses inside the stages: cheaper
         // than a branch around each of them)
@@ -912,59 +926,47 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if (FOLD && do_any) {     // the fold terms of this half (b1 = this tap's weights); fragments fetched above
-            if (do_row) {
-                if (wr == 0) {
+        if (FOLD && do_fold) {    // the fold term of this half (b1 = this tap's weights); fragment fetched above
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b1[j], axr, acc[1][j]);
-                } else {
+            for (int j = 0; j < 4; ++j) FA[j] = mfma16s<H16>(b1[j], axf, FA[j]);
+            if (do_cnr) {
+                axf = lds_frag(((kw == 0 ? aA00 : aA20) + f_st + f_rsel) ^ 64u);
+                if (l15 != (kw == 0 ? 1 : 14) || (p.dbg & 2048)) axf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b1[j], axr, acc[6][j]);
-                }
-            }
-            if (do_col)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) DT[j] = mfma16s<H16>(b1[j], axc, DT[j]);
-            if (do_cnr) {         // once per chunk in the four corner tiles: not worth registers for a prefetch
-                axr = lds_frag(((kw == 0 ? aA00 : aA20) + f_st + f_rsel) ^ 64u);
-                if (l15 != (kw == 0 ? 1 : 14)) axr = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (wr == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[1][j] = mfma16s<H16>(b1[j], axr, acc[1][j]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[6][j] = mfma16s<H16>(b1[j], axr, acc[6][j]);
-                }
+                for (int j = 0; j < 4; ++j) FA[j] = mfma16s<H16>(b1[j], axf, FA[j]);
             }
         }
         kc = kc2; t = t2; kh = kh2; kw = kw2; a_cur = a0n;
     }
 
+    if (FOLD && my_row) {               // the row term: same layout as the accumulators of tile row 1 / 14
+        if (t_top) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[1][j] += FA[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[6][j] += FA[j];
+        }
+    }
     if (FOLD && (f_left || f_right)) {
-        // the column folds: DT [channel 4 g4 + r of block j][tile row l15] -> LDS X[side][256 channels][16 rows] -> the
-        // lanes that hold pixel column 1 (left) / 14 (right) of each tile row
+        // the column term: FA [channel 4 g4 + r of block j][tile row l15] -> LDS X[256 channels][16 rows] -> the lanes
+        // that hold pixel column 1 (left) / 14 (right) of each tile row
         float* X = reinterpret_cast<float*>(smem);
         __syncthreads();                    // every wave is done reading the last stages
-        if (f_col) {
-            float* xs = X + (wr == 0 ? 0 : 4096);
+        if (my_col) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xs[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + l15] = DT[j][r];
+                for (int r = 0; r < 4; ++r) X[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + l15] = FA[j][r];
         }
         __syncthreads();
-        if ((f_left && l15 == 1) || (f_right && l15 == 14)) {
+        if (l15 == (f_left ? 1 : 14)) {
 #pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                if (!(side == 0 ? (f_left && l15 == 1) : (f_right && l15 == 14))) continue;
-                const float* xs = X + side * 4096;
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][j][r] += xs[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + wr * 8 + i];
-            }
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += X[(wc * 64 + j * 16 + 4 * g4 + r) * 16 + wr * 8 + i];
         }
     }
 
@@ -1067,7 +1069,6 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         sp[p.N + co] = md[0];
         sp[2 * p.N + co] = qd[0];
     }
-    if (FOLD) break;        // the reflect-fold variant stays one tile per workgroup: inside the loop it spills 46 registers
     __syncthreads();        // the next tile's prologue refills the stages: every wave must be done with this tile's
     }   // tiles of this workgroup
 }
@@ -2259,7 +2260,7 @@ int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d) {
 
 int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d) {
     return mmh_conv3x3_lp16_supported(d) && d->pad_mode == MMH_PAD_REFLECT && d->H % HT == 0 && d->W % HT == 0 &&
-           d->H >= HT && d->W >= HT && d->Cin % TBN == 0 && g_lp16_shape == 19;
+           d->H >= 2 * HT && d->W >= 2 * HT && d->Cin % TBN == 0 && g_lp16_shape == 19;
 }
 
 // mode 0: fprop  y[B,H,W,Cout] = conv(x16 [B,H,W,Cin], w16 = w_t [tap][Cout][Cin]) (+bias, act)
@@ -2274,7 +2275,7 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
     MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1 || mode == 2),
                 "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
     MMH_REQUIRE(mode != 2 || mmh_conv3x3_lp16_fold_supported(d),
-                "mmh_conv3x3_lp16: mode 2 (dgrad with the reflect fold) needs MMH_PAD_REFLECT, H and W multiples of 16 and "
+                "mmh_conv3x3_lp16: mode 2 (dgrad with the reflect fold) needs MMH_PAD_REFLECT, H and W multiples of 16 and >= 32, "
                 "the halo kernel (lp16_shape 19)");
     LpConvKP p{};
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
@@ -2313,7 +2314,7 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
     }
     if (ready != 0) return ready;
     if (g_lp16_shape == 19 && d->H >= HT && d->W >= HT) {       // halo kernel, fragment addresses precomputed (default)
-        constexpr int lds2 = 2 * HSTAGE_A2 + 2 * HSTAGE_B;
+        constexpr int lds2 = 2 * HSTAGE_A2 + 2 * HSTAGE_B + HROUNDS2 * 64 * 4;    // + the fold variant's row-offset table
         static int ready19 = -1;
         if (ready19 != 0) {
             hipError_t e = hipSuccess;
@@ -2330,10 +2331,10 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
         if (ready19 != 0) return ready19;
         LpConvKP ph = p;
         ph.MT = d->B * ((d->H + HT - 1) / HT) * ((d->W + HT - 1) / HT);
-        // one workgroup per tile, or - fprop and zero-pad dgrad with more tiles than CUs - one PERSISTENT workgroup per CU
+        // one workgroup per tile, or - with more tiles than CUs - one PERSISTENT workgroup per CU
         // that walks its XCD's tiles (mmh_set_option("lp16_persist", 0): off)
         int wpx = (ph.MT * ph.NT + 7) / 8;
-        if (mmh::g_lp16_persist && mode != 2) {
+        if (mmh::g_lp16_persist && (mode != 2 || mmh::g_lp16_persist == 1)) {     // option value 2: not the reflect-fold variant
             static int cus = 0;
             if (!cus) {
                 int dev = 0, n = 0;

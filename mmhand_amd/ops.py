@@ -703,7 +703,10 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
         d_ = conv_desc(B_, H_, W__, Cin_, Cout_, k_, stride, pad, reflect)
         d_.dtype = _dt(bf16)
         fused = (bool(bf16) and lp16_v2_ok(Cin_, Cout_, k_, stride, pad, 1) and not _wino_tile(B_, H_, W__, Cin_, Cout_, k_, stride, pad, bf16, "dgrad")
-                 and bool(L.load().mmh_conv3x3_lp16_dgrad_add_supported(C.byref(d_))))
+                 and bool(L.load().mmh_conv3x3_lp16_dgrad_add_supported(C.byref(d_)))
+                 # reflect padding off the in-kernel fold (images of one 16 x 16 tile either way): the border terms land after
+                 # the kernel, so a fused addend would change the order of the sums - keep (main + border) + addend there
+                 and (not reflect or (USE_LP16_FOLD and bool(L.load().mmh_conv3x3_lp16_fold_supported(C.byref(d_))))))
         if not fused:
             return _add_into(raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16, 0, dy16, False), addend)
     _chk(w, "w")

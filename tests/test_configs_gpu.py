@@ -183,11 +183,11 @@ def test_optimize_parameters_mse_perceptual_vs_oracle(dev):
 
 def test_bench_bf16_side_run_with_stack_meter(dev):
     """bench.py's `bf16_path` side key (the driver-visible 16-bit numbers): one bracketed step of the full-width model at
-    64x64 (16x16 feature maps, so the halo kernel with the reflect fold, its statistics epilogue and the nine-tap wgrad
+    128x128 (32x32 feature maps, so the halo kernel with the reflect fold, its statistics epilogue and the nine-tap wgrad
     all run) goes through StackMeter without an error - it once indexed ("fprop", "dgrad") with the dgrad's mode 2 - and
     reports every pass of the 256- and 512-channel convs, the dgrad WITHOUT border launches."""
     import bench
-    out = bench.side_train_run(dev, 2, 64, 1, warmup=1, stack=True, stack_steps=1, opt_level="O1")
+    out = bench.side_train_run(dev, 2, 128, 1, warmup=1, stack=True, stack_steps=1, opt_level="O1")
     assert "error" not in out and out["losses_finite"] and out["stack_frac"] > 0
     per = out["per_pass"]
     for k in ("fprop_256x256", "dgrad_256x256", "wgrad_256x256", "fprop_512x512", "dgrad_512x512", "wgrad_512x512"):

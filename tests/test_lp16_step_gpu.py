@@ -137,8 +137,9 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
     autograd's add.  One full-width 16-bit Generator + both Discriminator backward passes with and without tokens: every
     parameter gradient and the losses bit-identical - also with the stream-1 convs reading their 16-bit input in place
     from the previous gate's concat (ops.USE_LP16_CAT_TWIN: the same rounded values as a conversion pass writes) - (the
-    fused add is the same fp32 addition; at 16x16 feature maps
-    the reflect dgrad is the one-launch fold kernel, so no other term is reordered), the fused entry point engaged once
+    fused add is the same fp32 addition; at 32x32 feature maps - 128x128 inputs -
+    the reflect dgrad is the one-launch fold kernel, so no other term is reordered; smaller maps keep the border kernels
+    behind the conv and the add behind those), the fused entry point engaged once
     per PATBlock and per ResnetBlock pass, and no token left holding a gradient."""
     from mmhand_amd import lib, ops
     from mmhand_amd.mmhand_model import MMHandModel
@@ -156,8 +157,8 @@ def test_residual_tokens_change_nothing(dev, monkeypatch):
         torch.manual_seed(5)
         random.seed(5)
         ops.set_dropout_seed(777)
-        model = MMHandModel(_opt("O1"))
-        model.set_input(O.synthetic_batch(2, SIZE, SIZE, seed=11))
+        model = MMHandModel(_opt("O1", fineSize=128))
+        model.set_input(O.synthetic_batch(2, 128, 128, seed=11))
         model.forward()
         for o in model.optimizers:
             o.zero_grad()

@@ -28,7 +28,8 @@ for (B, H, Cin, Cout) in ((32, 64, 256, 256), (32, 64, 512, 512), (32, 64, 256, 
             return r
         return f
     variants = {"main term only": main, "mode 1 + border": lambda: run(False), "mode 2 (fold)": lambda: run(True),
-                "mode 2, folds switched off (timing only)": dbg(4), "no column folds": dbg(8), "no row folds": dbg(16)}
+                "mode 2, folds switched off (timing only)": dbg(4), "no column folds": dbg(8), "no row folds": dbg(16),
+                "column fragment from a conflict-free address (timing only)": dbg(64)}
     a, b_ = run(True).float(), run(False).float()
     print(f"B{B} {H}x{H} {Cout}->{Cin}: max |fold - border| / max = {float((a - b_).abs().max() / b_.abs().max()):.2e}")
     res = {k: [] for k in variants}
