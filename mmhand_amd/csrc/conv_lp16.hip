@@ -976,6 +976,13 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * 64 + j * 16 + 4 * g4 + r] : 0.f;
     const int ow = ow0 + l15;
+    // The activation as a compile-time constant per branch (a run-time test per element put the tanh expansion behind every
+    // one of the 128 values of a lane: 21 000 instructions of epilogue); the dgrad variants have none.
+    auto with_act = [&](auto&& body) {
+        if (SIGN > 0 && p.act == MMH_ACT_RELU) body(std::integral_constant<int, MMH_ACT_RELU>{});
+        else if (SIGN > 0 && p.act == MMH_ACT_TANH) body(std::integral_constant<int, MMH_ACT_TANH>{});
+        else body(std::integral_constant<int, MMH_ACT_NONE>{});
+    };
     if (p.y16 && !(p.dbg & 128)) {
         // 16-bit output: 16-byte stores after the lane-pair trade (common.h: pair_swap8) - 16 store instructions per tile
         // instead of 32; 256 -> 256 fprop 150 -> 134 us, the 16-bit step 102.5 -> 100.8 ms (tools/ab_lp16_stores.py;
@@ -987,37 +994,79 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
             for (int e = 0; e < 8; ++e) bo[jp][e] = p.bias ? p.bias[n0 + wc * 64 + jp * 32 + cb0 + e] : 0.f;
+        with_act([&](auto A) {
+            constexpr int ACT = decltype(A)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int oh = oh0 + wr * 8 + i;
-            const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+            for (int i = 0; i < 8; ++i) {
+                const int oh = oh0 + wr * 8 + i;
+                const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {
-                float v[8];
-                mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[8];
+                    mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = v[e] + bo[jp][e];
-                    v[e] = p.act == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (p.act == MMH_ACT_TANH ? tanhf(t) : t);
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = v[e] + bo[jp][e];
+                        v[e] = ACT == MMH_ACT_RELU ? (t > 0.f ? t : 0.f) : (ACT == MMH_ACT_TANH ? tanhf(t) : t);
+                    }
+                    if (oh < p.H && ow < p.W) {
+                        mmh::store8_lp16<H16>(p.y16 + (m * p.y_cs + (n0 + wc * 64 + jp * 32 + cb0)) * 2, v);
+                    }
                 }
-                if (oh < p.H && ow < p.W) {
-                    mmh::store8_lp16<H16>(p.y16 + (m * p.y_cs + (n0 + wc * 64 + jp * 32 + cb0)) * 2, v);
+            }
+        });
+    } else if (SIGN < 0 && p.addend) {
+        // dx = dgrad + addend, fp32 (mmh_conv3x3_lp16_dgrad_add: no bias, no activation).  The addend of tile row i + 1 is
+        // requested while row i is added and stored: written as "load, add, store" per accumulator the compiler put an
+        // s_waitcnt vmcnt(0) behind every load - 32 full memory round trips per tile, each also waiting for the store in
+        // front of it (256 -> 256: 182 us against 142 for the same dgrad without addend).
+        const size_t o00 = (((size_t)b * p.H + (oh0 + wr * 8)) * p.W + ow) * p.y_cs + (size_t)(n0 + wc * 64 + 4 * g4);
+        const size_t rstep = (size_t)p.W * p.y_cs;             // one tile row down
+        if (FOLD || (oh0 + HT <= p.H && ow0 + HT <= p.W)) {     // a full tile (always, with the fold): three rows in flight
+            constexpr int NB = 3;
+            f32x4 ad[NB][4];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ad[i][j] = *reinterpret_cast<const f32x4*>(p.addend + o00 + i * rstep + j * 16);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] += ad[i % NB][j];
+                    *reinterpret_cast<f32x4*>(p.y + o00 + i * rstep + j * 16) = acc[i][j];
+                }
+                if (i + NB < 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        ad[i % NB][j] = *reinterpret_cast<const f32x4*>(p.addend + o00 + (i + NB) * rstep + j * 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (oh0 + wr * 8 + i >= p.H || ow >= p.W) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] += *reinterpret_cast<const f32x4*>(p.addend + o00 + i * rstep + j * 16);
+                    *reinterpret_cast<f32x4*>(p.y + o00 + i * rstep + j * 16) = acc[i][j];
                 }
             }
         }
     } else {
+        with_act([&](auto A) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int oh = oh0 + wr * 8 + i;
-        if (oh >= p.H || ow >= p.W) continue;
-        const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
+            for (int i = 0; i < 8; ++i) {
+                const int oh = oh0 + wr * 8 + i;
+                if (oh >= p.H || ow >= p.W) continue;
+                const size_t m = ((size_t)b * p.H + oh) * p.W + ow;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const size_t elem = m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4);
-            if (SIGN < 0 && p.addend) acc[i][j] += *reinterpret_cast<const f32x4*>(p.addend + elem);
-            store4<H16>(p.y, p.y16, elem, acc[i][j], bv[j], p.act);
-        }
-    }
+                for (int j = 0; j < 4; ++j) {
+                    const size_t elem = m * p.y_cs + (n0 + wc * 64 + j * 16 + 4 * g4);
+                    store4<H16>(p.y, p.y16, elem, acc[i][j], bv[j], decltype(A)::value);
+                }
+            }
+        });
     }
     if (SIGN > 0 && !FOLD && p.stats) {
         // The InstanceNorm behind this conv (models/Generator.py:66-77) wants mean and M2 per (image, channel): each wave

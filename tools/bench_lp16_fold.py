@@ -27,7 +27,12 @@ for (B, H, Cin, Cout) in ((32, 64, 256, 256), (32, 64, 512, 512), (32, 64, 256, 
             lib.check(L.mmh_set_option(b"lp16_dbg", 0), "set")
             return r
         return f
-    variants = {"main term only": main, "mode 1 + border": lambda: run(False), "mode 2 (fold)": lambda: run(True),
+    addend = torch.randn(B, H, H, Cin, device=dev)
+    def run32(ad):
+        ops.USE_LP16_FOLD = True
+        return ops.raw_conv_dgrad(None, w, (B, H, H, Cin), 1, 1, True, bf16=True, dy16=dyb, out16=False, addend=ad)
+    variants = {"mode 2, fp32 dx": lambda: run32(None), "mode 2, fp32 dx + addend (dgrad_add)": lambda: run32(addend),
+                "main term only": main, "mode 1 + border": lambda: run(False), "mode 2 (fold)": lambda: run(True),
                 "mode 2, folds switched off (timing only)": dbg(4), "no column folds": dbg(8), "no row folds": dbg(16),
                 "column fragment from a conflict-free address (timing only)": dbg(64)}
     a, b_ = run(True).float(), run(False).float()
