@@ -221,6 +221,13 @@ int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout,
 /* The same two copies as IEEE fp16 (MMH_FP16; values beyond +-65504 become inf).          */
 int mmh_prep_weights_fp16(const void* w, int taps, int Cin, int Cout,
                           void* w_plain, void* w_t, mmh_stream_t s);
+/* Both copies of MANY weights in one launch (after an optimizer step every 16-bit copy of a network is stale: 78
+ * conversions of 5-15 us per 16-bit iteration).  table: n rows of eight int64 in device memory - {w pointer, w_plain
+ * pointer, w_t pointer (either copy may be 0), taps, Cin, Cout, first block, 1 for fp16 | 0 for bf16} - entry e owning
+ * the 256-thread blocks [first block of e, first block of e + 1), taps ceil(Cin / 64) ceil(Cout / 64) of them; total_blocks
+ * their sum.  Each entry gets exactly what mmh_prep_weights_bf16 | _fp16 writes.  The optimizer the reference steps
+ * (models/MMHandModel.py:317-330, apex O1 casting weights per forward) is where the copies go stale.           */
+int mmh_prep_weights_lp16_multi(const void* table, int n, int64_t total_blocks, mmh_stream_t s);
 int mmh_prep_weights_fp16_flat(const void* w, int taps, int Cin, int Cout,
                                void* w_flat, mmh_stream_t s);
 /* For fprop of convs whose Cin is not a multiple of 64 (the 7x7 stems): w_flat is

@@ -1768,6 +1768,80 @@ __global__ void prep_weights_bf16_kernel(const float* __restrict__ w, int taps, 
     }
 }
 
+// The same for MANY weights in one launch (mmh_prep_weights_lp16_multi): after an optimizer step every 16-bit copy of a
+// network is stale, and 78 conversions of 5-15 us each cannot fill the chip (0.86 ms of the 16-bit step).  table: n rows of
+// eight int64 - {w, plain, tr, taps, R, C, first block, fp16} - entry e owning the blocks [first(e), first(e + 1)): one
+// block per (tap, 64 x 64 tile of the R x C matrix).  The tile goes through LDS so that both copies are written in rows
+// (the one-weight kernel above scatters the transposed copy two bytes at a time: gathered into one launch that was
+// SLOWER than the 78 small ones).
+constexpr int PREP_TILE = 64;
+__global__ void __launch_bounds__(TPB) prep_weights_lp16_multi_kernel(const long long* __restrict__ table, int n) {
+    __shared__ int s_e;
+    __shared__ unsigned short tile[PREP_TILE][PREP_TILE + 2];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;                 // the last entry whose first block is <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        s_e = lo;
+    }
+    __syncthreads();
+    const long long* row = table + s_e * 8;
+    const float* __restrict__ w = reinterpret_cast<const float*>(row[0]);
+    unsigned short* __restrict__ plain = reinterpret_cast<unsigned short*>(row[1]);
+    unsigned short* __restrict__ tr = reinterpret_cast<unsigned short*>(row[2]);
+    const int R = (int)row[4], C = (int)row[5];
+    const bool h16 = row[7] != 0;
+    const int RT = (R + PREP_TILE - 1) / PREP_TILE, CT = (C + PREP_TILE - 1) / PREP_TILE;
+    int bidx = (int)((long long)blockIdx.x - row[6]);
+    const int ct = bidx % CT; bidx /= CT;
+    const int rt = bidx % RT;
+    const int t = bidx / RT;
+    const int r0 = rt * PREP_TILE, c0 = ct * PREP_TILE;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;        // 16 x 16 threads, four values each way
+    const float* wt = w + (int64_t)t * R * C;
+    const bool vec = (C % 4 == 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 16 * k, c = c0 + 4 * tx;
+        if (r >= R) continue;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && c + 3 < C) {
+            const float4 v = *reinterpret_cast<const float4*>(wt + (int64_t)r * C + c);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+            for (int e = 0; e < 4; ++e) if (c + e < C) f[e] = wt[(int64_t)r * C + c + e];
+        }
+        unsigned short h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = h16 ? __builtin_bit_cast(unsigned short, (_Float16)f[e]) : __builtin_bit_cast(unsigned short, (__bf16)f[e]);
+            tile[ty + 16 * k][4 * tx + e] = h[e];
+        }
+        if (plain) {
+            unsigned short* po = plain + ((int64_t)t * R + r) * C + c;
+            if (vec && c + 3 < C) *reinterpret_cast<uint2*>(po) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+            else for (int e = 0; e < 4; ++e) if (c + e < C) po[e] = h[e];
+        }
+    }
+    __syncthreads();
+    if (tr) {
+        const bool rvec = (R % 4 == 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 16 * k, r = r0 + 4 * tx;
+            if (c >= C) continue;
+            unsigned short h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = tile[4 * tx + e][ty + 16 * k];
+            unsigned short* po = tr + ((int64_t)t * C + c) * R + r;
+            if (rvec && r + 3 < R) *reinterpret_cast<uint2*>(po) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+            else for (int e = 0; e < 4; ++e) if (r + e < R) po[e] = h[e];
+        }
+    }
+}
+
 // w [taps][R][C] fp32 -> flat [C][Kpad] bf16 with k = t*R + r (zero padded): fprop of small-Cin convs
 template <typename T>
 __global__ void prep_weights_bf16_flat_kernel(const float* __restrict__ w, int taps, int R, int C,
@@ -2529,6 +2603,13 @@ int mmh_prep_weights_bf16(const void* w, int taps, int Cin, int Cout, void* w_pl
                        mmh::as_stream(s), static_cast<const float*>(w), taps, Cin, Cout,
                        static_cast<__bf16*>(w_plain), static_cast<__bf16*>(w_t));
     return mmh::check_launch("prep_weights_bf16");
+}
+
+int mmh_prep_weights_lp16_multi(const void* table, int n, int64_t total_blocks, mmh_stream_t s) {
+    MMH_REQUIRE(table && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "mmh_prep_weights_lp16_multi: bad arguments");
+    hipLaunchKernelGGL(prep_weights_lp16_multi_kernel, dim3((unsigned)total_blocks), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<const long long*>(table), n);
+    return mmh::check_launch("prep_weights_lp16_multi");
 }
 
 int mmh_prep_weights_fp16(const void* w, int taps, int Cin, int Cout, void* w_plain, void* w_t,

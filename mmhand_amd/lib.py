@@ -50,6 +50,7 @@ SIGNATURES = {
     "mmh_wino_gemm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_wino_gemm_levels": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_wino_weights_multi": (_i, [_vp, _i, _i64, _vp]),
+    "mmh_prep_weights_lp16_multi": (_i, [_vp, _i, _i64, _vp]),
     "mmh_wino_output": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mmh_norm_stats_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_norm_stats_merge2_ws_bytes": (_sz, [_i, _i]),

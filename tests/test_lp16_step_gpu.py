@@ -227,6 +227,47 @@ def test_gate_norm_fusion_changes_nothing(dev, monkeypatch):
         assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
 
 
+@pytest.mark.parametrize("level", ["O1", "O1_FP16"], ids=["bf16", "fp16"])
+def test_batched_weight_copies_change_nothing(level, dev, monkeypatch):
+    """ops._Lp16Batch: from the second optimizer step on, the 16-bit copies of a network's weights are refreshed by ONE
+    mmh_prep_weights_lp16_multi launch per network instead of one mmh_prep_weights_* launch per weight.  Three full
+    iterations with and without: losses, the generated image and every parameter bit-identical; in the third iteration the
+    batched path issues exactly three launches (G, D_PB, D_PP) and only the weights the batch does not cover (Cin % 64 != 0:
+    the stems) are converted on their own.  models/MMHandModel.py:317-330 (one optimizer step per network and iteration)."""
+    from mmhand_amd import lib, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_LP16_BATCH", on)
+        ops.bump_weights_epoch()
+        torch.manual_seed(5)
+        random.seed(5)
+        ops.set_dropout_seed(777)
+        model = MMHandModel(_opt(level))
+        calls = Counter()
+        real = lib.call
+        for it in range(3):
+            model.set_input(O.synthetic_batch(2, SIZE, SIZE, seed=11 + it))
+            if it == 2:
+                def spy(name, *a, _c=calls, _r=real):
+                    _c[name] += 1
+                    return _r(name, *a)
+                monkeypatch.setattr(lib, "call", spy)
+            model.optimize_parameters()
+        monkeypatch.setattr(lib, "call", real)
+        outs[on] = (model.netG.flat_param.detach().clone(), model.netD_PB.flat_param.detach().clone(),
+                    model.netD_PP.flat_param.detach().clone(), model.fake_nhwc.detach().clone(),
+                    [float(v) for v in model.get_current_errors().values()], calls)
+        del model
+    a, b = outs[True], outs[False]
+    single = ("mmh_prep_weights_bf16", "mmh_prep_weights_fp16")
+    assert a[5]["mmh_prep_weights_lp16_multi"] == 3 and b[5]["mmh_prep_weights_lp16_multi"] == 0, (a[5], b[5])
+    assert sum(b[5][k] for k in single) - sum(a[5][k] for k in single) >= 30, (a[5], b[5])     # NB = 2 blocks: 36 weights
+    assert a[4] == b[4], (a[4], b[4])
+    for x, y in zip(a[:4], b[:4]):
+        assert bool(torch.isfinite(x).all()) and torch.equal(x, y), float((x - y).abs().max())
+
+
 @pytest.mark.parametrize("mode", ["all", "bwd"])
 def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypatch):
     """mode "bwd" = --fp32_exact_grads (ops.set_winograd_mode("bwd")): direct fprop, F(6x6,3x3) dgrad and
