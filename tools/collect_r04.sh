@@ -13,4 +13,7 @@ cp $O/roofline_bf16_trace.txt $P/r04_roofline_lp16_kernel_trace.txt
 for f in breakdown_f32 breakdown_bf16 host_overhead; do grep -v "amdgpu.ids\|^WARNING" $O/$f.txt > $P/r04_${f/breakdown/step_breakdown}.txt; done
 grep -v "amdgpu.ids\|^WARNING" $O/breakdown_bf16_512.txt > $P/r04_step_breakdown_bf16_512.txt
 cp $O/r04_traffic.json $P/r04_traffic.json
+cp $O/r04_traffic_bf16.json $P/r04_traffic_bf16.json
 grep -v "amdgpu.ids\|^WARNING" $O/run_512.log > $P/r04_size512_bf16_b4_run.txt
+grep -h "^{" $O/full_f32_line.log > $P/r04_bench_f32_full_line.json
+grep -h "^{" $O/full_bf16_line.log > $P/r04_bench_bf16_full_line.json

@@ -5,6 +5,10 @@
 #   part B               : the headline fp32 step and the bf16 step - kernel stats, traces, roofline from the trace, traffic
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04prof; mkdir -p $O
 cd $R
+# counters first: the bench lines below read profiles/r04_traffic*.json for roofline.traffic
+bash $R/tools/traffic_r04.sh $O/r04_traffic.json > $O/traffic.log 2>&1
+cp $O/r04_traffic.json $O/r04_traffic_bf16.json $R/profiles/ 2>/dev/null
+cd $R
 python tools/host_overhead.py > $O/host_overhead.txt 2>&1
 python tools/step_breakdown.py --dtype bf16 --size 512 --batch 4 --top 60 > $O/breakdown_bf16_512.txt 2>&1
 python tools/step_breakdown.py --dtype bf16 > $O/breakdown_bf16.txt 2>&1
@@ -16,7 +20,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32 -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-side-runs > $O/prof_bf16_line.log 2>&1
 cd $R
 python tools/roofline_from_trace.py $O/prof_f32 "wino_gemm_kernel<128, 2>" > $O/roofline_f32_trace.txt 2>&1
-python tools/roofline_from_trace.py $O/prof_bf16 conv_lp16h2_kernel > $O/roofline_bf16_trace.txt 2>&1
+python tools/roofline_from_trace.py $O/prof_bf16 "conv_lp16h2_kernel<false, 1, false>" > $O/roofline_bf16_trace.txt 2>&1
 for f in prof_infer prof_512 prof_f32 prof_bf16; do find $O/$f -name "*kernel_stats.csv" -exec cp {} $O/$f.kernel_stats.csv \; ; rm -rf $O/$f; done
-bash $R/tools/traffic_r04.sh $O/r04_traffic.json > $O/traffic.log 2>&1
+# part C: the driver's own command (every side key on one line), and the same with the 16-bit step as the headline region
+cd $R
+python bench.py > $O/full_f32_line.log 2>&1
+python bench.py --dtype bf16 --no-side-runs > $O/full_bf16_line.log 2>&1
 ls -la $O

@@ -27,7 +27,7 @@ def clusters(v, gap=1.12):
     return out
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
     print(f"{str(k):>22s} {len(v):9d} {statistics.mean(v):10.1f} {min(v):10.1f} {max(v):10.1f} {sum(v)/1e3:10.1f}")
-    if ("batched" in pat or "wino_gemm" in pat) and max(v) > 1.5 * min(v):
+    if ("batched" in pat or "wino_gemm" in pat or "lp16h2" in pat) and max(v) > 1.5 * min(v):
         for c in clusters(v):
             if len(c) >= 5:
                 print(f"{'  duration cluster':>22s} {len(c):9d} {statistics.mean(c):10.1f} {min(c):10.1f} {max(c):10.1f} {sum(c)/1e3:10.1f}")
@@ -39,11 +39,13 @@ if "wino_gemm" in pat:
           "= 154.6 GFLOP); bench.py's roofline.achieved = that FLOP count / its HIP-event mean over the fprop\n"
           "launches.  The other clusters: 512->256 / 256->512 and 256->256 convs (1/2 and 1/4 of the FLOPs).")
 elif "lp16" in pat:
-    print("conv_lp16h2_kernel (also conv_lp16h / conv_lp16p): workgroups = 8 x ceil(pixel tiles x column tiles / 8), tiles of\n"
-          "256 pixels (16x16) x 256 channels; (1024,1,1) = 512 pixel tiles x 2 column tiles = the 3x3 convs with 512 output\n"
-          "columns at 64x64, B=32: 512->512 fprop and dgrad (618.5 GFLOP per launch; the reflect dgrad carries the ring fold)\n"
-          "and the dgrad of 512->256 (half the FLOPs; the fast end of the range); (512,1,1) = the 256-column convs:\n"
-          "256->256, and 512->256 fprop.  bench.py --dtype bf16 times the 512->512 fprop launches with HIP events.")
+    print("conv_lp16h2_kernel<H16, SIGN, FOLD> is persistent since round 4: 8 XCDs x min(tiles / 8, CUs / 8) workgroups walk tile\n"
+          "lists (tiles of 16x16 pixels x 256 channels), so a 256-workgroup grid carries every shape and shapes are told apart\n"
+          "by duration.  Give the full template list: <false, 1, false> = bf16 fprop (bench.py --dtype bf16 / bf16_path times\n"
+          "its 512->512 launches @64x64, B=32, with HIP events: 618.5 GFLOP per launch, 16 per step = the SLOWEST cluster of\n"
+          "the B=32 launches; the two discriminators' merged real+fake passes run B=64 at 256 channels), <false, -1, true> = the\n"
+          "complete reflect dgrad (ring folded), <false, -1, false> = zero-pad dgrad.  Clusters below it: 512->256 (half the\n"
+          "FLOPs) and 256->256 (a quarter; B=64 launches of it take as long as 512->256).")
 elif "batched" in pat:
     print("workgroups (4, 64, 36) = 4 column tiles x 64 row tiles x 36 Winograd planes = [8192x512].[512x512] per\n"
           "plane: the F(4x4,3x3) GEMMs of a 3x3 512->512 conv at 64x64, B=32 (fprop and dgrad launches both have this\n"
