@@ -211,6 +211,9 @@ __global__ void thin_reflect_fold_kernel(const float* __restrict__ dxp, float* _
 // previous step computes); a thread reads the 38 staged inputs of its row once and slides the
 // 7-wide window over them in registers: 38 + 32 LDS reads per 448 packed FMAs.
 // Partial sums per workgroup go to `slab`, thin_wgrad_reduce_kernel adds them in a fixed order.
+// A strip is cut into row segments (thin_wg_segs: a function of the shape only, so the order of the sums is too) when
+// images x strips x chunks alone would not fill the chip: 4 images of 512 x 512 are 64 strips on 256 CUs (1251 us;
+// 32 images of 256 x 256 took 676) - each segment pays the 6 halo rows of its prologue again.
 // ---------------------------------------------------------------------------
 constexpr int WGW = 32;                 // strip width (output columns per workgroup)
 constexpr int WGC = WGW + 6;            // staged input columns
@@ -223,6 +226,7 @@ struct ThinWgKP {
     float* slab;                        // [nblk][49][64][4]
     int B, H, W, Cin, x_cs, dy_cs, reflect;
     int strips, chunks;
+    int segs, seg_rows;                 // row segments per strip, rows per segment
 };
 
 __global__ void __launch_bounds__(448) thin_wgrad7_kernel(const ThinWgKP p) {
@@ -232,8 +236,10 @@ __global__ void __launch_bounds__(448) thin_wgrad7_kernel(const ThinWgKP p) {
     const int lane = tid & 63, kh = tid >> 6;
     int t = blockIdx.x;
     const int chunk = t % p.chunks; t /= p.chunks;
-    const int strip = t % p.strips;
-    const int b = t / p.strips;
+    const int strip = t % p.strips; t /= p.strips;
+    const int seg = t % p.segs;
+    const int b = t / p.segs;
+    const int r0 = seg * p.seg_rows, r1 = min(p.H, r0 + p.seg_rows);
     const int w0 = strip * WGW;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
@@ -279,13 +285,13 @@ __global__ void __launch_bounds__(448) thin_wgrad7_kernel(const ThinWgKP p) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) { acc[k][0] = (f2){0.f, 0.f}; acc[k][1] = (f2){0.f, 0.f}; }
 
-    // prologue: input rows -3 .. 2 (slots 0..5); row 3 and dy row 0 complete step 0
-    for (int ir = -3; ir <= 2; ++ir) { load_row(ir, p.H); store_row(ir, 1); }   // dy slot 1 gets zeros (unused)
-    load_row(3, 0);
-    store_row(3, 0);
+    // prologue: input rows r0 - 3 .. r0 + 2; row r0 + 3 and dy row r0 complete the first step
+    for (int ir = r0 - 3; ir <= r0 + 2; ++ir) { load_row(ir, p.H); store_row(ir, r0 + 1); }   // dy slot (r0 + 1) & 1 gets zeros (unused)
+    load_row(r0 + 3, r0);
+    store_row(r0 + 3, r0);
     __syncthreads();
-    for (int r = 0; r < p.H; ++r) {
-        if (r + 1 < p.H) load_row(r + 4, r + 1);        // next step's new row, in flight during the FMAs
+    for (int r = r0; r < r1; ++r) {
+        if (r + 1 < r1) load_row(r + 4, r + 1);         // next step's new row, in flight during the FMAs
         const float* xr = &ring[(r + kh) & 7][0][lane];  // input row r + kh - 3
         float xv[WGC];
 #pragma unroll
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(448) thin_wgrad7_kernel(const ThinWgKP p) {
                 acc[kw][1] = __builtin_elementwise_fma(xb, d23, acc[kw][1]);
             }
         }
-        if (r + 1 < p.H) store_row(r + 4, r + 1);       // slot (r + 7) & 7 is not read in step r
+        if (r + 1 < r1) store_row(r + 4, r + 1);        // slot (r + 7) & 7 is not read in step r
         __syncthreads();
     }
     float* out = p.slab + ((size_t)blockIdx.x * 49 + kh * 7) * 256 + lane * 4;
@@ -409,9 +415,17 @@ int mmh_conv7_thin_dgrad(const mmh_conv_desc* d, const void* dy, const void* w, 
     return 0;
 }
 
+// row segments per strip: one workgroup per CU (two per CU share the vector ALUs this kernel is bound by: 962 us against
+// 676 at B = 32, 256 x 256), at least 32 rows per segment
+static int thin_wg_segs(const mmh_conv_desc* d) {
+    const long long base = (long long)d->B * ((d->W + WGW - 1) / WGW) * (d->Cin / 64);
+    const long long want = (256 + base - 1) / base;
+    return (int)std::max<long long>(1, std::min<long long>(want, d->H / 32));
+}
+
 size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d) {
     if (!thin_shape_ok(d) || d->Cin % 64) return 0;
-    const size_t nblk = (size_t)d->B * ((d->W + WGW - 1) / WGW) * (d->Cin / 64);
+    const size_t nblk = (size_t)d->B * ((d->W + WGW - 1) / WGW) * (d->Cin / 64) * thin_wg_segs(d);
     return nblk * 49 * 64 * 4 * sizeof(float);
 }
 
@@ -433,12 +447,14 @@ int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, 
     p.reflect = d->pad_mode == MMH_PAD_REFLECT;
     p.strips = (d->W + WGW - 1) / WGW;
     p.chunks = d->Cin / 64;
-    const int nblk = d->B * p.strips * p.chunks;
+    p.segs = thin_wg_segs(d);
+    p.seg_rows = (d->H + p.segs - 1) / p.segs;
+    const int nblk = d->B * p.segs * p.strips * p.chunks;
     hipLaunchKernelGGL(thin_wgrad7_kernel, dim3(nblk), dim3(448), 0, st, p);
     if (int rc = mmh::check_launch("thin_wgrad7_kernel")) return rc;
     const int n4 = 49 * d->Cin;
     hipLaunchKernelGGL(thin_wgrad_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, st, p.slab, static_cast<float*>(dw),
-                       d->B * p.strips, p.chunks, d->Cin, accumulate);
+                       d->B * p.segs * p.strips, p.chunks, d->Cin, accumulate);
     return mmh::check_launch("thin_wgrad_reduce_kernel");
 }
 
