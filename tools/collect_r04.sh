@@ -17,3 +17,9 @@ cp $O/r04_traffic_bf16.json $P/r04_traffic_bf16.json
 grep -v "amdgpu.ids\|^WARNING" $O/run_512.log > $P/r04_size512_bf16_b4_run.txt
 grep -h "^{" $O/full_f32_line.log > $P/r04_bench_f32_full_line.json
 grep -h "^{" $O/full_bf16_line.log > $P/r04_bench_bf16_full_line.json
+python3 - "$O/cpu_all_cores_line.log" > $P/r04_cpu_all_cores.json <<'PY'
+import json, sys
+l = [x for x in open(sys.argv[1]) if x.startswith("{")][-1]
+j = json.loads(l)
+print(json.dumps({"command": "python bench.py --steps 2 --warmup 1 --no-side-runs --cpu-all-cores 200", "cpu_baseline": j.get("cpu_baseline")}, indent=1))
+PY

@@ -26,4 +26,6 @@ for f in prof_infer prof_512 prof_f32 prof_bf16; do find $O/$f -name "*kernel_st
 cd $R
 python bench.py > $O/full_f32_line.log 2>&1
 python bench.py --dtype bf16 --no-side-runs > $O/full_bf16_line.log 2>&1
+# the cpu_baseline on every logical CPU of the box; bounded: 200 s budget, hard timeout behind it
+python bench.py --steps 2 --warmup 1 --no-side-runs --cpu-all-cores 200 > $O/cpu_all_cores_line.log 2>&1
 ls -la $O
