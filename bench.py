@@ -884,7 +884,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
             # SURVEY.md §8(d) asks for os.cpu_count() threads.  On the GPU box's 256 logical CPUs oneDNN is far slower
             # at 128+ threads than at 16 (tools/cpu_probe.py; one B=2 step did not finish in 240 s): opt-in
-            # (--cpu-all-cores SECONDS; the round-4 measurement is profiles/r04_cpu_all_cores.json), not paid by every default run
+            # (--cpu-all-cores SECONDS; the round-4 measurement, profiles/r04_cpu_all_cores.json, timed out at 256 threads), not paid by every default run
             if a.cpu_all_cores and (os.cpu_count() or 0) > CPU_THREADS:
                 allc = cpu_baseline(H, W, a.norm, budget_s=a.cpu_all_cores, hard_timeout_s=int(a.cpu_all_cores * 2 + 60),
                                     threads=os.cpu_count(), max_steps=2)
