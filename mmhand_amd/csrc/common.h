@@ -200,9 +200,10 @@ extern int g_wino_wgrad_dma;
 int launch_slab_reduce(const float* slab, float* dw, int64_t n4_total, int splits, int accumulate, int64_t n4, hipStream_t st);
 // 16-bit fprop of the 3x3 stride-2 convs with register-resident weights and an LDS-resident input halo (conv_s2_lp16.hip)
 bool conv_s2f_ok(const mmh_conv_desc* d, int mode);
+bool conv_s1f_ok(const mmh_conv_desc* d, int mode);     // its stride-1 form: 64 -> 64, zero padding, mode 0 fprop | 1 dgrad
 int conv_s2f_stats_chunks(const mmh_conv_desc* d);
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16, int act,
-                    const void* zeros, hipStream_t st, float* stats = nullptr);
+                    const void* zeros, hipStream_t st, float* stats = nullptr, int mode = 0);
 bool conv_s2d_ok(const mmh_conv_desc* d, int mode);
 int launch_conv_s2d(const mmh_conv_desc* d, const void* g16, const void* w16, const void* bias, void* dx, int dx_is16, int act,
                     const void* zeros, hipStream_t st);

@@ -2525,6 +2525,8 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
         return mmh::launch_conv_s2f(d, x16, w16, bias, y, y_is16, act, zeros, mmh::as_stream(s));
     if (mmh::conv_s2d_ok(d, mode) && d->x_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
         return mmh::launch_conv_s2d(d, x16, w16, bias, y, y_is16, act, zeros, mmh::as_stream(s));
+    if (mmh::conv_s1f_ok(d, mode) && d->x_cs % 4 == 0 && d->y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+        return mmh::launch_conv_s2f(d, x16, w16, bias, y, y_is16, act, zeros, mmh::as_stream(s), nullptr, mode);
     LpGConvKP p{};
     const int K = mode == 0 ? d->Cin : d->Cout, N = mode == 0 ? d->Cout : d->Cin;
     p.x = static_cast<const char*>(x16);

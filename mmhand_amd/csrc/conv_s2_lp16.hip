@@ -35,13 +35,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 16;                  // output tile
-constexpr int HH = 2 * TH + 1, HWD = 2 * TW + 1; // halo 17 x 33 input pixels
-constexpr int PITCH = 34;                       // LDS slots per halo row (even: slot parity = row parity)
-constexpr int ODD0 = 17;                        // first slot of the odd columns
-constexpr int ROWS = HH * PITCH;                // 578 LDS rows of 128 B per chunk buffer
-constexpr int BUF_B = ROWS * 128;               // 73984 B
-constexpr int ROUNDS = (ROWS + 63) / 64;        // 10 DMA instructions per wave and chunk
-constexpr int LDS_B = 2 * BUF_B;                // 147968 B
+constexpr int ODD0 = 17;                        // stride 2: first slot of the odd columns (halo 17 x 33 input pixels in 34-slot
+                                                // rows: 578 LDS rows of 128 B = 73984 B per chunk buffer, 10 DMA instructions per
+                                                // wave and chunk, two buffers = 147968 B; HaloGeom below)
 
 struct S2KP {
     const char* x;          // 16-bit [B][H][W][cs]
@@ -56,6 +52,7 @@ struct S2KP {
     int nsplit;             // N / 128
     int lists;              // tile lists = workgroups / nsplit
     float* stats;           // per (image, tile, row half, channel) count / mean / M2 of the stored outputs, [B][chunks][3][N], or null
+    int rev;                // taps mirrored (w = the plain copy [tap][Cin][Cout]: the input gradient of a stride-1 conv)
     int dbg;                // timing-only ablations (mmh_set_option "lp16_dbg"; results wrong): 1 no halo DMA after the first, 2 no MFMAs
 };
 
@@ -91,12 +88,25 @@ __device__ __forceinline__ void store4(float* y, char* y16, size_t elem, f32x4 v
 typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
 __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>(addr); }
 
-// KC = C / 64 chunks; MW waves along the rows (MI = 8 / MW rows each), NJ column tiles per wave
-template <bool H16, int KC, int MW, int NJ, bool STATS>
+// The halo of an 8 x 16 output tile under image stride S: S = 2 as above (de-interleaved rows); S = 1 (the stride-1 form of the
+// same kernel: VGG19's conv1_2, 64 -> 64 at full resolution, losses/L1_plus_perceptualLoss.py:22-27 - on the general
+// kernel 359-400 us = 0.16 of the peak, three launches per step, because that kernel re-stages the input once per tap: 360 KB
+// per 256-pixel tile where this one brings 23 KB) a plain 10 x 18 halo, the taps starting at slots 0 / 1 / 2.
+template <int S> struct HaloGeom {
+    static constexpr int HH = S * TH + (3 - S), HWD = S * TW + (3 - S);
+    static constexpr int PITCH = S == 2 ? 34 : 18;      // LDS slots per halo row (even: slot parity = row parity)
+    static constexpr int ROWS = HH * PITCH, BUF_B = ROWS * 128, ROUNDS = (ROWS + 63) / 64, LDS_B = 2 * BUF_B;
+};
+
+// KC = C / 64 chunks; MW waves along the rows (MI = 8 / MW rows each), NJ column tiles per wave; S the image stride; NOUT the
+// output channels of one workgroup (128; 64 for the 64 -> 64 convs)
+template <bool H16, int KC, int MW, int NJ, bool STATS, int S = 2, int NOUT = 128>
 __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
     constexpr int MI = TH / MW;             // output rows (16-pixel MFMA column tiles) per wave
     constexpr int NG = 8 / MW;              // column groups
-    static_assert(NG * NJ * 16 == 128, "a workgroup covers 128 output channels");
+    static_assert(NG * NJ * 16 == NOUT, "a workgroup covers NOUT output channels");
+    typedef HaloGeom<S> G;
+    constexpr int PITCH = G::PITCH, ROWS = G::ROWS, BUF_B = G::BUF_B, ROUNDS = G::ROUNDS, HWD = G::HWD;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,7 +121,7 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
     const int t_begin = xcd * per_xcd + lst * per_list;
     const int t_end = min(min(t_begin + per_list, (xcd + 1) * per_xcd), p.tiles);
     if (t_begin >= t_end) return;
-    const int n0 = nh * 128 + wn * (NJ * 16);
+    const int n0 = nh * NOUT + wn * (NJ * 16);
 
     // the wave's weights: fragment (tap, k32 step s, column tile j) = rows n0 + 16 j + l15, K-values 32 s + 8 g4 .. + 7
     bf16x8 wf[9][2 * KC][NJ];
@@ -121,8 +131,8 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         for (int s = 0; s < 2 * KC; ++s)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                wf[t][s][j] = *reinterpret_cast<const bf16x8*>(
-                    p.w + ((size_t)(t * p.N + n0 + 16 * j + l15) * p.C + 32 * s + 8 * g4) * 2);
+                wf[t][s][j] = *reinterpret_cast<const bf16x8*>(       // p.rev: the taps mirrored (the dgrad of a stride-1 conv)
+                    p.w + ((size_t)((p.rev ? 8 - t : t) * p.N + n0 + 16 * j + l15) * p.C + 32 * s + 8 * g4) * 2);
     float bv[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -137,14 +147,14 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         const int b = tile / (p.TX * p.TY);
         const int rem = tile - b * (p.TX * p.TY);
         const int ty = rem / p.TX, tx = rem - ty * p.TX;
-        const int ih0 = 2 * ty * TH - 1, iw0 = 2 * tx * TW - 1;
+        const int ih0 = S * ty * TH - 1, iw0 = S * tx * TW - 1;
         const char* xb = p.x + (size_t)kc * 128;
         const unsigned dst = lds0 + (unsigned)buf * BUF_B + (unsigned)wave * 1024u;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             const int r = rd * 64 + wave * 8 + (lane >> 3);
             const int hy = r / PITCH, sl = r - hy * PITCH;
-            const int hx = sl < ODD0 ? 2 * sl : 2 * (sl - ODD0) + 1;
+            const int hx = S == 1 ? sl : (sl < ODD0 ? 2 * sl : 2 * (sl - ODD0) + 1);
             const int ih = ih0 + hy, iw = iw0 + hx;
             const bool row = r < ROWS && sl < HWD;
             const bool ok = row && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
@@ -162,10 +172,10 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
     unsigned aL[3][2];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const unsigned sl = (unsigned)((kw == 0 ? 0 : (kw == 1 ? ODD0 : 1)) + l15);
+        const unsigned sl = (unsigned)((S == 1 ? kw : (kw == 0 ? 0 : (kw == 1 ? ODD0 : 1))) + l15);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-            aL[kw][hf] = lds0 + ((unsigned)(2 * wm * MI) * PITCH + sl) * 128u + ((((unsigned)(4 * hf + g4)) ^ (sl & 6u)) << 4);
+            aL[kw][hf] = lds0 + ((unsigned)(S * wm * MI) * PITCH + sl) * 128u + ((((unsigned)(4 * hf + g4)) ^ (sl & 6u)) << 4);
     }
 
     f32x4 acc[MI][NJ];
@@ -200,7 +210,7 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
             auto frag = [&](int blk, int i) -> bf16x8 {
                 const int tap = blk / (2 * RH), r2 = blk - tap * (2 * RH), hf = r2 / RH, rh = r2 - hf * RH;
                 const int kh = tap / 3, kw = tap - kh * 3;
-                return lds_frag(aL[kw][hf] + boff + (unsigned)((2 * (rh * RB + i) + kh) * PITCH) * 128u);
+                return lds_frag(aL[kw][hf] + boff + (unsigned)((S * (rh * RB + i) + kh) * PITCH) * 128u);
             };
             bf16x8 af[2][RB];
             if (!(p.dbg & 2)) {
@@ -227,7 +237,8 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
         // epilogue: lane (l15, g4) holds channels 4 g4 .. + 3 of pixel l15 of each of its rows, in each of its NJ column tiles
         // (tried: the lanes g4 / g4 ^ 1 trading one accumulator each so that a lane stores 16 bytes - half the store
         // instructions, what gives conv_lp16h2_kernel 11 % at 256 -> 256 (common.h: pair_swap8) - ran 152 us (__shfl_xor) and
-        // 163 us (v_permlane16_swap) against 116: tools/bench_s2f.py)
+        // 163 us (v_permlane16_swap) against 116: tools/bench_s2f.py; and in the stride-1 form, which has registers to spare,
+        // 246 us against 210: tools/bench_s1f.py)
         const int b = tile / (p.TX * p.TY);
         const int rem = tile - b * (p.TX * p.TY);
         const int ty = rem / p.TX, tx = rem - ty * p.TX;
@@ -405,6 +416,16 @@ int g_cus = 0;
 
 namespace mmh {
 
+// the stride-1 form: 64 -> 64, zero padding (VGG19 conv1_2 forward, mode 0, and its input gradient, mode 1)
+bool conv_s1f_ok(const mmh_conv_desc* d, int mode) {
+    if (!g_lp16_s2f || !d || (mode != 0 && mode != 1)) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != MMH_PAD_ZERO) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->Cin != 64 || d->Cout != 64 || d->Ho != d->H || d->Wo != d->W || d->H % TH || d->W % TW) return false;
+    if ((long long)d->B * d->H * d->W * std::max(d->x_cs, d->y_cs) >= (1ll << 31)) return false;
+    return true;
+}
+
 bool conv_s2f_ok(const mmh_conv_desc* d, int mode) {
     if (!g_lp16_s2f || mode != 0 || !d) return false;
     if (d->kh != 3 || d->kw != 3 || d->stride != 2 || d->pad != 1 || d->pad_mode != MMH_PAD_ZERO) return false;
@@ -470,8 +491,32 @@ int launch_conv_s2d(const mmh_conv_desc* d, const void* g16, const void* w16, co
 }
 
 int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, const void* bias, void* y, int y_is16,
-                    int act, const void* zeros, hipStream_t st, float* stats) {
+                    int act, const void* zeros, hipStream_t st, float* stats, int mode) {
     S2KP p{};
+    if (d->stride == 1) {       // 64 -> 64: fprop, or (mode 1) the input gradient = the same conv of dy with the taps mirrored
+        p.x = static_cast<const char*>(x16);
+        p.w = static_cast<const char*>(w16);
+        p.zeros = static_cast<const char*>(zeros);
+        if (y_is16) p.y16 = static_cast<char*>(y); else p.y = static_cast<float*>(y);
+        p.bias = static_cast<const float*>(bias);
+        p.B = d->B; p.H = d->H; p.W = d->W; p.cs = mode == 0 ? d->x_cs : d->y_cs; p.C = 64;
+        p.Ho = d->H; p.Wo = d->W; p.N = 64; p.y_cs = mode == 0 ? d->y_cs : d->x_cs; p.act = act;
+        p.TX = p.Wo / TW; p.TY = p.Ho / TH; p.tiles = p.B * p.TX * p.TY;
+        p.nsplit = 1; p.rev = mode == 1; p.dbg = g_lp16_dbg;
+        if (!g_cus) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            g_cus = n;
+        }
+        const int per_xcd1 = (p.tiles + 7) / 8;
+        p.lists = 8 * std::max(1, std::min(g_cus / 8, per_xcd1));      // one per CU (206 registers: one workgroup is resident)
+        const dim3 grid1(p.lists);
+        constexpr int lds1 = HaloGeom<1>::LDS_B;
+        if (d->dtype == MMH_FP16) hipLaunchKernelGGL((conv_s2f_kernel<true, 1, 4, 2, false, 1, 64>), grid1, dim3(512), lds1, st, p);
+        else hipLaunchKernelGGL((conv_s2f_kernel<false, 1, 4, 2, false, 1, 64>), grid1, dim3(512), lds1, st, p);
+        return check_launch("conv_s2f_kernel<stride 1>");
+    }
     p.x = static_cast<const char*>(x16);
     p.w = static_cast<const char*>(w16);
     p.zeros = static_cast<const char*>(zeros);
@@ -502,11 +547,11 @@ int launch_conv_s2f(const mmh_conv_desc* d, const void* x16, const void* w16, co
         static bool ready = false;                                                                                 \
         if (!ready) {                                                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, HaloGeom<2>::LDS_B);    \
             if (e != hipSuccess) return fail("hipFuncSetAttribute(conv_s2f): %s", hipGetErrorString(e));           \
             ready = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL(kfn, grid, dim3(512), LDS_B, st, p);                                                    \
+        hipLaunchKernelGGL(kfn, grid, dim3(512), HaloGeom<2>::LDS_B, st, p);                                       \
     }
     if (p.C == 64) { if (h16) MMH_S2F(true, 1, 2, 2) else MMH_S2F(false, 1, 2, 2) }
     else { if (h16) MMH_S2F(true, 2, 1, 1) else MMH_S2F(false, 2, 1, 1) }
