@@ -139,3 +139,46 @@ def test_stride2_dgrad_vs_general_kernel_and_fp64(B, H, W, lp, out16, bias, dev)
                              None if b is None else b.double().cpu(), stride=2, padding=1, output_padding=1)
     tol = 2e-5 if not out16 else (3e-3 if lp is True else 4e-4)
     assert _rel(new.cpu(), ref.permute(0, 2, 3, 1)) <= tol, _rel(new.cpu(), ref.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 8, 16), (3, 24, 48), (1, 40, 40)])
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("mode,out16,bias,act", [(0, True, True, 1), (0, False, False, 0), (1, True, False, 0), (1, False, False, 0)])
+def test_stride1_64_to_64_vs_general_kernel_and_fp64(B, H, W, lp, mode, out16, bias, act, dev):
+    """The stride-1 form of the register-resident-weights kernel (conv_s2f_kernel<..., S = 1, NOUT = 64>): VGG19's conv1_2 as the
+    perceptual loss runs it (losses/L1_plus_perceptualLoss.py:22-27: 64 -> 64, zero padding, bias + ReLU) and its input
+    gradient (the same conv of dy with mirrored taps on the plain weight copy) - against the general kernel it replaces behind
+    mmh_conv_lp16 and against the fp64 convolution / transposed convolution of the same 16-bit operands; a shape off the
+    8 x 16 tile (40 x 40) stays on the general kernel."""
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(H * 5 + W + mode)
+    xin = torch.randn((B, H, W, 64), generator=gen, device=dev)           # x (mode 0) or dy (mode 1)
+    w = torch.randn((3, 3, 64, 64), generator=gen, device=dev) * 0.05
+    b = torch.randn((64,), generator=gen, device=dev) if bias else None
+    x16 = ops.lp16_twin(xin, lp)
+    outs = {}
+    for on in (1, 0):
+        L.check(L.load().mmh_set_option(b"lp16_s2f", on), "set_option")
+        try:
+            outs[on] = ops.raw_conv_lp16g(ops.conv_desc(B, H, W, 64, 64, 3, 1, 1, False), mode, x16, w, b, act, lp, out16=out16)
+        finally:
+            L.check(L.load().mmh_set_option(b"lp16_s2f", 1), "set_option")
+    torch.cuda.synchronize()
+    new, old = outs[1], outs[0]
+    assert new.dtype == (ops._wd(lp) if out16 else torch.float32) and bool(torch.isfinite(new.float()).all())
+    if mode == 0 or H % 8 or W % 16:
+        assert torch.equal(new, old)            # fprop: the same order of summation; off-tile shapes: the same kernel
+    else:
+        assert _rel(new, old) <= (2e-6 if not out16 else 2e-3)      # dgrad: taps in mirrored order
+    wp, wt = ops.bf16_weights(w, lp)            # wp [3,3,Cin,Cout], wt [3,3,Cout,Cin], 16-bit
+    xr = x16.double().permute(0, 3, 1, 2).cpu()
+    if mode == 0:
+        ref = F.conv2d(xr, wt.double().permute(2, 3, 0, 1).cpu(), None if b is None else b.double().cpu(), stride=1, padding=1)
+        if act == 1:
+            ref = ref.relu()
+    else:                                       # dx = conv_transpose of dy with the OIHW weight [Cout, Cin, 3, 3]
+        ref = F.conv_transpose2d(xr, wp.double().permute(3, 2, 0, 1).cpu(), None, stride=1, padding=1)
+    ref = ref.permute(0, 2, 3, 1)
+    tol = 2e-5 if not out16 else (3e-3 if lp is True else 4e-4)
+    assert _rel(new.cpu(), ref) <= tol, _rel(new.cpu(), ref)
