@@ -603,6 +603,18 @@ size_t mmh_conv7_thin_wgrad_ws_bytes(const mmh_conv_desc* d);
 int mmh_conv7_thin_wgrad(const mmh_conv_desc* d, const void* x, const void* dy, void* dw,
                          void* ws, size_t ws_bytes, int accumulate, mmh_stream_t s);
 
+/* The input gradient of the Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7): models/Generator.py:254-259, reached
+ * from the L1 / perceptual / GAN losses of models/MMHandModel.py:236-275) in 16-bit mode, as a stem-shaped convolution
+ * (conv_stem16.hip): dy fp32 [B,H,W,y_cs] (channels 0..3: the head's Cout padded to 4) is embedded, in 16 bits and 8
+ * channels, into the zero-padded (H+6) x (W+6) domain, convolved 'same' with the mirrored, transposed filter (4 -> 64
+ * channels) and the pad ring folded back (the transpose of ReflectionPad2d(3)): dx fp32 or 16-bit [B,H,W,x_cs] (64
+ * channels written).  d describes the head conv itself (Cin = 64, Cout = 4, 7x7, stride 1, MMH_PAD_REFLECT, 16-bit
+ * dtype); w is its fp32 weight [7][7][64][4]; ws >= mmh_conv7_head_dgrad_lp16_ws_bytes(d), 256-byte aligned.          */
+int mmh_conv7_head_dgrad_lp16_supported(const mmh_conv_desc* d);
+size_t mmh_conv7_head_dgrad_lp16_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv7_head_dgrad_lp16(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, int dx_is16, void* ws,
+                              size_t ws_bytes, const void* zeros, mmh_stream_t s);
+
 /* The same two convolutions from 16-bit tensors on the 16-column MFMA (conv7_n4.hip): an (8+6) x (16+6) pixel halo of
  * the 64-channel input and the whole [49][4][64] filter resident in LDS, 4 of the 16 weight rows meaningful.
  * mode 0: fprop of the Generator head (models/Generator.py:254-259): x16 [B,H,W,x_cs >= 64] 16-bit, w the head's fp32

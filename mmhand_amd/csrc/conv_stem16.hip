@@ -215,6 +215,93 @@ __global__ void prep_stem16_w_kernel(const float* __restrict__ w, int Cin, int C
     out[i] = h16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
+// ---- the Generator head's input gradient as a stem-shaped convolution (mmh_conv7_head_dgrad_lp16) ----
+// The head (ReflectionPad2d(3) + Conv2d(64, 3, 7), models/Generator.py:254-259) sends a 4-column gradient back to 64
+// channels: dxpad[u][v][ci] = sum w[kh][kw][ci][co] dy[u - kh][v - kw][co] over the padded domain, then the pad ring folded
+// back.  That is a 'same' zero-padded 7x7 conv from 4 (-> C8 = 8) to 64 channels of dy embedded in the padded domain, with
+// the filter mirrored and transposed: the shape the stem kernel above is built for (as an fp32 implicit GEMM with 196-deep
+// contraction plus an fp32 fold pass it cost 0.9 ms of the 16-bit step).
+
+// head weight fp32 [7][7][64 ci][4 co] -> stem16 layout [7 kh'][64 n = ci][pitch], k = kw' * 8 + co, of the mirrored filter
+__global__ void head_dgrad_w_kernel(const float* __restrict__ w, int pitch, int h16, unsigned short* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 7 * 64 * pitch) return;
+    const int j = i % pitch, n = (i / pitch) & 63, kh = i / (pitch * 64);
+    const int kw = j / 8, c = j - kw * 8;
+    const float v = (kw < 7 && c < 4) ? w[((size_t)((6 - kh) * 7 + (6 - kw)) * 64 + n) * 4 + c] : 0.f;
+    out[i] = h16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+// dy fp32 [B][H][W][cs] (4 channels) -> E 16-bit [B][H + 6][W + 6][8]: dy at offset (3, 3), zeros around and in channels 4..7
+__global__ void head_dgrad_embed_kernel(const float* __restrict__ dy, int B, int H, int W, int cs, int h16,
+                                        uint4* __restrict__ E) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hp = H + 6, Wp = W + 6;
+    if (i >= (int64_t)B * Hp * Wp) return;
+    const int x = (int)(i % Wp) - 3;
+    const int64_t t = i / Wp;
+    const int y = (int)(t % Hp) - 3, b = (int)(t / Hp);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * H + y) * W + x) * cs);
+        auto cv = [&](float f) -> unsigned {
+            return h16 ? (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f) : (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+        };
+        o.x = cv(v.x) | (cv(v.y) << 16);
+        o.y = cv(v.z) | (cv(v.w) << 16);
+    }
+    E[i] = o;
+}
+
+// transpose of ReflectionPad2d(3) on a 16-bit padded-domain gradient [B][H + 6][W + 6][64]: 8 channels per thread, fp32 sums,
+// dx fp32 or 16-bit [B][H][W][cs]
+template <bool H16>
+__global__ void head_dgrad_fold_kernel(const uint4* __restrict__ dxp, int B, int H, int W, int cs, float* __restrict__ dx,
+                                       char* __restrict__ dx16) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (pixel, 8-channel group)
+    if (i >= (int64_t)B * H * W * 8) return;
+    const int c8 = (int)(i & 7);
+    const int64_t px = i >> 3;
+    const int w = (int)(px % W);
+    const int64_t t = px / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    int ph[3], pw[3], nh = 0, nw = 0;
+    ph[nh++] = h + 3;
+    if (h >= 1 && h <= 3) ph[nh++] = 3 - h;
+    if (h >= H - 4 && h <= H - 2) ph[nh++] = 2 * (H - 1) - h + 3;
+    pw[nw++] = w + 3;
+    if (w >= 1 && w <= 3) pw[nw++] = 3 - w;
+    if (w >= W - 4 && w <= W - 2) pw[nw++] = 2 * (W - 1) - w + 3;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nh; ++a)
+        for (int c = 0; c < nw; ++c) {
+            const uint4 v = dxp[((size_t)(b * (H + 6) + ph[a]) * (W + 6) + pw[c]) * 8 + c8];
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned short lo = (unsigned short)(u[e] & 0xffffu), hi = (unsigned short)(u[e] >> 16);
+                s[2 * e] += H16 ? (float)__builtin_bit_cast(_Float16, lo) : (float)__builtin_bit_cast(__bf16, lo);
+                s[2 * e + 1] += H16 ? (float)__builtin_bit_cast(_Float16, hi) : (float)__builtin_bit_cast(__bf16, hi);
+            }
+        }
+    const size_t o = (size_t)px * cs + c8 * 8;
+    if (dx16) {
+        unsigned q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned lo = H16 ? (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s[2 * e])
+                                    : (unsigned)__builtin_bit_cast(unsigned short, (__bf16)s[2 * e]);
+            const unsigned hi = H16 ? (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s[2 * e + 1])
+                                    : (unsigned)__builtin_bit_cast(unsigned short, (__bf16)s[2 * e + 1]);
+            q[e] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4*>(dx16 + o * 2) = make_uint4(q[0], q[1], q[2], q[3]);
+    } else {
+        *reinterpret_cast<float4*>(dx + o) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(dx + o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    }
+}
+
 struct Plan { int Jt, pitch, rp, halo_b, wst_b, lds, rw; };
 
 bool plan(const mmh_conv_desc* d, int C8, Plan& q) {
@@ -320,4 +407,57 @@ static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, co
         else hipLaunchKernelGGL((conv_stem16_kernel<false, 4>), grid, dim3(256), q.lds, st, p);
     }
     return mmh::check_launch("conv_stem16_kernel");
+}
+
+// ---- mmh_conv7_head_dgrad_lp16: see the kernels above.  d = the head conv (Cin = 64, Cout = 4 incl. padding, 7x7, reflect) ----
+static bool head_dgrad_desc(const mmh_conv_desc* d, mmh_conv_desc& e) {
+    if (!d || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->pad_mode != MMH_PAD_REFLECT) return false;
+    if (d->Cin != 64 || d->Cout != 4 || d->Ho != d->H || d->Wo != d->W || d->H < 8 || d->W < 8) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->y_cs < 4 || d->y_cs % 4 || d->x_cs < 64 || d->x_cs % 8) return false;
+    e = *d;
+    e.H = e.Ho = d->H + 6; e.W = e.Wo = d->W + 6; e.Cin = 4; e.Cout = 64; e.pad_mode = MMH_PAD_ZERO; e.x_cs = 8; e.y_cs = 64;
+    return mmh_conv_stem16_supported(&e, 8) != 0;
+}
+
+int mmh_conv7_head_dgrad_lp16_supported(const mmh_conv_desc* d) {
+    mmh_conv_desc e;
+    return head_dgrad_desc(d, e) ? 1 : 0;
+}
+
+size_t mmh_conv7_head_dgrad_lp16_ws_bytes(const mmh_conv_desc* d) {
+    mmh_conv_desc e;
+    if (!head_dgrad_desc(d, e)) return 0;
+    const size_t px = (size_t)e.B * e.H * e.W;
+    return ((mmh_conv_stem16_weights_bytes(8) + 255) & ~(size_t)255) + px * 8 * 2 + px * 64 * 2;
+}
+
+int mmh_conv7_head_dgrad_lp16(const mmh_conv_desc* d, const void* dy, const void* w, void* dx, int dx_is16, void* ws,
+                              size_t ws_bytes, const void* zeros, mmh_stream_t s) {
+    mmh_conv_desc e;
+    MMH_REQUIRE(head_dgrad_desc(d, e), "mmh_conv7_head_dgrad_lp16: the head conv only (7x7 / reflect pad 3 / 64 -> 4, 16-bit dtype)");
+    MMH_REQUIRE(dy && w && dx && ws && zeros && ws_bytes >= mmh_conv7_head_dgrad_lp16_ws_bytes(d) &&
+                    (reinterpret_cast<uintptr_t>(ws) & 255) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0,
+                "mmh_conv7_head_dgrad_lp16: bad buffers (ws 256-byte aligned, mmh_conv7_head_dgrad_lp16_ws_bytes)");
+    hipStream_t st = mmh::as_stream(s);
+    const int h16 = d->dtype == MMH_FP16 ? 1 : 0;
+    char* wst = static_cast<char*>(ws);
+    char* E = wst + ((mmh_conv_stem16_weights_bytes(8) + 255) & ~(size_t)255);
+    const size_t px = (size_t)e.B * e.H * e.W;
+    char* dxp = E + px * 16;
+    const int pitch = 32 * ((7 * 8 + 31) / 32) + 8;
+    hipLaunchKernelGGL(head_dgrad_w_kernel, dim3((7 * 64 * pitch + 255) / 256), dim3(256), 0, st, static_cast<const float*>(w),
+                       pitch, h16, reinterpret_cast<unsigned short*>(wst));
+    hipLaunchKernelGGL(head_dgrad_embed_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(dy), d->B, d->H, d->W, d->y_cs, h16, reinterpret_cast<uint4*>(E));
+    if (int rc = mmh::check_launch("head_dgrad_embed_kernel")) return rc;
+    if (int rc = conv_stem16_impl(&e, E, 8, wst, nullptr, dxp, 1, MMH_ACT_NONE, zeros, nullptr, s)) return rc;
+    const size_t n = (size_t)d->B * d->H * d->W * 8;
+    if (h16) hipLaunchKernelGGL(head_dgrad_fold_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                reinterpret_cast<const uint4*>(dxp), d->B, d->H, d->W, d->x_cs,
+                                dx_is16 ? nullptr : static_cast<float*>(dx), dx_is16 ? static_cast<char*>(dx) : nullptr);
+    else hipLaunchKernelGGL(head_dgrad_fold_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                            reinterpret_cast<const uint4*>(dxp), d->B, d->H, d->W, d->x_cs,
+                            dx_is16 ? nullptr : static_cast<float*>(dx), dx_is16 ? static_cast<char*>(dx) : nullptr);
+    return mmh::check_launch("head_dgrad_fold_kernel");
 }

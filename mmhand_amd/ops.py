@@ -164,6 +164,9 @@ def _lp_of(t):
 # first request after a step refreshes all of them, in the buffers the batch keeps, with one launch (78 launches of
 # 5-15 us, 0.86 ms per 16-bit iteration, become three).  MMH_LP16_BATCH=0: every weight on its own.
 USE_LP16_BATCH = os.environ.get("MMH_LP16_BATCH", "1") != "0"
+# the Generator head's input gradient (64 <- 4 channels, 7x7 reflect) on the 16-bit stem kernel (MMH_HEAD_DGRAD16=0: the fp32
+# implicit GEMM over the padded domain + fold pass)
+USE_HEAD_DGRAD16 = os.environ.get("MMH_HEAD_DGRAD16", "1") != "0"
 _lp16_batches = {}
 
 
@@ -776,6 +779,20 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
             return _add_into(raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16, 0, dy16, False), addend)
     _chk(w, "w")
     B, H, W_, Cin = x_shape
+    if (USE_HEAD_DGRAD16 and bf16 and w.shape[0] == 7 and w.shape[3] == 4 and Cin == 64 and reflect and stride == 1 and pad == 3
+            and dy is not None and dy.dtype == torch.float32 and not dx_channels):
+        # the Generator head's input gradient as a stem-shaped 16-bit convolution (mmh_conv7_head_dgrad_lp16)
+        d = conv_desc(B, H, W_, Cin, 4, 7, 1, 3, True)
+        d.dtype = _dt(bf16)
+        if L.load().mmh_conv7_head_dgrad_lp16_supported(C.byref(d)):
+            nbytes = L.load().mmh_conv7_head_dgrad_lp16_ws_bytes(C.byref(d))
+            ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=dy.device)
+            off = (-ws.data_ptr()) % 256 // 4
+            dx = torch.empty((B, H, W_, Cin), dtype=_wd(bf16) if out16 else torch.float32, device=dy.device)
+            L.call("mmh_conv7_head_dgrad_lp16", C.byref(d), _ptr(dy), _ptr(w), _ptr(dx), int(out16), _ptr(ws[off:]), nbytes,
+                   _ptr(zero_page(dy.device)), _stream())
+            _count_desc("mfma", d)
+            return dx
     if dy is None or out16:
         assert bf16 and (dy16 is not None or dy is not None) and _dgrad_takes_dy16(B, H, W_, Cin, w.shape[3], w.shape[0],
                                                                                   stride, pad, reflect, bf16)

@@ -1158,3 +1158,41 @@ def test_round3_fp32_kernels_random_shapes(dev):
             return dU
         dU, dU0 = both(b"wino_wgrad_dma", gemm)
         assert R.rel_l1(dU, dU0) < 3e-6, ("wino_wgrad_dma", P, T, cin, cout, R.rel_l1(dU, dU0))
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("out16", [False, True], ids=["dx32", "dx16"])
+@pytest.mark.parametrize("case", [(2, 32, 48), (1, 8, 8), (3, 19, 33), (1, 64, 64)])
+def test_head_dgrad_on_the_stem_kernel(case, lp, out16, dev, monkeypatch):
+    """mmh_conv7_head_dgrad_lp16: the input gradient of the Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7),
+    models/Generator.py:254-259) computed in 16-bit mode as a 'same' zero-padded 7x7 conv of dy - embedded in the padded
+    domain, 4 -> 64 channels, mirrored transposed filter - on conv_stem16.hip, the pad ring folded back: against the fp64
+    oracle on operands rounded to the storage type, and against the fp32 path it replaces (MMH_HEAD_DGRAD16=0)."""
+    from mmhand_amd import lib, ops
+    B, H, W = case
+    w = _mk((7, 7, 64, 4), 2, dev) * 0.05
+    w[..., 3] = 0                                   # the head has three real output channels; the fourth is padding
+    dy = _mk((B, H, W, 4), 4, dev)
+    dy[..., 3] = 0
+    ops.bump_weights_epoch()
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dx = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 1, 3, True, bf16=lp, out16=out16)
+    finally:
+        lib.call = orig
+    assert calls.get("mmh_conv7_head_dgrad_lp16") == 1 and len(calls) == 1, calls
+    assert dx.dtype == (ops._wd(lp) if out16 else torch.float32) and tuple(dx.shape) == (B, H, W, 64)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    _, dxr, _, _ = R.conv2d_grads(torch.zeros(B, H, W, 64), rb(w), None, rb(dy), 1, 3, True)
+    tol = 2e-5 if not out16 else (2e-3 if lp == 2 else 8e-3)
+    # the padded-domain gradient is stored in 16 bits before the fold: one more rounding than the oracle's fp64 sums
+    tol = max(tol, 1.5e-3 if lp == 2 else 6e-3)
+    assert R.rel_l1(dx.float(), dxr) < tol, R.rel_l1(dx.float(), dxr)
+    monkeypatch.setattr(ops, "USE_HEAD_DGRAD16", False)
+    old = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 1, 3, True, bf16=lp, out16=False)
+    assert R.rel_l1(dx.float(), old.cpu()) < (4e-3 if lp == 2 else 1.6e-2)
