@@ -343,18 +343,26 @@ def comm_exposed_ms(model, dev, ms_with_comm, steps):
     collective stubbed out (gradient buckets and SyncBN exchanges: dp.set_no_comm).  ~0 = the all-reduces are hidden
     beneath the backward passes.  Run it LAST on a model: without collectives the replicas drift apart."""
     from mmhand_amd import dp as DP
-    DP.set_no_comm(True)
-    try:
+
+    def timed():
         model.optimize_parameters()
         _sync(True)
         t0 = time.perf_counter()
         for _ in range(steps):
             model.optimize_parameters()
         _sync(True)
-        ms0, _ = _rank_ms(time.perf_counter() - t0, steps, dev)
+        return _rank_ms(time.perf_counter() - t0, steps, dev)[0]
+    DP.set_no_comm(True)
+    try:
+        ms0 = timed()
     finally:
         DP.set_no_comm(False)
-    return {"value": round(ms_with_comm - ms0, 2), "ms_per_step_without_collectives": round(ms0, 2), "steps": steps}
+    # ... and WITH the collectives once more, back to back with the run without: on some boxes the first timed region of a
+    # process runs 2-5 % slow (268 against 262 ms for the same fp32 step a minute later), which the difference against the
+    # region's own earlier figure would book as 13 ms of "exposed communication" at world size 1
+    ms1 = timed()
+    return {"value": round(ms1 - ms0, 2), "ms_per_step_without_collectives": round(ms0, 2),
+            "ms_per_step_with_collectives": round(ms1, 2), "ms_per_step_region": round(ms_with_comm, 2), "steps": steps}
 
 
 def gradient_parity_run(dev, size, norm):
@@ -551,7 +559,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--norm", default="instance", choices=["instance", "batch"])
@@ -803,7 +811,7 @@ def main():
         guarded("norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch",
                                                           opt_level="O1" if a.dtype == "bf16" else "O0"),
                                            note="the reference's script default --norm batch (BatchNorm2d affine, conv bias off)"))
-        guarded("dp_rccl_world1", lambda: dict(rccl_child_run(n_side, 2, a.batch, a.size),
+        guarded("dp_rccl_world1", lambda: dict(rccl_child_run(n_side, max(2, a.warmup), a.batch, a.size),
                                                note="same fp32 step through the data-parallel path (MMH_FORCE_DP=1) on RCCL, "
                                                     "world size 1, own process"))
         guarded("size512_bf16_b4", lambda: dict(side_train_run(dev, 4, 512, n_side, opt_level="O1"),

@@ -343,10 +343,15 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
     # fp32 vector-ALU kernel of conv_thin.hip in both precisions unless conv7_n4.hip takes it (H, W >= 8)
     head16 = k == 7 and Cout == 4 and ops.conv7_n4_ok(ops.conv_desc(B, H, W, Cin, Cout, k, s, p, refl), 0, lp)
     y_ref = yf if (k == 7 and Cout == 4 and not head16) else yr     # the head: 16-column MFMA kernel where it applies
-    dx_ref = dxr if Cout % 64 == 0 else dxf
+    # the head's input gradient (64 <- 4 channels, reflect): on the 16-bit stem kernel (mmh_conv7_head_dgrad_lp16) - rounded
+    # operands, and the padded-domain gradient stored in 16 bits before the fold: one rounding to the storage type, as every
+    # 16-bit dx has
+    head_dg = k == 7 and Cout == 4 and Cin == 64 and refl and s == 1 and ops.USE_HEAD_DGRAD16 and H >= 8 and W >= 8
+    dx_ref = dxr if (Cout % 64 == 0 or head_dg) else dxf
+    dx_tol = (1e-3 if lp == 2 else 8e-3) if head_dg else 5e-5
     if not ops._wino_tile(B, H, W, Cin, Cout, k, s, p, True):
         assert R.rel_l1(y, y_ref) < 5e-5, ("fprop vs matching-precision oracle", R.rel_l1(y, y_ref))
-        assert R.rel_l1(dx, dx_ref) < 5e-5, ("dgrad vs matching-precision oracle", R.rel_l1(dx, dx_ref))
+        assert R.rel_l1(dx, dx_ref) < dx_tol, ("dgrad vs matching-precision oracle", R.rel_l1(dx, dx_ref))
         dw_ref = dwf if (k == 7 and Cout == 4 and Cin % 64 == 0) else dwr    # head wgrad: fp32 thin kernel
         assert R.rel_l1(dw, dw_ref) < 5e-5, ("bf16 wgrad vs matching-precision oracle", R.rel_l1(dw, dw_ref))
     # else: bf16 Winograd F(2x2,3x3) rounds the TRANSFORMED operands (and M), so there is no
