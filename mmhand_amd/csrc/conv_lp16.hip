@@ -810,6 +810,15 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     const int col_wr = t_top ? 1 : (t_bot ? 0 : (f_left ? 0 : 1));
     const bool my_col = (f_left || f_right) && wr == col_wr;
     const int fold_kh = t_top ? 0 : 2, fold_kw = f_left ? 0 : 2;    // the taps of this wave's term
+    unsigned fold_taps = 0, cnr_taps = 0;       // bit t = 3 kh + kw: this wave multiplies a fold term / the corner term at tap t
+    if (FOLD) {
+        for (int tt = 0; tt < 9; ++tt) {
+            const int kh_ = tt / 3, kw_ = tt - 3 * kh_;
+            const bool row = my_row && kh_ == fold_kh;
+            if (row || (my_col && kw_ == fold_kw)) fold_taps |= 1u << tt;
+            if (row && ((kw_ == 0 && f_left) || (kw_ == 2 && f_right))) cnr_taps |= 1u << tt;
+        }
+    }
     f32x4 FA[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) FA[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -845,14 +854,17 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
         // k-step of a left / right tile with kw = 0 / 2.  The fragment is fetched BEFORE the MFMA block of each half so
         // that the LDS latency hides behind it: the tap's halo row 1 / 16 at this lane's column, or the halo column 1 / 16
         // at this lane's row; lane 1 / 14 of the dw = 0 / 2 variant for the corner.
-        const bool do_row = FOLD && my_row && kh == fold_kh;
-        const bool do_fold = do_row || (FOLD && my_col && kw == fold_kw);
-        const bool do_cnr = do_row && ((kw == 0 && f_left) || (kw == 2 && f_right)) && !(p.dbg & 1024);
-        const unsigned f_dhb = (unsigned)((2 - kh) * (HP2 * ROWB)), f_st = (unsigned)((kc & 1) * HSTAGE_A2);
-        const unsigned f_addr = my_row ? a_cur - f_dhb + f_rsel
-                                       : ((p.dbg & 64) ? a_cur : baseT + f_st + f_dhb);    // dbg 64: timing only
+        // (one bit test per k-step outside the fold taps: fold_taps / cnr_taps are this wave's nine-bit tap masks of the tile)
+        const bool do_fold = FOLD && ((fold_taps >> t) & 1u);
+        const bool do_cnr = FOLD && ((cnr_taps >> t) & 1u);
+        const unsigned f_st = (unsigned)((kc & 1) * HSTAGE_A2);
+        unsigned f_addr = 0;
         bf16x8 axf;
-        if (FOLD && do_fold) axf = lds_frag(f_addr);
+        if (FOLD && do_fold) {
+            const unsigned f_dhb = (unsigned)((2 - kh) * (HP2 * ROWB));
+            f_addr = my_row ? a_cur - f_dhb + f_rsel : baseT + f_st + f_dhb;
+            axf = lds_frag(f_addr);
+        }
         // ---- half 0: multiply (ks, 0) while the fragments of (ks, 1) stream in
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = lds_frag(bb1 + j * (16 * ROWB));
