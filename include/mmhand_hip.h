@@ -512,6 +512,11 @@ int mmh_act_bwd(const void* g, const void* y, void* dx, int64_t n, int act,
  * mmh_cvt_lp16.                                                                               */
 int mmh_act_bwd_lp16(const void* g, const void* y, int64_t n, int act, int dtype, void* out16,
                      mmh_stream_t s);
+/* ... with g and / or y already in 16 bits (g_is16, y_is16; the storage type is `dtype`): the 16-bit edge between VGG19's
+ * conv1_1 and conv1_2 (ops.VggPairFn) - the gradient comes out of conv1_2's 16-bit dgrad, the mask from conv1_1's 16-bit
+ * output.                                                                                                      */
+int mmh_act_bwd_lp16_io(const void* g, int g_is16, const void* y, int y_is16, int64_t n, int act, int dtype,
+                        void* out16, mmh_stream_t s);
 
 /* ---- PATBlock gate + concat (models/Generator.py:115-130) -----------------
  * out = x1 + s1*sigmoid(s2)*sigmoid(s3);  x2n = cat(s3,out); x3n = cat(s2,out)

@@ -1212,6 +1212,25 @@ __global__ void act_bwd_lp16_kernel(const float* __restrict__ g, const float* __
     }
 }
 
+// the same with g and / or y already in 16 bits (inside the VGG head the edge between conv1_1 and conv1_2 is 16-bit: the
+// gradient arrives from conv1_2's 16-bit dgrad, the mask from conv1_1's 16-bit output)
+template <bool GW, bool YW>
+__global__ void act_bwd_lp16_io_kernel(const void* __restrict__ g, const void* __restrict__ y, void* __restrict__ out,
+                                       int64_t n8, int act, int h16) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        Raw8<GW> gr; Raw8<YW> yr;
+        ldraw(gr, g, i); ldraw(yr, y, i);
+        const f8 gv = widen(gr, h16 != 0), yv = widen(yr, h16 != 0);
+        f8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            r.v[e] = act == MMH_ACT_RELU ? (yv.v[e] > 0.f ? gv.v[e] : 0.f) : gv.v[e] * (1.f - yv.v[e] * yv.v[e]);
+        st8<true>(out, i, r, h16 != 0);
+    }
+}
+
 // ------------------------------------------------------------------ PATBlock gate
 __global__ void gate_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ s1,
                                 const void* __restrict__ s2, const void* __restrict__ s3,
@@ -2337,6 +2356,21 @@ int mmh_act_bwd_lp16(const void* g, const void* y, int64_t n, int act, int dtype
                        static_cast<const float*>(g), static_cast<const float*>(y), out16, n / 8, act,
                        dtype == MMH_FP16 ? 1 : 0);
     return mmh::check_launch("act_bwd_lp16");
+}
+
+int mmh_act_bwd_lp16_io(const void* g, int g_is16, const void* y, int y_is16, int64_t n, int act, int dtype, void* out16,
+                        mmh_stream_t s) {
+    MMH_REQUIRE(g && y && out16 && n > 0 && n % 8 == 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_act_bwd_lp16_io: bad arguments (n %% 8 == 0, dtype MMH_BF16 | MMH_FP16)");
+    MMH_REQUIRE(act == MMH_ACT_RELU || act == MMH_ACT_TANH, "mmh_act_bwd_lp16_io: act must be relu or tanh");
+    const dim3 grid(grid_for(n / 8));
+    const int h16 = dtype == MMH_FP16 ? 1 : 0;
+    hipStream_t st = mmh::as_stream(s);
+    if (g_is16 && y_is16) hipLaunchKernelGGL((act_bwd_lp16_io_kernel<true, true>), grid, dim3(TPB), 0, st, g, y, out16, n / 8, act, h16);
+    else if (g_is16) hipLaunchKernelGGL((act_bwd_lp16_io_kernel<true, false>), grid, dim3(TPB), 0, st, g, y, out16, n / 8, act, h16);
+    else if (y_is16) hipLaunchKernelGGL((act_bwd_lp16_io_kernel<false, true>), grid, dim3(TPB), 0, st, g, y, out16, n / 8, act, h16);
+    else hipLaunchKernelGGL((act_bwd_lp16_io_kernel<false, false>), grid, dim3(TPB), 0, st, g, y, out16, n / 8, act, h16);
+    return mmh::check_launch("act_bwd_lp16_io");
 }
 
 int mmh_patblock_gate_fwd(const void* x1, const void* s1, const void* s2, const void* s3, void* out,

@@ -138,6 +138,7 @@ SIGNATURES = {
                                        _vp, _i, _i, _f, _vp]),
     "mmh_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mmh_act_bwd_lp16": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "mmh_act_bwd_lp16_io": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "mmh_patblock_gate_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mmh_patblock_gate_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mmh_patblock_gate_norm_supported": (_i, [_i, _i64, _i]),

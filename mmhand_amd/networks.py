@@ -797,6 +797,10 @@ class VGGHead(nn.Module):
 
     def forward_nhwc(self, x):
         n = len(self.layers)
+        if [k for _, k, _, _ in self.layers] == ["conv", "relu", "conv", "relu"]:
+            m1, m2 = self.net[self.layers[0][0]], self.net[self.layers[2][0]]
+            if ops.vgg_pair_ok(x, m1.weight, m2.weight, self.bf16):     # 16-bit mode: one node, 16-bit edge inside (ops.VggPairFn)
+                return ops.VggPairFn.apply(x, m1.weight, m1.bias, m2.weight, m2.bias, self.bf16)
         for pos, (i, kind, _, _) in enumerate(self.layers):
             if kind == "conv":
                 m = self.net[i]

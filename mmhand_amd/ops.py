@@ -2297,6 +2297,50 @@ class NormActMultiFn(torch.autograd.Function):
         return tuple(out)
 
 
+# VGG19 conv1_1 + ReLU + conv1_2 + ReLU (losses/L1_plus_perceptualLoss.py:22-27 with the shipped --perceptual_layers 3) as ONE
+# node in 16-bit mode, with the edge between the two convs 16-bit: conv1_1 writes its ReLU output in 16 bits (as separate nodes
+# it wrote fp32 and a conversion pass made conv1_2's operand), conv1_2's dgrad hands its gradient back in 16 bits and conv1_1's
+# ReLU backward reads both in 16 bits.  Same values as the two nodes (rounding and masking commute); the weights are frozen:
+# only the image gradient goes back.  MMH_VGG_PAIR=0: two Conv2dFn nodes.
+USE_VGG_PAIR = os.environ.get("MMH_VGG_PAIR", "1") != "0"
+
+
+def vgg_pair_ok(x, w1, w2, bf16):
+    if not (USE_VGG_PAIR and bf16 and x.dim() == 4 and x.shape[3] == 4 and tuple(w1.shape) == (3, 3, 4, 64)
+            and tuple(w2.shape) == (3, 3, 64, 64)):
+        return False
+    B, H, W_, _ = x.shape
+    d1 = conv_desc(B, H, W_, 4, 64, 3, 1, 1, False)
+    d2 = conv_desc(B, H, W_, 64, 64, 3, 1, 1, False)
+    return bool(lp16_flat_ok(d1, bf16) and conv7_n4_ok(d1, 1, bf16) and lp16g_ok(d2, 0, bf16) and lp16g_ok(d2, 1, bf16))
+
+
+class VggPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, bf16):
+        B, H, W_, _ = x.shape
+        y1 = raw_conv_lp16_flat(conv_desc(B, H, W_, 4, 64, 3, 1, 1, False), x, w1, b1, L.ACT_RELU, bf16, out16=True)
+        y2 = raw_conv_lp16g(conv_desc(B, H, W_, 64, 64, 3, 1, 1, False), 0, y1, w2, b2, L.ACT_RELU, bf16, out16=False)
+        ctx.bf16 = bf16
+        ctx.x_shape = tuple(x.shape)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(y1, y2, w1, w2)
+        return y2
+
+    @staticmethod
+    def backward(ctx, g):
+        y1, y2, w1, w2 = ctx.saved_tensors
+        bf16 = ctx.bf16
+        B, H, W_, _ = ctx.x_shape
+        g2 = raw_act_bwd_lp16(g.contiguous(), y2, L.ACT_RELU, bf16)                 # 16-bit (g * [y2 > 0])
+        dy1 = raw_conv_lp16g(conv_desc(B, H, W_, 64, 64, 3, 1, 1, False), 1, g2, w2, None, L.ACT_NONE, bf16, out16=True)
+        g1 = torch.empty_like(dy1)
+        L.call("mmh_act_bwd_lp16_io", _ptr(dy1), 1, _ptr(y1), 1, dy1.numel(), L.ACT_RELU, _dt(bf16), _ptr(g1), _stream())
+        dx = torch.empty((B, H, W_, 4), dtype=torch.float32, device=g.device)
+        raw_conv7_n4(conv_desc(B, H, W_, 4, 64, 3, 1, 1, False), 1, g1, w1, None, dx, L.ACT_NONE, bf16)
+        return dx, None, None, None, None, None
+
+
 class AffineActFn(torch.autograd.Function):
     """out = relu?(x*scale[c] + shift[c]) with fixed per-channel scale/shift: eval-mode
     BatchNorm (aug.py:38-39) and the ImageNet pre-normalisation of the perceptual loss

@@ -362,3 +362,39 @@ def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypat
     assert calls["mmh_conv2d_dgrad_folded"] + calls["mmh_conv2d_dgrad"] >= 2 * 6 and calls["mmh_convT2d_fprop"] >= 2 * 2, calls
     assert calls["mmh_conv2d_wgrad"] >= 2 * 6 and calls["mmh_conv2d_fprop_stats"] >= 2 * 5, calls
     assert calls["mmh_wino_gemm"] >= 2 * 6 * NB and calls["mmh_wino_gemm_levels"] >= 2 * 6 * NB, calls
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_vgg_pair_node_changes_nothing(lp, dev, monkeypatch):
+    """ops.VggPairFn: VGG19 conv1_1 + ReLU + conv1_2 + ReLU (losses/L1_plus_perceptualLoss.py:22-27, --perceptual_layers 3) as one
+    node with a 16-bit edge between the convs, against the two Conv2dFn nodes it replaces: the features bit-identical (conv1_1's
+    16-bit epilogue writes what the conversion pass made of its fp32 output), the image gradient bit-identical (rounding
+    conv1_2's input gradient to 16 bits and masking it commute), two mmh_cvt_lp16 / one mmh_act_bwd_lp16 pass fewer."""
+    from mmhand_amd import lib, ops
+    from mmhand_amd.networks import VGGHead
+    torch.manual_seed(3)
+    vgg = VGGHead(3).init_random().to(dev)
+    vgg.bf16 = lp
+    x0 = torch.randn(2, 64, 48, 4, device=dev)
+    x0[..., 3] = 0
+    gout = torch.randn(2, 64, 48, 64, device=dev)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_VGG_PAIR", on)
+        calls = Counter()
+        real = lib.call
+
+        def spy(name, *a, _c=calls, _r=real):
+            _c[name] += 1
+            return _r(name, *a)
+        monkeypatch.setattr(lib, "call", spy)
+        x = x0.clone().requires_grad_(True)
+        f = vgg.forward_nhwc(x)
+        f.backward(gout)
+        monkeypatch.setattr(lib, "call", real)
+        res[on] = (f.detach().clone(), x.grad.detach().clone(), calls)
+    a, b = res[True], res[False]
+    assert a[2]["mmh_act_bwd_lp16_io"] == 1 and b[2]["mmh_act_bwd_lp16_io"] == 0, (a[2], b[2])
+    assert a[2]["mmh_cvt_lp16"] < b[2]["mmh_cvt_lp16"] or b[2]["mmh_cvt_lp16"] == 0, (a[2], b[2])
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    assert bool(torch.isfinite(a[1]).all()) and torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
