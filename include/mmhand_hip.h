@@ -571,6 +571,17 @@ int mmh_l1_fwd(const void* a, const void* b, int64_t n, float weight,
 /* da = gscalar[0] * weight/denom * sign(a-b)                                */
 int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight,
                double denom, const void* gscalar, void* da, mmh_stream_t s);
+/* The perceptual term on 16-bit VGG features (losses/L1_plus_perceptualLoss.py:60-66 under apex O1, where the VGG
+ * convolutions return fp16 and F.l1_loss runs on them): a16, b16 are the bf16 / fp16 feature maps (`dtype`), the
+ * difference and the sum are fp32.  n % 8 == 0; ws as for mmh_l1_fwd (mmh_reduce_ws_bytes(n)).
+ * mmh_l1_relu_bwd_lp16 is the L1 gradient folded with the mask of the ReLU that produced a16 (features[3]), written in
+ * `dtype` for the 16-bit dgrad of conv1_2:  out16 = [a16 > 0] * gscalar[0] * weight/denom * sign(a16 - b16)          */
+int mmh_l1_fwd_lp16(const void* a16, const void* b16, int64_t n, float weight,
+                    double denom, int dtype, void* out, void* ws, size_t ws_bytes,
+                    mmh_stream_t s);
+int mmh_l1_relu_bwd_lp16(const void* a16, const void* b16, int64_t n, float weight,
+                         double denom, const void* gscalar, int dtype, void* out16,
+                         mmh_stream_t s);
 
 /* MSE mean (F.mse_loss, the --percep_is_l1 0 branch of losses/L1_plus_perceptualLoss.py:68-71):
  * out = weight * sum (a-b)^2 / denom;  da = gscalar[0] * weight/denom * 2 (a-b)            */

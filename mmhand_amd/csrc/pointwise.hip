@@ -1530,6 +1530,41 @@ __global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restri
     }
 }
 
+// L1 between two 16-bit maps (the perceptual term on 16-bit VGG features: each feature is rounded once, the difference and
+// the sum are fp32) and its gradient folded with the ReLU mask of the layer that produced `a`: out = [a > 0] * k * sign(a - b)
+__global__ void l1_partial_lp16_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n8, int h16,
+                                       float* __restrict__ partial) {
+    __shared__ float sh[TPB / 64];
+    float acc = 0.f;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        Raw8<true> ar, br;
+        ldraw(ar, a, i); ldraw(br, b, i);
+        const f8 av = widen(ar, h16 != 0), bv = widen(br, h16 != 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += fabsf(av.v[e] - bv.v[e]);
+    }
+    float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void l1_relu_bwd_lp16_kernel(const void* __restrict__ a, const void* __restrict__ b, int64_t n8, int h16,
+                                        float k, const float* __restrict__ gs, void* __restrict__ out) {
+    const float kk = k * gs[0];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n8; i += stride) {
+        Raw8<true> ar, br;
+        ldraw(ar, a, i); ldraw(br, b, i);
+        const f8 av = widen(ar, h16 != 0), bv = widen(br, h16 != 0);
+        f8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[e] = av.v[e] > 0.f ? kk * sgn(av.v[e] - bv.v[e]) : 0.f;
+        st8<true>(out, i, r, h16 != 0);
+    }
+}
+
 __global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n4,
                                float k, const float* __restrict__ gs, float* __restrict__ da) {
     const float kk = 2.f * k * gs[0];
@@ -2515,6 +2550,29 @@ int mmh_l1_bwd(const void* a, const void* b, int64_t n, float weight, double den
                        (float)((double)weight / denom), static_cast<const float*>(gscalar),
                        static_cast<float*>(da));
     return mmh::check_launch("l1_bwd");
+}
+
+int mmh_l1_fwd_lp16(const void* a16, const void* b16, int64_t n, float weight, double denom, int dtype, void* out,
+                    void* ws, size_t ws_bytes, mmh_stream_t s) {
+    MMH_REQUIRE(a16 && b16 && out && ws && n > 0 && n % 8 == 0 && denom > 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_l1_fwd_lp16: bad arguments (n %% 8 == 0, dtype MMH_BF16 | MMH_FP16)");
+    const int blocks = grid_for(n / 8, 4096);
+    MMH_REQUIRE(ws_bytes >= blocks * sizeof(float), "mmh_l1_fwd_lp16: workspace too small (mmh_reduce_ws_bytes(n))");
+    hipStream_t st = mmh::as_stream(s);
+    hipLaunchKernelGGL(l1_partial_lp16_kernel, dim3(blocks), dim3(TPB), 0, st, a16, b16, n / 8, dtype == MMH_FP16 ? 1 : 0,
+                       static_cast<float*>(ws));
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(TPB), 0, st, static_cast<const float*>(ws), blocks,
+                       (double)weight / denom, static_cast<float*>(out));
+    return mmh::check_launch("l1_fwd_lp16");
+}
+
+int mmh_l1_relu_bwd_lp16(const void* a16, const void* b16, int64_t n, float weight, double denom, const void* gscalar,
+                         int dtype, void* out16, mmh_stream_t s) {
+    MMH_REQUIRE(a16 && b16 && gscalar && out16 && n > 0 && n % 8 == 0 && denom > 0 && (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_l1_relu_bwd_lp16: bad arguments (n %% 8 == 0, dtype MMH_BF16 | MMH_FP16)");
+    hipLaunchKernelGGL(l1_relu_bwd_lp16_kernel, dim3(grid_for(n / 8)), dim3(TPB), 0, mmh::as_stream(s), a16, b16, n / 8,
+                       dtype == MMH_FP16 ? 1 : 0, (float)((double)weight / denom), static_cast<const float*>(gscalar), out16);
+    return mmh::check_launch("l1_relu_bwd_lp16");
 }
 
 int mmh_maxpool2x2_fwd(const void* x, int B, int H, int W, int C, void* y, mmh_stream_t s) {

@@ -150,6 +150,8 @@ SIGNATURES = {
     "mmh_bce_logits_bwd": (_i, [_vp, _i64, _f, _f, _d, _vp, _vp, _vp]),
     "mmh_l1_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_l1_bwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _vp]),
+    "mmh_l1_fwd_lp16": (_i, [_vp, _vp, _i64, _f, _d, _i, _vp, _vp, _sz, _vp]),
+    "mmh_l1_relu_bwd_lp16": (_i, [_vp, _vp, _i64, _f, _d, _vp, _i, _vp, _vp]),
     "mmh_mse_fwd": (_i, [_vp, _vp, _i64, _f, _d, _vp, _vp, _sz, _vp]),
     "mmh_maxpool2x2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mmh_maxpool2x2_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

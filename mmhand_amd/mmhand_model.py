@@ -150,10 +150,18 @@ class L1PlusPerceptualLoss:
     def __call__(self, fake, real):
         B, H, W, _ = fake.shape
         loss_l1 = ops.L1MeanFn.apply(fake, real, self.lambda_L1, float(B * 3 * H * W))
-        f = self.features(fake)
+        xf = ops.AffineActFn.apply(fake, self.scale, self.shift, False)
         with torch.no_grad():
-            r = self.features(real)
-        loss_p = self.percep_fn.apply(f, r, self.lambda_perceptual, float(f.numel()))
+            xr = ops.AffineActFn.apply(real, self.scale, self.shift, False)
+        pair = self.vgg.l1_pair(xf) if self.percep_fn is ops.L1MeanFn else None
+        if pair is not None:        # 16-bit mode, the shipped slice: features and their L1 as one node (ops.VggL1Fn)
+            m1, m2 = pair
+            loss_p = ops.VggL1Fn.apply(xf, xr, m1.weight, m1.bias, m2.weight, m2.bias, self.lambda_perceptual, self.vgg.bf16)
+        else:
+            f = self.vgg.forward_nhwc(xf)
+            with torch.no_grad():
+                r = self.vgg.forward_nhwc(xr)
+            loss_p = self.percep_fn.apply(f, r, self.lambda_perceptual, float(f.numel()))
         return loss_l1 + loss_p, loss_l1, loss_p
 
 

@@ -795,12 +795,23 @@ class VGGHead(nn.Module):
                   if k.startswith("features.") and k.split(".")[1] in keep}
         return super().load_state_dict({"net." + k: v for k, v in sd.items()}, strict)
 
-    def forward_nhwc(self, x):
-        n = len(self.layers)
+    def _pair(self, x):
+        """(conv1_1, conv1_2) when this is the shipped slice and x takes the 16-bit pair kernels, else None"""
         if [k for _, k, _, _ in self.layers] == ["conv", "relu", "conv", "relu"]:
             m1, m2 = self.net[self.layers[0][0]], self.net[self.layers[2][0]]
-            if ops.vgg_pair_ok(x, m1.weight, m2.weight, self.bf16):     # 16-bit mode: one node, 16-bit edge inside (ops.VggPairFn)
-                return ops.VggPairFn.apply(x, m1.weight, m1.bias, m2.weight, m2.bias, self.bf16)
+            if ops.vgg_pair_ok(x, m1.weight, m2.weight, self.bf16):
+                return m1, m2
+        return None
+
+    def l1_pair(self, x):
+        return self._pair(x) if ops.USE_VGG_L1_LP16 else None
+
+    def forward_nhwc(self, x):
+        n = len(self.layers)
+        pair = self._pair(x)
+        if pair is not None:            # 16-bit mode: one node, 16-bit edge inside (ops.VggPairFn)
+            m1, m2 = pair
+            return ops.VggPairFn.apply(x, m1.weight, m1.bias, m2.weight, m2.bias, self.bf16)
         for pos, (i, kind, _, _) in enumerate(self.layers):
             if kind == "conv":
                 m = self.net[i]

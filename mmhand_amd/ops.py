@@ -2341,6 +2341,51 @@ class VggPairFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+USE_VGG_L1_LP16 = os.environ.get("MMH_VGG_L1_LP16", "1") != "0"
+
+
+class VggL1Fn(torch.autograd.Function):
+    """lambda * mean|vgg(x_fake) - vgg(x_real)| for the shipped slice (conv1_1, ReLU, conv1_2, ReLU) in 16-bit mode, as ONE
+    node whose feature maps are 16-bit - what apex O1 does to losses/L1_plus_perceptualLoss.py:60-66 (the convolutions
+    return fp16, F.l1_loss takes them as they are).  Against VggPairFn + L1MeanFn: the two 64-channel feature maps are
+    written and read in 2 bytes, and the backward starts from one pass (mmh_l1_relu_bwd_lp16: L1 gradient x ReLU mask ->
+    16 bits) instead of the fp32 L1 gradient followed by the mask pass.  The loss differs from the fp32-feature form by
+    the rounding of the features (relative 2^-9 per element, unbiased)."""
+
+    @staticmethod
+    def forward(ctx, x_fake, x_real, w1, b1, w2, b2, weight, bf16):
+        B, H, W_, _ = x_fake.shape
+        d1, d2 = conv_desc(B, H, W_, 4, 64, 3, 1, 1, False), conv_desc(B, H, W_, 64, 64, 3, 1, 1, False)
+        y1 = raw_conv_lp16_flat(d1, x_fake, w1, b1, L.ACT_RELU, bf16, out16=True)
+        f = raw_conv_lp16g(d2, 0, y1, w2, b2, L.ACT_RELU, bf16, out16=True)
+        r = raw_conv_lp16g(d2, 0, raw_conv_lp16_flat(d1, x_real, w1, b1, L.ACT_RELU, bf16, out16=True), w2, b2,
+                           L.ACT_RELU, bf16, out16=True)
+        n = f.numel()
+        ws = _ws(L.load().mmh_reduce_ws_bytes(n), x_fake)
+        out = _empty((), x_fake)
+        L.call("mmh_l1_fwd_lp16", _ptr(f), _ptr(r), n, float(weight), float(n), _dt(bf16), _ptr(out), _ptr(ws),
+               ws.numel() * 4, _stream())
+        ctx.cfg = (float(weight), bf16, tuple(x_fake.shape))
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(y1, f, r, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y1, f, r, w1, w2 = ctx.saved_tensors
+        weight, bf16, (B, H, W_, _) = ctx.cfg
+        g = g.contiguous().float()
+        g2 = torch.empty_like(f)
+        L.call("mmh_l1_relu_bwd_lp16", _ptr(f), _ptr(r), f.numel(), weight, float(f.numel()), _ptr(g), _dt(bf16), _ptr(g2),
+               _stream())
+        dy1 = raw_conv_lp16g(conv_desc(B, H, W_, 64, 64, 3, 1, 1, False), 1, g2, w2, None, L.ACT_NONE, bf16, out16=True)
+        g1 = g2                                               # g2 is dead once the dgrad has read it
+        L.call("mmh_act_bwd_lp16_io", _ptr(dy1), 1, _ptr(y1), 1, dy1.numel(), L.ACT_RELU, _dt(bf16), _ptr(g1), _stream())
+        dx = torch.empty((B, H, W_, 4), dtype=torch.float32, device=g.device)
+        raw_conv7_n4(conv_desc(B, H, W_, 4, 64, 3, 1, 1, False), 1, g1, w1, None, dx, L.ACT_NONE, bf16)
+        return dx, None, None, None, None, None, None, None
+
+
 class AffineActFn(torch.autograd.Function):
     """out = relu?(x*scale[c] + shift[c]) with fixed per-channel scale/shift: eval-mode
     BatchNorm (aug.py:38-39) and the ImageNet pre-normalisation of the perceptual loss

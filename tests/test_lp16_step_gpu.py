@@ -398,3 +398,51 @@ def test_vgg_pair_node_changes_nothing(lp, dev, monkeypatch):
     assert a[2]["mmh_cvt_lp16"] < b[2]["mmh_cvt_lp16"] or b[2]["mmh_cvt_lp16"] == 0, (a[2], b[2])
     assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
     assert bool(torch.isfinite(a[1]).all()) and torch.equal(a[1], b[1]), float((a[1] - b[1]).abs().max())
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_vgg_l1_node_on_16bit_features(lp, dev, monkeypatch):
+    """ops.VggL1Fn: the perceptual term (losses/L1_plus_perceptualLoss.py:60-66) with 16-bit VGG features as one node.
+    The loss is exactly lambda * mean|round16(f) - round16(r)| of the features the two-node form computes in fp32, and the
+    image gradient is the one VggPairFn returns for the upstream gradient lambda / n * sign(round16(f) - round16(r))
+    (bit-identical: the mask and the 16-bit rounding commute).  Against fp32 features the loss moves by the rounding only."""
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import L1PlusPerceptualLoss
+    from mmhand_amd.networks import VGGHead
+    torch.manual_seed(5)
+    vgg = VGGHead(3).init_random().to(dev)
+    vgg.bf16 = lp
+    crit = L1PlusPerceptualLoss(10.0, 10.0, vgg, 1)
+    fake0 = torch.tanh(torch.randn(2, 64, 48, 4, device=dev))
+    real = torch.tanh(torch.randn(2, 64, 48, 4, device=dev))
+    fake0[..., 3] = 0
+    real[..., 3] = 0
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_VGG_L1_LP16", on)
+        fake = fake0.clone().requires_grad_(True)
+        _, _, lp_ = crit(fake, real)
+        lp_.backward()
+        res[on] = (float(lp_.detach()), fake.grad.detach().clone())
+    wd = torch.bfloat16 if lp is True else torch.float16
+    xf = ops.AffineActFn.apply(fake0, crit.scale, crit.shift, False).requires_grad_(True)
+    xr = ops.AffineActFn.apply(real, crit.scale, crit.shift, False)
+    f = vgg.forward_nhwc(xf)
+    r = vgg.forward_nhwc(xr)
+    f16, r16 = f.detach().to(wd), r.to(wd)
+    want = 10.0 * float((f16.double() - r16.double()).abs().mean())
+    assert abs(res[True][0] - want) <= 2e-6 * want, (res[True][0], want)
+    tol = 2e-3 if lp is True else 3e-4
+    assert abs(res[True][0] - res[False][0]) <= tol * res[False][0], (res[True][0], res[False][0])
+    gout = (10.0 / f.numel()) * torch.sign(f16.float() - r16.float())
+    f.backward(gout)
+    want_g = xf.grad * crit.scale.reshape(1, 1, 1, -1)
+    got = res[True][1]
+    assert bool(torch.isfinite(got).all())
+    if lp is True:
+        assert torch.equal(got, want_g), float((got - want_g).abs().max())
+    else:       # fp16 flushes features below 6e-8 to zero: the mask may differ on those
+        assert float((got - want_g).abs().max()) <= 1e-3 * float(want_g.abs().max())
+    # and against the fp32-feature form: same direction, the sign flips only where |f - r| is below the rounding
+    a, b = got.flatten().double(), res[False][1].flatten().double()
+    assert float((a @ b) / (a.norm() * b.norm())) > 0.995
