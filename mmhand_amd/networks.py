@@ -83,6 +83,27 @@ class NormParam(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0
+
+    # nn.BatchNorm2d adds 1 to num_batches_tracked in every training forward; with momentum 0.1 (the reference never passes
+    # None) nothing reads it but state_dict().  A device-side add per norm site is 101 one-element kernels per iteration:
+    # the forwards are counted on the host and folded into the buffer when it is read out.
+    def count_batch(self):
+        self._pending_batches += 1
+
+    def flush_batches(self):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+        return self.num_batches_tracked
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_batches()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
 
 class Bag(nn.Module):
@@ -145,7 +166,7 @@ def normact_multi(entries):
             else:
                 seed = ops.next_dropout_seed()
         np_ = e["bag"][e["idx"]]
-        np_.num_batches_tracked += 1
+        np_.count_batch()
         if defer:
             assert x16 is None and not out_lp and (defer == 3 or e.get("residual") is None)
         flat += [x, np_.weight, np_.bias, e.get("residual"), np_.running_mean, np_.running_var, relu, drop_p, seed, mask,
@@ -340,7 +361,7 @@ class _Net(nn.Module):
                 return ops.NormActFn.apply(x, None, None, residual, None, None, "instance", False, 0.0, 0, None, None,
                                            0, None, 3)
             np_ = bag[idx]
-            np_.num_batches_tracked += 1
+            np_.count_batch()
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean, np_.running_var, "batch",
                                        False, 0.0, 0, None, self.sync_group, 0, None, 3)
         if defer:
@@ -350,7 +371,7 @@ class _Net(nn.Module):
                 sync = None
             else:
                 np_ = bag[idx]
-                np_.num_batches_tracked += 1
+                np_.count_batch()
                 args, groups = (np_.weight, np_.bias, None, np_.running_mean, np_.running_var, "batch"), 1
                 sync = self.sync_group
             p, scale, shift, drows = ops.NormActFn.apply(x, *args, relu, drop_p, seed, mask, sync, 0, None, defer)
@@ -362,7 +383,7 @@ class _Net(nn.Module):
                                        drop_p, seed, mask, None, out_lp, x16, 0, res_tok, want_twin)
         np_ = bag[idx]
         if self.training:
-            np_.num_batches_tracked += 1
+            np_.count_batch()
             return ops.NormActFn.apply(x, np_.weight, np_.bias, residual, np_.running_mean,
                                        np_.running_var, "batch", relu, drop_p, seed, mask,
                                        self.sync_group, out_lp, x16, 0, res_tok, want_twin)

@@ -2157,8 +2157,13 @@ def _norm_bwd_finish(ctx, g, s1l, s2l, s1, s2):
     gamma = ctx.saved_tensors[4]
     dgamma = dbeta = None
     if gamma is not None:
-        dgamma = s2l.sum(0) if groups > 1 else s2l.reshape(-1).clone()
-        dbeta = s1l.sum(0) if groups > 1 else s1l.reshape(-1).clone()
+        # autograd may keep what it is handed as the parameter's .grad and add later contributions into it: a copy, unless
+        # nobody reads the local sums after this call - under SyncBN the apply pass takes the all-reduced ones (separate
+        # tensors), and an apply pass that is not deferred is enqueued below, ahead of any later writer (202 copies per
+        # --norm batch step otherwise)
+        own = (s1l is not s1 and s2l is not s2) or not ctx.defer
+        dgamma = s2l.sum(0) if groups > 1 else (s2l.reshape(-1) if own else s2l.reshape(-1).clone())
+        dbeta = s1l.sum(0) if groups > 1 else (s1l.reshape(-1) if own else s1l.reshape(-1).clone())
     if ctx.defer:
         x, dbits, mean, invstd, gamma, scale, shift, drows = ctx.saved_tensors
         e = NormBwdDefer()

@@ -131,6 +131,22 @@ def test_state_dict_roundtrip_and_layout():
         g.load_state_dict(bad)
 
 
+def test_num_batches_tracked_is_counted_on_the_host_and_read_out_by_state_dict():
+    """nn.BatchNorm2d bumps num_batches_tracked in every training forward (a checkpoint key of the reference's --norm batch
+    nets); here the forwards are counted on the host and folded into the buffer when state_dict() reads it."""
+    from mmhand_amd.networks import NormParam
+    np_ = NormParam(8)
+    for _ in range(3):
+        np_.count_batch()
+    assert int(np_.state_dict()["num_batches_tracked"]) == 3
+    np_.count_batch()
+    assert int(np_.state_dict()["num_batches_tracked"]) == 4 and int(np_.flush_batches()) == 4
+    other = NormParam(8)
+    other.count_batch()
+    other.load_state_dict(np_.state_dict())         # a loaded count replaces what was pending
+    assert int(other.state_dict()["num_batches_tracked"]) == 4
+
+
 def test_flat_parameter_views():
     from mmhand_amd.networks import Discriminator
     d = Discriminator(6, 8, "batch", False, 1).init_weights("normal", seed=1)
