@@ -216,6 +216,7 @@ extern int g_lp16_tap_inner;
 extern int g_lp16_dbg;
 extern int g_lp16_wgrad_ring;
 extern int g_pw_v2;
+extern int g_col_chunks, g_row_chunks;   // workgroups per launch the column-reduce / row kernels aim for
 
 }  // namespace mmh
 

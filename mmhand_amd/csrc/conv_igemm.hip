@@ -3164,6 +3164,8 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "lp16_persist")) { mmh::g_lp16_persist = value; return 0; }
     if (!strcmp(key, "lp16_tap_inner")) { mmh::g_lp16_tap_inner = value; return 0; }
     if (!strcmp(key, "pw_v2")) { mmh::g_pw_v2 = value; return 0; }
+    if (!strcmp(key, "col_chunks") && value > 0) { mmh::g_col_chunks = value; return 0; }
+    if (!strcmp(key, "row_chunks") && value > 0) { mmh::g_row_chunks = value; return 0; }
     if (!strcmp(key, "dgrad_s2_halo")) { mmh::g_dgrad_s2_halo = value; return 0; }
     if (!strcmp(key, "wgrad_s2_strip")) { mmh::g_wgrad_s2_strip = value; return 0; }
     if (!strcmp(key, "stem_f32")) { mmh::g_stem_f32 = value; return 0; }

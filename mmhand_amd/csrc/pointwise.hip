@@ -8,7 +8,7 @@
 #include <cmath>
 #include "common.h"
 
-namespace mmh { int g_pw_v2 = 1; }   // mmh_set_option("pw_v2"): 0 = first-generation pointwise kernels (A/B)
+namespace mmh { int g_pw_v2 = 1; int g_col_chunks = 2048; int g_row_chunks = 4096; }   // mmh_set_option("pw_v2"): 0 = first-generation pointwise kernels (A/B)
 
 namespace {
 
@@ -65,7 +65,7 @@ inline ColGeom col_geom(int groups, int64_t rows, int C) {
     ColGeom g;
     g.lpp = C / 4;
     g.rpi = TPB / g.lpp;
-    int64_t want = std::max<int64_t>(1, 2048 / std::max(groups, 1));
+    int64_t want = std::max<int64_t>(1, mmh::g_col_chunks / std::max(groups, 1));
     int64_t maxc = std::max<int64_t>(1, rows / ((int64_t)g.rpi * 8));
     g.chunks = (int)std::min<int64_t>(std::min(want, maxc), 1024);
     g.rows_per_chunk = mmh::cdiv(rows, g.chunks);
@@ -481,7 +481,7 @@ inline RowGeom row_geom(int groups, int64_t rows, int C) {
     g.c8 = C / 8;
     g.rpi = TPB / g.c8;
     const int64_t step = (int64_t)g.rpi * UNR;                  // rows one block covers per iteration
-    const int64_t want = std::max<int64_t>(1, 4096 / std::max(groups, 1));
+    const int64_t want = std::max<int64_t>(1, mmh::g_row_chunks / std::max(groups, 1));
     const int64_t maxc = std::max<int64_t>(1, rows / (2 * step));
     g.chunks = (int)std::min(want, maxc);
     g.rows_per_chunk = mmh::cdiv(mmh::cdiv(rows, g.chunks), step) * step;

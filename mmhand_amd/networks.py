@@ -820,7 +820,8 @@ class VGGHead(nn.Module):
         """(conv1_1, conv1_2) when this is the shipped slice and x takes the 16-bit pair kernels, else None"""
         if [k for _, k, _, _ in self.layers] == ["conv", "relu", "conv", "relu"]:
             m1, m2 = self.net[self.layers[0][0]], self.net[self.layers[2][0]]
-            if ops.vgg_pair_ok(x, m1.weight, m2.weight, self.bf16):
+            frozen = not any(t.requires_grad for t in (m1.weight, m1.bias, m2.weight, m2.bias))    # the pair nodes return no weight gradients
+            if frozen and ops.vgg_pair_ok(x, m1.weight, m2.weight, self.bf16):
                 return m1, m2
         return None
 
