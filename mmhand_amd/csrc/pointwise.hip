@@ -65,7 +65,9 @@ inline ColGeom col_geom(int groups, int64_t rows, int C) {
     ColGeom g;
     g.lpp = C / 4;
     g.rpi = TPB / g.lpp;
-    int64_t want = std::max<int64_t>(1, mmh::g_col_chunks / std::max(groups, 1));
+    // few groups (a small batch of large images) -> many chunks per group, and the one-work-group-row final pass walks them all:
+    // half as many chunks below 16 groups (512x512 B=4 bf16: -0.23 ms per step; neutral at B=32: tools/ab_step.py opt:col_chunks)
+    int64_t want = std::max<int64_t>(1, (groups < 16 ? mmh::g_col_chunks / 2 : mmh::g_col_chunks) / std::max(groups, 1));
     int64_t maxc = std::max<int64_t>(1, rows / ((int64_t)g.rpi * 8));
     g.chunks = (int)std::min<int64_t>(std::min(want, maxc), 1024);
     g.rows_per_chunk = mmh::cdiv(rows, g.chunks);
