@@ -347,3 +347,36 @@ def test_prep_weights_16bit_copies(shape, lp, dev):
     wp2 = torch.zeros_like(wp)
     L.call(fn, ops._ptr(w), taps, cin, cout, ops._ptr(wp2), None, ops._stream())
     assert torch.equal(wp2, wp)
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("n", [8, 4096, 2 * 37 * 41 * 64])
+def test_l1_on_16bit_maps_and_its_relu_masked_gradient(lp, n, dev):
+    """mmh_l1_fwd_lp16 / mmh_l1_relu_bwd_lp16 (F.l1_loss on the fp16 VGG features of apex O1, losses/L1_plus_perceptualLoss.py:66,
+    and its gradient times the mask of features[3]) against fp64 on the same 16-bit values, through the C-ABI; n % 8 != 0 refused."""
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    wd = torch.bfloat16 if lp is True else torch.float16
+    g = torch.Generator().manual_seed(n)
+    a = torch.relu(torch.randn(n, generator=g)).to(wd).to(dev)         # post-ReLU features: half of them exactly zero
+    b = torch.relu(torch.randn(n, generator=g)).to(wd).to(dev)
+    b[: n // 16] = a[: n // 16]                                            # equal pairs: sign 0
+    weight, denom = 10.0, float(n)
+    ws = torch.empty(max(int(L.load().mmh_reduce_ws_bytes(n)), 16) // 4 + 4, dtype=torch.float32, device=dev)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    L.call("mmh_l1_fwd_lp16", a.data_ptr(), b.data_ptr(), n, weight, denom, ops._dt(lp), out.data_ptr(), ws.data_ptr(),
+           ws.numel() * 4, ops._stream())
+    want = weight * float((a.double() - b.double()).abs().sum()) / denom
+    assert abs(float(out) - want) <= 2e-6 * max(want, 1e-6), (float(out), want)
+    gs = torch.tensor(0.75, dtype=torch.float32, device=dev)
+    got = torch.empty_like(a)
+    L.call("mmh_l1_relu_bwd_lp16", a.data_ptr(), b.data_ptr(), n, weight, denom, gs.data_ptr(), ops._dt(lp), got.data_ptr(),
+           ops._stream())
+    k = torch.tensor(weight / denom, dtype=torch.float32) * 0.75
+    ref = (torch.sign(a.float() - b.float()) * (a.float() > 0) * k.to(dev)).to(wd)
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    lib = L.load()
+    assert lib.mmh_l1_fwd_lp16(a.data_ptr(), b.data_ptr(), 12, weight, 12.0, ops._dt(lp), out.data_ptr(), ws.data_ptr(),
+                               ws.numel() * 4, ops._stream()) != 0
+    assert lib.mmh_l1_relu_bwd_lp16(a.data_ptr(), b.data_ptr(), 12, weight, 12.0, gs.data_ptr(), 0, got.data_ptr(),
+                                    ops._stream()) != 0               # and a dtype that is not 16-bit
