@@ -186,6 +186,18 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # MMH_OPTIONS="key=value,key=value": kernel-selection switches of mmh_set_option for a whole run (A/B on a node this code
+    # cannot be edited on, e.g. "lp16_persist=0" under data parallelism when the collectives' kernels hold CUs); an unknown key
+    # or a malformed entry stops the run
+    for item in filter(None, (x.strip() for x in os.environ.get("MMH_OPTIONS", "").split(","))):
+        key, sep, val = item.partition("=")
+        try:
+            ival = int(val)
+        except ValueError:
+            ival = None
+        if not sep or ival is None:
+            raise RuntimeError(f"MMH_OPTIONS: '{item}' is not key=integer")
+        check(lib.mmh_set_option(key.strip().encode(), ival), f"MMH_OPTIONS {item}")
     return lib
 
 

@@ -52,6 +52,17 @@ def test_abi_rejects_bad_arguments_without_gpu(built_lib):
     assert l.mmh_loss_scale_update(None, None, 2.0, 0.5, 2000, 1.0, 2.0 ** 24, None) != 0
 
 
+def test_mmh_options_environment(built_lib):
+    """MMH_OPTIONS=key=value,... reaches mmh_set_option when the library loads; an unknown key stops the run"""
+    code = "from mmhand_amd import lib; lib.load(); print('loaded')"
+    ok = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
+                        env=dict(os.environ, MMH_OPTIONS="lp16_persist=0, col_chunks=1024"))
+    assert ok.returncode == 0 and "loaded" in ok.stdout, ok.stderr[-400:]
+    for bad in ("no_such_key=1", "lp16_persist", "lp16_persist=x"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, MMH_OPTIONS=bad))
+        assert r.returncode != 0 and "MMH_OPTIONS" in r.stderr, (bad, r.stderr[-300:])
+
+
 def test_product_path_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "mmhand_amd")):
         for f in files:
