@@ -380,3 +380,33 @@ def test_l1_on_16bit_maps_and_its_relu_masked_gradient(lp, n, dev):
                                ws.numel() * 4, ops._stream()) != 0
     assert lib.mmh_l1_relu_bwd_lp16(a.data_ptr(), b.data_ptr(), 12, weight, 12.0, gs.data_ptr(), 0, got.data_ptr(),
                                     ops._stream()) != 0               # and a dtype that is not 16-bit
+
+
+@pytest.mark.parametrize("groups,chunks,C", [(2, 8, 64), (3, 32, 256), (2, 127, 64), (4, 128, 256), (2, 300, 96), (1, 1024, 32)])
+def test_norm_stats_merge_finalize_vs_fp64(groups, chunks, C, dev):
+    """mmh_norm_stats_merge_finalize: Chan's merge of per-tile (count, mean, M2) partials - what the conv epilogues leave for
+    the InstanceNorm behind them (models/Generator.py:66-77) - into mean / invstd / scale / shift, against fp64 on the same
+    partials, at 8 to 1024 partials per group (the 512x512 shapes have 128), empty partials skipped."""
+    from mmhand_amd import lib as L
+    from mmhand_amd import ops
+    g = torch.Generator().manual_seed(groups * 1000 + chunks)
+    n = torch.randint(0, 5, (groups, chunks, 1, C), generator=g).float() * 16          # some partials empty (count 0)
+    n[:, 0] = 64
+    mean_p = torch.randn(groups, chunks, 1, C, generator=g) * 0.5 + 3.0
+    m2_p = torch.rand(groups, chunks, 1, C, generator=g) * n
+    part = torch.cat([n, mean_p, m2_p], 2).contiguous().to(dev)                        # [groups][chunks][3][C]
+    count = n.sum(1).squeeze(1).double()                                               # [groups][C]
+    nd, md, qd = n.double().squeeze(2), mean_p.double().squeeze(2), m2_p.double().squeeze(2)
+    mean_w = (nd * md).sum(1) / count
+    m2_w = (qd + nd * (md - mean_w[:, None]) ** 2).sum(1)
+    rows = float(count.max())       # the entry point takes ONE count (rows per plane): use partials with equal totals
+    sel = count == rows
+    outs = [torch.empty(groups, C, device=dev) for _ in range(5)]
+    L.call("mmh_norm_stats_merge_finalize", part.data_ptr(), groups, chunks, C, rows, ops.EPS, *[o.data_ptr() for o in outs],
+           ops._stream())
+    mean, m2, scale, shift, invstd = [o.cpu().double() for o in outs]
+    assert float((mean - mean_w).abs().max()) <= 2e-6 * 3.5
+    assert float(((m2 - m2_w).abs() / m2_w.clamp_min(1e-3)).max()) <= 2e-5
+    is_w = 1.0 / torch.sqrt(m2_w / rows + ops.EPS)
+    assert float(((invstd - is_w).abs() / is_w)[sel].max() if bool(sel.any()) else 0.0) <= 2e-5
+    assert torch.allclose(scale, invstd) and torch.allclose(shift, -(mean * invstd), rtol=1e-5, atol=1e-6)
