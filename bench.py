@@ -882,7 +882,7 @@ def main():
             "losses": {k: round(v, 5) for k, v in losses.items()},
             # ranks the collective backend really connects (an all-reduce of ones); 0 = single process, no
             # process group.  N > 1: gradients of G / D_PB / D_PP all-reduced over RCCL (mmhand_amd/dp.py)
-            "rccl_ranks": n_rccl, "backend": ("nccl(RCCL)" if dist.is_initialized() else None),
+            "rccl_ranks": n_rccl, "backend": (("nccl(RCCL)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist.is_initialized() else None),
         }
         line.update(dp_info)
         line.update(side)
