@@ -20,7 +20,9 @@ from .networks import Generator
 from .options import default_train_opt
 
 
-def main(argv):
+def main(argv, ngf=64, n_blocks=9, size=None):
+    """argv as the reference's aug.py; ngf / n_blocks / size are the reference's hard-coded 64 / 9 / 256 (aug.py:31-39),
+    keyword-overridable so that a test can drive the whole path on a small checkpoint."""
     ckp, dst = argv[0], argv[1]
     n_batches = int(argv[2]) if len(argv) > 2 else 4
     batch = int(argv[3]) if len(argv) > 3 else 1
@@ -28,24 +30,32 @@ def main(argv):
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
     weights = torch.load(os.path.join("checkpoints", ckp, "latest_net_netG.pth"), map_location="cpu")
-    model = Generator(input_nc=[3, 42, 6], output_nc=3, ngf=64, norm_layer="batch", use_dropout=True,
-                      n_blocks=9)
+    model = Generator(input_nc=[3, 42, 6], output_nc=3, ngf=ngf, norm_layer="batch", use_dropout=True,
+                      n_blocks=n_blocks)
     model.load_state_dict(weights)
     gen = InferenceGenerator(model.to(dev).eval(), use_graph=True)
     opt = default_train_opt(batchSize=batch, local_rank=device, isTrain=False)
-    loader = SyntheticHandLoader(opt, n_batches * batch)
+    loader = SyntheticHandLoader(opt, n_batches * batch, size=size)
     os.makedirs(dst, exist_ok=True)
+    written = []
     for i, sample in enumerate(loader):
         fake = gen([sample["H1"], torch.cat((sample["P1"], sample["P2"]), 1),
                     torch.cat((sample["D1"], sample["D2"]), 1)])
         img = ((fake.permute(0, 2, 3, 1) * 0.5 + 0.5) * 255.0).round().clamp(0, 255).to(torch.uint8)
         arr = img.cpu().numpy()                                     # RGB, what the PNG stores
-        try:
-            from PIL import Image
-            for j in range(arr.shape[0]):
-                Image.fromarray(arr[j]).save(os.path.join(dst, "fake_%05d_%d.png" % (i, j)))
-        except ImportError:
-            np.save(os.path.join(dst, "fake_%05d.npy" % i), arr)
+        for j in range(arr.shape[0]):
+            # aug.py:66-71: <dst>/<folder of the target image>/<its file name>
+            *_, folder, name = sample["H2_path"][j].split("/")
+            os.makedirs(os.path.join(dst, folder), exist_ok=True)
+            path = os.path.join(dst, folder, name)
+            try:
+                from PIL import Image
+                Image.fromarray(arr[j]).save(path)
+            except ImportError:
+                path = os.path.splitext(path)[0] + ".npy"
+                np.save(path, arr[j])
+            written.append(path)
+    return written
 
 
 if __name__ == "__main__":

@@ -1162,6 +1162,7 @@ struct LpGConvKP {
     int reflect;
     int OH, OW, os, oh0, ow0, y_cs, N;
     int act, MT, NT;
+    int st16;               // 16-byte epilogue stores allowed (y_cs % 8 == 0: the address (pix*y_cs + n)*2 is 16-byte aligned)
 };
 
 template <bool H16, int BNT>
@@ -1314,7 +1315,7 @@ __device__ __forceinline__ void conv_lp16g_body(const LpGConvKP& p) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? p.bias[n0 + wc * (BNT / 4) + j * 16 + 4 * g4 + r] : 0.f;
-    if (p.y16 && NJ % 2 == 0) {      // 16-byte stores after the lane-pair trade (common.h: pair_swap8)
+    if (p.y16 && NJ % 2 == 0 && p.st16) {      // 16-byte stores after the lane-pair trade (common.h: pair_swap8)
         const int cb0 = ((g4 & 1) ? 16 : 0) + 4 * (g4 & 2);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -2356,6 +2357,7 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
     p.h16 = d->dtype == MMH_FP16;
     p.tap_inner = mmh::g_lp16_tap_inner;
     p.dbg = mmh::g_lp16_dbg;
+    if (y_is16 && p.y_cs % 8 != 0) p.dbg |= 128;       // 8-byte stores: 16-byte ones need (pix*y_cs + n)*2 16-byte aligned
     p.stats = static_cast<float*>(stats);
     p.addend = static_cast<const float*>(addend);
     const long long M = (long long)d->B * d->H * d->W;
@@ -2566,6 +2568,7 @@ int mmh_conv_lp16(const mmh_conv_desc* d, int mode, const void* x16, const void*
     const long long M = (long long)p.B * p.MH * p.MW;
     MMH_REQUIRE(p.y_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0,
                 "mmh_conv_lp16: the output's pixel stride must be a multiple of 4 channels and y 16-byte aligned");
+    p.st16 = p.y_cs % 8 == 0;       // else the 8-byte store4 epilogue (a stride of 4 mod 8 misaligns dwordx4 stores)
     MMH_REQUIRE((long long)p.B * p.SH * p.SW * p.cs < (1ll << 31) && (long long)p.B * p.OH * p.OW < (1ll << 31) &&
                     p.SH < 16384 && p.SW < 32768,
                 "mmh_conv_lp16: tensor too large");

@@ -3,7 +3,7 @@
 //
 // The library has no link-time dependency on librccl: the process that trains already holds ONE RCCL communicator per
 // GPU (torch.distributed's "nccl" backend IS RCCL on ROCm) and the RCCL image that communicator lives in.  mmh_rccl_bind()
-// resolves ncclAllReduce from THAT image (dlopen of the path the caller names, RTLD_NOLOAD first), so the collective below
+// resolves ncclAllReduce from THAT image (dlopen of the path the caller names with RTLD_NOLOAD: never loads one), so the collective below
 // runs on the caller's communicator and the caller's stream: no second communicator, no second RCCL in the process.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -22,9 +22,11 @@ extern "C" {
 
 int mmh_rccl_bind(const char* librccl_path) {
     MMH_REQUIRE(librccl_path && *librccl_path, "mmh_rccl_bind: path of the RCCL library the process uses is required");
+    // RTLD_NOLOAD only: the image must ALREADY be mapped (the caller names the one its communicator lives in, from
+    // /proc/self/maps).  Loading a second RCCL image and handing it a communicator created by the first would read a
+    // foreign struct layout - so a miss is an error and the caller keeps torch.distributed's own all_reduce.
     void* h = dlopen(librccl_path, RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen(librccl_path, RTLD_NOW | RTLD_LOCAL);
-    MMH_REQUIRE(h, "mmh_rccl_bind: dlopen(%s): %s", librccl_path, dlerror());
+    MMH_REQUIRE(h, "mmh_rccl_bind: %s is not loaded in this process (refusing to load a second RCCL image)", librccl_path);
     p_allreduce = reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce"));
     p_errstr = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
     p_count = reinterpret_cast<count_fn>(dlsym(h, "ncclCommCount"));

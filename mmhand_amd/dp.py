@@ -51,10 +51,16 @@ def set_no_comm(flag):
 def native_comm(group=None):
     """(ncclComm_t as int, None) of torch.distributed's RCCL communicator for `group` with mmh_allreduce_bucket bound to
     the RCCL image it lives in, or (None, reason) - then the buckets go through dist.all_reduce."""
-    if os.environ.get("MMH_DP_NATIVE", "1") == "0":
+    mode = os.environ.get("MMH_DP_NATIVE", "auto")
+    if mode == "0":
         return None, "MMH_DP_NATIVE=0"
     if not dist.is_initialized() or dist.get_backend(group) != "nccl":
         return None, "backend is not nccl(RCCL)"
+    # ADVICE r4: the native path shares torch.distributed's communicator behind ProcessGroupNCCL's back and has only
+    # ever run with ONE rank.  Until a world > 1 hardware run (with SyncBN's collectives interleaved) has passed it is
+    # opt-in there: MMH_DP_NATIVE=1 forces it, the default ("auto") uses it at world size 1 only.
+    if mode != "1" and dist.get_world_size(group) > 1:
+        return None, "world > 1: dist.all_reduce is the shipped path (MMH_DP_NATIVE=1 opts in)"
     try:
         pg = group if group is not None else dist.group.WORLD
         backend = pg._get_backend(torch.device("cuda", torch.cuda.current_device()))
@@ -64,9 +70,9 @@ def native_comm(group=None):
         if not comm:
             return None, "communicator not initialised yet"
         from . import lib as L
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if not os.path.exists(path):
-            return None, f"{path} not found"
+        path = loaded_rccl_path()
+        if path is None:
+            return None, "no librccl image is mapped into this process"
         L.call("mmh_rccl_bind", path.encode())
         n = L.load().mmh_rccl_comm_ranks(C.c_void_p(comm))
         if n != dist.get_world_size(group):
@@ -74,6 +80,21 @@ def native_comm(group=None):
         return comm, None
     except Exception as e:      # noqa: BLE001 - any surprise in torch's private API: the torch path still works
         return None, f"{type(e).__name__}: {e}"
+
+
+def loaded_rccl_path():
+    """Path of the RCCL image this process has ALREADY mapped (the one torch.distributed's communicator lives in), read
+    from /proc/self/maps - never a guess at torch/lib: binding a second RCCL image to a communicator created by another
+    is undefined behaviour."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rstrip("\n").split(None, 5)[-1] if line.count("/") else ""
+                if "/" in path and os.path.basename(path).startswith("librccl.so"):
+                    return path
+    except OSError:
+        pass
+    return None
 
 
 _trackers = []      # weak references to live GradBuckets objects: the conv shims report parameter uses / contributions
@@ -153,6 +174,8 @@ class GradBuckets:
         self._armed = False
         self._n = len(params)
         self._uses = [0] * self._n
+        self._dones = [0] * self._n
+        self._untracked = [False] * self._n
         self._complete = [False] * self._n
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(params)]
         # the shims find a parameter by the address of its slice of the flat PARAMETER buffer
@@ -175,11 +198,17 @@ class GradBuckets:
             self._uses[i] += 1
 
     def done(self, p):
+        """Complete on an EXACT match only: every counted use has reported done.  A done without a counted use (the
+        forward ran before begin(), or a shim reported twice) leaves the parameter untracked - its bucket then goes
+        out with launch_remaining() at the end of the pass, never early under a later in-place add."""
         i = self._index.get(p.data_ptr())
         if i is None or not self._armed:
             return
-        self._uses[i] -= 1
-        if self._uses[i] <= 0:
+        if self._uses[i] <= 0 or self._untracked[i]:
+            self._untracked[i] = True
+            return
+        self._dones[i] += 1
+        if self._dones[i] == self._uses[i]:
             self._param_complete(i)
 
     def _param_complete(self, i):
@@ -221,6 +250,8 @@ class GradBuckets:
         self._left = list(self._need)
         self._works = [None] * len(self.buckets)
         self._uses = [0] * self._n
+        self._dones = [0] * self._n
+        self._untracked = [False] * self._n
         self._complete = [False] * self._n
         self._armed = True
 

@@ -102,23 +102,34 @@ class ImagePool:
     def query(self, images):
         if self.pool_size == 0:
             return images
-        out = []
-        snap = None         # ONE copy of the batch per query, made when the first image is stored: the pool keeps views of it
-                            # (the reference clones image by image - 64 device copies per iteration at B = 32; same values,
-                            # same host RNG sequence; a stored view keeps its 25 MB snapshot alive, at most pool_size of them)
+        # Pass 1 walks the batch with the reference's host RNG sequence and only records decisions; pass 2 makes ONE
+        # gather of the images that are actually stored into a compact buffer the pool keeps views of (the reference
+        # clones image by image - 64 device copies per iteration at B = 32).  A stored view pins only the images
+        # stored by the same query, never the whole batch: the pool holds at most pool_size images plus those that
+        # left it while a sibling of the same query is still inside.
+        out = []                    # per output slot: a tensor, or an int k = "the k-th image stored by this query"
+        stored = []                 # batch indices stored by this query, in order
+        pool = self.images          # entries: tensors (earlier queries) or ints (this query)
         for i in range(images.shape[0]):
-            img = images[i:i + 1]
-            if len(self.images) < self.pool_size:
-                snap = images.clone() if snap is None else snap
-                self.images.append(snap[i:i + 1])
-                out.append(img)
+            if len(pool) < self.pool_size:
+                pool.append(len(stored))
+                stored.append(i)
+                out.append(images[i:i + 1])
             elif random.uniform(0, 1) > 0.5:
                 j = random.randint(0, self.pool_size - 1)
-                out.append(self.images[j])
-                snap = images.clone() if snap is None else snap
-                self.images[j] = snap[i:i + 1]
+                out.append(pool[j])
+                pool[j] = len(stored)
+                stored.append(i)
             else:
-                out.append(img)
+                out.append(images[i:i + 1])
+        if stored:
+            # torch.cat of slices: one device copy and no host-to-device index transfer (which would stall the host
+            # that runs an iteration ahead of the GPU)
+            compact = images.clone() if len(stored) == images.shape[0] else torch.cat([images[i:i + 1] for i in stored], 0)
+            for j, e in enumerate(pool):
+                if isinstance(e, int):
+                    pool[j] = compact[e:e + 1]
+            out = [compact[e:e + 1] if isinstance(e, int) else e for e in out]
         return torch.cat(out, 0)
 
 
@@ -280,6 +291,10 @@ class MMHandModel(torch.nn.Module):
                 self.criterionL1 = L1PlusPerceptualLoss(opt.lambda_A, opt.lambda_B, self.vgg,
                                                         opt.percep_is_l1)
             elif opt.L1_type == "origin":
+                # The reference builds torch.nn.L1Loss() here (models/MMHandModel.py:81-82) and backward_G then indexes
+                # its 0-dim result (`losses[0]`, :247-250): IndexError on the first iteration - the branch cannot train
+                # there.  Intended behaviour, implemented in backward_G below and tested (test_l1_type_origin):
+                # pair_L1loss = origin_L1 = mean|fake - H2| with weight 1, perceptual = 0, no VGG.
                 self.vgg = None
                 self.criterionL1 = None
             else:

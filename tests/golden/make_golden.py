@@ -229,29 +229,46 @@ def make_adam():
 
 
 def make_pose():
+    """8 uv sets: seven at 64x64 - the three of round 1 unchanged, four more incl. joints on the image
+    border, between pixels and two joints on the same pixel - and one at the training resolution 256x256 with joints
+    drawn as the synthetic loader draws them (uv ~ U(20, H - 20), data/generic_dataset.py:191-217)."""
     from data.generic_dataset import Genericdataset
     from util.util import map_to_cord as ref_map_to_cord
-    H = W = 64
     rs = np.random.RandomState(49)
     uvs = rs.uniform(4, 60, size=(3, 21, 2))
     uvs[0, 0] = (10.0, 20.0)          # exact integer centre -> value 1.0 at the peak
     uvs[0, 1] = (-30.0, -30.0)        # off-image joint -> all-zero map -> MISSING (-1)
     uvs[0, 2] = (63.0, 0.0)           # corner
-    maps, cords = [], []
+    rs2 = np.random.RandomState(50)
+    more = rs2.uniform(-2, 66, size=(4, 21, 2))     # some joints just outside the image: clipped supports
+    more[0, 0] = (31.5, 31.5)         # between four pixels: a four-way tie of the maximum -> FIRST arg-max wins
+    more[0, 1] = more[0, 2] = (17.0, 40.0)          # two joints on one pixel
+    more[1, 0] = (0.0, 0.0)
+    more[1, 1] = (63.0, 63.0)
+    more[2, 0] = (82.0, 30.0)         # 19 px outside: the support radius (18 px at the 0.0099 threshold) does not reach
+    more[2, 1] = (81.0, 30.0)         # 18 px outside: one column may survive the threshold
+    uvs = np.concatenate([uvs, more], 0)
+    uv256 = np.random.RandomState(51).uniform(20, 236, size=(1, 21, 2))
 
     class _D:                           # gen_heatmap only needs self.gaussian_kernel
         gaussian_kernel = staticmethod(Genericdataset.gaussian_kernel)
-    for uv in uvs:
-        m = np.stack([Genericdataset.gen_heatmap(_D, x, y, (H, W), 6).astype(np.float32) for x, y in uv])
-        om = O.pose_heatmaps(uv, H, W)
-        assert np.array_equal(m, om), "oracle pose map mismatch"
-        c = ref_map_to_cord(np.transpose(m, (1, 2, 0)))
-        assert np.array_equal(c, O.map_to_cord(np.transpose(m, (1, 2, 0)))), "oracle map_to_cord mismatch"
-        maps.append(m)
-        cords.append(c)
-    np.savez_compressed(os.path.join(HERE, "pose.npz"), uv=uvs, maps=np.stack(maps),
-                        cords=np.stack(cords).astype(np.int64))
-    print("pose.npz", np.stack(maps).shape, "nonzero frac", float((np.stack(maps) > 0).mean()))
+
+    def run(uvset, H, W):
+        maps, cords = [], []
+        for uv in uvset:
+            m = np.stack([Genericdataset.gen_heatmap(_D, x, y, (H, W), 6).astype(np.float32) for x, y in uv])
+            om = O.pose_heatmaps(uv, H, W)
+            assert np.array_equal(m, om), "oracle pose map mismatch"
+            c = ref_map_to_cord(np.transpose(m, (1, 2, 0)))
+            assert np.array_equal(c, O.map_to_cord(np.transpose(m, (1, 2, 0)))), "oracle map_to_cord mismatch"
+            maps.append(m)
+            cords.append(c)
+        return np.stack(maps), np.stack(cords).astype(np.int64)
+    maps, cords = run(uvs, 64, 64)
+    maps256, cords256 = run(uv256, 256, 256)
+    np.savez_compressed(os.path.join(HERE, "pose.npz"), uv=uvs, maps=maps, cords=cords,
+                        uv256=uv256, maps256=maps256, cords256=cords256)
+    print("pose.npz", maps.shape, maps256.shape, "nonzero frac", float((maps > 0).mean()), float((maps256 > 0).mean()))
 
 
 def make_visuals():

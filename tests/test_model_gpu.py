@@ -396,3 +396,79 @@ def test_get_current_visuals_strip(dev):
                   min(max(int((cords[a][1] + cords[b][1]) // 2), 0), Hs - 1)] != 0).any()
                for (a, b), _ in V.BONES]
         assert np.mean(hit) > 0.7, hit          # a bone's midpoint lies inside its ellipse unless a later bone covers it
+
+
+def test_aug_main_end_to_end(dev, tmp_path, monkeypatch):
+    """The generation driver as a whole (aug.py:26-71): a reference-format `latest_net_netG.pth` on disk
+    -> mmhand_amd.aug.main -> BN-folded, hipGraph-replayed Generator -> PNG files under <dst>/<folder of H2_path>/<name>.
+    The PNG bytes must decode to cv2.imwrite's rounding (saturate_cast: nearest, clamped) of (fake * 0.5 + 0.5) * 255 of
+    the eval-mode ORACLE forward on the same checkpoint and inputs - within 1 LSB where fp32 paths round differently - and
+    to util.tensor2im of it (which truncates) within 1 LSB everywhere."""
+    from PIL import Image
+
+    from mmhand_amd import aug
+    from mmhand_amd import visuals as V
+    from mmhand_amd.data import SyntheticHandLoader
+    from mmhand_amd.networks import Generator
+    from mmhand_amd.options import default_train_opt
+    net = Generator([3, 42, 6], 3, S["ngf"], "batch", True, S["n_blocks"])
+    sd = RC.recipe_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    for k in sd:
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=torch.Generator().manual_seed(1))
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(2))
+    os.makedirs(tmp_path / "checkpoints" / "tiny")
+    torch.save(sd, tmp_path / "checkpoints" / "tiny" / "latest_net_netG.pth")
+    monkeypatch.chdir(tmp_path)
+    Hs, n_batches, batch = 32, 3, 2
+    written = aug.main(["tiny", "out", str(n_batches), str(batch), "0"], ngf=S["ngf"], n_blocks=S["n_blocks"], size=Hs)
+    assert len(written) == n_batches * batch and all(os.path.isfile(p) for p in written)
+    # the same synthetic samples, through the CPU oracle in eval mode
+    onet = O._Net(sd, "batch", True); onet.training = False
+    loader = SyntheticHandLoader(default_train_opt(batchSize=batch, local_rank=0, isTrain=False), n_batches * batch, size=Hs)
+    k = 0
+    for sample in loader:
+        g_in = [sample["H1"].cpu(), torch.cat((sample["P1"], sample["P2"]), 1).cpu(),
+                torch.cat((sample["D1"], sample["D2"]), 1).cpu()]
+        ref = O.generator_forward(onet, g_in, S["n_blocks"])
+        for j in range(batch):
+            *_, folder, name = sample["H2_path"][j].split("/")
+            path = os.path.join("out", folder, name)
+            assert os.path.abspath(path) == os.path.abspath(written[k]), (path, written[k])
+            png = np.asarray(Image.open(path))
+            assert png.dtype == np.uint8 and png.shape == (Hs, Hs, 3)
+            want = ((ref[j].permute(1, 2, 0).numpy() * 0.5 + 0.5) * 255.0)
+            nearest = np.clip(np.rint(want), 0, 255).astype(np.int64)
+            d = np.abs(png.astype(np.int64) - nearest)
+            assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+            t2i = V.tensor2im(ref[j:j + 1]).astype(np.int64)
+            assert np.abs(png.astype(np.int64) - t2i).max() <= 1
+            assert png.std() > 0
+            k += 1
+    assert k == len(written)
+
+
+def test_l1_type_origin(dev):
+    """--L1_type origin (options/train_options.py:31).  In the reference this branch builds torch.nn.L1Loss()
+    (models/MMHandModel.py:81-82) and then backward_G indexes its 0-dim result, `losses[0]` (:247-250): IndexError on the
+    first iteration - the branch cannot train there.  The build implements what the option says instead of reproducing
+    the crash: pair_L1loss = origin_L1 = mean|fake - H2| with weight 1 (nn.L1Loss's mean, no lambda_A), perceptual = 0,
+    no VGG built; everything else of the step unchanged.  Checked against the oracle's leaf functions."""
+    from mmhand_amd.mmhand_model import MMHandModel
+    model = MMHandModel(_small_opt("instance", L1_type="origin"))
+    assert model.vgg is None and model.criterionL1 is None
+    random.seed(3)
+    batch = O.synthetic_batch(S["B"], S["H"], S["W"], seed=21)
+    model.set_input(batch)
+    model.optimize_parameters()
+    err = model.get_current_errors()
+    fake = model.fake_p2.detach().cpu()
+    l1 = float((fake - batch["H2"]).abs().mean())
+    assert abs(float(err["origin_L1"]) - l1) < 1e-4 * l1
+    assert abs(float(err["pair_L1loss"]) - l1) < 1e-4 * l1 and float(err["perceptual"]) == 0.0
+    assert all(np.isfinite(float(v)) for v in err.values())
+    g = model.netG.flat_grad
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    with pytest.raises(Exception, match="Unsurportted"):
+        MMHandModel(_small_opt("instance", L1_type="nope"))

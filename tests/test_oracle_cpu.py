@@ -101,12 +101,16 @@ def test_mse_perceptual_branch_matches_reference_fixture():
 
 def test_pose_maps_bit_exact():
     fix = _load("pose.npz")
-    for uv, maps, cords in zip(fix["uv"], fix["maps"], fix["cords"]):
-        m = O.pose_heatmaps(uv, 64, 64)
-        assert np.array_equal(m, maps)                      # values and support mask, bit-exact
-        assert np.array_equal(O.map_to_cord(np.transpose(m, (1, 2, 0))), cords)
+    assert len(fix["uv"]) + len(fix["uv256"]) == 8          # eight uv sets, one at 256 x 256
+    for size, sfx in ((64, ""), (256, "256")):
+        for uv, maps, cords in zip(fix["uv" + sfx], fix["maps" + sfx], fix["cords" + sfx]):
+            m = O.pose_heatmaps(uv, size, size)
+            assert np.array_equal(m, maps)                  # values and support mask, bit-exact
+            assert np.array_equal(O.map_to_cord(np.transpose(m, (1, 2, 0))), cords)
     assert (fix["cords"][0][1] == -1).all()                 # off-image joint -> MISSING_VALUE
     assert fix["maps"][0][0].max() == 1.0
+    assert (fix["cords"][3][0] == (31, 31)).all()           # four-way tie of the maximum: the first arg-max
+    assert (fix["cords"][5][0] == -1).all()                 # 19 px outside: nothing survives the threshold
 
 
 @pytest.mark.parametrize("norm", ["batch", "instance"])

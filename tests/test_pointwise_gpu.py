@@ -248,13 +248,19 @@ def test_pose_maps_bit_exact_vs_reference_fixture(dev):
     """a15: support mask and arg-max indices bit-exact, values within 1 ulp (fp32)."""
     from mmhand_amd import ops
     fix = dict(np.load(os.path.join(G, "pose.npz")))
-    for uv, maps, cords in zip(fix["uv"], fix["maps"], fix["cords"]):
-        out = ops.pose_heatmaps(torch.from_numpy(uv).to(dev), 64, 64).cpu().numpy()
-        assert np.array_equal(out > 0, maps > 0)
-        ulp = np.abs(out.view(np.int32).astype(np.int64) - maps.view(np.int32).astype(np.int64))
-        assert ulp.max() <= 1
-        c = ops.map_to_cord(torch.from_numpy(maps).to(dev)).cpu().numpy()
-        assert np.array_equal(c, cords)
+    n = 0
+    for size, sfx in ((64, ""), (256, "256")):               # seven sets at 64 x 64, one at the training resolution
+        for uv, maps, cords in zip(fix["uv" + sfx], fix["maps" + sfx], fix["cords" + sfx]):
+            out = ops.pose_heatmaps(torch.from_numpy(uv).to(dev), size, size).cpu().numpy()
+            assert np.array_equal(out > 0, maps > 0)
+            ulp = np.abs(out.view(np.int32).astype(np.int64) - maps.view(np.int32).astype(np.int64))
+            assert ulp.max() <= 1
+            c = ops.map_to_cord(torch.from_numpy(maps).to(dev)).cpu().numpy()
+            assert np.array_equal(c, cords)
+            # and the indices of the DEVICE maps (values may differ by 1 ulp: ties must still resolve alike)
+            assert np.array_equal(ops.map_to_cord(torch.from_numpy(out).to(dev)).cpu().numpy(), cords)
+            n += 1
+    assert n == 8
 
 
 def test_decode_inputs_bit_exact(dev):
