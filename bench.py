@@ -110,7 +110,7 @@ def cpu_baseline_child(H, W, norm, budget_s, threads=CPU_THREADS, max_steps=10):
     batch = O.synthetic_batch(B, H, W, seed=49)
     t0 = time.time()
     nwarm = 0
-    while nwarm < 2 and (nwarm < 1 or time.time() - t0 < budget_s / 2):
+    while nwarm < (1 if max_steps <= 2 else 2) and (nwarm < 1 or time.time() - t0 < budget_s / 2):
         orc.step(batch); nwarm += 1
     warm = time.time() - t0
     n, t1 = 0, time.time()
@@ -155,6 +155,30 @@ def cpu_baseline(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=CPU_THRE
     """The oracle (pure PyTorch restatement, pinned against the reference modules) timed on this
     host's cores on a bounded sample of the same workload, in a child process with a hard timeout."""
     return cpu_baseline_collect(cpu_baseline_start(H, W, norm, budget_s, hard_timeout_s, threads, max_steps))
+
+
+CPU_SWEEP = (32, 64)    # beside CPU_THREADS: "is 16 the fastest this host does" measured on the line itself (VERDICT r4 #5b)
+
+
+def cpu_baseline_with_sweep(H, W, norm):
+    """cpu_baseline at CPU_THREADS (the SURVEY 8(d) protocol: 2 warm-up + 10 timed steps) plus the same oracle at 32 and 64
+    threads - 1 warm-up + 2 timed steps each, one child per thread count, 25 s budget and a hard 75 s timeout each (oneDNN
+    at 128+ threads did not finish a step in 240 s on this host: profiles/r04_cpu_all_cores.json) - run one after the
+    other so that they do not share cores.  `value` / `cores` = the FASTEST of the three; `thread_sweep` keeps all."""
+    base = cpu_baseline(H, W, norm)
+    sweep = {str(base.get("cores", CPU_THREADS)): {"value": base.get("value"), "sample": base.get("sample")}}
+    best = base
+    for t in CPU_SWEEP:
+        if (os.cpu_count() or 0) < t:
+            sweep[str(t)] = {"value": None, "sample": f"host has {os.cpu_count()} logical CPUs"}
+            continue
+        r = cpu_baseline(H, W, norm, budget_s=25.0, hard_timeout_s=75, threads=t, max_steps=2)
+        sweep[str(t)] = {"value": r.get("value"), "sample": r.get("sample")}
+        if r.get("value") and (not best.get("value") or r["value"] > best["value"]):
+            best = r
+    out = dict(best)
+    out["thread_sweep"] = sweep
+    return out
 
 
 def infer_main(a):
@@ -282,21 +306,66 @@ def _sync(dp):
     torch.cuda.synchronize()
 
 
-def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, dp=False, seed=49, **opt_kw):
+class CallCounter:
+    """C-ABI calls of the enclosed region (every launch goes through lib.call)"""
+
+    def __enter__(self):
+        from mmhand_amd import lib as L
+        self.L, self.real, self.n = L, L.call, 0
+
+        def counted(name, *args):
+            self.n += 1
+            return self.real(name, *args)
+        L.call = counted
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call = self.real
+
+
+def host_enqueue(model, dp, reps=2):
+    """What the HOST spends on one optimize_parameters() (tools/host_overhead.py, VERDICT r4 #5d): the wall time of the
+    call itself with the GPU idle when it starts - the call returns when everything is enqueued (overflow flags are read
+    one iteration late) - and the C-ABI calls it makes.  enqueue / step near 1 = the configuration is host-bound."""
+    best, calls = None, 0
+    for _ in range(reps):
+        _sync(dp)
+        with CallCounter() as c:
+            t0 = time.perf_counter()
+            model.optimize_parameters()
+            ms = (time.perf_counter() - t0) * 1e3
+        best = ms if best is None else min(best, ms)
+        calls = c.n
+    _sync(dp)
+    return round(best, 2), calls
+
+
+def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, dp=False, seed=49, lib_options=None, **opt_kw):
     """A fresh MMHandModel with option overrides: images/s over `steps` optimize_parameters() calls (inputs resident),
     measured like the headline region; optionally the 16-bit stack fraction from a separate bracketed pass.
     dp: the model is built on the process group (distributed=True): barriers around the timed region, the slowest rank's
     time counts, images/s is the whole job's, and `comm_exposed_ms` = the step minus the same step with every
     collective stubbed out (dp.set_no_comm: gradients stay rank-local - measured LAST, the replicas drift apart)."""
-    import gc
-    from mmhand_amd import dp as DP
-    from mmhand_amd import ops
-    from mmhand_amd.mmhand_model import MMHandModel
-    from mmhand_amd.options import default_train_opt
+    from mmhand_amd import lib as L
     world = dist.get_world_size() if (dp and dist.is_initialized()) else 1
     kw = dict(batchSize=B, norm="instance", name="bench_side", local_rank=dev.index, checkpoints_dir="/tmp/mmh_bench",
               distributed=bool(dp))
     kw.update(opt_kw)
+    # lib_options: {key: (value for this region, value to restore)} of mmh_set_option (kernel-selection switches)
+    for k, (v, _) in (lib_options or {}).items():
+        L.call("mmh_set_option", k.encode(), int(v))
+    try:
+        return _side_train_run(dev, B, size, steps, warmup, stack, stack_steps, dp, seed, world, kw)
+    finally:
+        for k, (_, v0) in (lib_options or {}).items():
+            L.call("mmh_set_option", k.encode(), int(v0))
+
+
+def _side_train_run(dev, B, size, steps, warmup, stack, stack_steps, dp, seed, world, kw):
+    import gc
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    from mmhand_amd.options import default_train_opt
     model = MMHandModel(default_train_opt(**kw))
     model.set_input(synthetic_batch_gpu(B, size, size, seed, dev))
     for _ in range(warmup):
@@ -330,6 +399,10 @@ def side_train_run(dev, B, size, steps, warmup=2, stack=False, stack_steps=2, dp
                                "kernel": f"conv_lp16h2_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
                                          f"{c[1] / c[0] / 1e9:.1f} GFLOP/launch, {c[2] / c[0]:.3f} ms avg over {c[0]} launches"}
     out["losses_finite"] = all(torch.isfinite(v).item() for v in model.get_current_errors().values())
+    enq, calls = host_enqueue(model, dp)
+    out["host_enqueue_ms"] = enq
+    out["c_abi_calls_per_step"] = calls
+    out["host_enqueue_over_step"] = round(enq / ms, 3)
     if dp:
         out["comm_exposed_ms"] = comm_exposed_ms(model, dev, ms, max(2, min(3, steps)))
     del model
@@ -461,7 +534,8 @@ def rccl_child_run(steps, warmup, batch, size, timeout_s=600):
             return {"images_per_s": j["value"], "ms_per_step": j["ms_per_step"], "steps": steps,
                     "rccl_ranks": j.get("rccl_ranks"), "backend": j.get("backend"),
                     **{k: j[k] for k in ("bucket_allreduce", "inplace_param_grads", "comm_exposed_ms", "dp_bf16_path",
-                                         "dp_norm_batch", "dp_size512_bf16_b4") if k in j}}
+                                         "dp_norm_batch", "dp_norm_batch_o1", "dp_bf16_path_nopersist", "dp_size512_bf16_b4",
+                                         "dp_size512_bf16_b4_norm_batch") if k in j}}
     return {"error": f"rc {out.returncode}: " + out.stderr[-400:]}
 
 
@@ -737,10 +811,28 @@ def main():
                                                  note="the reference's script default --norm batch under data parallelism = "
                                                       "SyncBN (apex convert_syncbn_model): statistics over the global batch, "
                                                       "collectives of independent norm sites packed"))
+        if a.dtype == "f32":
+            guarded_dp("dp_norm_batch_o1", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, dp=True, seed=49 + rank,
+                                                                       norm="batch", opt_level="O1"),
+                                                        note="the reference's SHIPPED combination (scripts/mm-train-ratio.sh:7-40): "
+                                                             "--norm batch (SyncBN under DP) with --opt_level O1 (16-bit compute), dropout on"))
+            if world > 1:
+                # the 16-bit halo kernels launch ONE persistent workgroup per CU; an RCCL kernel holding CUs
+                # while such a launch starts delays the workgroups that find no CU.  The same region with one workgroup per
+                # tile (lp16_persist = 0; 3-8 % slower alone) answers on the first multi-GPU run which of the two wins there.
+                guarded_dp("dp_bf16_path_nopersist",
+                           lambda: dict(side_train_run(dev, a.batch, a.size, n_side, dp=True, seed=49 + rank, opt_level="O1",
+                                                       norm=a.norm, lib_options={"lp16_persist": (0, 1)}),
+                                        note="dp_bf16_path with mmh_set_option('lp16_persist', 0): one workgroup per tile instead "
+                                             "of persistent tile lists in the 16-bit 3x3 kernels (A/B against RCCL's CU use)"))
         if world == 4 or a.dp_512:
             guarded_dp("dp_size512_bf16_b4", lambda: dict(side_train_run(dev, 4, 512, n_side, dp=True, seed=49 + rank, opt_level="O1"),
                                                           note="BASELINE.json configs[4]: 512x512, per-GPU batch 4 (global 16 at "
                                                                "4 GPUs), bf16"))
+            guarded_dp("dp_size512_bf16_b4_norm_batch",
+                       lambda: dict(side_train_run(dev, 4, 512, n_side, dp=True, seed=49 + rank, opt_level="O1", norm="batch"),
+                                    note="configs[4]'s shape under SyncBN: the configuration closest to host-bound "
+                                         "(host_enqueue_over_step; profiles/r04_host_overhead.txt: 0.71 at world 1)"))
     if side_ok:
         # (1) the reference's set_input inside the loop: the batch comes from pinned HOST memory every
         # step (H2D over PCIe + the NHWC pack), as train.py:35 does per iteration
@@ -811,6 +903,11 @@ def main():
         guarded("norm_batch", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch",
                                                           opt_level="O1" if a.dtype == "bf16" else "O0"),
                                            note="the reference's script default --norm batch (BatchNorm2d affine, conv bias off)"))
+        if a.dtype == "f32":
+            guarded("norm_batch_o1", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, norm="batch", opt_level="O1"),
+                                                  note="the reference's SHIPPED combination (scripts/mm-train-ratio.sh:7-40, "
+                                                       "options/base_options.py:66-70): --norm batch with --opt_level O1 "
+                                                       "(16-bit compute, dynamic loss scaling), dropout on"))
         guarded("dp_rccl_world1", lambda: dict(rccl_child_run(n_side, max(2, a.warmup), a.batch, a.size),
                                                note="same fp32 step through the data-parallel path (MMH_FORCE_DP=1) on RCCL, "
                                                     "world size 1, own process"))
@@ -889,7 +986,7 @@ def main():
         if cpu_child is not None:
             line["cpu_baseline"] = cpu_baseline_collect(cpu_child)
         if world == 1 and not force_dp and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(H, W, a.norm)
+            line["cpu_baseline"] = cpu_baseline_with_sweep(H, W, a.norm)
             # SURVEY.md §8(d) asks for os.cpu_count() threads.  On the GPU box's 256 logical CPUs oneDNN is far slower
             # at 128+ threads than at 16 (tools/cpu_probe.py; one B=2 step did not finish in 240 s): opt-in
             # (--cpu-all-cores SECONDS; the round-4 measurement, profiles/r04_cpu_all_cores.json, timed out at 256 threads), not paid by every default run

@@ -197,3 +197,19 @@ def test_bench_bf16_side_run_with_stack_meter(dev):
     # epilogue, with the residual gradient added): fprop launches == dgrad launches == wgrad launches + frozen-D passes
     assert per["fprop_256x256"]["launches"] == per["dgrad_256x256"]["launches"], per
     assert out["roofline"]["frac"] > 0
+
+
+def test_bench_norm_batch_o1_side_run_reports_host_enqueue(dev):
+    """bench.py's `norm_batch_o1` side key (VERDICT r4 #5a: the reference's shipped --norm batch + --opt_level O1,
+    scripts/mm-train-ratio.sh:7-40) and the host-side figures every side region now carries (#5d): the wall time of the
+    optimize_parameters() CALL with the GPU idle when it starts, and the C-ABI calls it makes."""
+    import bench
+    out = bench.side_train_run(dev, 2, 64, 1, warmup=1, norm="batch", opt_level="O1")
+    assert "error" not in out and out["losses_finite"] and out["images_per_s"] > 0
+    assert out["host_enqueue_ms"] > 0 and out["c_abi_calls_per_step"] > 100
+    assert abs(out["host_enqueue_over_step"] - out["host_enqueue_ms"] / out["ms_per_step"]) < 2e-3
+    # a kernel-selection switch applied for one region only is restored behind it
+    from mmhand_amd import lib as L
+    out2 = bench.side_train_run(dev, 2, 64, 1, warmup=1, opt_level="O1", lib_options={"lp16_persist": (0, 1)})
+    assert out2["losses_finite"]
+    L.call("mmh_set_option", b"lp16_persist", 1)

@@ -221,6 +221,21 @@ def _w_grad_buckets_inplace(rank, world, port):
     # reported complete twice
     assert log.index(("bucket", 0)) < log.index(("param", 0))
     assert len([e for e in log if e[0] == "param"]) == 2 * n_layers
+    # a `done` without a counted `use` - the forward ran BEFORE begin() - must not complete the parameter early
+    # (its bucket would go out under a later in-place add): the shim path leaves such a parameter alone and it completes
+    # where autograd's AccumulateGrad node of the weight runs - after BOTH contributions (the post-accumulate hook fires
+    # for a weight whose shim returned no gradient, too) - or with launch_remaining().  A bucket that left between the
+    # two in-place adds would hold the sum over ranks plus one rank-local term: the comparison below would see it.
+    gflat.zero_()
+    log.clear()
+    ya, yb = net(xa), net(xb)               # the forward passes precede begin(): their uses are not counted
+    bk.begin()
+    (ya.square().mean() + yb.square().mean()).backward()
+    assert all(bk._untracked[2 * i] and bk._dones[2 * i] == 0 for i in range(n_layers))     # the shim path stood aside
+    bk.launch_remaining()
+    bk.wait()
+    assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7), (gflat - ref).abs().max()
+    assert [e for e in log if e[0] == "bucket"] == [("bucket", i) for i in range(n_layers)], log
     bk.remove()
     assert not dp.tracking()
     dist.destroy_process_group()

@@ -287,10 +287,15 @@ def test_bench_two_ranks_on_one_gpu_carry_every_multi_gpu_key(dev):
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["config"]["global_batch"] == 4 and j["value"] > 0
     assert j["inplace_param_grads"] is True and j["bucket_allreduce"].startswith("dist.all_reduce")
     assert "value" in j["comm_exposed_ms"] and j["ms_per_step_fastest_rank"] <= j["ms_per_step"]
-    for key in ("dp_bf16_path", "dp_norm_batch", "dp_size512_bf16_b4"):
+    # the shipped combination under DP (SyncBN + O1), the persistent-kernel A/B against RCCL's CU use, and
+    # configs[4]'s shape under SyncBN with the host's enqueue time per step on the line
+    for key in ("dp_bf16_path", "dp_norm_batch", "dp_norm_batch_o1", "dp_bf16_path_nopersist", "dp_size512_bf16_b4",
+                "dp_size512_bf16_b4_norm_batch"):
         r = j[key]
         assert "error" not in r, (key, r)
         assert r["n_gpus"] == 2 and r["images_per_s"] > 0 and r["losses_finite"] and "value" in r["comm_exposed_ms"], (key, r)
+        assert r["host_enqueue_ms"] > 0 and r["c_abi_calls_per_step"] > 100 and r["host_enqueue_over_step"] > 0, (key, r)
+    assert j["dp_norm_batch_o1"]["syncbn_collectives_per_step"]["all_gather"] == 50, j["dp_norm_batch_o1"]
     assert j["dp_norm_batch"]["syncbn_collectives_per_step"]["all_gather"] == 50, j["dp_norm_batch"]
     assert j["dp_norm_batch"]["syncbn_collectives_per_step"]["all_reduce"] == 50
     assert j["dp_bf16_path"]["syncbn_collectives_per_step"] is None

@@ -262,3 +262,23 @@ def test_bench_refuses_a_mismatched_launch():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode != 0 and "1-rank launch" in out.stderr
+
+
+def test_cpu_baseline_thread_sweep_reports_the_fastest(monkeypatch):
+    """bench.cpu_baseline_with_sweep (VERDICT r4 #5b): 16 / 32 / 64 threads, the fastest is `value`, all three are kept."""
+    import bench
+    seen = []
+
+    def fake(H, W, norm, budget_s=60.0, hard_timeout_s=300, threads=bench.CPU_THREADS, max_steps=10):
+        seen.append((threads, max_steps, hard_timeout_s))
+        v = {16: 0.6, 32: 0.9, 64: None}[threads]
+        return {"value": v, "unit": "images/s", "cores": threads, "kind": "port", "sample": f"{threads} threads"}
+    monkeypatch.setattr(bench, "cpu_baseline", fake)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    out = bench.cpu_baseline_with_sweep(256, 256, "instance")
+    assert [t for t, _, _ in seen] == [16, 32, 64] and seen[0][1] == 10 and seen[1][1] == 2 and seen[2][2] <= 90
+    assert out["value"] == 0.9 and out["cores"] == 32 and out["kind"] == "port"
+    assert set(out["thread_sweep"]) == {"16", "32", "64"} and out["thread_sweep"]["64"]["value"] is None
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 8)
+    out = bench.cpu_baseline_with_sweep(256, 256, "instance")
+    assert out["value"] == 0.6 and out["thread_sweep"]["32"]["value"] is None
