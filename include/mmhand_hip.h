@@ -68,8 +68,8 @@ typedef struct mmh_conv_desc {
 
 const char* mmh_last_error(void);
 int mmh_version(void);
-/* Tuning knobs for A/B measurements inside one process: kernel variants ("lp16_shape" 16 | 17 |
- * 18 | 19 = the builds of the 16-bit 3x3 kernel, "lp16_wgrad_ring" 0 | 1 | 2, "conv_dbuf",
+/* Tuning knobs for A/B measurements inside one process: kernel variants ("lp16_shape" 19 = the halo
+ * kernel (default) | 17 = row tiles | 20 = one wave per SIMD (make AB=1 builds only), "lp16_wgrad_ring" 2 | 3, "conv_dbuf",
  * "wino_gemm_levels", ...) and work-list parameters ("wgrad_slots", "conv_xcd", ...): the results
  * stay within the kernels' documented tolerances.  The "*_dbg" keys are NOT such knobs: "conv_dbg",
  * "lp16_dbg" (bits 1-16), "dgrad_s2_dbg", "stem_f32_dbg" switch parts of a kernel OFF for timing

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmhand_hip.so")
+# MMH_LIB_PATH: another BUILD of the same library for A/B tools (make AB=1 ... OUT=../libmmhand_hip_ab.so adds the kernels that
+# lost their comparison); never a different implementation, and a missing file is an error like the default one
+LIB_PATH = os.environ.get("MMH_LIB_PATH") or os.path.join(_HERE, "libmmhand_hip.so")
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2

@@ -1612,7 +1612,7 @@ class Conv2dFn(torch.autograd.Function):
         v2 = bool(bf16) and lp16_v2_ok(Cin, w.shape[3], k, stride, pad, 0)
         if v2 or chain:
             # 16-bit path: one 16-bit twin of x (or the producer's own 16-bit output) feeds the fprop and,
-            # kept instead of x, the wgrad.  256 / 512-channel stride-1 stack: conv_lp16s_kernel, the other
+            # kept instead of x, the wgrad.  256 / 512-channel stride-1 stack: conv_lp16h2_kernel, the other
             # 3x3 convs (stride 2, 64 / 128 columns): conv_lp16g_kernel
             if x16 is None:
                 # x_twin: a 16-bit copy of x that already exists (a channel slice of the gate's 16-bit concat)

@@ -360,15 +360,15 @@ def test_conv2d_bf16_mfma_path(case, wino, lp, dev, monkeypatch):
         R.rel_l1(y, yf), R.rel_l1(dx, dxf), R.rel_l1(dw, dwf))
 
 
-@pytest.mark.parametrize("shape", [16, 17, 18, 19, 32])
+@pytest.mark.parametrize("shape", [17, 19])
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 9, 11, 64, 256, True), (1, 16, 16, 256, 512, False), (3, 7, 5, 512, 256, True),
                                   (1, 20, 12, 256, 256, True), (2, 17, 33, 256, 256, True), (1, 32, 48, 64, 256, False)])
 def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
-    """conv_lp16.hip through the C-ABI: fprop (MFMA 16x16x32 (16), the same with the fragment reads
-    pipelined into the MFMA stream (17), with the activation halo resident in LDS for all nine taps on
-    16x16 pixel tiles (18, the default; images smaller than a tile take 17), 32x32x16), zero-pad dgrad and wgrad from 16-bit
-    twins against the fp64 oracle on operands rounded to the same type (accumulation is fp32)."""
+    """conv_lp16.hip / conv_lp16_halo.hip through the C-ABI: fprop on 256-pixel row tiles (17: conv_lp16p_kernel, what images
+    smaller than 16x16 always take) and with the activation halo resident in LDS for all nine taps on 16x16 pixel tiles (19, the
+    default), zero-pad dgrad and wgrad from 16-bit twins against the fp64 oracle on operands rounded to the same type
+    (accumulation is fp32).  (The round 2-4 generations 16 / 18 / 32 left the binary in round 5.)"""
     from mmhand_amd import lib, ops
     B, H, W, Cin, Cout, refl = case
     lib.check(lib.load().mmh_set_option(b"lp16_shape", shape), "set")
@@ -401,10 +401,10 @@ def test_conv3x3_lp16_v2_kernels(case, lp, shape, dev):
 @pytest.mark.parametrize("mode", [0, 1], ids=["fprop", "dgrad"])
 @pytest.mark.parametrize("case", [(32, 64, 64, 256, 512), (32, 64, 64, 512, 256), (4, 128, 128, 256, 256)])
 def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
-    """The builds of the 16-bit 3x3 kernel on the training shapes (too large for the CPU oracle): the
-    pipelined (17) and halo (18) kernels against the plain one (16), three runs each - a missing wait on
-    the LDS-DMA showed up exactly here, as run-to-run differences on two-column-tile shapes - and the two
-    wgrad kernels (two stages / ring of half stages) bit-identical."""
+    """The two implementations of the 16-bit 3x3 kernel on the training shapes (too large for the CPU oracle): the halo kernel
+    (19) against the row-tile kernel (17), three runs each - a missing wait on the LDS-DMA showed up exactly here, as run-to-run
+    differences on two-column-tile shapes - and the nine-tap wgrad with and without the staggered DMA issue bit-identical and
+    reproducible run to run."""
     from mmhand_amd import lib, ops
     B, H, W, Cin, Cout = case
     L_ = lib.load()
@@ -413,10 +413,10 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
     ops.bump_weights_epoch()
     xb = ops.lp16_twin(x, True)
     try:
-        lib.check(L_.mmh_set_option(b"lp16_shape", 16), "set")
+        lib.check(L_.mmh_set_option(b"lp16_shape", 17), "set")
         ref = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
         scale = float(ref.abs().max())
-        for shape in (17, 18, 19):
+        for shape in (19,):
             lib.check(L_.mmh_set_option(b"lp16_shape", shape), "set")
             for _ in range(3):
                 y = ops.raw_conv3x3_lp16(xb, w, None, mode == 0, 0, True, mode)
@@ -425,15 +425,12 @@ def test_conv3x3_lp16_kernels_agree_at_full_size(case, mode, dev):
             dy = _mk((B, H, W, Cout), 3, dev)
             dyb = ops.lp16_twin(dy, True)
             outs = []
-            for ring in (0, 1, 1, 2, 2, 2):
+            for ring in (2, 2, 2, 3, 3):
                 lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", ring), "set")
                 outs.append(ops.raw_wgrad3x3_lp16(xb, dyb, True, True))
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
-            # the tap-resident kernel (2, the default) sums the pixels in another order (4 x 16 blocks, other
-            # split ranges): equal to the ring kernel up to fp32 summation order, and reproducible run to run
-            assert torch.equal(outs[3], outs[4]) and torch.equal(outs[4], outs[5])
-            sc = float(outs[0].abs().max())
-            assert float((outs[3] - outs[0]).abs().max()) < 2e-5 * sc, (float((outs[3] - outs[0]).abs().max()), sc)
+            assert all(torch.equal(outs[0], o) for o in outs[1:])
+            # (its values: against the fp64 oracle at small sizes in test_conv3x3_lp16_v2_kernels, at full size through the
+            # adjoint identities of tests/test_configs_gpu.py)
     finally:
         lib.check(L_.mmh_set_option(b"lp16_shape", 19), "set")
         lib.check(L_.mmh_set_option(b"lp16_wgrad_ring", 2), "set")
@@ -1201,3 +1198,38 @@ def test_head_dgrad_on_the_stem_kernel(case, lp, out16, dev, monkeypatch):
     monkeypatch.setattr(ops, "USE_HEAD_DGRAD16", False)
     old = ops.raw_conv_dgrad(dy, w, (B, H, W, 64), 1, 3, True, bf16=lp, out16=False)
     assert R.rel_l1(dx.float(), old.cpu()) < (4e-3 if lp == 2 else 1.6e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (1, 48, 16, 256, 512)])
+def test_conv3x3_lp16_one_wave_per_simd_ab_build(case, dev):
+    """conv_lp16q_kernel (lp16_shape 20: one wave per SIMD, 512 registers, 256 AGPR accumulators, inline-asm MFMAs and counted
+    LDS waits - the kernel VERDICT r4 #1 asked for, which LOSES by 30 %: DESIGN.md 4.3d) is compiled into A/B builds only
+    (make AB=1).  Where it is present every entry point is bit-identical to the two-waves-per-SIMD kernel (same k order, same
+    MFMA shape); in the default build the option is refused with a message that says how to get it."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout = case
+    L_ = lib.load()
+    x = _mk((B, H, W, Cin), 1, dev); dy = _mk((B, H, W, Cout), 2, dev)
+    w = _mk((3, 3, Cin, Cout), 3, dev) * 0.05
+    bias = _mk((Cout,), 4, dev)
+    addend = _mk((B, H, W, Cin), 5, dev)
+    ops.bump_weights_epoch()
+    xb, dyb = ops.lp16_twin(x, True), ops.lp16_twin(dy, True)
+    fns = [lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True),
+           lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 1, True, 0),
+           lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)]
+    if H >= 32 and W >= 32:
+        fns += [lambda: ops.raw_conv3x3_lp16(dyb, w, None, True, 0, True, 2, out16=True),
+                lambda: ops.raw_conv3x3_lp16(dyb, w, None, True, 0, True, 2, addend=addend)]
+    try:
+        refs = [f() for f in fns]
+        lib.check(L_.mmh_set_option(b"lp16_shape", 20), "set")
+        try:
+            outs = [f() for f in fns]
+        except RuntimeError as e:
+            assert "A/B builds only" in str(e), e
+            pytest.skip("default build: conv_lp16q_kernel not compiled in (make AB=1)")
+        for r, o in zip(refs, outs):
+            assert torch.equal(r, o)
+    finally:
+        lib.check(L_.mmh_set_option(b"lp16_shape", 19), "set")

@@ -431,7 +431,8 @@ def test_aug_main_end_to_end(dev, tmp_path, monkeypatch):
     for sample in loader:
         g_in = [sample["H1"].cpu(), torch.cat((sample["P1"], sample["P2"]), 1).cpu(),
                 torch.cat((sample["D1"], sample["D2"]), 1).cpu()]
-        ref = O.generator_forward(onet, g_in, S["n_blocks"])
+        with torch.no_grad():
+            ref = O.generator_forward(onet, g_in, S["n_blocks"])
         for j in range(batch):
             *_, folder, name = sample["H2_path"][j].split("/")
             path = os.path.join("out", folder, name)

@@ -1,5 +1,6 @@
-"""conv_lp16h_kernel (mmh_conv3x3_lp16, lp16_shape 18) as the 16-bit training step calls it: fprop with bias and a
-16-bit epilogue, dgrad main term with a 16-bit epilogue, on the PATBlock shapes; interleaved rounds in one process."""
+"""The halo kernel (mmh_conv3x3_lp16, lp16_shape 19: conv_lp16h2_kernel) as the 16-bit training step calls it, beside the row-tile
+kernel (17: conv_lp16p_kernel): fprop with bias and a 16-bit epilogue, dgrad main term with a 16-bit epilogue, on the PATBlock
+shapes; interleaved rounds in one process."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,8 +27,8 @@ for (Cin, Cout) in ((256, 256), (512, 512), (512, 256)):
     fp = lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True)
     dg = lambda: ops.raw_conv3x3_lp16(dyb, w, None, False, 0, True, 1, out16=True)
     fps = lambda: ops.raw_conv3x3_lp16(xb, w, bias, True, 0, True, 0, out16=True, want_stats=True)
-    variants = {"h(18) fprop": mk(18, fp), "h2(19) fprop": mk(19, fp), "h2 fprop + statistics": mk(19, fps),
-                "h(18) dgrad": mk(18, dg), "h2(19) dgrad": mk(19, dg)}
+    variants = {"p(17) fprop": mk(17, fp), "h2(19) fprop": mk(19, fp), "h2 fprop + statistics": mk(19, fps),
+                "p(17) dgrad": mk(17, dg), "h2(19) dgrad": mk(19, dg)}
     res = {k: [] for k in variants}
     for f in variants.values(): f()
     torch.cuda.synchronize()
