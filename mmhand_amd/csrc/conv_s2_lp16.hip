@@ -268,10 +268,23 @@ __global__ void __launch_bounds__(512) conv_s2f_kernel(const S2KP p) {
 // [2q + b] = sum over the taps of parity class (a, b) of dy[p + dh][q + dw] . w[kh][kw], dh = (kh == 0), dw = (kw == 0) - one
 // tap for class (0,0), two for (0,1) and (1,0), four for (1,1).  The general kernel runs the four classes as four GEMMs that
 // each re-stage dy and their taps' weights; here a tile of 8 x 16 dy positions brings its 9 x 17 halo of dy (128 channels:
-// 41 KB) in ONCE for all nine taps and all four classes, and the weights are register-resident as in the fprop kernel: a wave
-// owns one 16-channel column tile of dx (64 channels = 4 column tiles) and four of the tile's eight rows, all nine taps (144
-// VGPRs) and all four classes (64 accumulator VGPRs).  Per (row, k-step) FOUR pixel fragments - (dh, dw) in {0,1}^2 - feed the
-// nine MFMAs.  Only for 128 -> 64 channels (the dgrad of the 64 -> 128 down-sampling conv, the ConvTranspose2d 128 -> 64).
+// 41 KB) in ONCE for all nine taps and all four classes, and the weights are register-resident as in the fprop kernel.
+//
+// Round 5: the waves split the CLASSES, not the rows.  Round 4's form gave a wave one 16-channel column tile of dx, four of the
+// tile's eight rows, all nine taps (144 weight registers) and all four classes (64 accumulators): with the double-buffered
+// fragments that is 260 live registers against the 256 two waves per SIMD leave - 37 dwords in scratch, and every reload is a
+// scratch_load followed by s_waitcnt vmcnt(0): in front of each of the six halo-DMA instructions (the DMA addresses had gone
+// to scratch) and inside the MFMA block (weight fragments had), i.e. every tile waited for its own next-tile DMA and for the
+// previous tile's stores.  That is the "stores and DMA each cost what they would alone and nothing overlaps" of round 4's
+// ablations - found with VERDICT r4 #2's counters (no memory-side stall: TCC_EA0_WRREQ_STALL 0.25 M against a plain fill's
+// 3.2 M on the same bytes, profiles/r05_pmc_s2d.txt) and then in the ISA (tools/isa.sh: private segment 148 bytes).
+// Now a wave owns one column tile, ALL eight rows and the taps of TWO classes: type 0 (waves 0-3) the classes (1,1) + (0,0) -
+// five taps, 80 weight registers -, type 1 (waves 4-7) the classes (0,1) + (1,0) - four taps, 64 registers; wave w and w + 4
+// share a SIMD, so every SIMD multiplies 5 + 4 taps as before.  Per (k32 step, row) the shifted fragments (dh, dw) of row i
+// are the (0, dw) fragments of row i + 1: a ring of four row slots (two fragments each) is refilled one row ahead of use -
+// 18 reads per k-step instead of 32.  ~200 registers, nothing in scratch: the DMA of the next tile's halo and the stores of the
+// last one now really are in flight under the multiplies.  Only for 128 -> 64 channels (the dgrad of the 64 -> 128
+// down-sampling conv, the ConvTranspose2d 128 -> 64).
 constexpr int DH = TH + 1, DW = TW + 1;            // halo 9 x 17 positions of dy
 constexpr int DPITCH = 18;
 constexpr int DROWS = DH * DPITCH;                 // 162 LDS rows per 64-channel chunk image
@@ -291,27 +304,35 @@ struct S2DKP {
     int TX, TY, tiles, lists;
 };
 
-template <bool H16>
-__global__ void __launch_bounds__(512) conv_s2d_kernel(const S2DKP p) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// TYPE 0: taps (1,1) -> class (0,0) [slot 0]; (2,2), (2,0), (0,2), (0,0) -> class (1,1) [slot 1]
+// TYPE 1: taps (1,2), (1,0) -> class (0,1) [slot 0]; (2,1), (0,1) -> class (1,0) [slot 1]
+// per tap: weight index 3 kh + kw, accumulator slot, shift (dh, dw) = (kh == 0, kw == 0); the unshifted taps first (their
+// fragments are the older ones of the ring)
+template <int TYPE> struct S2DTaps;
+template <> struct S2DTaps<0> {
+    static constexpr int N = 5;
+    static constexpr int tap[5] = {4, 8, 6, 2, 0}, slot[5] = {0, 1, 1, 1, 1}, dh[5] = {0, 0, 0, 1, 1}, dw[5] = {0, 0, 1, 0, 1};
+    static constexpr int cls[2] = {0, 3};          // class 2 a + b of the two accumulator slots
+};
+template <> struct S2DTaps<1> {
+    static constexpr int N = 4;
+    static constexpr int tap[4] = {5, 3, 7, 1}, slot[4] = {0, 0, 1, 1}, dh[4] = {0, 0, 0, 1}, dw[4] = {0, 1, 0, 0};
+    static constexpr int cls[2] = {1, 2};
+};
+
+template <bool H16, int TYPE>
+__device__ __forceinline__ void conv_s2d_body(const S2DKP& p, char* smem, int lane, int wave, int t_begin, int t_end) {
+    typedef S2DTaps<TYPE> T;
     const int l15 = lane & 15, g4 = lane >> 4;
-    const int nj = wave & 3, rh = wave >> 2;        // column tile of dx, row half of the tile
-    const int xcd = blockIdx.x & 7, lst = blockIdx.x >> 3;
-    const int per_xcd = (p.tiles + 7) / 8, lists_x = p.lists / 8;
-    const int per_list = (per_xcd + lists_x - 1) / lists_x;
-    const int t_begin = xcd * per_xcd + lst * per_list;
-    const int t_end = min(min(t_begin + per_list, (xcd + 1) * per_xcd), p.tiles);
-    if (t_begin >= t_end) return;
+    const int nj = wave & 3;                        // column tile of dx
     const int n0 = nj * 16;
 
-    bf16x8 wf[9][4];        // (tap, k32 step): rows n0 + l15 of [tap][64][128], K-values 32 s + 8 g4 .. + 7
+    bf16x8 wf[T::N][4];     // (tap, k32 step): rows n0 + l15 of [tap][64][128], K-values 32 s + 8 g4 .. + 7
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < T::N; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            wf[t][k] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)(t * 64 + n0 + l15) * 128 + 32 * k + 8 * g4) * 2);
+            wf[t][k] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)(T::tap[t] * 64 + n0 + l15) * 128 + 32 * k + 8 * g4) * 2);
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[n0 + 4 * g4 + r] : 0.f;
@@ -340,74 +361,92 @@ __global__ void __launch_bounds__(512) conv_s2d_kernel(const S2DKP p) {
             }
         }
     };
-    // pixel fragment of tile row rh * 4 + i, shift (dh, dw), k32 step (kc, hf): LDS row (rh 4 + i + dh) * DPITCH + dw + l15
+    // pixel fragment of halo row r (0..8), column shift dw, k32 step (kc, hf): LDS row r * DPITCH + dw + l15
     unsigned aL[2][2];
 #pragma unroll
     for (int dw = 0; dw < 2; ++dw) {
         const unsigned sl = (unsigned)(dw + l15);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-            aL[dw][hf] = lds0 + ((unsigned)(rh * 4) * DPITCH + sl) * 128u + ((((unsigned)(4 * hf + g4)) ^ (sl & 6u)) << 4);
+            aL[dw][hf] = lds0 + sl * 128u + ((((unsigned)(4 * hf + g4)) ^ (sl & 6u)) << 4);
     }
 
-    f32x4 acc[4][4];        // [class 2 a + b][row]
+    f32x4 acc[2][TH];       // [accumulator slot][row]
     int nt = 0;
     issue_tile(t_begin, 0);
     bool after_store = false;
     for (int tile = t_begin; tile < t_end; ++tile, ++nt) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < TH; ++i) acc[c][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (after_store) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // all but the 16 stores behind the halo DMA
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (tile + 1 < t_end) issue_tile(tile + 1, (nt + 1) & 1);
         const unsigned boff = (unsigned)(nt & 1) * DBUF_B;
-        // 16 blocks (k32 step, row): four fragments, nine MFMAs; the fragments of block n + 1 requested before block n multiplies
-        auto frag = [&](int blk, int d) -> bf16x8 {
-            const int k = blk >> 2, i = blk & 3, kc = k >> 1, hf = k & 1, dh = d >> 1, dw = d & 1;
-            return lds_frag(aL[dw][hf] + boff + (unsigned)kc * DCHUNK_B + (unsigned)((i + dh) * DPITCH) * 128u);
+        // Row slots L = 9 k + r (k32 step k, halo row r): 36 per tile, two fragments each (dw = 0, 1), in a ring of four.
+        // Block (k, i) multiplies the slots 9 k + i (dh = 0) and 9 k + i + 1 (dh = 1) and first requests every slot up to
+        // three ahead of its own (the ring slot it overwrites belongs to a block that is done).
+        bf16x8 R[4][2];
+        auto load_slot = [&](int L) {
+            const int k = L / 9, r = L - 9 * k, kc = k >> 1, hf = k & 1;
+            const unsigned a = boff + (unsigned)kc * DCHUNK_B + (unsigned)(r * DPITCH) * 128u;
+            R[L & 3][0] = lds_frag(aL[0][hf] + a);
+            if (TYPE == 0 || r != TH) R[L & 3][1] = lds_frag(aL[1][hf] + a);     // type 1 never shifts row 8 sideways
         };
-        bf16x8 af[2][4];
+        load_slot(0); load_slot(1); load_slot(2);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) af[0][d] = frag(0, d);
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int blk = 0; blk < 16; ++blk) {
-            const int k = blk >> 2, i = blk & 3;
-            if (blk + 1 < 16) {
+            for (int i = 0; i < TH; ++i) {
+                const int base = 9 * k + i;
+                const int prev_hi = (k == 0 && i == 0) ? 2 : ((i == 0 ? 9 * (k - 1) + TH - 1 : base - 1) + 3 > 35 ? 35 : (i == 0 ? 9 * (k - 1) + TH - 1 : base - 1) + 3);
+                const int hi = base + 3 > 35 ? 35 : base + 3;
+                int nload = 0;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) af[(blk + 1) & 1][d] = frag(blk + 1, d);
+                for (int L = 0; L < 36; ++L)
+                    if (L > prev_hi && L <= hi) { load_slot(L); nload += (TYPE == 0 || (L % 9) != TH) ? 2 : 1; }
+#pragma unroll
+                for (int t = 0; t < T::N; ++t)
+                    acc[T::slot[t]][i] = mfma<H16>(wf[t][k], R[(base + T::dh[t]) & 3][T::dw[t]], acc[T::slot[t]][i]);
+                if (nload == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                else if (nload == 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                else if (nload == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (nload == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, T::N, 0);
             }
-            const bf16x8 f00 = af[blk & 1][0], f01 = af[blk & 1][1], f10 = af[blk & 1][2], f11 = af[blk & 1][3];
-            // tap (kh, kw) = wf[3 kh + kw]; shift dh = (kh == 0), dw = (kw == 0); class a = (kh != 1), b = (kw != 1)
-            acc[0][i] = mfma<H16>(wf[4][k], f00, acc[0][i]);        // (1,1)
-            acc[1][i] = mfma<H16>(wf[3][k], f01, acc[1][i]);        // (1,0)
-            acc[1][i] = mfma<H16>(wf[5][k], f00, acc[1][i]);        // (1,2)
-            acc[2][i] = mfma<H16>(wf[1][k], f10, acc[2][i]);        // (0,1)
-            acc[2][i] = mfma<H16>(wf[7][k], f00, acc[2][i]);        // (2,1)
-            acc[3][i] = mfma<H16>(wf[0][k], f11, acc[3][i]);        // (0,0)
-            acc[3][i] = mfma<H16>(wf[2][k], f10, acc[3][i]);        // (0,2)
-            acc[3][i] = mfma<H16>(wf[6][k], f01, acc[3][i]);        // (2,0)
-            acc[3][i] = mfma<H16>(wf[8][k], f00, acc[3][i]);        // (2,2)
-            if (blk + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
         }
-        // epilogue: class (a, b), row i -> dx pixel (2 (ty 8 + rh 4 + i) + a, 2 (tx 16 + l15) + b), channels n0 + 4 g4 .. + 3
+        // epilogue: slot c = class (a, b), row i -> dx pixel (2 (ty 8 + i) + a, 2 (tx 16 + l15) + b), channels n0 + 4 g4 .. + 3
         const int b = tile / (p.TX * p.TY);
         const int rem = tile - b * (p.TX * p.TY);
         const int ty = rem / p.TX, tx = rem - ty * p.TX;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int oh = 2 * (ty * TH + rh * 4 + i) + (c >> 1), ow = 2 * (tx * TW + l15) + (c & 1);
+            for (int i = 0; i < TH; ++i) {
+                const int oh = 2 * (ty * TH + i) + (T::cls[c] >> 1), ow = 2 * (tx * TW + l15) + (T::cls[c] & 1);
                 const size_t pix = ((size_t)b * (2 * p.Ho) + oh) * (2 * p.Wo) + ow;
                 store4<H16>(p.y, p.y16, pix * p.y_cs + (n0 + 4 * g4), acc[c][i], bv, p.act);
             }
         after_store = true;
     }
+}
+
+template <bool H16>
+__global__ void __launch_bounds__(512) conv_s2d_kernel(const S2DKP p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, lst = blockIdx.x >> 3;
+    const int per_xcd = (p.tiles + 7) / 8, lists_x = p.lists / 8;
+    const int per_list = (per_xcd + lists_x - 1) / lists_x;
+    const int t_begin = xcd * per_xcd + lst * per_list;
+    const int t_end = min(min(t_begin + per_list, (xcd + 1) * per_xcd), p.tiles);
+    if (t_begin >= t_end) return;
+    if (wave < 4) conv_s2d_body<H16, 0>(p, smem, lane, wave, t_begin, t_end);
+    else conv_s2d_body<H16, 1>(p, smem, lane, wave, t_begin, t_end);
 }
 
 int g_cus = 0;
