@@ -28,6 +28,9 @@ __device__ __forceinline__ void split3(const float* v, bf16x8& t0, bf16x8& t1, b
 //         3: one product (plain bf16 operands)
 //         4: six products, one accumulator, LARGE term first
 //         5: as 1, and both accumulators restarted every 128 k and folded into fp32 totals (two-level, as the native kernel's)
+//         6: ONE accumulator set: per k32 step the six products chained from C = 0 (small terms first, a0b0 last) into a
+//            transient, folded into the total by one fp32 add - two-level summation with a 32-deep inner chain
+//         7: as 6 with the transient spanning TWO k32 steps (64-deep inner chain)
 template <int VARIANT>
 __global__ void __launch_bounds__(64) split_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                          int64_t M, int K, int N) {
@@ -56,6 +59,10 @@ __global__ void __launch_bounds__(64) split_gemm_kernel(const float* __restrict_
                 tot += hi + lo;
                 hi = (f32x4){0.f, 0.f, 0.f, 0.f}; lo = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        } else if (VARIANT == 6 || VARIANT == 7) {
+            if (VARIANT == 6 || (k0 & 32) == 0) lo = (f32x4){0.f, 0.f, 0.f, 0.f};
+            MM(lo, a2, b0); MM(lo, a0, b2); MM(lo, a1, b1); MM(lo, a1, b0); MM(lo, a0, b1); MM(lo, a0, b0);
+            if (VARIANT == 6 || (k0 & 32) != 0) tot += lo;
         } else if (VARIANT == 2) {
             MM(hi, a1, b0); MM(hi, a0, b1); MM(hi, a0, b0);
         } else if (VARIANT == 3) {
@@ -65,7 +72,7 @@ __global__ void __launch_bounds__(64) split_gemm_kernel(const float* __restrict_
         }
 #undef MM
     }
-    const f32x4 out = VARIANT == 5 ? tot + (hi + lo) : (VARIANT == 1 ? hi + lo : hi);
+    const f32x4 out = VARIANT == 5 ? tot + (hi + lo) : (VARIANT == 1 ? hi + lo : ((VARIANT == 6 || VARIANT == 7) ? tot : hi));
     // D: column (second operand's row) = l15, row (first operand's row) = 4 g4 + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) C[(m0 + 4 * g4 + r) * N + n0 + l15] = out[r];
@@ -99,6 +106,8 @@ extern "C" int split6_gemm(const float* A, const float* B, float* C, int64_t M, 
         case 3: hipLaunchKernelGGL(split_gemm_kernel<3>, grid, dim3(64), 0, st, A, B, C, M, K, N); break;
         case 4: hipLaunchKernelGGL(split_gemm_kernel<4>, grid, dim3(64), 0, st, A, B, C, M, K, N); break;
         case 5: hipLaunchKernelGGL(split_gemm_kernel<5>, grid, dim3(64), 0, st, A, B, C, M, K, N); break;
+        case 6: hipLaunchKernelGGL(split_gemm_kernel<6>, grid, dim3(64), 0, st, A, B, C, M, K, N); break;
+        case 7: hipLaunchKernelGGL(split_gemm_kernel<7>, grid, dim3(64), 0, st, A, B, C, M, K, N); break;
         case 10: hipLaunchKernelGGL(chain_gemm_kernel<1>, dim3((unsigned)((M * N + 255) / 256), 1, P), dim3(256), 0, st, A, B, C, M, K, N); break;
         case 11: hipLaunchKernelGGL(chain_gemm_kernel<2>, dim3((unsigned)((M * N + 255) / 256), 1, P), dim3(256), 0, st, A, B, C, M, K, N); break;
         default: return 2;

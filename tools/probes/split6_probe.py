@@ -59,6 +59,8 @@ rows = [("native fp32 MFMA, one level (mmh_wino_gemm_levels 1)", native(1)),
         ("SIX bf16 products, one accumulator, large term first", split(4)),
         ("SIX bf16 products, hi / lo accumulators", split(1)),
         ("SIX bf16 products, hi / lo, folded into totals every 128 k", split(5)),
+        ("SIX bf16 products, ONE set: chain from 0 per k32, fp32 fold", split(6)),
+        ("SIX bf16 products, ONE set: chain from 0 per k64, fp32 fold", split(7)),
         ("three bf16 products (a0b0 + a0b1 + a1b0)", split(2)),
         ("one bf16 product (plain bf16 operands)", split(3))]
 print(f"B={B}: {P} planes x [{tiles} x {Cin}] . [{Cin} x {Cout}], real F(6x6,3x3) operands; relative L1 / max-norm error against fp64")
