@@ -397,6 +397,15 @@ int mmh_norm_stats_merge2(const void* partials, int chunks, int C, int sub, void
 int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, int C, double count,
                                   float eps, void* mean, void* m2, void* scale, void* shift,
                                   void* invstd, mmh_stream_t s);
+/* SyncBN (apex convert_syncbn_model, models/MMHandModel.py:109-116): the (count, mean, M2) triples of one norm site as the
+ * ranks' all-gather delivered them - rank r's triple at gathered + r * rank_stride floats, [3][C] - merged in rank order
+ * (Chan) AND finalised (affine, running statistics with momentum and the unbiased variance) in one launch: the same values as
+ * mmh_norm_stats_merge on the [ranks][3][C] block followed by mmh_norm_finalize, without the block copy and the two launches.
+ * count = rows over all ranks.                                                                                          */
+int mmh_syncbn_merge_finalize(const void* gathered, int ranks, int64_t rank_stride, int C, double count,
+                              float eps, const void* gamma, const void* beta, void* mean, void* m2,
+                              void* scale, void* shift, void* invstd, void* running_mean,
+                              void* running_var, float momentum, mmh_stream_t s);
 /* scale = gamma*rsqrt(m2/count+eps), shift = beta - mean*scale, invstd.
  * gamma/beta may be NULL (affine=False).  If running_mean != NULL (batch
  * norm, groups==1) they are updated with momentum and the unbiased variance

@@ -138,7 +138,13 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
                                  float* __restrict__ mean, float* __restrict__ m2, double count = 0.0,
                                  float eps = 0.f, float* __restrict__ scale = nullptr,
                                  float* __restrict__ shift = nullptr, float* __restrict__ invstd = nullptr,
-                                 float* __restrict__ cnt = nullptr, int ostride = 0) {
+                                 float* __restrict__ cnt = nullptr, int ostride = 0, int64_t istride = 0,
+                                 const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                 float* __restrict__ rmean = nullptr, float* __restrict__ rvar = nullptr,
+                                 float momentum = 0.f) {
+    // istride != 0: chunk k of group g starts at (g * chunks + k) * istride instead of ... * 3 C (the SyncBN message of several
+    // norm sites gathered as one row per rank: a site's triple sits at a column offset of every row)
+    const int64_t cstride = istride ? istride : (int64_t)3 * C;
     // 32 channels x 8 chunk-lanes per block: each lane merges its chunks (Chan), then the 8
     // lanes are merged in a fixed order.
     __shared__ double sh[3][8][32];
@@ -164,7 +170,7 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
             float nb[8], mb[8], qb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int64_t o = ((int64_t)(grp * chunks + k + 8 * u) * 3) * C + c;
+                const int64_t o = (int64_t)(grp * chunks + k + 8 * u) * cstride + c;
                 nb[u] = ws[o]; mb[u] = ws[o + C]; qb[u] = ws[o + 2 * C];
             }
 #pragma unroll
@@ -174,14 +180,14 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
             float nb[4], mb[4], qb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t o = ((int64_t)(grp * chunks + k + 8 * u) * 3) * C + c;
+                const int64_t o = (int64_t)(grp * chunks + k + 8 * u) * cstride + c;
                 nb[u] = ws[o]; mb[u] = ws[o + C]; qb[u] = ws[o + 2 * C];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) merge(nb[u], mb[u], qb[u]);
         }
         for (; k < chunks; k += 8) {
-            const int64_t o = ((int64_t)(grp * chunks + k) * 3) * C + c;
+            const int64_t o = (int64_t)(grp * chunks + k) * cstride + c;
             merge(ws[o], ws[o + C], ws[o + 2 * C]);
         }
     }
@@ -202,13 +208,20 @@ __global__ void norm_stats_final(const float* __restrict__ ws, int groups, int C
         mean[oi] = meanf;
         m2[oi] = m2f;
         if (cnt) cnt[oi] = (float)na;
-        if (scale) {
+        if (scale) {        // norm_finalize_kernel's arithmetic, operation for operation
             const float var = (float)((double)m2f / count);
             const float is = 1.f / sqrtf(var + eps);
-            const float sc = 1.f * is;
+            const float gm = gamma ? gamma[c] : 1.f;
+            const float bt = beta ? beta[c] : 0.f;
+            const float sc = gm * is;
             scale[i] = sc;
-            shift[i] = 0.f - meanf * sc;
+            shift[i] = bt - meanf * sc;
             invstd[i] = is;
+            if (rmean && i < C) {
+                const float unb = count > 1.0 ? (float)((double)m2f / (count - 1.0)) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * meanf;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+            }
         }
     }
 }
@@ -2054,6 +2067,20 @@ int mmh_norm_stats_merge_finalize(const void* partials, int groups, int chunks, 
                        static_cast<float*>(m2), count, eps, static_cast<float*>(scale), static_cast<float*>(shift),
                        static_cast<float*>(invstd));
     return mmh::check_launch("norm_stats_merge_finalize");
+}
+
+int mmh_syncbn_merge_finalize(const void* gathered, int ranks, int64_t rank_stride, int C, double count, float eps,
+                              const void* gamma, const void* beta, void* mean, void* m2, void* scale, void* shift, void* invstd,
+                              void* running_mean, void* running_var, float momentum, mmh_stream_t s) {
+    MMH_REQUIRE(gathered && mean && m2 && scale && shift && invstd && ranks > 0 && C > 0 && count > 0 && rank_stride >= 3 * (int64_t)C,
+                "mmh_syncbn_merge_finalize: bad arguments (rank_stride >= 3 C floats)");
+    MMH_REQUIRE(!running_mean || running_var, "mmh_syncbn_merge_finalize: running_mean without running_var");
+    hipLaunchKernelGGL(norm_stats_final, dim3((C + 31) / 32), dim3(TPB), 0, mmh::as_stream(s), static_cast<const float*>(gathered), 1, C,
+                       ranks, static_cast<float*>(mean), static_cast<float*>(m2), count, eps, static_cast<float*>(scale),
+                       static_cast<float*>(shift), static_cast<float*>(invstd), nullptr, 0, rank_stride,
+                       static_cast<const float*>(gamma), static_cast<const float*>(beta), static_cast<float*>(running_mean),
+                       static_cast<float*>(running_var), momentum);
+    return mmh::check_launch("syncbn_merge_finalize");
 }
 
 int mmh_norm_finalize(const void* mean, const void* m2, double count, const void* gamma,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "mmh_norm_stats_ws_bytes": (_sz, [_i, _i64, _i]),
     "mmh_norm_stats": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _i, _vp]),
     "mmh_norm_finalize": (_i, [_vp, _vp, _d, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+    "mmh_syncbn_merge_finalize": (_i, [_vp, _i, _i64, _i, _d, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "mmh_scale_shift_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _i, _vp]),
     "mmh_scale_shift_act_twin": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _f, _u64, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "mmh_norm_bwd_ws_bytes": (_sz, [_i, _i64, _i]),
@@ -211,4 +212,6 @@ def check(rc, what):
 
 def call(name, *args):
     """Invoke a status-returning entry point and raise on error."""
-    check(getattr(load(), name)(*args), name)
+    rc = getattr(_lib or load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -26,9 +26,18 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
     # current stream of the CURRENT device: MMHandModel / the drivers set the device to the rank's
-    # GPU before anything runs (one process per GPU), tensors are created on that same device
+    # GPU before anything runs (one process per GPU), tensors are created on that same device.
+    # Through torch's raw bindings: torch.cuda.current_stream() builds a Stream object behind three layers of device-index
+    # helpers - 9 us per call, 1000 calls per step: 4.4 of the 40 ms the host needs to enqueue a 512x512 SyncBN step
+    # (tools/probes/host_profile.py) - the raw pair is 0.3 us and returns the same handle (tests/test_pointwise_gpu.py)
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -1938,6 +1947,8 @@ def _sync_stats(mean, m2, rows, group):
         # flat [world*3, C]: the shape both RCCL and gloo accept for all_gather_into_tensor
         gathered = torch.empty((world * 3, packed.shape[1]), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(gathered, packed, group=group)
+        if USE_SYNCBN_FUSED:
+            return _GatheredStats(gathered.view(world, 3 * packed.shape[1]), 0, world, mean.shape[1], rows * world), None, rows * world
         gmean = torch.empty_like(mean)
         gm2 = torch.empty_like(m2)
         L.call("mmh_norm_stats_merge", _ptr(gathered), 1, world, mean.shape[1], _ptr(gmean), _ptr(gm2), _stream())
@@ -1954,6 +1965,29 @@ def _sync_stats(mean, m2, rows, group):
 
 # collectives issued by the norm layers (SyncBN), for tests / diagnostics: {"all_gather": n, "all_reduce": n}
 collective_counter = {}
+
+
+class _GatheredStats:
+    """One site's (count, mean, M2) triples as the all-gather delivered them: rank r's at buf[r, off : off + 3 C].  The merge
+    over the ranks happens together with the finalisation (mmh_syncbn_merge_finalize: one launch per site instead of a block
+    copy, a merge and a finalise - 101 sites per iteration).  MMH_SYNCBN_FUSED=0: merge here, finalise later (the round-4
+    path; same values)."""
+    __slots__ = ("buf", "off", "world", "C", "count")
+
+    def __init__(self, buf, off, world, Cc, count):
+        self.buf, self.off, self.world, self.C, self.count = buf, off, world, Cc, count
+
+    def finalize(self, gamma, beta, running_mean, running_var, momentum=0.1):
+        dev = self.buf.device
+        mean = torch.empty((1, self.C), dtype=torch.float32, device=dev)
+        m2 = torch.empty_like(mean); scale = torch.empty_like(mean); shift = torch.empty_like(mean); invstd = torch.empty_like(mean)
+        L.call("mmh_syncbn_merge_finalize", C.c_void_p(self.buf.data_ptr() + 4 * self.off), self.world, self.buf.stride(0), self.C,
+               float(self.count), EPS, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(m2), _ptr(scale), _ptr(shift), _ptr(invstd),
+               _ptr(running_mean), _ptr(running_var), momentum, _stream())
+        return mean, m2, scale, shift, invstd
+
+
+USE_SYNCBN_FUSED = os.environ.get("MMH_SYNCBN_FUSED", "1") != "0"
 
 
 def _sync_stats_multi(items, group):
@@ -1979,6 +2013,10 @@ def _sync_stats_multi(items, group):
     out, off = [], 0
     for m, m2, rows in items:
         Cc = m.shape[1]
+        if m.is_cuda and USE_SYNCBN_FUSED:
+            out.append((_GatheredStats(gathered, off, world, Cc, rows * world), None, rows * world))
+            off += 3 * Cc
+            continue
         blk = gathered[:, off:off + 3 * Cc].reshape(world * 3, Cc).contiguous()        # [world][3][C]
         off += 3 * Cc
         if m.is_cuda:
@@ -2066,7 +2104,10 @@ def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, runni
         count = rows
         if synced is not None:
             mean, m2, count = synced
-        scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var)
+        if isinstance(mean, _GatheredStats):        # SyncBN: merge over the ranks and finalise in one launch
+            mean, m2, scale, shift, invstd = mean.finalize(gamma, beta, running_mean, running_var)
+        else:
+            scale, shift, invstd = raw_norm_finalize(mean, m2, count, gamma, beta, running_mean, running_var)
     ctx.defer = int(defer)
     if defer == 3:
         # defer 3 (a block's last norm: no ReLU, no dropout; its output feeds a gate / residual add and is

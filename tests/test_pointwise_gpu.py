@@ -416,3 +416,48 @@ def test_norm_stats_merge_finalize_vs_fp64(groups, chunks, C, dev):
     is_w = 1.0 / torch.sqrt(m2_w / rows + ops.EPS)
     assert float(((invstd - is_w).abs() / is_w)[sel].max() if bool(sel.any()) else 0.0) <= 2e-5
     assert torch.allclose(scale, invstd) and torch.allclose(shift, -(mean * invstd), rtol=1e-5, atol=1e-6)
+
+
+def test_stream_handle_fast_path_matches_torch(dev):
+    """ops._stream() reads the current stream through torch's raw bindings (0.3 us instead of 9 us per C-ABI call): the same
+    handle torch.cuda.current_stream() reports - on the default stream, inside a side-stream context and after it."""
+    from mmhand_amd import ops
+    assert ops._stream().value == torch.cuda.current_stream().cuda_stream or (
+        ops._stream().value is None and torch.cuda.current_stream().cuda_stream == 0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert ops._stream().value == side.cuda_stream
+        assert ops._stream().value == torch.cuda.current_stream().cuda_stream
+    assert (ops._stream().value or 0) == torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("world,C,affine", [(1, 64, True), (2, 256, True), (8, 512, True), (4, 128, False)])
+def test_syncbn_merge_finalize_equals_merge_then_finalize(world, C, affine, dev):
+    """mmh_syncbn_merge_finalize (one launch per SyncBN site instead of a block copy, mmh_norm_stats_merge and
+    mmh_norm_finalize) on a site's triples at a column offset of the all-gather's rows: mean, M2, scale, shift, invstd and the
+    running statistics bit for bit those of the two calls on the copied [ranks][3][C] block."""
+    import ctypes as C_
+    from mmhand_amd import lib as L, ops
+    g = torch.Generator().manual_seed(world * 1000 + C)
+    off, other = 3 * 32, 3 * 48                      # two more sites packed around this one in the message
+    rows = 4096.0
+    buf = torch.randn((world, off + 3 * C + other), generator=g).to(dev)
+    blk = buf[:, off:off + 3 * C].reshape(world, 3, C)
+    blk[:, 0] = rows
+    blk[:, 2] = blk[:, 2].abs() * 50.0
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev) if affine else None
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev) if affine else None
+    rm0, rv0 = torch.randn(C, generator=g).to(dev), (1.0 + torch.rand(C, generator=g)).to(dev)
+    count = rows * world
+    # the two-call path
+    cb = blk.reshape(world * 3, C).contiguous()
+    mean_a = torch.empty((1, C), device=dev); m2_a = torch.empty_like(mean_a)
+    L.call("mmh_norm_stats_merge", ops._ptr(cb), 1, world, C, ops._ptr(mean_a), ops._ptr(m2_a), ops._stream())
+    rm_a, rv_a = rm0.clone(), rv0.clone()
+    sc_a, sh_a, is_a = ops.raw_norm_finalize(mean_a, m2_a, count, gamma, beta, rm_a, rv_a)
+    # the fused call, reading the message in place
+    rm_b, rv_b = rm0.clone(), rv0.clone()
+    mean_b, m2_b, sc_b, sh_b, is_b = ops._GatheredStats(buf, off, world, C, count).finalize(gamma, beta, rm_b, rv_b)
+    for a, b in ((mean_a, mean_b), (m2_a, m2_b), (sc_a, sc_b), (sh_a, sh_b), (is_a, is_b), (rm_a, rm_b), (rv_a, rv_b)):
+        assert torch.equal(a, b)
+    assert not torch.equal(rm_a, rm0) and torch.isfinite(sc_b).all()
