@@ -1857,17 +1857,18 @@ def set_dropout_seed(seed):
     _seed_counter[0] = int(seed) % (1 << 64)
 
 
-def raw_norm_stats(x, groups):
+def raw_norm_stats(x, groups, out=None):
     """mean, M2 per (group, channel); groups = B (instance) or 1 (batch).  For instance norm right
     after a Winograd F(6x6,3x3) conv the per-tile partials written by its output transform are
-    merged instead of reading x again."""
+    merged instead of reading x again.  out = (mean, m2): contiguous [groups, C] fp32 tensors to write into (slots of a
+    SyncBN message buffer: no packing pass afterwards)."""
     B, H, W_, Cc = x.shape
     rows = (B // groups) * H * W_
     pend = _take_stats(x) if groups in (B, 1) else None
     if pend is not None:
         stats = pend[0]         # [B][chunks][3][C]; BatchNorm (groups == 1): the same array as one group of B * chunks
-        mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
-        m2 = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+        mean = out[0] if out is not None else torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+        m2 = out[1] if out is not None else torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
         chunks = stats.shape[1] * (B // groups)
         if groups == 1 and B > 1 and chunks >= 128:
             # one group, B * chunks-per-image partials per channel: merge per image in parallel, then the B results
@@ -1878,8 +1879,8 @@ def raw_norm_stats(x, groups):
             L.call("mmh_norm_stats_merge", _ptr(stats), groups, chunks, Cc, _ptr(mean), _ptr(m2), _stream())
         return mean, m2, rows
     ws = torch.empty(L.load().mmh_norm_stats_ws_bytes(groups, rows, Cc) // 4 + 4, dtype=torch.float32, device=x.device)
-    mean = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
-    m2 = torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+    mean = out[0] if out is not None else torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
+    m2 = out[1] if out is not None else torch.empty((groups, Cc), dtype=torch.float32, device=x.device)
     L.call("mmh_norm_stats", _ptr(x), groups, rows, Cc, Cc, _ptr(mean), _ptr(m2), _ptr(ws),
            ws.numel() * 4, _tdt(x), _stream())
     return mean, m2, rows
@@ -1988,21 +1989,47 @@ class _GatheredStats:
 
 
 USE_SYNCBN_FUSED = os.environ.get("MMH_SYNCBN_FUSED", "1") != "0"
+# the statistics / backward-sum kernels of a packed SyncBN node write straight into the collective's message buffer
+# (stats_message / sums_message); MMH_SYNCBN_MSG=0: separate tensors, packed by torch.cat afterwards (the round-4 path)
+USE_SYNCBN_MSG = os.environ.get("MMH_SYNCBN_MSG", "1") != "0"
 
 
-def _sync_stats_multi(items, group):
+def stats_message(sizes, rows, device):
+    """The all-gather message of a pack of SyncBN sites, allocated BEFORE the sites compute their statistics: per site
+    [count | mean | M2], C floats each.  The count slots are filled here (one launch when the sites share a row count, as
+    the packs of the step do), the statistics kernels write mean / M2 straight into their slots (raw_norm_stats out=): no
+    full_like / cat / cat per site afterwards (~6 tiny torch kernels and 60 us of host time per site).
+    -> (buffer, [(mean view, m2 view) per site])"""
+    total = 3 * sum(sizes)
+    if len(set(rows)) == 1:
+        buf = torch.full((total,), float(rows[0]), dtype=torch.float32, device=device)
+    else:
+        buf = torch.empty((total,), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for Cc, r in zip(sizes, rows):
+        if len(set(rows)) != 1:
+            buf[off:off + Cc].fill_(float(r))
+        views.append((buf[off + Cc:off + 2 * Cc].view(1, Cc), buf[off + 2 * Cc:off + 3 * Cc].view(1, Cc)))
+        off += 3 * Cc
+    return buf, views
+
+
+def _sync_stats_multi(items, group, packed=None):
     """SyncBN statistics of several norm sites with ONE collective: items = [(mean [1,C], m2 [1,C], rows), ...] ->
     [(gmean, gm2, count), ...].  The sites' (count, mean, M2) triples travel as one flat message (all_gather of
-    sum 3 C_i floats per rank); each site then merges its [world][3][C] block with Chan's formula on the device."""
+    sum 3 C_i floats per rank); each site then merges its [world][3][C] block with Chan's formula on the device.
+    packed: the message, already holding every site's triple (stats_message)."""
     import torch.distributed as dist
-    if len(items) == 1:
+    if len(items) == 1 and packed is None:
         return [_sync_stats(*items[0], group)]
     if DP_NO_COMM:
         return [(m, m2, rows) for m, m2, rows in items]
     world = dist.get_world_size(group)
     collective_counter["all_gather"] = collective_counter.get("all_gather", 0) + 1
-    collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(items)
-    packed = torch.cat([torch.cat([torch.full_like(m, float(rows)), m, m2], 0).reshape(-1) for m, m2, rows in items])
+    if len(items) > 1:
+        collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(items)
+    if packed is None:
+        packed = torch.cat([torch.cat([torch.full_like(m, float(rows)), m, m2], 0).reshape(-1) for m, m2, rows in items])
     gathered = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
     if packed.is_cuda:
         dist.all_gather_into_tensor(gathered.view(-1), packed, group=group)
@@ -2030,6 +2057,17 @@ def _sync_stats_multi(items, group):
     return out
 
 
+def sums_message(sizes, device):
+    """The all-reduce message of a pack of SyncBN sites' backward sums, allocated before the reduce kernels run: per site
+    [s1 | s2], C floats each; the kernels write into their slots (_norm_bwd_local sums_out=).  -> (buffer, [(s1, s2) views])"""
+    buf = torch.empty((2 * sum(sizes),), dtype=torch.float32, device=device)
+    views, off = [], 0
+    for Cc in sizes:
+        views.append((buf[off:off + Cc].view(1, Cc), buf[off + Cc:off + 2 * Cc].view(1, Cc)))
+        off += 2 * Cc
+    return buf, views
+
+
 def _sync_bwd_sums_multi(pairs, group):
     """the backward sums (s1, s2) of several norm sites all-reduced as ONE message; pairs = [(s1, s2), ...]"""
     import torch.distributed as dist
@@ -2048,6 +2086,26 @@ def _sync_bwd_sums_multi(pairs, group):
     return out
 
 
+def _sync_bwd_sums_inplace(packed, pairs, group):
+    """As _sync_bwd_sums_multi when the pairs already ARE the slots of the message `packed` (sums_message): the local sums are
+    kept in ONE clone (the affine parameters' gradients want them), the all-reduce runs in place and the global sums are the
+    same views -> (local pairs, global pairs)."""
+    import torch.distributed as dist
+    if DP_NO_COMM:
+        return list(pairs), list(pairs)
+    collective_counter["all_reduce"] = collective_counter.get("all_reduce", 0) + 1
+    if len(pairs) > 1:
+        collective_counter["packed_sites"] = collective_counter.get("packed_sites", 0) + len(pairs)
+    local = packed.clone()
+    dist.all_reduce(packed, group=group)
+    loc, off = [], 0
+    for s1, s2 in pairs:
+        n = s1.numel()
+        loc.append((local[off:off + n].view_as(s1), local[off + n:off + 2 * n].view_as(s2)))
+        off += 2 * n
+    return loc, list(pairs)
+
+
 class _SiteCtx:
     """What the norm forward / backward phases below need of an autograd ctx, for ONE site of a multi-site node"""
 
@@ -2064,7 +2122,7 @@ class _SiteCtx:
 # The norm node in four phases, so that several sites can share their collectives (NormActMultiFn):
 #   forward:  _norm_fwd_local (statistics of this rank) -> [SyncBN: all-gather + merge] -> _norm_fwd_finish
 #   backward: _norm_bwd_local (sums of this rank)       -> [SyncBN: all-reduce]         -> _norm_bwd_finish
-def _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16):
+def _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16, stat_out=None):
     ctx.in_lp = x16 is not None
     ctx.out_lp = bool(out_lp)
     if x16 is not None:
@@ -2080,7 +2138,7 @@ def _norm_fwd_local(ctx, x, gamma, beta, mode, relu, drop_p, out_lp, x16):
     fast = raw_norm_stats_finalize_pending(x, groups) if (mode == "instance" and gamma is None and beta is None) else None
     if fast is not None:
         return x, groups, fast, None, None, fast[4]
-    mean, m2, rows = raw_norm_stats(x, groups)
+    mean, m2, rows = raw_norm_stats(x, groups, out=stat_out)
     return x, groups, None, mean, m2, rows
 
 
@@ -2158,8 +2216,9 @@ def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, runni
 USE_NORM_BWD_PLANE = os.environ.get("MMH_NORM_BWD_PLANE", "0") == "1"
 
 
-def _norm_bwd_local(ctx, g):
-    """this rank's sums (s1 = sum dz, s2 = sum dz * xhat per plane) -> (g, s1, s2)"""
+def _norm_bwd_local(ctx, g, sums_out=None):
+    """this rank's sums (s1 = sum dz, s2 = sum dz * xhat per plane) -> (g, s1, s2); sums_out = (s1, s2): slots of a SyncBN
+    message buffer to write into (groups == 1)"""
     groups, rows, count, relu, drop_p, sync_group, has_res = ctx.cfg
     ctx.fused_dx = None
     if ctx.defer:
@@ -2167,7 +2226,7 @@ def _norm_bwd_local(ctx, g):
         g = g.contiguous()
         Cc = x.shape[3]
         ws = _ws(L.load().mmh_norm_bwd_ws_bytes(groups, rows, Cc), x)
-        s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+        s1, s2 = sums_out if sums_out is not None else (_empty((groups, Cc), x), _empty((groups, Cc), x))
         L.call("mmh_norm_bwd_reduce_rc", _ptr(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift),
                _ptr(dbits), groups, rows, Cc, int(relu), drop_p, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4, _stream())
         return g, s1, s2
@@ -2178,7 +2237,7 @@ def _norm_bwd_local(ctx, g):
     g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
     Cc = x.shape[3]
     masked = 2 if (relu or drop_p > 0) else 0
-    s1 = _empty((groups, Cc), x); s2 = _empty((groups, Cc), x)
+    s1, s2 = sums_out if sums_out is not None else (_empty((groups, Cc), x), _empty((groups, Cc), x))
     if (USE_NORM_BWD_PLANE and sync_group is None and x.dtype != torch.float32 and g.dtype in (torch.float32, x.dtype)
             and L.load().mmh_norm_bwd_fused_supported(groups, rows, Cc, masked, _tdt(g), _tdt(x))):
         dx = torch.empty_like(x)
@@ -2292,16 +2351,22 @@ class NormActMultiFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         assert len(flat) == n * NORM_SITE_ARGS
         sites, args, states = [], [], []
+        # SyncBN on the device: the all-gather's message exists first and the statistics kernels write into it (stats_message)
+        msg = slots = None
+        if sync_group is not None and USE_SYNCBN_MSG and not DP_NO_COMM and all(flat[i * NORM_SITE_ARGS].is_cuda for i in range(n)):
+            xs = [flat[i * NORM_SITE_ARGS] for i in range(n)]
+            msg, slots = stats_message([x.shape[3] for x in xs], [x.shape[0] * x.shape[1] * x.shape[2] for x in xs], xs[0].device)
         for i in range(n):
             a = flat[i * NORM_SITE_ARGS:(i + 1) * NORM_SITE_ARGS]
             x, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, out_lp, x16, defer, _ = a
             sc = _SiteCtx()
-            states.append(_norm_fwd_local(sc, x, gamma, beta, "batch", relu, drop_p, out_lp, x16))
+            states.append(_norm_fwd_local(sc, x, gamma, beta, "batch", relu, drop_p, out_lp, x16,
+                                          stat_out=slots[i] if slots is not None else None))
             sites.append(sc)
             args.append(a)
         synced = [None] * n
         if sync_group is not None:
-            synced = _sync_stats_multi([(st[3], st[4], st[5]) for st in states], sync_group)
+            synced = _sync_stats_multi([(st[3], st[4], st[5]) for st in states], sync_group, packed=msg)
         outs, saved, counts, nondiff = [], [], [], []
         for sc, st, sy, a in zip(sites, states, synced, args):
             x, gamma, beta, residual, rmean, rvar, relu, drop_p, seed, mask, out_lp, x16, defer, _ = a
@@ -2326,10 +2391,21 @@ class NormActMultiFn(torch.autograd.Function):
             sc.saved_tensors = saved[off:off + c]
             off += c
         live = [i for i in range(n) if grads[i * NORM_SITE_OUTS] is not None]
-        loc = {i: _norm_bwd_local(ctx.sites[i], grads[i * NORM_SITE_OUTS]) for i in live}
+        # SyncBN on the device: the reduce kernels write their sums into the all-reduce's message (sums_message)
+        msg = slots = None
+        if (ctx.sync_group is not None and live and USE_SYNCBN_MSG and not DP_NO_COMM
+                and all(grads[i * NORM_SITE_OUTS].is_cuda and ctx.sites[i].cfg[0] == 1 for i in live)):
+            msg, sl = sums_message([ctx.sites[i].saved_tensors[0].shape[3] for i in live], grads[live[0] * NORM_SITE_OUTS].device)
+            slots = dict(zip(live, sl))
+        loc = {i: _norm_bwd_local(ctx.sites[i], grads[i * NORM_SITE_OUTS], sums_out=slots[i] if slots is not None else None)
+               for i in live}
         glob = {i: (loc[i][1], loc[i][2]) for i in live}
         if ctx.sync_group is not None and live:
-            red = _sync_bwd_sums_multi([glob[i] for i in live], ctx.sync_group)
+            if msg is not None:
+                lo, red = _sync_bwd_sums_inplace(msg, [glob[i] for i in live], ctx.sync_group)
+                loc = {i: (loc[i][0], l1, l2) for i, (l1, l2) in zip(live, lo)}
+            else:
+                red = _sync_bwd_sums_multi([glob[i] for i in live], ctx.sync_group)
             glob = dict(zip(live, red))
         out = [None, None]
         for i in range(n):
