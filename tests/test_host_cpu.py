@@ -282,3 +282,33 @@ def test_cpu_baseline_thread_sweep_reports_the_fastest(monkeypatch):
     monkeypatch.setattr(bench.os, "cpu_count", lambda: 8)
     out = bench.cpu_baseline_with_sweep(256, 256, "instance")
     assert out["value"] == 0.6 and out["thread_sweep"]["32"]["value"] is None
+
+
+def test_stride2_dgrad_kernel_has_no_register_spills():
+    """conv_s2d_kernel must not touch scratch: a spilled DMA address or weight fragment is reloaded inside the tile loop by
+    scratch_load + s_waitcnt vmcnt(0), which drains the halo DMA of the next tile and the stores of the last one - the kernel
+    ran 205 us instead of 130 until round 5 found it (tools/scratch_audit.sh lists every kernel with scratch).
+    hipcc cross-compiles without a GPU: this is a build-time property."""
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "mmhand_amd", "csrc")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-Wno-unused-function",
+                          "-Wno-inline-asm", "-Rpass-analysis=kernel-resource-usage", "-c", "conv_s2_lp16.hip", "-o", os.devnull],
+                         cwd=src, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    name, seen = None, {}
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            seen[name] = int(m.group(1))
+    s2d = {k: v for k, v in seen.items() if "conv_s2d_kernel" in k}
+    assert len(s2d) == 2 and all(v == 0 for v in s2d.values()), s2d
+    # the default instantiations of the fprop kernel (64 -> 128 stride 2; the 64 -> 64 stride-1 form) are spill-free as well
+    dflt = {k: v for k, v in seen.items() if "conv_s2f_kernel" in k and ("ELi1ELi2ELi2ELb0ELi2ELi128" in k or "ELi1ELi4ELi2ELb0ELi1ELi64" in k)}
+    assert len(dflt) == 4 and all(v == 0 for v in dflt.values()), dflt
