@@ -353,6 +353,19 @@ int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const 
                         void* ws, size_t ws_bytes, int accumulate, const void* zeros,
                         mmh_stream_t s);
 
+/* Weight gradient of the Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7) + Tanh, models/Generator.py:254-259;
+ * Cout = 3 padded to 4) in 16 bits: d describes the head conv (Cin = 64, Cout = 4, reflect pad 3, dtype BF16 | FP16),
+ * x16 = its 16-bit input [B,H,W,x_cs >= 64], dy = the fp32 gradient of its output [B,H,W,y_cs >= 4] (after the Tanh
+ * backward).  dw[kh][kw][ci][co] = sum over q of the padded domain of xpad[q][ci] * E[q + (3-kh, 3-kw)][co] with E = dy
+ * embedded at offset (3,3): the stem wgrad above on the padded domain with the roles of the operands swapped (E is the
+ * 8-channel "input", the 64 channels of x the "output gradient", read through reflected source addresses), mirrored and
+ * transposed by the slab reduction.  dw [7][7][64][4] fp32 (+)= ...; ws 16-byte aligned.  Replaces the fp32 vector-ALU
+ * kernel mmh_conv7_thin_wgrad in 16-bit mode.                                                                        */
+int mmh_conv7_head_wgrad_lp16_supported(const mmh_conv_desc* d);
+size_t mmh_conv7_head_wgrad_lp16_ws_bytes(const mmh_conv_desc* d);
+int mmh_conv7_head_wgrad_lp16(const mmh_conv_desc* d, const void* x16, const void* dy, void* dw, void* ws,
+                              size_t ws_bytes, int accumulate, const void* zeros, mmh_stream_t s);
+
 /* Transpose of ReflectionPad2d(p): dx[b,h,w,c] = sum of dxp over the padded
  * positions that mirror onto (h,w).  dxp is [B,H+2p,W+2p,C].               */
 int mmh_reflect_fold(const void* dxp, void* dx, int B, int H, int W, int C,

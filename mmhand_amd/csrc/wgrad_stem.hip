@@ -48,6 +48,7 @@ struct StemWgKP {
     int TR, TC, nblk, bps, S, KG;
     int Jt, JP;             // j tiles of 32, JP = 32 * Jt
     int rp;                 // LDS bytes per halo row = 22 * C8 * 2
+    int dyH, dyW, dyo;      // dy's own extent; dyo > 0: output pixel (oh, ow) reads dy at reflect(oh - dyo, ow - dyo) (head wgrad)
     int xstage, tstage;     // x bytes per stage (rounded up to the DMA rounds' footprint), stage bytes
 };
 
@@ -127,7 +128,14 @@ __global__ void __launch_bounds__(512, 2) wgrad_stem_kernel(const StemWgKP p) {
         {
             const int oh = r0 + d_py, ow = c0 + d_px;
             const bool ok = live && oh < p.H && ow < p.W;
-            const char* g = ok ? p.dy + (size_t)((nb_img * p.H + oh) * p.W + ow) * (size_t)(p.dy_cs * 2) + d_ck
+            int sh = oh - p.dyo, sw = ow - p.dyo;
+            if (p.dyo) {
+                sh = sh < 0 ? -sh : sh;
+                sw = sw < 0 ? -sw : sw;
+                sh = sh >= p.dyH ? 2 * (p.dyH - 1) - sh : sh;
+                sw = sw >= p.dyW ? 2 * (p.dyW - 1) - sw : sw;
+            }
+            const char* g = ok ? p.dy + (size_t)((nb_img * p.dyH + sh) * p.dyW + sw) * (size_t)(p.dy_cs * 2) + d_ck
                                : p.zeros + (lane & 7) * 16;
             mmh::lds_dma16(g, wdst + sbase + (unsigned)p.xstage);
         }
@@ -212,8 +220,9 @@ __global__ void __launch_bounds__(512, 2) wgrad_stem_kernel(const StemWgKP p) {
 
 // dw[kh][kw][c][n] (+)= sum over splits of slab[s][kh][kw * C8 + c][n], c < Cin: fixed order (slab group g of 8 sums slabs
 // g, g + 8, ...; then the eight partial sums in order)
+// flipT (head wgrad): the result is written as dw[6 - kh][6 - kw][n][c] with 4 columns c instead of dw[kh][kw][c][n]
 __global__ void __launch_bounds__(512) stem_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                                               int JP, int C8, int Cin, int accumulate) {
+                                                               int JP, int C8, int Cin, int accumulate, int flipT) {
     __shared__ float part[8][64];
     const int n = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int t = blockIdx.x;                                   // over 49 * Cin
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(512) stem_slab_reduce_kernel(const float* __re
         float a = part[0][n];
 #pragma unroll
         for (int q = 1; q < 8; ++q) a += part[q][n];
-        const int i = t * 64 + n;
+        const int i = flipT ? (((6 - kh) * 7 + (6 - kw)) * 64 + n) * 4 + c : t * 64 + n;
         dw[i] = accumulate ? dw[i] + a : a;
     }
 }
@@ -275,19 +284,40 @@ size_t mmh_wgrad_stem_lp16_ws_bytes(const mmh_conv_desc* d, int C8) {
     return (size_t)q.S * 7 * q.JP * 64 * sizeof(float);
 }
 
-int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const void* dy16, void* dw, void* ws,
-                        size_t ws_bytes, int accumulate, const void* zeros, mmh_stream_t s) {
-    Plan q;
-    MMH_REQUIRE(plan(d, C8, q) && x16p && dy16 && dw && ws && zeros,
-                "mmh_wgrad_stem_lp16: 7x7 / stride 1 / pad 3, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype");
-    MMH_REQUIRE(ws_bytes >= mmh_wgrad_stem_lp16_ws_bytes(d, C8), "mmh_wgrad_stem_lp16: workspace too small");
-    MMH_REQUIRE((long long)d->B * d->H * d->W * std::max(C8, d->y_cs) < (1ll << 31), "mmh_wgrad_stem_lp16: tensor too large");
+namespace {
+
+// dy fp32 [B][H][W][cs] (4 channels) -> E 16-bit [B][H + 6][W + 6][8]: dy at offset (3, 3), zeros around and in channels 4..7
+__global__ void head_wgrad_embed_kernel(const float* __restrict__ dy, int B, int H, int W, int cs, int h16,
+                                        uint4* __restrict__ E) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hp = H + 6, Wp = W + 6;
+    if (i >= (int64_t)B * Hp * Wp) return;
+    const int x = (int)(i % Wp) - 3;
+    const int64_t t = i / Wp;
+    const int y = (int)(t % Hp) - 3, b = (int)(t / Hp);
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+        const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)(b * H + y) * W + x) * cs);
+        auto cv = [&](float f) -> unsigned {
+            return h16 ? (unsigned)__builtin_bit_cast(unsigned short, (_Float16)f)
+                       : (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f);
+        };
+        o.x = cv(v.x) | (cv(v.y) << 16);
+        o.y = cv(v.z) | (cv(v.w) << 16);
+    }
+    E[i] = o;
+}
+
+// d: the stem-shaped problem (x = 16-bit [B][H][W][C8], 64 dy channels).  dyo / dyH / dyW: see StemWgKP
+int launch_stem_wgrad(const mmh_conv_desc* d, const Plan& q, const void* x16p, int C8, const void* dy16, int dyH, int dyW,
+                      int dyo, void* dw, void* slab, int accumulate, int flipT, const void* zeros, hipStream_t st) {
     StemWgKP p{};
     p.x = static_cast<const char*>(x16p); p.dy = static_cast<const char*>(dy16); p.zeros = static_cast<const char*>(zeros);
-    p.slab = static_cast<float*>(ws);
+    p.slab = static_cast<float*>(slab);
     p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.dy_cs = d->y_cs; p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
     p.TR = q.TR; p.TC = q.TC; p.nblk = q.nblk; p.bps = q.bps; p.S = q.S; p.KG = q.KG; p.Jt = q.Jt; p.JP = q.JP;
     p.rp = q.rp; p.xstage = q.xstage; p.tstage = q.tstage;
+    p.dyH = dyH; p.dyW = dyW; p.dyo = dyo;
     const int lds = RING * q.tstage;
     static int ready = -1;
     if (ready != 0) {
@@ -299,11 +329,76 @@ int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const 
         ready = e == hipSuccess ? 0 : mmh::fail("wgrad_stem_kernel: %s", hipGetErrorString(e));
     }
     if (ready != 0) return ready;
-    hipStream_t st = mmh::as_stream(s);
     const int per_xcd = (q.S * q.KG + 7) / 8;
     if (d->dtype == MMH_FP16) hipLaunchKernelGGL(wgrad_stem_kernel<true>, dim3(8 * per_xcd), dim3(512), lds, st, p);
     else hipLaunchKernelGGL(wgrad_stem_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, st, p);
-    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3(49 * d->Cin), dim3(512), 0, st, static_cast<const float*>(ws),
-                       static_cast<float*>(dw), q.S, q.JP, C8, d->Cin, accumulate);
+    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3(49 * d->Cin), dim3(512), 0, st, static_cast<const float*>(slab),
+                       static_cast<float*>(dw), q.S, q.JP, C8, d->Cin, accumulate, flipT);
     return mmh::check_launch("wgrad_stem_kernel");
+}
+
+// the head conv d (7x7 / reflect pad 3 / 64 -> 4 incl. padding) as the stem-shaped problem e on the padded domain
+bool head_wgrad_desc(const mmh_conv_desc* d, mmh_conv_desc& e, Plan& q) {
+    if (!d || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->pad_mode != MMH_PAD_REFLECT) return false;
+    if (d->Cin != 64 || d->Cout != 4 || d->Ho != d->H || d->Wo != d->W || d->H < 8 || d->W < 8) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->y_cs < 4 || d->y_cs % 4 || d->x_cs < 64 || d->x_cs % 8) return false;
+    e = *d;
+    e.H = e.Ho = d->H + 6; e.W = e.Wo = d->W + 6; e.Cin = 4; e.Cout = 64; e.pad_mode = MMH_PAD_ZERO; e.x_cs = 8;
+    e.y_cs = d->x_cs;
+    return plan(&e, 8, q) && (long long)e.B * e.H * e.W * std::max(8, e.y_cs) < (1ll << 31);
+}
+
+}  // namespace
+
+int mmh_wgrad_stem_lp16(const mmh_conv_desc* d, const void* x16p, int C8, const void* dy16, void* dw, void* ws,
+                        size_t ws_bytes, int accumulate, const void* zeros, mmh_stream_t s) {
+    Plan q;
+    MMH_REQUIRE(plan(d, C8, q) && x16p && dy16 && dw && ws && zeros,
+                "mmh_wgrad_stem_lp16: 7x7 / stride 1 / pad 3, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype");
+    MMH_REQUIRE(ws_bytes >= mmh_wgrad_stem_lp16_ws_bytes(d, C8), "mmh_wgrad_stem_lp16: workspace too small");
+    MMH_REQUIRE((long long)d->B * d->H * d->W * std::max(C8, d->y_cs) < (1ll << 31), "mmh_wgrad_stem_lp16: tensor too large");
+    return launch_stem_wgrad(d, q, x16p, C8, dy16, d->H, d->W, 0, dw, ws, accumulate, 0, zeros, mmh::as_stream(s));
+}
+
+// ---- the Generator head's weight gradient (ReflectionPad2d(3) + Conv2d(64, 3, 7), models/Generator.py:254-259) ----
+//   dw[kh][kw][ci][co] = sum_p xpad[p + (kh, kw)][ci] * dy[p][co]
+// With q = p + (kh, kw) running over the padded domain D = (H + 6) x (W + 6) and E = dy embedded in D at offset (3, 3) (zeros
+// around, 4 -> 8 channels) this is  sum_q xpad[q][ci] * E[q + (3 - kh, 3 - kw)][co]: the STEM's weight gradient on D with E
+// as the 8-channel input, the 64 channels of xpad as the output gradient and the taps mirrored - so the stem kernel runs it
+// (the reflect padding of x is folded into its dy loader's source addresses; nothing is materialised but E), and the slab
+// reduction writes the mirrored, transposed result.  Both operands in 16 bits, fp32 accumulation (it was an fp32 vector-ALU
+// kernel reading the fp32 x: 0.7 ms at B = 32, 256 x 256).
+int mmh_conv7_head_wgrad_lp16_supported(const mmh_conv_desc* d) {
+    mmh_conv_desc e;
+    Plan q;
+    return head_wgrad_desc(d, e, q) ? 1 : 0;
+}
+
+size_t mmh_conv7_head_wgrad_lp16_ws_bytes(const mmh_conv_desc* d) {
+    mmh_conv_desc e;
+    Plan q;
+    if (!head_wgrad_desc(d, e, q)) return 0;
+    const size_t embed = ((size_t)e.B * e.H * e.W * 16 + 255) & ~(size_t)255;
+    return embed + (size_t)q.S * 7 * q.JP * 64 * sizeof(float);
+}
+
+int mmh_conv7_head_wgrad_lp16(const mmh_conv_desc* d, const void* x16, const void* dy, void* dw, void* ws, size_t ws_bytes,
+                              int accumulate, const void* zeros, mmh_stream_t s) {
+    mmh_conv_desc e;
+    Plan q;
+    MMH_REQUIRE(head_wgrad_desc(d, e, q),
+                "mmh_conv7_head_wgrad_lp16: the head conv only (7x7 / reflect pad 3 / 64 -> 4, 16-bit dtype)");
+    MMH_REQUIRE(x16 && dy && dw && ws && zeros && ws_bytes >= mmh_conv7_head_wgrad_lp16_ws_bytes(d) &&
+                    (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                "mmh_conv7_head_wgrad_lp16: bad buffers (ws 16-byte aligned, mmh_conv7_head_wgrad_lp16_ws_bytes)");
+    hipStream_t st = mmh::as_stream(s);
+    const size_t px = (size_t)e.B * e.H * e.W;
+    char* E = static_cast<char*>(ws);
+    char* slab = E + ((px * 16 + 255) & ~(size_t)255);
+    hipLaunchKernelGGL(head_wgrad_embed_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(dy), d->B, d->H, d->W, d->y_cs, d->dtype == MMH_FP16 ? 1 : 0,
+                       reinterpret_cast<uint4*>(E));
+    if (int rc = mmh::check_launch("head_wgrad_embed_kernel")) return rc;
+    return launch_stem_wgrad(&e, q, E, 8, x16, d->H, d->W, 3, dw, slab, accumulate, 1, zeros, st);
 }

@@ -100,6 +100,9 @@ SIGNATURES = {
     "mmh_wgrad_stem_lp16_supported": (_i, [_DP, _i]),
     "mmh_wgrad_stem_lp16_ws_bytes": (_sz, [_DP, _i]),
     "mmh_wgrad_stem_lp16": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
+    "mmh_conv7_head_wgrad_lp16_supported": (_i, [_DP]),
+    "mmh_conv7_head_wgrad_lp16_ws_bytes": (_sz, [_DP]),
+    "mmh_conv7_head_wgrad_lp16": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "mmh_wgrad_lp16_flat_supported": (_i, [_DP, _i]),
     "mmh_wgrad_lp16_flat_ws_bytes": (_sz, [_DP, _i]),
     "mmh_wgrad_lp16_flat": (_i, [_DP, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp, _vp]),

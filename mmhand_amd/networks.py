@@ -315,6 +315,14 @@ class _Net(nn.Module):
             return self.bf16 if ops.convT_lp16_ok(ws[3], ws[2], self.bf16) else 0
         return self.bf16 if ops.lp16_chain_ok(ws[2], ws[3], 3, stride, 1, reflect, self.bf16) else 0
 
+    def _lp_edge_head(self, cp, x):
+        """16-bit hand-over to the Generator's 7x7 head `cp` (x: its input, a tensor or a (proxy, x16) pair of that shape)"""
+        if not (self.bf16 and self.training and ops.USE_LP16_EDGES and cp is not None and cp.k == 7):
+            return 0
+        B, H, W, _ = (x[0] if isinstance(x, tuple) else x).shape
+        ws = cp.weight.shape
+        return self.bf16 if ops.head16_ok(B, H, W, ws[2], ws[3], 7, 1, 3, True, self.bf16) else 0
+
     def _lp_out(self, cp, stride=1, reflect=True):
         """the conv `cp` hands its output (and takes its gradient) in 16 bits"""
         return bool(ops.USE_LP16_EDGES and self._lp_edge(cp, stride, reflect))
@@ -640,9 +648,11 @@ class Generator(_Net):
         up = m["stream1_up"]
         y = x1
         for i in range(self.n_down):
-            nxt = up[3 * (i + 1)] if i + 1 < self.n_down else None      # the 7x7 head reads fp32
-            y = self.normact(up, 3 * i + 1, self.convT(up[3 * i], y, y_lp=self._lp_out(up[3 * i]), to_norm=True), True,
-                             out_lp=self._lp_edge(nxt))
+            nxt = up[3 * (i + 1)] if i + 1 < self.n_down else None
+            yc = self.convT(up[3 * i], y, y_lp=self._lp_out(up[3 * i]), to_norm=True)
+            # the 7x7 head takes its input in 16 bits where all three of its passes have 16-bit kernels (ops.head16_ok)
+            out_lp = self._lp_edge(nxt) if nxt is not None else self._lp_edge_head(up[3 * self.n_down + 1], yc)
+            y = self.normact(up, 3 * i + 1, yc, True, out_lp=out_lp)
         return self.conv(up[3 * self.n_down + 1], y, 1, 3, True, L.ACT_TANH)
 
     def forward(self, input):

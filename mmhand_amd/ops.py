@@ -734,6 +734,41 @@ def raw_conv7_n4(d, mode, x16, w, bias, y, act, lp):
     return y
 
 
+# The Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7) + Tanh, models/Generator.py:254-259) with a 16-bit input on all
+# three passes: fprop mmh_conv7_n4_lp16, input gradient mmh_conv7_head_dgrad_lp16, weight gradient
+# mmh_conv7_head_wgrad_lp16 - so the norm in front of it writes 16 bits only and takes a 16-bit gradient, as the 3x3 convs'
+# neighbours do (under apex O1 this conv runs in fp16 as well).  MMH_HEAD16=0: fp32 input, fp32 vector-ALU weight gradient.
+USE_HEAD16 = os.environ.get("MMH_HEAD16", "1") != "0"
+
+
+def head16_ok(B, H, W_, Cin, Cout, k, stride, pad, reflect, bf16):
+    if not (USE_HEAD16 and USE_THIN and USE_HEAD_DGRAD16 and bf16 and k == 7 and stride == 1 and pad == 3 and reflect
+            and Cin == 64 and Cout == 4):
+        return False
+    d = conv_desc(B, H, W_, Cin, Cout, k, stride, pad, reflect)
+    if not conv7_n4_ok(d, 0, bf16):
+        return False
+    d.dtype = _dt(bf16)
+    lib = L.load()
+    return bool(lib.mmh_conv7_head_dgrad_lp16_supported(C.byref(d)) and lib.mmh_conv7_head_wgrad_lp16_supported(C.byref(d)))
+
+
+def raw_head_wgrad16(x16, g, bf16, out=None):
+    """x16: the head's 16-bit input [B,H,W,64]; g: fp32 gradient of its output [B,H,W,4] -> dw [7,7,64,4] fp32 (added into `out`)"""
+    B, H, W_, Cin = x16.shape
+    assert x16.dtype == _wd(bf16) and x16.is_contiguous() and g.dtype == torch.float32 and g.is_contiguous()
+    d = conv_desc(B, H, W_, Cin, 4, 7, 1, 3, True)
+    d.dtype = _dt(bf16)
+    nbytes = L.load().mmh_conv7_head_wgrad_lp16_ws_bytes(C.byref(d))
+    ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=g.device)
+    off = (-ws.data_ptr()) % 256 // 4
+    dw = out if out is not None else torch.empty((7, 7, Cin, 4), dtype=torch.float32, device=g.device)
+    L.call("mmh_conv7_head_wgrad_lp16", C.byref(d), _ptr(x16), _ptr(g), _ptr(dw), _ptr(ws[off:]), nbytes, int(out is not None),
+           _ptr(zero_page(g.device)), _stream())
+    _count("mfma", 2.0 * B * (H + 6) * (W_ + 6) * 49 * 64 * 8)      # executed: 8 columns, 3 of them meaningful
+    return dw
+
+
 def raw_conv_dgrad_thin(dy, w, x_shape, reflect):
     """dgrad of a 7x7 / stride 1 / pad 3 conv for the first 4 input channels only (the others are
     returned as zeros): the Discriminator stems seen from the generated image.  dy: fp32 or 16-bit."""
@@ -1587,7 +1622,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.x_lp = x16 is not None
         ctx.y_lp = bool(y_lp)
         k = w.shape[0]
-        ctx.stem16 = False
+        ctx.stem16 = ctx.head16 = False
         if pro is not None:
             assert wt == 6 and not bf16 and x16 is None and not y_lp, "a deferred norm needs the fp32 F(6x6,3x3) path"
             if KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
@@ -1600,10 +1635,22 @@ class Conv2dFn(torch.autograd.Function):
             ctx.save_for_backward(None, w, y if act != L.ACT_NONE else None)
             return y
         chain = bool(bf16) and lp16_chain_ok(Cin, w.shape[3], k, stride, pad, reflect, bf16)
+        head16 = bool(bf16) and k == 7 and not y_lp and not dx_channels and pro is None \
+            and head16_ok(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect, bf16)
         if x16 is not None:
-            assert chain and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape), \
+            assert (chain or head16) and x16.dtype == _wd(bf16) and tuple(x16.shape) == tuple(x.shape), \
                 "a 16-bit input needs 16-bit kernels for all three passes"
         ctx.stem16 = False
+        ctx.head16 = head16
+        if head16:
+            # the Generator head: the 16-bit input (the producing norm's own output, or a twin of x) serves all three passes
+            if x16 is None:
+                x16 = lp16_twin(x, bf16)
+            d = conv_desc(B, H, W_, Cin, w.shape[3], k, stride, pad, reflect)
+            y = torch.empty((B, H, W_, w.shape[3]), dtype=torch.float32, device=x16.device)
+            raw_conv7_n4(d, 0, x16, w, bias, y, act, bf16)
+            ctx.save_for_backward(x16, w, y if act != L.ACT_NONE else None)
+            return y
         if y_lp and not chain:
             # a 7x7 stem handing its output over in 16 bits: flat-K fprop with a 16-bit epilogue; the
             # backward takes the 16-bit gradient into the thin dgrad, the wgrad and the bias sum
@@ -1686,6 +1733,19 @@ class Conv2dFn(torch.autograd.Function):
             # nothing but the 16-bit dgrad reads g * act'(y) - one pass writes it in 16 bits
             g16 = raw_act_bwd_lp16(g.contiguous(), y, act, bf16)
             dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, 0, dy16=g16)
+            return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
+        if ctx.head16:      # x is the head's 16-bit input; g the fp32 gradient of its four output columns
+            g = g.contiguous()
+            if act != L.ACT_NONE:
+                g = raw_act_bwd(g, y, act)
+            if ctx.needs_input_grad[0]:
+                dx = raw_conv_dgrad(g, w, ctx.x_shape, stride, pad, reflect, bf16, 0, out16=ctx.x_lp)
+                if ctx.x_lp:
+                    dx = lp_grad_out(dx)
+            if ctx.needs_input_grad[1]:
+                dw = _finish_param_grad(raw_head_wgrad16(x, g, bf16, out=wt_), wt_)
+            if want_db:
+                db = _finish_param_grad(raw_colsum(g.numel() // g.shape[3], g.shape[3], g, out=bt_), bt_)
             return _tok_add(dx, addend), dw, db, None, None, None, None, None, None, None, None, None, None, None, None, None
         if ctx.stem16:      # x is the stem's padded 16-bit input [B,H,W,C8] saved by the forward pass
             g16 = lp_grad_in(g, "Conv2dFn (stem)")

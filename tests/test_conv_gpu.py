@@ -1200,6 +1200,90 @@ def test_head_dgrad_on_the_stem_kernel(case, lp, out16, dev, monkeypatch):
     assert R.rel_l1(dx.float(), old.cpu()) < (4e-3 if lp == 2 else 1.6e-2)
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 32, 48), (1, 8, 8), (3, 19, 33), (1, 64, 64), (2, 70, 21)])
+def test_head_wgrad_on_the_stem_wgrad_kernel(case, lp, dev):
+    """mmh_conv7_head_wgrad_lp16: the weight gradient of the Generator head (ReflectionPad2d(3) + Conv2d(64, 3, 7),
+    models/Generator.py:254-259) in 16-bit mode - the stem wgrad kernel on the padded domain with the operands' roles
+    swapped (dy embedded as the 8-channel input, the 64 channels of x read through reflected addresses as the output
+    gradient), the slabs reduced into the mirrored, transposed layout: against the fp64 oracle on operands rounded to the
+    storage type, against the fp32 vector-ALU kernel it replaces, and accumulating into an existing gradient."""
+    from mmhand_amd import lib, ops
+    B, H, W = case
+    x = _mk((B, H, W, 64), 3, dev)
+    dy = _mk((B, H, W, 4), 4, dev)
+    dy[..., 3] = 0
+    x16 = ops.lp16_twin(x, lp)
+    calls = {}
+    orig = lib.call
+    def spy(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return orig(name, *a)
+    lib.call = spy
+    try:
+        dw = ops.raw_head_wgrad16(x16, dy, lp)
+    finally:
+        lib.call = orig
+    assert calls == {"mmh_conv7_head_wgrad_lp16": 1}, calls
+    assert tuple(dw.shape) == (7, 7, 64, 4) and dw.dtype == torch.float32
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    _, _, dwr, _ = R.conv2d_grads(rb(x), torch.zeros(7, 7, 64, 4), None, rb(dy), 1, 3, True)
+    assert float(dw[..., 3].abs().max()) == 0.0                      # the padding column's gradient is exactly zero
+    assert R.rel_l1(dw, dwr) < 2e-5, R.rel_l1(dw, dwr)
+    old = ops.raw_conv_wgrad(x, dy, 7, 1, 3, True, bf16=False)       # fp32 operands on the vector ALU
+    assert R.rel_l1(dw, old.cpu()) < (2e-3 if lp == 2 else 1.2e-2)
+    # accumulate: dw0 + dw, bit for bit the same sums added once
+    dw0 = _mk((7, 7, 64, 4), 9, dev)
+    acc = ops.raw_head_wgrad16(x16, dy, lp, out=dw0.clone())
+    assert torch.equal(acc, dw0 + dw)
+    # reproducible launch to launch (fixed split-K order)
+    assert torch.equal(ops.raw_head_wgrad16(x16, dy, lp), dw)
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+def test_head_conv_takes_a_16_bit_input_on_all_three_passes(lp, dev, monkeypatch):
+    """Conv2dFn on the Generator head with x16 handed over by the producer (ops.head16_ok): the fprop, the 16-bit input
+    gradient sent back through the 16-bit channel and the weight / bias gradients against the same node fed the fp32 tensor
+    with MMH_HEAD16 off (fp32 weight gradient kernel)."""
+    from mmhand_amd import lib, ops
+    B, H, W = 2, 32, 40
+    assert ops.head16_ok(B, H, W, 64, 4, 7, 1, 3, True, lp)
+    x = _mk((B, H, W, 64), 5, dev)
+    x16 = ops.lp16_twin(x, lp)
+    xr = x16.float()
+    w = (_mk((7, 7, 64, 4), 6, dev) * 0.05).requires_grad_(True)
+    b = (_mk((4,), 7, dev) * 0.1).requires_grad_(True)
+    g = _mk((B, H, W, 4), 8, dev)
+    ops.bump_weights_epoch()
+    got = []
+
+    class Tap(torch.autograd.Function):     # the node on the far side of the 16-bit edge (a leaf would copy the proxy)
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, gp):
+            got.append(ops.lp_grad_in(gp, "tap"))
+            return gp
+
+    proxy = Tap.apply(ops.lp_proxy(x.shape, x.device).requires_grad_(True))
+    y = ops.Conv2dFn.apply(proxy, w, b, 1, 3, True, lib.ACT_TANH, lp, 0, x16)
+    y.backward(g)
+    dx16, = got
+    assert dx16.dtype == ops._wd(lp) and tuple(dx16.shape) == (B, H, W, 64)
+    dw, db = w.grad.clone(), b.grad.clone()
+    w.grad = b.grad = None
+    monkeypatch.setattr(ops, "USE_HEAD16", False)
+    x2 = xr.clone().requires_grad_(True)
+    y2 = ops.Conv2dFn.apply(x2, w, b, 1, 3, True, lib.ACT_TANH, lp)
+    y2.backward(g)
+    assert torch.equal(y, y2)                                           # the same fprop kernel on the same 16-bit operand
+    assert R.rel_l1(dx16.float(), x2.grad) < (2e-3 if lp == 2 else 8e-3)
+    assert R.rel_l1(dw, w.grad) < (2e-3 if lp == 2 else 1.2e-2)
+    assert torch.equal(db, b.grad)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (1, 48, 16, 256, 512)])
 def test_conv3x3_lp16_one_wave_per_simd_ab_build(case, dev):
     """conv_lp16q_kernel (lp16_shape 20: one wave per SIMD, 512 registers, 256 AGPR accumulators, inline-asm MFMAs and counted
