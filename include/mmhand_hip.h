@@ -726,6 +726,13 @@ typedef struct mmh_plane_src {
  * dir 1: scatter nhwc -> srcs (backward of dir 0 / NHWC->NCHW export).     */
 int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B,
                   int H, int W, int Cd, int dir, mmh_stream_t s);
+/* The gather (dir 0) staged through LDS - 256 pixels per workgroup, read with the lanes along the pixels of a source
+ * plane, written as whole 16-byte lanes in address order - with, in the same pass, the 16-bit copy out16 [B,H,W,C8]
+ * (channels zero-padded to C8, C8 % 8 == 0, Cd <= C8 <= 56; dtype MMH_BF16 | MMH_FP16) that the 16-bit 7x7 stems read:
+ * what mmh_lp16_pad_cvt would make of nhwc, bit for bit.  nhwc or out16 may be NULL (only the other one is written).
+ * Cd % 4 == 0, Cd <= 56 (58 KB of LDS).  (MMHandModel.py:216-220,238,242,278-289: the concatenations in front of every stem.)      */
+int mmh_pack_nhwc_lp16(const mmh_plane_src* srcs, int nsrc, void* nhwc, void* out16, int B, int H, int W,
+                       int Cd, int C8, int dtype, mmh_stream_t s);
 
 /* ---- pose maps (data/generic_dataset.py:191-217,239-242; util/util.py:94-114)
  * uv: [n_maps][2] float64 (x,y).  out: [n_maps][H][W] fp32 =

@@ -1710,6 +1710,66 @@ __global__ void pack_nhwc_kernel(PackArgs a, float* __restrict__ nhwc, int B, in
     }
 }
 
+// Gather, second form: a workgroup takes 256 consecutive pixels, reads every source channel with its lanes along the pixels
+// (unit stride in an NCHW plane) into LDS and writes the NHWC side from there as whole 16-byte lanes in address order - the
+// kernel above gives every thread one pixel, i.e. stores 4 Cd bytes apart (2 TB/s at 24 channels).  In the same pass it
+// can write the 16-bit copy with the channels zero-padded to C8 that the 16-bit stems read (mmh_lp16_pad_cvt's output:
+// the same conversions of the same values), so that pass and its read of the fp32 tensor are gone; nhwc may be NULL then.
+constexpr int PACK_TP = 256;
+__global__ void __launch_bounds__(PACK_TP) pack_nhwc_tile_kernel(PackArgs a, float* __restrict__ nhwc, void* __restrict__ out16,
+                                                                 int64_t total, int H, int W, int Cd, int C8, int h16) {
+    extern __shared__ float pk[];                      // [PACK_TP][pitch], pitch odd
+    const int Cm = Cd > C8 ? Cd : C8, pitch = Cm | 1;
+    const int tid = threadIdx.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * PACK_TP; p0 < total; p0 += (int64_t)gridDim.x * PACK_TP) {
+        const int64_t i = p0 + tid;
+        if (i < total) {
+            const int w = (int)(i % W);
+            const int64_t t = i / W;
+            const int hh = (int)(t % H);
+            const int64_t b = t / H;
+            int c = 0;
+            for (int k = 0; k < a.nsrc; ++k) {
+                const mmh_plane_src& s = a.s[k];
+                const float* sp = static_cast<const float*>(s.ptr);
+                const float* q = sp ? sp + b * s.sb + hh * s.sh + w * s.sw : nullptr;
+                for (int e = 0; e < s.C; ++e, ++c) pk[tid * pitch + c] = q ? q[(int64_t)e * s.sc] : 0.f;
+            }
+            for (; c < Cm; ++c) pk[tid * pitch + c] = 0.f;
+        }
+        __syncthreads();
+        const int npx = (int)(total - p0 < PACK_TP ? total - p0 : PACK_TP);
+        if (nhwc) {
+            const int g4n = Cd / 4;
+            float4* o = reinterpret_cast<float4*>(nhwc + p0 * Cd);
+            for (int j = tid; j < npx * g4n; j += PACK_TP) {
+                const int px = j / g4n, g = j - px * g4n;
+                const float* r = pk + px * pitch + 4 * g;
+                o[j] = make_float4(r[0], r[1], r[2], r[3]);
+            }
+        }
+        if (out16) {
+            const int g8n = C8 / 8;
+            uint4* o = reinterpret_cast<uint4*>(static_cast<char*>(out16) + p0 * C8 * 2);
+            for (int j = tid; j < npx * g8n; j += PACK_TP) {
+                const int px = j / g8n, g = j - px * g8n;
+                const float* r = pk + px * pitch + 8 * g;
+                unsigned u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = 8 * g + 2 * e < Cd ? r[2 * e] : 0.f, hi = 8 * g + 2 * e + 1 < Cd ? r[2 * e + 1] : 0.f;
+                    u[e] = h16 ? ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)lo) |
+                                  ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)hi) << 16))
+                               : ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) |
+                                  ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16));
+                }
+                o[j] = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ pose maps
 __global__ void pose_heatmap_kernel(const double* __restrict__ uv, int n_maps, int H, int W,
                                     double sigma, float* __restrict__ out) {
@@ -2691,6 +2751,27 @@ int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B, int H,
     hipLaunchKernelGGL(pack_nhwc_kernel, dim3(grid_for((int64_t)B * H * W)), dim3(TPB), 0,
                        mmh::as_stream(s), a, static_cast<float*>(nhwc), B, H, W, Cd, dir);
     return mmh::check_launch("pack_nhwc");
+}
+
+int mmh_pack_nhwc_lp16(const mmh_plane_src* srcs, int nsrc, void* nhwc, void* out16, int B, int H, int W, int Cd, int C8,
+                       int dtype, mmh_stream_t s) {
+    MMH_REQUIRE(srcs && (nhwc || out16) && nsrc >= 1 && nsrc <= 4 && B > 0 && H > 0 && W > 0 && Cd > 0 && Cd % 4 == 0 &&
+                    Cd <= 56 && (reinterpret_cast<uintptr_t>(nhwc) & 15) == 0 && (reinterpret_cast<uintptr_t>(out16) & 15) == 0,
+                "mmh_pack_nhwc_lp16: bad arguments (Cd %% 4 == 0, Cd <= 56, 16-byte aligned buffers)");
+    MMH_REQUIRE(!out16 || ((dtype == MMH_BF16 || dtype == MMH_FP16) && C8 % 8 == 0 && C8 >= Cd && C8 <= 56),
+                "mmh_pack_nhwc_lp16: the 16-bit copy needs a 16-bit dtype and Cd <= C8 <= 56, C8 %% 8 == 0");
+    PackArgs a{};
+    a.nsrc = nsrc;
+    int tot = 0;
+    for (int i = 0; i < nsrc; ++i) { a.s[i] = srcs[i]; tot += srcs[i].C; }
+    MMH_REQUIRE(tot <= Cd, "mmh_pack_nhwc_lp16: %d source channels > Cd=%d", tot, Cd);
+    const int64_t total = (int64_t)B * H * W;
+    const int Cm = out16 && C8 > Cd ? C8 : Cd;
+    const size_t lds = (size_t)PACK_TP * (Cm | 1) * sizeof(float);
+    const int blocks = (int)std::min<int64_t>(mmh::cdiv(total, PACK_TP), 256 * 8);
+    hipLaunchKernelGGL(pack_nhwc_tile_kernel, dim3(blocks), dim3(PACK_TP), lds, mmh::as_stream(s), a,
+                       static_cast<float*>(nhwc), out16, total, H, W, Cd, out16 ? C8 : 0, dtype == MMH_FP16 ? 1 : 0);
+    return mmh::check_launch("pack_nhwc_tile");
 }
 
 int mmh_pose_heatmaps(const void* uv, int n_maps, int H, int W, double sigma, void* out,

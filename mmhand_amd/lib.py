@@ -166,6 +166,7 @@ SIGNATURES = {
     "mmh_grad_nonfinite": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "mmh_loss_scale_update": (_i, [_vp, _vp, _f, _f, _i, _f, _f, _vp]),
     "mmh_pack_nhwc": (_i, [C.POINTER(PlaneSrc), _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mmh_pack_nhwc_lp16": (_i, [C.POINTER(PlaneSrc), _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmh_pose_heatmaps": (_i, [_vp, _i, _i, _i, _d, _vp, _vp]),
     "mmh_map_to_cord": (_i, [_vp, _i, _i, _i, _f, _vp, _vp]),
     "mmh_decode_inputs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),

@@ -399,10 +399,14 @@ class MMHandModel(torch.nn.Module):
         o = self.opt
         B, _, H, W = t["H1"].shape
         hc, pc, dc = o.H_input_nc, o.P_input_nc, o.D_input_nc
-        # NHWC packs: concat + zero-pad to multiples of 4 in one kernel each
-        self.x_H1 = ops.raw_pack([(t["H1"], True, hc)], B, H, W, pad4(hc), dev)
-        self.x_P = ops.raw_pack([(t["P1"], True, pc), (t["P2"], True, pc)], B, H, W, pad4(2 * pc), dev)
-        self.x_D = ops.raw_pack([(t["D1"], True, dc), (t["D2"], True, dc)], B, H, W, pad4(2 * dc), dev)
+        # NHWC packs: concat + zero-pad to multiples of 4 in one kernel each.  16-bit training: the same pass leaves the
+        # generator stems' padded 16-bit inputs (ops.raw_pack twin; they stay valid for every step on this batch)
+        tw = self.bf16 if (self.isTrain and ops.USE_LP16_EDGES) else 0
+        for old in (getattr(self, "x_H1", None), getattr(self, "x_P", None), getattr(self, "x_D", None)):
+            ops.pack_twin_drop(old)
+        self.x_H1 = ops.raw_pack([(t["H1"], True, hc)], B, H, W, pad4(hc), dev, twin=tw, keep_twin=True)
+        self.x_P = ops.raw_pack([(t["P1"], True, pc), (t["P2"], True, pc)], B, H, W, pad4(2 * pc), dev, twin=tw, keep_twin=True)
+        self.x_D = ops.raw_pack([(t["D1"], True, dc), (t["D2"], True, dc)], B, H, W, pad4(2 * dc), dev, twin=tw, keep_twin=True)
         self.x_H2 = ops.raw_pack([(t["H2"], True, hc)], B, H, W, pad4(hc), dev)
         if "H1_path" in input:
             self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
@@ -438,13 +442,17 @@ class MMHandModel(torch.nn.Module):
         """cat(image, P2) -> NHWC [B,H,W,24]."""
         o = self.opt
         B, H, W, _ = img_nhwc.shape
-        return ops.PackFn.apply(pad4(o.H_input_nc + o.P_input_nc), img_nhwc, False, o.H_input_nc,
+        return ops.PackFn.apply((pad4(o.H_input_nc + o.P_input_nc), self._stem_twin()), img_nhwc, False, o.H_input_nc,
                                 self.input_P2, True, o.P_input_nc)
+
+    def _stem_twin(self):
+        """operand type of the padded 16-bit copy a pack leaves for the discriminator stem that reads it (16-bit training)"""
+        return self.bf16 if (self.isTrain and ops.USE_LP16_EDGES and torch.is_grad_enabled()) else 0
 
     def _cat_PP(self, img_nhwc):
         """cat(image, H1) -> NHWC [B,H,W,8] (6 real channels)."""
         o = self.opt
-        return ops.PackFn.apply(pad4(2 * o.H_input_nc), img_nhwc, False, o.H_input_nc,
+        return ops.PackFn.apply((pad4(2 * o.H_input_nc), self._stem_twin()), img_nhwc, False, o.H_input_nc,
                                 self.input_H1, True, o.H_input_nc)
 
     # ------------------------------------------------------------------ G
@@ -493,15 +501,25 @@ class MMHandModel(torch.nn.Module):
 
     def backward_D_basic(self, netD, real, fake, loss_id=0):
         """real: a [2B,H,W,C] buffer whose first half holds the real batch (backward_D_PB / _PP pack it there) when the two
-        passes run as one, else the [B,H,W,C] real batch."""
+        passes run as one - or _pack_real's (proxy, x16) pair in 16-bit training - else the [B,H,W,C] real batch."""
         o = self.opt
-        if real.shape[0] == 2 * fake.shape[0]:
+        merged16 = isinstance(real, tuple)
+        if merged16 or real.shape[0] == 2 * fake.shape[0]:
             # --norm instance: every sample is normalised on its own, so netD(real) and netD(fake) (two passes,
             # models/MMHandModel.py:263-274) ARE netD(cat(real, fake)) sample by sample - one pass over 2B images: half the
             # launches of a discriminator step and fuller tail rounds in every kernel.  (BatchNorm keeps the two passes: each
             # has its own batch statistics.)  MMH_MERGE_D=0: two passes.
             B = fake.shape[0]
-            real[B:].copy_(fake.detach())
+            if merged16:
+                # 16-bit training: the stem reads nothing but the padded 16-bit copy of its input, so only that is built -
+                # the real half by the pack kernel (_pack_real), the fake half by one conversion pass over the pool's
+                # images - and the fp32 [2B] buffer, its pack, the copy of the fake half and the conversion of the real half
+                # are gone; the stem finds the copy under the proxy's address (ops.pack_twin_put)
+                real, x16 = real
+                ops.lp16_pad8(fake.detach(), self.bf16, out=x16[B:])
+                ops.pack_twin_put(real, x16)
+            else:
+                real[B:].copy_(fake.detach())
             pred = netD.forward_nhwc(real)
             loss_D_real, loss_D_fake = ops.BCEWithLogitsHalvesFn.apply(pred, 1.0)
             loss_D = (loss_D_real * o.lambda_GAN + loss_D_fake * o.lambda_GAN) * 0.5
@@ -522,12 +540,25 @@ class MMHandModel(torch.nn.Module):
         merged = netD.norm == "instance" and MERGE_D_PASSES
         return torch.empty(((2 if merged else 1) * B, H, W, Cd), dtype=torch.float32, device=self.device)
 
+    def _pack_real(self, netD, srcs, B, H, W, Cd):
+        """the real batch of a discriminator step, packed: an fp32 buffer (see _real_buffer), or - one merged pass in 16-bit
+        training, where the stem reads only the padded 16-bit copy of its input - (proxy, x16 [2B,H,W,C8]) with the first
+        half written and the second left for backward_D_basic"""
+        merged = netD.norm == "instance" and MERGE_D_PASSES
+        if (merged and self.bf16 and ops.USE_PACK_TWIN and Cd <= 56
+                and netD._lp_out_stem(netD.model[1], 2 * B, H, W, False)):
+            x16 = torch.empty((2 * B, H, W, (Cd + 7) // 8 * 8), dtype=ops._wd(self.bf16), device=self.device)
+            ops.raw_pack(srcs, B, H, W, Cd, self.device, twin=self.bf16, twin_out=x16[:B], only16=True)
+            return ops.lp_proxy((2 * B, H, W, Cd), self.device), x16
+        real = self._real_buffer(netD, B, H, W, Cd)
+        ops.raw_pack(srcs, B, H, W, Cd, self.device, out=real[:B])
+        return real
+
     def backward_D_PB(self):
         o = self.opt
         B, _, H, W = self.input_H2.shape
-        real_PB = self._real_buffer(self.netD_PB, B, H, W, pad4(o.H_input_nc + o.P_input_nc))
-        ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_P2, True, o.P_input_nc)],
-                     B, H, W, pad4(o.H_input_nc + o.P_input_nc), self.device, out=real_PB[:B])
+        real_PB = self._pack_real(self.netD_PB, [(self.input_H2, True, o.H_input_nc), (self.input_P2, True, o.P_input_nc)],
+                                  B, H, W, pad4(o.H_input_nc + o.P_input_nc))
         kept = getattr(self, "_fake_cats", None)
         if kept is not None and kept[0] is self.fake_nhwc:
             fake_now = kept[1]
@@ -540,9 +571,8 @@ class MMHandModel(torch.nn.Module):
     def backward_D_PP(self):
         o = self.opt
         B, _, H, W = self.input_H2.shape
-        real_PP = self._real_buffer(self.netD_PP, B, H, W, pad4(2 * o.H_input_nc))
-        ops.raw_pack([(self.input_H2, True, o.H_input_nc), (self.input_H1, True, o.H_input_nc)],
-                     B, H, W, pad4(2 * o.H_input_nc), self.device, out=real_PP[:B])
+        real_PP = self._pack_real(self.netD_PP, [(self.input_H2, True, o.H_input_nc), (self.input_H1, True, o.H_input_nc)],
+                                  B, H, W, pad4(2 * o.H_input_nc))
         kept = getattr(self, "_fake_cats", None)
         if kept is not None and kept[0] is self.fake_nhwc:
             fake_now = kept[2]

@@ -1142,12 +1142,52 @@ def flat8_weights(w, bf16):
     return ent
 
 
-def lp16_pad8(x, bf16):
-    """fp32 NHWC [B,H,W,C] -> 16-bit [B,H,W,C8], channels zero-padded to a multiple of 8"""
-    _chk(x, "x")
+# The stems' padded 16-bit inputs straight from the pack kernel (mmh_pack_nhwc_lp16 writes them beside - or instead of - the
+# fp32 NHWC tensor): raw_pack(twin=lp) parks the copy here under the fp32 tensor's address and version, lp16_pad8 takes it
+# instead of running mmh_lp16_pad_cvt over the tensor.  MMH_PACK_TWIN=0: off.
+USE_PACK_TWIN = os.environ.get("MMH_PACK_TWIN", "1") != "0"
+_pack_twins = {}
+
+
+def pack_twin_put(x, x16p, keep=False):
+    """x16p is what lp16_pad8(x) would return; x may be a zero-stride proxy (lp_proxy) that is never read.  keep: the entry
+    survives its use (a model input that several steps read; dropped by pack_twin_drop), else the first lp16_pad8 takes it."""
+    while len(_pack_twins) >= 16:       # bounded: entries of tensors that never reached a stem
+        _pack_twins.pop(next(iter(_pack_twins)))
+    _pack_twins[x.data_ptr()] = (x, x._version, x16p, keep)     # x is held so that its address stays unique
+
+
+def pack_twin_drop(x):
+    if x is not None:
+        _pack_twins.pop(x.data_ptr(), None)
+
+
+def pack_twin_get(x, bf16, pop=True):
+    ent = _pack_twins.get(x.data_ptr())
+    if ent is None:
+        return None
+    x0, ver, x16p, keep = ent
+    B, H, W_, Cc = x.shape
+    ok = ((x0 is x or (x0.shape == x.shape and x0.stride() == x.stride())) and x0._version == ver and x._version == ver
+          and x16p.dtype == _wd(bf16) and tuple(x16p.shape) == (B, H, W_, (Cc + 7) // 8 * 8))
+    if not ok or (pop and not keep):
+        del _pack_twins[x.data_ptr()]
+    return x16p if ok else None
+
+
+def lp16_pad8(x, bf16, out=None):
+    """fp32 NHWC [B,H,W,C] -> 16-bit [B,H,W,C8], channels zero-padded to a multiple of 8 (out: written there)"""
     B, H, W_, Cc = x.shape
     c8 = (Cc + 7) // 8 * 8
-    x16p = torch.empty((B, H, W_, c8), dtype=_wd(bf16), device=x.device)
+    twin = pack_twin_get(x, bf16, pop=out is None) if USE_PACK_TWIN else None
+    if twin is not None:
+        if out is None:
+            return twin
+        out.copy_(twin)
+        return out
+    _chk(x, "x")
+    x16p = out if out is not None else torch.empty((B, H, W_, c8), dtype=_wd(bf16), device=x.device)
+    assert x16p.is_contiguous() and x16p.dtype == _wd(bf16) and tuple(x16p.shape) == (B, H, W_, c8)
     L.call("mmh_lp16_pad_cvt", _ptr(x), B * H * W_, Cc, c8, _dt(bf16), _ptr(x16p), _stream())
     return x16p
 
@@ -2875,20 +2915,39 @@ def _plane(t, nchw):
     return L.PlaneSrc(t.data_ptr(), Cc, sb, sc, sh, sw)
 
 
-def raw_pack(srcs, B, H, W_, Cd, device, out=None):
+def raw_pack(srcs, B, H, W_, Cd, device, out=None, twin=0, twin_out=None, only16=False, keep_twin=False):
     """srcs: list of (tensor, is_nchw, n_channels).  Returns NHWC [B,H,W,Cd] (zero padded); out: write into this
-    contiguous [B,H,W,Cd] tensor (e.g. one half of a two-batch buffer) instead of a new one."""
+    contiguous [B,H,W,Cd] tensor (e.g. one half of a two-batch buffer) instead of a new one.
+    twin (operand type of the 16-bit mode): the same pass also writes the 16-bit copy with channels padded to a multiple of 8
+    that a 16-bit stem reads (lp16_pad8 of the result) - into twin_out, else parked for lp16_pad8 (pack_twin_put).
+    only16: the fp32 tensor is not written at all; returns the 16-bit copy."""
     arr = (L.PlaneSrc * len(srcs))()
     for i, (t, nchw, nch) in enumerate(srcs):
         assert t.dtype == torch.float32 and t.is_cuda
         p = _plane(t, nchw)
         p.C = nch
         arr[i] = p
-    if out is None:
+    c8 = (Cd + 7) // 8 * 8
+    tiled = USE_PACK_TWIN and Cd <= 56
+    if only16:
+        assert twin and out is None and tiled, "a 16-bit-only pack needs the tiled kernel (Cd <= 56, MMH_PACK_TWIN)"
+    elif out is None:
         out = torch.empty((B, H, W_, Cd), dtype=torch.float32, device=device)
     else:
         assert tuple(out.shape) == (B, H, W_, Cd) and out.is_contiguous() and out.dtype == torch.float32
-    L.call("mmh_pack_nhwc", arr, len(srcs), _ptr(out), B, H, W_, Cd, 0, _stream())
+    if not tiled:
+        L.call("mmh_pack_nhwc", arr, len(srcs), _ptr(out), B, H, W_, Cd, 0, _stream())
+        return out
+    x16p = None
+    if twin:
+        x16p = twin_out if twin_out is not None else torch.empty((B, H, W_, c8), dtype=_wd(twin), device=device)
+        assert x16p.is_contiguous() and x16p.dtype == _wd(twin) and tuple(x16p.shape) == (B, H, W_, c8)
+    L.call("mmh_pack_nhwc_lp16", arr, len(srcs), _ptr(out), _ptr(x16p), B, H, W_, Cd, c8, _dt(twin) if twin else L.BF16,
+           _stream())
+    if only16:
+        return x16p
+    if twin and twin_out is None:
+        pack_twin_put(out, x16p, keep=keep_twin)
     return out
 
 
@@ -2913,6 +2972,8 @@ class PackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Cd, *args):
+        """Cd: the packed channel count, or (Cd, lp): also leave the padded 16-bit copy for a 16-bit stem (raw_pack twin)"""
+        Cd, twin = Cd if isinstance(Cd, tuple) else (Cd, 0)
         srcs = [(args[i], args[i + 1], args[i + 2]) for i in range(0, len(args), 3)]
         t0, nchw0, _ = srcs[0]
         if nchw0:
@@ -2920,7 +2981,7 @@ class PackFn(torch.autograd.Function):
         else:
             B, H, W_, _ = t0.shape
         ctx.meta = [(tuple(t.shape), nchw, nch) for t, nchw, nch in srcs]
-        return raw_pack(srcs, B, H, W_, Cd, t0.device)
+        return raw_pack(srcs, B, H, W_, Cd, t0.device, twin=twin)
 
     @staticmethod
     def backward(ctx, g):

@@ -284,6 +284,55 @@ def test_optimize_parameters_bf16_opt_level_O1(ngf, dev, monkeypatch):
     assert not np.array_equal(rows["O1"], rows["O0"])       # the bf16 kernels really ran
 
 
+@pytest.mark.parametrize("pool", [0, 3])
+def test_16bit_step_with_pack_twins_is_the_same_step(pool, dev, monkeypatch):
+    """16-bit training with the stems' padded 16-bit inputs written by the pack kernel (ops.USE_PACK_TWIN: the generator
+    inputs, the discriminator concatenations, the merged real / fake batch built in 16 bits only) against the same steps with
+    the fp32 packs and mmh_lp16_pad_cvt: the same conversions of the same values, so every loss and every parameter is
+    bit-identical after three iterations (image pool on and off).  Full width (ngf = ndf = 64), where every stem and the
+    generator head take their 16-bit routes."""
+    from mmhand_amd import ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    from mmhand_amd.options import default_train_opt
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_PACK_TWIN", on)
+        opt = default_train_opt(batchSize=2, ngf=64, ndf=64, n_layers_D=2, G_n_blocks=2, norm="instance", pool_size=pool,
+                                name="twin", checkpoints_dir="/tmp/mmh_pytest_ckpt", local_rank=0, opt_level="O1")
+        model = MMHandModel(opt)
+        for tag, net in (("G", model.netG), ("DPB", model.netD_PB), ("DPP", model.netD_PP)):
+            shapes = OrderedDict((f"{tag}/{k}", tuple(v.shape)) for k, v in net.state_dict().items())
+            sd = RC.recipe_state_dict(shapes)
+            net.load_state_dict(OrderedDict((k.split("/", 1)[1], v) for k, v in sd.items()))
+        model.vgg.load_state_dict(RC.vgg_recipe())
+        random.seed(49)
+        ops.set_dropout_seed(1234)
+        calls = {}
+        from mmhand_amd import lib
+        orig = lib.call
+        def spy(name, *a):
+            calls[name] = calls.get(name, 0) + 1
+            return orig(name, *a)
+        lib.call = spy
+        try:
+            losses = []
+            for it in range(3):
+                model.set_input(O.synthetic_batch(2, 32, 32, seed=100 + it))
+                model.optimize_parameters()
+                losses.append([float(v) for v in model.get_current_errors().values()])
+        finally:
+            lib.call = orig
+        res[on] = (losses, [p.detach().clone() for n in (model.netG, model.netD_PB, model.netD_PP) for p in n.parameters()], calls)
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[True][1], res[False][1]))
+    on, off = res[True][2], res[False][2]
+    assert on.get("mmh_pack_nhwc_lp16", 0) > 0 and off.get("mmh_pack_nhwc_lp16", 0) == 0
+    # per iteration: 7 stem inputs converted by their own pass without the twins, 2 (the pool's halves) with them; VGG19's
+    # conv1_1 converts its two images either way
+    assert off["mmh_lp16_pad_cvt"] == 3 * 9 and on["mmh_lp16_pad_cvt"] == 3 * 4, (on["mmh_lp16_pad_cvt"], off["mmh_lp16_pad_cvt"])
+    assert on.get("mmh_conv7_head_wgrad_lp16") == 3
+
+
 def test_generator_512x512_config5_shape(dev):
     """BASELINE.json configs[4]: 512x512 inputs (PATBlocks at 128x128) — same kernels, larger tiles."""
     from mmhand_amd.networks import Generator

@@ -231,6 +231,55 @@ def test_pack_unpack_concat(dev):
     assert torch.equal(x.grad[..., :3], torch.ones_like(x.grad[..., :3])) and float(x.grad[..., 3].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,W,cs,Cd", [(2, 8, 10, (3, 21), 24), (3, 17, 19, (3, 3), 8), (1, 32, 32, (21, 21), 44),
+                                          (2, 5, 7, (3,), 4), (1, 16, 16, (3, 3), 56)])
+def test_pack_writes_the_stems_16bit_input_in_the_same_pass(B, H, W, cs, Cd, lp, dev):
+    """mmh_pack_nhwc_lp16 (the gather staged through LDS): the fp32 NHWC tensor equals cat + zero pad, the 16-bit copy
+    equals mmh_lp16_pad_cvt of it bit for bit (what the 16-bit stems read, ops.lp16_pad8 - which then takes the parked copy
+    instead of converting), alone (only16), into one half of a two-batch buffer, and from NHWC / strided sources."""
+    from mmhand_amd import ops, lib
+    srcs = [_mk((B, c, H, W), 10 + i, dev) for i, c in enumerate(cs)]
+    ref = torch.zeros(B, H, W, Cd, device=dev)
+    ref[..., :sum(cs)] = torch.cat(srcs, 1).permute(0, 2, 3, 1)
+    plain = ops.raw_pack([(t, True, c) for t, c in zip(srcs, cs)], B, H, W, Cd, dev)
+    assert torch.equal(plain, ref)
+    want16 = ops.lp16_pad8(ref, lp)                         # mmh_lp16_pad_cvt: nothing is parked for `ref`
+    calls = []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        out = ops.raw_pack([(t, True, c) for t, c in zip(srcs, cs)], B, H, W, Cd, dev, twin=lp)
+        got16 = ops.lp16_pad8(out, lp)
+        again = ops.lp16_pad8(out, lp)                      # the parked copy is handed out once
+    finally:
+        lib.call = orig
+    assert calls == ["mmh_pack_nhwc_lp16", "mmh_lp16_pad_cvt"], calls
+    assert torch.equal(out, ref) and torch.equal(got16.view(torch.int16), want16.view(torch.int16))
+    assert torch.equal(again.view(torch.int16), want16.view(torch.int16)) and again.data_ptr() != got16.data_ptr()
+    only = ops.raw_pack([(t, True, c) for t, c in zip(srcs, cs)], B, H, W, Cd, dev, twin=lp, only16=True)
+    assert torch.equal(only.view(torch.int16), want16.view(torch.int16))
+    two = torch.full((2 * B, H, W, want16.shape[3]), 7.0, dtype=want16.dtype, device=dev)
+    ops.raw_pack([(t, True, c) for t, c in zip(srcs, cs)], B, H, W, Cd, dev, twin=lp, twin_out=two[B:], only16=True)
+    assert torch.equal(two[B:].view(torch.int16), want16.view(torch.int16)) and float(two[:B].float().min()) == 7.0
+    # a kept copy survives its use until the tensor changes
+    out = ops.raw_pack([(t, True, c) for t, c in zip(srcs, cs)], B, H, W, Cd, dev, twin=lp, keep_twin=True)
+    k1, k2 = ops.lp16_pad8(out, lp), ops.lp16_pad8(out, lp)
+    assert k1.data_ptr() == k2.data_ptr()
+    out.mul_(2.0)
+    k3 = ops.lp16_pad8(out, lp)
+    assert k3.data_ptr() != k1.data_ptr() and torch.equal(k3.view(torch.int16), ops.lp16_pad8(ref * 2.0, lp).view(torch.int16))
+    # NHWC source (the generated image) + a strided NCHW source
+    nh = _mk((B, H, W, 4), 30, dev)
+    st = srcs[0].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    mix = ops.raw_pack([(nh, False, 3), (st, True, cs[0])], B, H, W, 56, dev, twin=lp)
+    refm = torch.zeros(B, H, W, 56, device=dev)
+    refm[..., :3] = nh[..., :3]
+    refm[..., 3:3 + cs[0]] = srcs[0].permute(0, 2, 3, 1)
+    assert torch.equal(mix, refm)
+    assert torch.equal(ops.lp16_pad8(mix, lp).view(torch.int16), ops.lp16_pad8(refm, lp).view(torch.int16))
+
+
 @pytest.mark.parametrize("p,H,W", [(1, 8, 8), (3, 16, 12), (3, 5, 5), (1, 3, 4)])
 def test_reflect_fold_is_pad_transpose(p, H, W, dev):
     from mmhand_amd import ops, lib as L
