@@ -234,11 +234,11 @@ def _json_only_stdout():
 class StackMeter:
     """HIP-event brackets around every C-ABI call of the 3x3 / stride-1 stack with 256 / 512 channels (SURVEY.md
     §2.3 K4: the PATBlocks' and the Discriminators' residual convs) in 16-bit mode - fprop (mmh_conv3x3_lp16,
-    mmh_conv3x3_lp16_fprop_stats), dgrad (mmh_conv3x3_lp16 / mmh_conv3x3_lp16_dgrad_add mode 2, or mode 1 + the border terms of
+    mmh_conv3x3_lp16_fprop_stats), dgrad (mmh_conv3x3_lp16 / mmh_conv3x3_lp16_dgrad_add / _dgrad_nbr mode 2, or mode 1 + the border terms of
     mmh_conv2d_dgrad_border where the fold does not apply) and the wgrad (mmh_wgrad3x3_lp16) - during a few steps.  stack fraction = sum(algorithmic FLOPs 2.B.H.W.Cin.Cout.9 of every
     pass) / sum(bracketed time) / peak: the north_star's ">= 40 % MFMA on the 3x3 generator conv stack" as measured."""
-    NAMES = ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_fprop_stats", "mmh_conv3x3_lp16_dgrad_add", "mmh_wgrad3x3_lp16",
-             "mmh_conv2d_dgrad_border")
+    NAMES = ("mmh_conv3x3_lp16", "mmh_conv3x3_lp16_fprop_stats", "mmh_conv3x3_lp16_dgrad_add", "mmh_conv3x3_lp16_dgrad_nbr",
+             "mmh_wgrad3x3_lp16", "mmh_conv2d_dgrad_border")
 
     def __init__(self):
         self.rec = []
@@ -263,7 +263,9 @@ class StackMeter:
                 kind = "wgrad"
             elif name.endswith("fprop_stats"):
                 kind = "fprop"
-            elif name.endswith("dgrad_add"):
+            elif name.endswith("dgrad_add") or name.endswith("dgrad_nbr"):
+                # (dgrad_nbr: the bracket also holds the first norm's backward sums, taken in the epilogue, and their
+                # finishing launch - work of a row kernel counted against the stack's time)
                 kind = "dgrad"
             else:       # mmh_conv3x3_lp16 mode: 0 fprop, 1 zero-pad dgrad (+ border call), 2 the complete reflect dgrad
                 kind = "fprop" if int(args[1]) == 0 else "dgrad"

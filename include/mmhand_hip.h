@@ -268,6 +268,22 @@ int mmh_conv3x3_lp16(const mmh_conv_desc* d, int mode, const void* x16, const vo
  * channel) of the values as stored - the mmh_norm_stats_merge[_finalize] layout, so the InstanceNorm
  * behind the conv (models/Generator.py:66-77) does not read y for statistics.  chunks =
  * mmh_conv3x3_lp16_stats_chunks(d) = 2 (H/16)(W/16); 0 = not available (H or W not a multiple of 16). */
+/* dgrad (mode 1 | 2) of the 3x3 stack with a 16-bit dx that is the gradient of a norm's OUTPUT (conv -> norm -> ReLU ->
+ * Dropout -> pad -> conv, models/Generator.py:66-77, models/Discriminator.py:35-48): the epilogue also takes that norm's
+ * backward sums s1 = sum dz, s2 = sum dz * xhat per (group, channel) - dz = keep ? g * dsc : 0 of the values as stored -
+ * as partials per (image, half tile) in ws, which mmh_norm_bwd_sums_final adds up: mmh_norm_bwd_reduce's pass over g, x
+ * and the keep bits is gone.  xn: the norm's input, 16-bit [B,H,W,Cin] contiguous; bits: its keep bits (16 per 8
+ * elements, mmh_scale_shift_act's) or NULL; mean / invstd fp32 [groups][Cin], groups = B (InstanceNorm) | 1
+ * (BatchNorm); s1 / s2 fp32 [groups][Cin]; ws >= B * chunks * 2 * Cin floats, 16-byte aligned.
+ * _chunks: partials per image, 0 = not available (ragged tiles, strided dx, another kernel selected).               */
+int mmh_conv3x3_lp16_dgrad_nbr_chunks(const mmh_conv_desc* d, int mode);
+int mmh_conv3x3_lp16_dgrad_nbr(const mmh_conv_desc* d, int mode, const void* dy16, const void* w16, void* dx16,
+                               const void* xn, const void* bits, const void* mean, const void* invstd, int groups,
+                               float drop_p, void* s1, void* s2, void* ws, size_t ws_bytes, const void* zeros,
+                               mmh_stream_t s);
+/* partials [groups][chunks][2][C] -> s1, s2 [groups][C]: the second half of mmh_norm_bwd_reduce alone */
+int mmh_norm_bwd_sums_final(const void* part, int groups, int C, int chunks, void* s1, void* s2, mmh_stream_t s);
+
 /* dgrad (mode 1 | 2) with an fp32 dx that also receives `addend` (fp32, same layout as dx) in the epilogue:
  * dx = dgrad(dy) + addend.  The conv's input has a second consumer - the residual stream of a PATBlock
  * (models/Generator.py:115-130) or a ResnetBlock (models/Discriminator.py:50) - whose gradient

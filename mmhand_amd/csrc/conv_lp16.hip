@@ -935,9 +935,16 @@ int mmh_conv3x3_lp16_fold_supported(const mmh_conv_desc* d) {
 //                (the caller adds the border terms: mmh_conv2d_dgrad_border)
 // mode 2: dgrad of a reflect-padded conv COMPLETE: mode 1 plus the pad ring's gradient folded onto rows 1 / H-2 and
 //                columns 1 / W-2 inside the kernel (mmh_conv3x3_lp16_fold_supported; no border call follows)
+struct LpNbr {      // the norm-backward sums taken by a dgrad's epilogue (LpConvKP::nbr_*)
+    const void *x, *bits, *mean, *invstd;
+    float* part;
+    float dsc;
+    int groups;
+};
+
 static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, const void* w16, const void* bias,
                              void* y, int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s,
-                             const void* addend = nullptr) {
+                             const void* addend = nullptr, const LpNbr* nbr = nullptr) {
     MMH_REQUIRE(mmh_conv3x3_lp16_supported(d) && x16 && w16 && y && zeros && (mode == 0 || mode == 1 || mode == 2),
                 "mmh_conv3x3_lp16: 3x3 / stride 1 / pad 1, Cin, Cout %% 64 == 0, 16-bit dtype");
     MMH_REQUIRE(mode != 2 || mmh_conv3x3_lp16_fold_supported(d),
@@ -964,6 +971,11 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
     if (y_is16 && p.y_cs % 8 != 0) p.dbg |= 128;       // 8-byte stores: 16-byte ones need (pix*y_cs + n)*2 16-byte aligned
     p.stats = static_cast<float*>(stats);
     p.addend = static_cast<const float*>(addend);
+    if (nbr) {
+        p.nbr_x = static_cast<const char*>(nbr->x); p.nbr_bits = static_cast<const uint16_t*>(nbr->bits);
+        p.nbr_mean = static_cast<const float*>(nbr->mean); p.nbr_invstd = static_cast<const float*>(nbr->invstd);
+        p.nbr_part = nbr->part; p.nbr_dsc = nbr->dsc; p.nbr_groups = nbr->groups;
+    }
     const long long M = (long long)d->B * d->H * d->W;
     MMH_REQUIRE(M * (long long)std::max(p.cs, p.y_cs) < (1ll << 31) && d->H < 32768 && d->W < 65536,
                 "mmh_conv3x3_lp16: tensor too large");
@@ -986,7 +998,7 @@ static int conv3x3_lp16_impl(const mmh_conv_desc* d, int mode, const void* x16, 
         ready17 = e == hipSuccess ? 0 : mmh::fail("conv_lp16p_kernel: %s", hipGetErrorString(e));
     }
     if (ready17 != 0) return ready17;
-    MMH_REQUIRE(!p.stats && !p.addend, "mmh_conv3x3_lp16: epilogue statistics / addend need the halo kernel");
+    MMH_REQUIRE(!p.stats && !p.addend && !p.nbr_part, "mmh_conv3x3_lp16: epilogue statistics / addend / sums need the halo kernel");
     if (p.h16)
         hipLaunchKernelGGL(conv_lp16p_kernel<true>, dim3(8 * per_xcd), dim3(512), 2 * STAGE, mmh::as_stream(s), p);
     else
@@ -1012,6 +1024,34 @@ int mmh_conv3x3_lp16_dgrad_add(const mmh_conv_desc* d, int mode, const void* dy1
                 "mmh_conv3x3_lp16_dgrad_add: mode 1 | 2 on the halo kernel (H, W >= 16, Cin %% 256 == 0)");
     MMH_REQUIRE((reinterpret_cast<uintptr_t>(addend) & 15) == 0, "mmh_conv3x3_lp16_dgrad_add: addend must be 16-byte aligned");
     return conv3x3_lp16_impl(d, mode, dy16, w16, nullptr, dx, 0, MMH_ACT_NONE, zeros, nullptr, s, addend);
+}
+
+// dgrad (mode 1 | 2) with a 16-bit dx that is the gradient of a norm's OUTPUT (conv -> norm -> ReLU -> Dropout -> pad -> conv,
+// models/Generator.py:66-77: the second conv's input gradient enters the first norm's backward): the epilogue also takes
+// that norm's backward sums s1 = sum dz, s2 = sum dz * xhat (dz = keep ? g * dsc : 0 of the values as stored) per half tile,
+// and mmh_norm_bwd_sums_final adds the partials up - mmh_norm_bwd_reduce's pass over g, x and the keep bits (4.25 bytes
+// per element) becomes a read of x and the bits inside this epilogue.  xn: the norm's input, 16-bit [B,H,W,Cin] contiguous;
+// bits: its keep bits (16 per 8 elements) or NULL; mean / invstd [groups][Cin], groups = B (instance) | 1 (batch).
+// Returns the chunks per image (0: not available - ragged tiles, another kernel selected, a strided dx).
+int mmh_conv3x3_lp16_dgrad_nbr_chunks(const mmh_conv_desc* d, int mode) {
+    if (!mmh_conv3x3_lp16_dgrad_add_supported(d) || d->H % HT || d->W % HT || d->x_cs != d->Cin || d->Cin % 8) return 0;
+    if (mode == 2 ? !mmh_conv3x3_lp16_fold_supported(d) : mode != 1) return 0;
+    return 2 * (d->H / HT) * (d->W / HT);
+}
+
+int mmh_conv3x3_lp16_dgrad_nbr(const mmh_conv_desc* d, int mode, const void* dy16, const void* w16, void* dx16, const void* xn,
+                               const void* bits, const void* mean, const void* invstd, int groups, float drop_p, void* s1,
+                               void* s2, void* ws, size_t ws_bytes, const void* zeros, mmh_stream_t s) {
+    const int cpi = mmh_conv3x3_lp16_dgrad_nbr_chunks(d, mode);
+    MMH_REQUIRE(cpi > 0, "mmh_conv3x3_lp16_dgrad_nbr: needs the halo kernel, H and W multiples of 16, a contiguous dx "
+                         "(ask mmh_conv3x3_lp16_dgrad_nbr_chunks)");
+    MMH_REQUIRE(xn && mean && invstd && s1 && s2 && ws && (groups == 1 || groups == d->B) && drop_p >= 0.f && drop_p < 1.f &&
+                    ws_bytes >= (size_t)d->B * cpi * 2 * d->Cin * sizeof(float) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(xn) & 15) == 0,
+                "mmh_conv3x3_lp16_dgrad_nbr: bad arguments (groups 1 | B, ws >= B * chunks * 2 * Cin floats, 16-byte aligned)");
+    LpNbr nbr{xn, bits, mean, invstd, static_cast<float*>(ws), bits ? 1.f / (1.f - drop_p) : 1.f, groups};
+    if (int rc = conv3x3_lp16_impl(d, mode, dy16, w16, nullptr, dx16, 1, MMH_ACT_NONE, zeros, nullptr, s, nullptr, &nbr)) return rc;
+    return mmh_norm_bwd_sums_final(ws, groups, d->Cin, groups == 1 ? d->B * cpi : cpi, s1, s2, s);
 }
 
 // fprop with a 16-bit output whose per-(image, half tile, channel) partial statistics come out of the epilogue:

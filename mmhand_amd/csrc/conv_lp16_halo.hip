@@ -79,7 +79,7 @@ __device__ __forceinline__ void lgk_wait() { asm volatile("s_waitcnt lgkmcnt(%0)
 //            instruction at a time between the MFMA groups of half 1 (a DMA instruction costs its wave's issue slot
 //            tens of cycles: MI355X guide, cycle constants).  DESIGN.md section 4.3d: why there is no fifth "producer" wave -
 //            a kernel has ONE register allocation, and a fifth wave does not fit beside four 512-register waves.
-template <bool H16, int SIGN, bool FOLD, int NWC>
+template <bool H16, int SIGN, bool FOLD, int NWC, bool NBR = false>
 __device__ __forceinline__ void conv_lp16h2_body(const LpConvKP& p) {
     constexpr int NWAVES = 2 * NWC;
     constexpr int NJ = 16 / NWC;                    // 16-channel MFMA column tiles per wave
@@ -564,6 +564,108 @@ __device__ __forceinline__ void conv_lp16h2_body(const LpConvKP& p) {
         // mmh_set_option("lp16_dbg", 128) = 8-byte stores)
         const bool odd = (g4 & 1) != 0;
         const int cb0 = (odd ? 16 : 0) + 4 * (g4 & 2);      // this lane's 8 channels within a 32-channel tile pair
+        if (NBR) {
+            // dx is the gradient g of a norm's output: the norm's backward sums of the values AS STORED, from here (full
+            // tiles: host side).  Per lane 8 rows x 8 channels x NJ / 2 blocks: s1 += dz, sx += dz * x with
+            // dz = keep ? g * dsc : 0; the 16 pixel lanes are summed by four swizzles, lane 0 of each channel group turns
+            // sx into s2 = invstd * (sx - mean * s1) and writes the partial of this (image, half tile).  The norm's input
+            // comes back from LDS (nbx), its keep bits from kq: both requested above.
+            // This wave's slice of the norm's input (8 rows x 16 pixels x WCH channels) comes by LDS-DMA into the stage
+            // buffers the k-loop is done with - every lane's 16 bytes land where the lane reads them back, 16 KiB per wave
+            // behind the column fold's 16 KiB - and its keep bits into registers: all of it in flight at once, under the
+            // stores of dx.  (Through registers one tile row ahead the epilogue waited a memory round trip per row, 10 us
+            // per tile; four rows ahead the ring spilled.  The DMA is inline asm: issued through the builtin, the compiler
+            // waits for it in front of the next LDS read of any kind.)
+            // The keep bits of a pixel's WCH channels are 16 contiguous bytes: two more DMA instructions bring the wave's
+            // 8 x 16 of them (lane (l15, g4) of instruction q: row 4 q + g4), read back as 16-bit words - in registers the
+            // 16 words were what spilled.
+            static_assert(NJ == 4, "the keep-bit DMA assumes 64 channels per wave");
+            char* const nbx = smem + wave * 18432;
+            {
+                const size_t e00 = (((size_t)b * p.H + (oh0 + wr * 8)) * p.W + ow) * p.N + (size_t)(n0 + wc * WCH + cb0);
+                const size_t erow = (size_t)p.W * p.N;
+                const unsigned nb0 = __builtin_amdgcn_readfirstlane(mmh::lds_addr_of(nbx));
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading LDS
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int jp = 0; jp < NJ / 2; ++jp)
+                        mmh::lds_dma16(p.nbr_x + (e00 + i * erow + jp * 32) * 2, nb0 + (unsigned)(i * (NJ / 2) + jp) * 1024u);
+                if (p.nbr_bits) {
+                    const size_t k00 = (((size_t)b * p.H + (oh0 + wr * 8 + g4)) * p.W + ow) * p.N + (size_t)(n0 + wc * WCH);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        mmh::lds_dma16(p.nbr_bits + ((k00 + (size_t)(4 * q) * erow) >> 3), nb0 + 16384u + (unsigned)q * 1024u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {               // the stores first: they do not depend on what is in flight
+                const size_t m = ((size_t)b * p.H + oh0 + wr * 8 + i) * p.W + ow;
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    float v[8];
+                    mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+                    mmh::store8_lp16<H16>(p.y16 + (m * p.y_cs + (n0 + wc * WCH + jp * 32 + cb0)) * 2, v);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the DMA above has landed (this wave reads only its own)
+            // one 32-channel block at a time, one tile row after the other (sched_barrier: unrolled freely the scheduler
+            // gathers all the LDS reads in front and spills - and a spill in this epilogue is a memory round trip nothing hides)
+#define MMH_SWZ(val, s) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, val), 0x1f | ((s) << 10)))
+#pragma unroll
+            for (int jp = 0; jp < NJ / 2; ++jp) {
+                float ns1[8], nsx[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ns1[e] = nsx[e] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v[8];
+                    mmh::pair_swap8(acc[i][2 * jp], acc[i][2 * jp + 1], v);
+                    const uint4 xr = *reinterpret_cast<const uint4*>(nbx + (i * (NJ / 2) + jp) * 1024 + lane * 16);
+                    const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w};
+                    const unsigned kb = p.nbr_bits ? *reinterpret_cast<const unsigned short*>(
+                                                         nbx + 16384 + (i >> 2) * 1024 + ((i & 3) * 16 + l15) * 16 + (jp * 4 + (cb0 >> 3)) * 2)
+                                                   : 0xffffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned short xs = (unsigned short)((e & 1) ? (xw[e >> 1] >> 16) : (xw[e >> 1] & 0xffffu));
+                        const float xf = H16 ? (float)__builtin_bit_cast(_Float16, xs) : __builtin_bit_cast(float, (unsigned)xs << 16);
+                        const float gr = H16 ? (float)(_Float16)v[e] : (float)(__bf16)v[e];
+                        const float gg = ((kb >> (e < 4 ? e : e + 4)) & 1u) ? gr * p.nbr_dsc : 0.f;
+                        ns1[e] += gg;
+                        nsx[e] = fmaf(gg, xf, nsx[e]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a1 = ns1[e], ax = nsx[e];
+                    a1 += MMH_SWZ(a1, 8); ax += MMH_SWZ(ax, 8);
+                    a1 += MMH_SWZ(a1, 4); ax += MMH_SWZ(ax, 4);
+                    a1 += MMH_SWZ(a1, 2); ax += MMH_SWZ(ax, 2);
+                    a1 += MMH_SWZ(a1, 1); ax += MMH_SWZ(ax, 1);
+                    ns1[e] = a1; nsx[e] = ax;
+                }
+                if (l15 == 0) {
+                    const int chunks = TX * TY * 2;
+                    const int grp = p.nbr_groups == 1 ? 0 : b;
+                    const int c0 = n0 + wc * WCH + jp * 32 + cb0;
+                    float* pp = p.nbr_part + ((size_t)(b * chunks + (ty * TX + tx) * 2 + wr) * 2) * p.N + c0;
+                    float o2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float mu = p.nbr_mean[(size_t)grp * p.N + c0 + e], is = p.nbr_invstd[(size_t)grp * p.N + c0 + e];
+                        o2[e] = is * (nsx[e] - mu * ns1[e]);
+                    }
+                    *reinterpret_cast<f32x4*>(pp) = (f32x4){ns1[0], ns1[1], ns1[2], ns1[3]};
+                    *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){ns1[4], ns1[5], ns1[6], ns1[7]};
+                    *reinterpret_cast<f32x4*>(pp + p.N) = (f32x4){o2[0], o2[1], o2[2], o2[3]};
+                    *reinterpret_cast<f32x4*>(pp + p.N + 4) = (f32x4){o2[4], o2[5], o2[6], o2[7]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef MMH_SWZ
+        } else
         with_act([&](auto A) {
             constexpr int ACT = decltype(A)::value;
 #pragma unroll
@@ -701,6 +803,13 @@ __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
     conv_lp16h2_body<H16, SIGN, FOLD, 4>(p);
 }
 
+// the 16-bit dgrad whose epilogue also takes the norm-backward sums of what it stores (LpConvKP::nbr_*): its own
+// instantiations, so that the register budget of the plain variants is untouched
+template <bool H16, bool FOLD>
+__global__ void __launch_bounds__(512, 2) conv_lp16h2_nbr_kernel(const LpConvKP p) {
+    conv_lp16h2_body<H16, -1, FOLD, 4, true>(p);
+}
+
 // One wave per SIMD, 512 registers per lane (256 of them accumulators): the NWC = 2 form of the body above.  It LOSES to the
 // two-waves-per-SIMD form by 30 % (profiles/r05_lp16q_ablation.txt) and is compiled into A/B builds
 // only (make AB=1: -DMMH_AB_KERNELS; mmh_set_option("lp16_shape", 20), tools/bench_lp16q.py).
@@ -735,6 +844,10 @@ int launch_conv_lp16_halo(const LpConvKP& p, const mmh_conv_desc* d, int mode, b
                             reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1, false>),
                             reinterpret_cast<const void*>(conv_lp16h2_kernel<false, -1, true>),
                             reinterpret_cast<const void*>(conv_lp16h2_kernel<true, -1, true>),
+                            reinterpret_cast<const void*>(conv_lp16h2_nbr_kernel<false, false>),
+                            reinterpret_cast<const void*>(conv_lp16h2_nbr_kernel<true, false>),
+                            reinterpret_cast<const void*>(conv_lp16h2_nbr_kernel<false, true>),
+                            reinterpret_cast<const void*>(conv_lp16h2_nbr_kernel<true, true>),
 #ifdef MMH_AB_KERNELS
                             reinterpret_cast<const void*>(conv_lp16q_kernel<false, 1, false>),
                             reinterpret_cast<const void*>(conv_lp16q_kernel<false, -1, false>),
@@ -776,6 +889,18 @@ int launch_conv_lp16_halo(const LpConvKP& p, const mmh_conv_desc* d, int mode, b
         else if (mode == 0) hipLaunchKernelGGL((KERNEL<false, 1, false>), grid, dim3(THREADS), lds2, st, ph);              \
         else hipLaunchKernelGGL((KERNEL<false, -1, false>), grid, dim3(THREADS), lds2, st, ph);                            \
     } while (0)
+    if (p.nbr_part) {
+        MMH_REQUIRE(!solo && mode != 0 && p.y16 && !(ph.dbg & 128) && p.nbr_x && p.nbr_mean && p.nbr_invstd,
+                    "conv_lp16h2_nbr_kernel: a 16-bit dgrad on the two-waves-per-SIMD kernel with 16-byte stores");
+        if (mode == 2) {
+            if (p.h16) hipLaunchKernelGGL((conv_lp16h2_nbr_kernel<true, true>), grid, dim3(512), lds2, st, ph);
+            else hipLaunchKernelGGL((conv_lp16h2_nbr_kernel<false, true>), grid, dim3(512), lds2, st, ph);
+        } else {
+            if (p.h16) hipLaunchKernelGGL((conv_lp16h2_nbr_kernel<true, false>), grid, dim3(512), lds2, st, ph);
+            else hipLaunchKernelGGL((conv_lp16h2_nbr_kernel<false, false>), grid, dim3(512), lds2, st, ph);
+        }
+        return mmh::check_launch("conv_lp16h2_nbr_kernel");
+    }
 #ifdef MMH_AB_KERNELS
     if (solo) { MMH_LAUNCH_HALO(conv_lp16q_kernel, 256); return mmh::check_launch("conv_lp16q_kernel"); }
 #endif

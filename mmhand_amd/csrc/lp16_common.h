@@ -35,6 +35,17 @@ struct LpConvKP {
                             // outputs, [B][chunks][3][N] (mmh_norm_stats_merge layout), or nullptr
     const float* addend;    // conv_lp16h2_kernel, fp32 output: y += addend (same [M][y_cs] layout) - the other gradient
                             // of a tensor with two consumers, added in the dgrad's epilogue instead of by a pass of its own
+    // conv_lp16h2_kernel, 16-bit dgrad whose output is the gradient of a norm's output (the first norm of a two-conv block,
+    // models/Generator.py:66-77): the epilogue also takes that norm's backward sums of the values it stores -
+    // s1 = sum dz, s2 = sum dz * xhat per (group, channel), dz = keep ? g * dsc : 0 - as partials per (image, half tile),
+    // nbr_part [B][chunks][2][N] (mmh_norm_bwd_reduce's partial layout), so the reduce pass over g and x is gone
+    const char* nbr_x;          // the norm's input, 16-bit [M][N] contiguous
+    const uint16_t* nbr_bits;   // its keep bits (16 per 8 elements, scale_shift_act's layout) or nullptr
+    const float* nbr_mean;      // [groups][N]
+    const float* nbr_invstd;
+    float* nbr_part;            // nullptr: off
+    float nbr_dsc;              // 1 / (1 - drop_p) where bits are given, else 1
+    int nbr_groups;             // B (instance) or 1 (batch)
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {

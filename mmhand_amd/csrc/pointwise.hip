@@ -2261,6 +2261,16 @@ int mmh_norm_bwd_reduce(const void* g, const void* out, const void* x, const voi
     return mmh::check_launch("norm_bwd_reduce");
 }
 
+// the second half of mmh_norm_bwd_reduce alone: partials [groups][chunks][2][C] (written by a convolution's epilogue,
+// mmh_conv3x3_lp16_dgrad_nbr) -> s1, s2 [groups][C], summed in the reduce pass's fixed order
+int mmh_norm_bwd_sums_final(const void* part, int groups, int C, int chunks, void* s1, void* s2, mmh_stream_t s) {
+    MMH_REQUIRE(part && s1 && s2 && groups > 0 && C > 0 && chunks > 0, "mmh_norm_bwd_sums_final: bad arguments");
+    hipStream_t st = mmh::as_stream(s);
+    MMH_COL_FINAL(groups * C, chunks, st, static_cast<const float*>(part), groups, C, chunks, 2, static_cast<float*>(s1),
+                  static_cast<float*>(s2), 0);
+    return mmh::check_launch("norm_bwd_sums_final");
+}
+
 int mmh_norm_bwd_apply(const void* g, const void* out, const void* x, const void* mean,
                        const void* invstd, const void* gamma, const void* s1, const void* s2,
                        double count, int groups, int64_t rows, int C, int masked, float drop_p,

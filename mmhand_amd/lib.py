@@ -118,6 +118,9 @@ SIGNATURES = {
     "mmh_wgrad3x3_lp16": (_i, [_DP, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "mmh_conv3x3_lp16": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_conv3x3_lp16_stats_chunks": (_i, [_DP]),
+    "mmh_conv3x3_lp16_dgrad_nbr_chunks": (_i, [_DP, _i]),
+    "mmh_conv3x3_lp16_dgrad_nbr": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "mmh_norm_bwd_sums_final": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "mmh_conv3x3_lp16_dgrad_add_supported": (_i, [_DP]),
     "mmh_conv3x3_lp16_dgrad_add": (_i, [_DP, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmh_conv3x3_lp16_fprop_stats": (_i, [_DP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

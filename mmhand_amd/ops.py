@@ -802,11 +802,14 @@ def _add_into(dx, addend):
     return dx.add_(addend)
 
 
-def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None, out16=False, addend=None):
+def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels=0, dy16=None, out16=False, addend=None,
+                   nbr=None):
     """dx_channels > 0: only the first dx_channels input channels need a gradient (the caller
     ignores the rest, which may come back as zeros).  dy16: an existing 16-bit twin of dy (dy itself
     may then be None); out16: return dx in 16 bits (conv_lp16 path only).  addend (fp32, dx's shape): returns
-    dx + addend - in the halo kernel's epilogue where that kernel runs, else by one in-place add."""
+    dx + addend - in the halo kernel's epilogue where that kernel runs, else by one in-place add.
+    nbr (NormBwdSite): dx is the output gradient of that norm - where the halo kernel can, it fills in the norm's backward
+    sums (raw_conv3x3_lp16)."""
     if addend is not None:
         assert not out16 and not dx_channels
         _chk(addend, "addend")
@@ -863,8 +866,10 @@ def raw_conv_dgrad(dy, w, x_shape, stride, pad, reflect, bf16=False, dx_channels
         d.dtype = _dt(bf16)
         if reflect and USE_LP16_FOLD and L.load().mmh_conv3x3_lp16_fold_supported(C.byref(d)):
             # H, W multiples of 16: the halo kernel folds the pad ring's gradient in itself (mode 2), no border call
-            return raw_conv3x3_lp16(dy16, w, None, True, L.ACT_NONE, bf16, 2, out16=out16, addend=addend)
-        dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16, addend=addend)
+            return raw_conv3x3_lp16(dy16, w, None, True, L.ACT_NONE, bf16, 2, out16=out16, addend=addend, nbr=nbr)
+        # (with reflect padding off the in-kernel fold the border terms land after the kernel: no sums from its epilogue)
+        dx = raw_conv3x3_lp16(dy16, w, None, False, L.ACT_NONE, bf16, 1, out16=out16, addend=addend,
+                              nbr=None if reflect else nbr)
         if reflect:
             ws = torch.empty(L.load().mmh_conv2d_dgrad_border_ws_bytes(C.byref(d)) // 4 + 4, dtype=torch.float32,
                              device=dx.device)
@@ -1040,10 +1045,43 @@ def lp16_v2_ok(Cin, Cout, k, stride, pad, mode):
     return USE_LP16_V2 and k == 3 and stride == 1 and pad == 1 and Cin % 64 == 0 and Cout % 64 == 0 and n % 256 == 0
 
 
-def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_stats=False, addend=None):
+# The first norm of a two-conv block (conv -> norm -> ReLU -> Dropout -> pad -> conv, models/Generator.py:66-77) receives its
+# output gradient from the second conv's dgrad: that kernel's epilogue takes the norm's backward sums of the values it stores
+# (mmh_conv3x3_lp16_dgrad_nbr), and the norm's reduce pass over g, x and the keep bits is gone.  The norm's forward leaves a
+# NormBwdSite under its 16-bit output; the consuming conv picks it up, its backward fills in g / s1 / s2, the norm's backward
+# takes them.  MMH_FUSE_NORM_BWD_REDUCE=0: off.
+USE_NBR = os.environ.get("MMH_FUSE_NORM_BWD_REDUCE", "1") != "0"
+NBR_MIN_C = int(os.environ.get("MMH_NBR_MIN_C", "256"))      # channel counts from which the fused form is used
+
+
+class NormBwdSite:
+    __slots__ = ("x", "bits", "mean", "invstd", "groups", "drop_p", "g", "s1", "s2")
+
+    def __init__(self, x, bits, mean, invstd, groups, drop_p):
+        self.x, self.bits, self.mean, self.invstd, self.groups, self.drop_p = x, bits, mean, invstd, groups, drop_p
+        self.g = self.s1 = self.s2 = None
+
+
+_nbr_sites = {}
+
+
+def nbr_site_put(a16, site):
+    while len(_nbr_sites) >= 8:         # bounded: sites whose consumer was not a conv of this kind
+        _nbr_sites.pop(next(iter(_nbr_sites)))
+    _nbr_sites[a16.data_ptr()] = (a16, site)
+
+
+def nbr_site_take(a16):
+    ent = _nbr_sites.pop(a16.data_ptr(), None)
+    return ent[1] if ent is not None and ent[0] is a16 else None
+
+
+def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_stats=False, addend=None, nbr=None):
     """mode 0: y = conv(x16, w) (+bias, act); mode 1: dx = zero-pad correlation of x16 (= dy) with the
     flipped filter (the caller adds the reflect border terms); mode 2: the complete dgrad of a
-    ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight."""
+    ReflectionPad2d(1) conv (border terms folded in the kernel).  w: the fp32 physical weight.
+    nbr (NormBwdSite; dgrad, 16-bit dx): where the kernel can, it also fills in the sums of the norm whose output gradient dx
+    is (nbr.g = dx, nbr.s1, nbr.s2)."""
     B, H, W_, Cx = x16.shape
     _, _, Cin, Cout = w.shape
     assert x16.dtype == _wd(bf16) and Cx == (Cin if mode == 0 else Cout)
@@ -1062,6 +1100,17 @@ def raw_conv3x3_lp16(x16, w, bias, reflect, act, bf16, mode, out16=False, want_s
         L.call("mmh_conv3x3_lp16_fprop_stats", C.byref(d), _ptr(x16), _ptr(wt), _ptr(bias), _ptr(y), _ptr(stats),
                _ptr(zero_page(x16.device)), _stream())
         _park_stats(y, stats)
+    elif (nbr is not None and USE_NBR and mode != 0 and out16 and addend is None and tuple(nbr.x.shape) == tuple(y.shape)
+          and nbr.x.dtype == y.dtype and nbr.x.is_contiguous()
+          and L.load().mmh_conv3x3_lp16_dgrad_nbr_chunks(C.byref(d), mode) > 0):
+        cpi = L.load().mmh_conv3x3_lp16_dgrad_nbr_chunks(C.byref(d), mode)
+        ws = _ws(B * cpi * 2 * N * 4, y)
+        s1 = torch.empty((nbr.groups, N), dtype=torch.float32, device=y.device)
+        s2 = torch.empty((nbr.groups, N), dtype=torch.float32, device=y.device)
+        L.call("mmh_conv3x3_lp16_dgrad_nbr", C.byref(d), mode, _ptr(x16), _ptr(wp), _ptr(y), _ptr(nbr.x), _ptr(nbr.bits),
+               _ptr(nbr.mean), _ptr(nbr.invstd), nbr.groups, float(nbr.drop_p), _ptr(s1), _ptr(s2), _ptr(ws), ws.numel() * 4,
+               _ptr(zero_page(x16.device)), _stream())
+        nbr.g, nbr.s1, nbr.s2 = y, s1, s2
     elif addend is not None:        # dgrad: dx = dgrad(dy) + addend in the epilogue
         assert mode != 0 and not out16 and bias is None and act == L.ACT_NONE and tuple(addend.shape) == tuple(y.shape)
         L.call("mmh_conv3x3_lp16_dgrad_add", C.byref(d), mode, _ptr(x16), _ptr(wp), _ptr(addend), _ptr(y),
@@ -1370,6 +1419,7 @@ def lp_grads_reset():
     """drop gradients parked by a backward pass that did not finish"""
     _lp_grads.clear()
     _nb_defer.clear()
+    _nbr_sites.clear()
 
 
 # Norm-apply fused into the neighbouring convolutions (fp32, Winograd F(6x6,3x3) stack; models/Generator.py:66-77
@@ -1663,6 +1713,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.y_lp = bool(y_lp)
         k = w.shape[0]
         ctx.stem16 = ctx.head16 = False
+        ctx.nbr = nbr_site_take(x16) if (x16 is not None and torch.is_tensor(x16)) else None
         if pro is not None:
             assert wt == 6 and not bf16 and x16 is None and not y_lp, "a deferred norm needs the fp32 F(6x6,3x3) path"
             if KEEP_WINOGRAD_INPUT and ctx.needs_input_grad[1]:
@@ -1809,7 +1860,8 @@ class Conv2dFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 fuse = addend is not None and not ctx.x_lp and not ctx.dx_channels
                 dx = raw_conv_dgrad(None, w, ctx.x_shape, stride, pad, reflect, bf16, ctx.dx_channels, dy16=g16,
-                                    out16=ctx.x_lp, addend=addend if fuse else None)
+                                    out16=ctx.x_lp, addend=addend if fuse else None,
+                                    nbr=ctx.nbr if (ctx.x_lp and not ctx.dx_channels) else None)
                 if fuse:
                     addend = None       # added by the dgrad itself
                 if ctx.x_lp:
@@ -2297,6 +2349,12 @@ def _norm_fwd_finish(ctx, st, synced, gamma, beta, residual, running_mean, runni
     ctx.cfg = (groups, rows, count, bool(relu), float(drop_p), sync_group,
                residual is not None)
     ctx.save_for_backward(x, kb, mean, invstd, gamma)
+    ctx.nbr_site = None
+    if (USE_NBR and out_lp and masked and residual is None and x.dtype != torch.float32 and x.shape[3] >= NBR_MIN_C
+            and x.shape[3] % 256 == 0):
+        # the conv that consumes `out` may take this norm's backward sums in its dgrad epilogue (NormBwdSite)
+        ctx.nbr_site = NormBwdSite(x, kb, mean, invstd, groups, float(drop_p))
+        nbr_site_put(out, ctx.nbr_site)
     if want_twin and not out_lp:        # (out, twin | None): the caller asked for the pair
         if twin is not None:
             ctx.mark_non_differentiable(twin)
@@ -2337,6 +2395,16 @@ def _norm_bwd_local(ctx, g, sums_out=None):
     g = lp_grad_in(g, "NormActFn") if ctx.out_lp else g.contiguous()
     Cc = x.shape[3]
     masked = 2 if (relu or drop_p > 0) else 0
+    site = getattr(ctx, "nbr_site", None)
+    if site is not None and site.g is g and site.s1 is not None:
+        # the dgrad that produced g took the sums in its epilogue (mmh_conv3x3_lp16_dgrad_nbr): no reduce pass
+        s1, s2 = site.s1, site.s2
+        site.g = site.s1 = site.s2 = None
+        if sums_out is not None:
+            sums_out[0].copy_(s1.view_as(sums_out[0]))
+            sums_out[1].copy_(s2.view_as(sums_out[1]))
+            s1, s2 = sums_out
+        return g, s1, s2
     s1, s2 = sums_out if sums_out is not None else (_empty((groups, Cc), x), _empty((groups, Cc), x))
     if (USE_NORM_BWD_PLANE and sync_group is None and x.dtype != torch.float32 and g.dtype in (torch.float32, x.dtype)
             and L.load().mmh_norm_bwd_fused_supported(groups, rows, Cc, masked, _tdt(g), _tdt(x))):

@@ -1284,6 +1284,67 @@ def test_head_conv_takes_a_16_bit_input_on_all_three_passes(lp, dev, monkeypatch
     assert torch.equal(db, b.grad)
 
 
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256, "instance", 0.5, True), (1, 48, 32, 256, 512, "batch", 0.0, True),
+                                  (3, 32, 64, 512, 256, "instance", 0.0, False), (2, 16, 16, 256, 256, "instance", 0.5, False)])
+def test_dgrad_epilogue_takes_the_norm_backward_sums(case, lp, dev):
+    """mmh_conv3x3_lp16_dgrad_nbr: the second conv of a two-conv block sends its input gradient into the first norm's
+    backward (models/Generator.py:66-77); its epilogue takes that norm's sums s1 = sum dz, s2 = sum dz * xhat of the values it
+    stores.  dx is bit-identical to the plain dgrad's; the sums equal mmh_norm_bwd_reduce's over that dx (another order of
+    the same fp32 terms: 2e-5 relative to the sum of magnitudes), for InstanceNorm and BatchNorm statistics, with and
+    without keep bits, reflect fold and zero padding."""
+    from mmhand_amd import lib, ops
+    import ctypes as C
+    B, H, W, Cin, Cout, mode, drop_p, reflect = case
+    td = ops._wd(lp)
+    dy16 = _mk((B, H, W, Cout), 1, dev).to(td)
+    w = _mk((3, 3, Cin, Cout), 2, dev) * 0.05
+    xn = (_mk((B, H, W, Cin), 3, dev) * 1.5 + 0.3).to(td)
+    groups = B if mode == "instance" else 1
+    xf = xn.float().reshape(groups, -1, Cin)
+    mean = xf.mean(1).contiguous()
+    invstd = (1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5)).contiguous()
+    masked = drop_p > 0 or mode == "batch"
+    bits = None
+    if masked:
+        keep = (torch.rand((B * H * W * Cin // 8, 8), generator=torch.Generator().manual_seed(7)) < 0.6).to(dev)
+        sh = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11], device=dev)
+        bits = (keep.to(torch.int32) << sh).sum(1).to(torch.int16).contiguous()
+    ops.bump_weights_epoch()
+    if reflect and (H < 32 or W < 32):
+        pytest.skip("the in-kernel fold needs two tiles each way")
+    plain = ops.raw_conv3x3_lp16(dy16, w, None, reflect, lib.ACT_NONE, lp, 2 if reflect else 1, out16=True)
+    site = ops.NormBwdSite(xn, bits, mean, invstd, groups, drop_p)
+    calls = []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        dx = ops.raw_conv3x3_lp16(dy16, w, None, reflect, lib.ACT_NONE, lp, 2 if reflect else 1, out16=True, nbr=site)
+    finally:
+        lib.call = orig
+    assert calls == ["mmh_conv3x3_lp16_dgrad_nbr"], calls
+    assert site.g is dx and torch.equal(dx.view(torch.int16), plain.view(torch.int16))
+    rows = B * H * W // groups
+    s1 = torch.empty((groups, Cin), device=dev); s2 = torch.empty((groups, Cin), device=dev)
+    nws = lib.load().mmh_norm_bwd_ws_bytes(groups, rows, Cin)
+    ws = torch.empty(nws // 4 + 4, device=dev)
+    lib.call("mmh_norm_bwd_reduce", dx.data_ptr(), bits.data_ptr() if masked else None, xn.data_ptr(), mean.data_ptr(),
+             invstd.data_ptr(), groups, rows, Cin, 2 if masked else 0, drop_p, s1.data_ptr(), s2.data_ptr(), ws.data_ptr(),
+             ws.numel() * 4, ops._tdt(dx), ops._tdt(xn), torch.cuda.current_stream().cuda_stream)
+    # scale: the sum of the magnitudes of the terms
+    g = dx.float().reshape(groups, rows, Cin)
+    if masked:
+        kf = keep.reshape(groups, rows, Cin).float() / (1.0 - drop_p)
+        g = g * kf
+    xh = (xn.float().reshape(groups, rows, Cin) - mean[:, None]) * invstd[:, None]
+    m1, m2 = g.abs().sum(1), (g * xh).abs().sum(1)
+    assert float(((site.s1 - s1).abs() / m1.clamp_min(1e-20)).max()) < 2e-5
+    assert float(((site.s2 - s2).abs() / m2.clamp_min(1e-20)).max()) < 2e-5
+    ref1, ref2 = g.double().sum(1), (g.double() * xh.double()).sum(1)
+    assert float(((site.s1 - ref1).abs() / m1.clamp_min(1e-20)).max()) < 2e-5
+    assert float(((site.s2 - ref2).abs() / m2.clamp_min(1e-20)).max()) < 2e-5
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (1, 48, 16, 256, 512)])
 def test_conv3x3_lp16_one_wave_per_simd_ab_build(case, dev):
     """conv_lp16q_kernel (lp16_shape 20: one wave per SIMD, 512 registers, 256 AGPR accumulators, inline-asm MFMAs and counted

@@ -189,6 +189,58 @@ def test_two_conv_block_16bit_edges_vs_fp32_edges(lp, last_norm, dev, monkeypatc
         assert R.rel_l1(a, b) < tol, R.rel_l1(a, b)
 
 
+@pytest.mark.parametrize("lp", [True, 2])
+@pytest.mark.parametrize("norm,drop", [("instance", True), ("batch", False)])
+def test_first_norm_backward_sums_from_the_dgrad_epilogue(lp, norm, drop, dev, monkeypatch):
+    """Two-conv block with 16-bit edges: the second conv's input gradient is the first norm's output gradient, and its dgrad
+    takes that norm's backward sums in its epilogue (ops.USE_NBR, mmh_conv3x3_lp16_dgrad_nbr) - no mmh_norm_bwd_reduce for
+    that norm.  Against the same block with the reduce pass: output identical, the 16-bit gradient handed to the norm
+    identical, every gradient equal to summation-order rounding."""
+    from mmhand_amd import lib, networks, ops
+    torch.manual_seed(0)
+
+    class Net(networks._Net):
+        def __init__(self):
+            super().__init__(norm, drop)
+            self.blk = networks.Bag()
+            self._conv(self.blk, 1, 256, 256, 3)
+            self._normp(self.blk, 2, 256)
+            self._conv(self.blk, 6 if drop else 5, 256, 256, 3)
+            self._normp(self.blk, 7 if drop else 6, 256)
+
+    net = Net().init_weights("normal", seed=3).to(dev)
+    net.flatten_parameters()
+    net.bf16 = lp
+    net.train()
+    x = _mk((2, 32, 48, 256), 1, dev)
+    gy = _mk((2, 32, 48, 256), 2, dev)
+    mask = (torch.rand(x.shape, generator=torch.Generator().manual_seed(5)) >= 0.5).to(torch.uint8).to(dev)
+    res, calls = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "USE_NBR", on)
+        net._mask_src = {"site": mask}
+        xin = x.clone().requires_grad_(True)
+        net.zero_grad()
+        seen = calls.setdefault(on, {})
+        orig = lib.call
+        def spy(name, *a, _seen=seen):
+            _seen[name] = _seen.get(name, 0) + 1
+            return orig(name, *a)
+        lib.call = spy
+        try:
+            y = net.two_conv_block(net.blk, xin, "site", True)
+            y.backward(gy)
+        finally:
+            lib.call = orig
+        res[on] = (y.detach().clone(), xin.grad.clone(), net.flat_grad.clone())
+        assert not ops._lp_grads and not ops._nbr_sites
+    assert calls[True].get("mmh_conv3x3_lp16_dgrad_nbr") == 1 and "mmh_conv3x3_lp16_dgrad_nbr" not in calls[False]
+    assert calls[False]["mmh_norm_bwd_reduce"] == calls[True].get("mmh_norm_bwd_reduce", 0) + 1
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert R.rel_l1(a, b) < 2e-4, R.rel_l1(a, b)
+
+
 def test_lost_16bit_gradient_fails_loudly(dev):
     from mmhand_amd import ops
     g = ops.lp_proxy((1, 2, 2, 4), dev)
