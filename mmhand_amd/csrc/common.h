@@ -215,6 +215,7 @@ extern int g_lp16_shape;
 extern int g_lp16_tap_inner;
 extern int g_lp16_dbg;
 extern int g_lp16_wgrad_ring;
+extern int g_lp16_wgrad_s2;     // 1: the stride-2 3x3 wgrads on the nine-tap halo kernel (wgrad_lp16t.hip), 0: flat rows
 extern int g_pw_v2;
 extern int g_col_chunks, g_row_chunks;   // workgroups per launch the column-reduce / row kernels aim for
 

@@ -3175,6 +3175,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "dgrad_s2_dbg")) { mmh::g_dgrad_s2_dbg = value; return 0; }
     if (!strcmp(key, "lp16_dbg")) { mmh::g_lp16_dbg = value; return 0; }
     if (!strcmp(key, "lp16_wgrad_ring")) { mmh::g_lp16_wgrad_ring = value; return 0; }
+    if (!strcmp(key, "lp16_wgrad_s2")) { mmh::g_lp16_wgrad_s2 = value; return 0; }
     if (!strcmp(key, "border_bn64")) { g_border_bn64 = value; return 0; }
     if (!strcmp(key, "wino_gemm_occ")) { g_wino_gemm_occ = value; return 0; }
     if (!strcmp(key, "wino_gemm_levels")) { g_wino_gemm_levels = value; return 0; }

@@ -904,7 +904,7 @@ __global__ void cvt_lp16_kernel(const float* __restrict__ x, void* __restrict__ 
 // wgrad kernel (mmh_set_option "lp16_wgrad_ring"): 2 = wgrad_lp16t_kernel (default: nine taps of a 64 x 128 tile resident, the
 // input halo of a 4 x 16 pixel block staged once: wgrad_lp16t.hip), 3 = the same with both waves of a SIMD issuing their DMA
 // behind the barrier.  The one-tap ring kernels (0, 1) were removed in round 5.
-namespace mmh { int g_lp16_shape = 19; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 2; int g_lp16_persist = 1; }
+namespace mmh { int g_lp16_shape = 19; int g_lp16_tap_inner = 0; int g_lp16_dbg = 0; int g_lp16_wgrad_ring = 2; int g_lp16_persist = 1; int g_lp16_wgrad_s2 = 1; }
 using mmh::g_lp16_shape;
 
 extern "C" {
@@ -1244,11 +1244,19 @@ int mmh_wgrad_lp16_flat_supported(const mmh_conv_desc* d, int C8) {
            (d->pad_mode != MMH_PAD_REFLECT || d->stride == 1);
 }
 
+// the 3x3 / stride-2 / zero-pad convs with Cin % 64 == 0, Cout % 128 == 0 (the downsampling convs and ConvTranspose2d's
+// adjoint view) go to the nine-tap halo kernel's stride-2 form (wgrad_lp16t.hip) instead of the flat im2col rows, which
+// stage every x pixel 2.25 times and pad 576 flat rows to 768 (mmh_set_option("lp16_wgrad_s2", 0): the flat kernel)
+static bool wgrad_s2_halo(const mmh_conv_desc* d, int C8) {
+    return mmh::g_lp16_wgrad_s2 && d->stride == 2 && C8 == d->Cin && mmh::wgrad_lp16t_supported(d);
+}
+
 size_t mmh_wgrad_lp16_flat_ws_bytes(const mmh_conv_desc* d, int C8) {
     if (!mmh_wgrad_lp16_flat_supported(d, C8)) return 0;
     int ntw, MT, NT, S, ksteps;
     lp16f_geometry(d, C8, ntw, MT, NT, S, ksteps);
-    return (size_t)S * MT * 256 * d->Cout * sizeof(float);
+    const size_t flat = (size_t)S * MT * 256 * d->Cout * sizeof(float);
+    return wgrad_s2_halo(d, C8) ? std::max(flat, (size_t)mmh::wgrad_lp16t_splits(d) * 9 * d->Cin * d->Cout * sizeof(float)) : flat;
 }
 
 // dw [kh][kw][Cin][Cout] (fp32) (+)= wgrad of conv d from the 16-bit x16 [B][H][W][x_cs] (C8 channels per
@@ -1258,6 +1266,19 @@ int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_c
     MMH_REQUIRE(mmh_wgrad_lp16_flat_supported(d, C8) && x16 && dy16 && dw && ws && zeros && x_cs >= C8 && x_cs % 8 == 0,
                 "mmh_wgrad_lp16_flat: square kernel, stride 1|2, Cout %% 64 == 0, C8 %% 8 == 0 >= Cin, 16-bit dtype");
     MMH_REQUIRE(ws_bytes >= mmh_wgrad_lp16_flat_ws_bytes(d, C8), "mmh_wgrad_lp16_flat: workspace too small");
+    if (wgrad_s2_halo(d, C8)) {
+        MMH_REQUIRE((long long)d->B * d->H * d->W * x_cs < (1ll << 31) && (long long)d->B * d->Ho * d->Wo * d->y_cs < (1ll << 31),
+                    "mmh_wgrad_lp16_flat: tensor too large");
+        mmh_conv_desc e = *d;
+        e.x_cs = x_cs;
+        hipStream_t st2 = mmh::as_stream(s);
+        if (int rc = mmh::launch_wgrad_lp16t(&e, x16, dy16, static_cast<float*>(ws), zeros, st2)) return rc;
+        const int64_t n4t = (int64_t)9 * d->Cin * d->Cout / 4;
+        hipLaunchKernelGGL(lp16_slab_reduce_kernel, dim3((unsigned)std::min<int64_t>(mmh::cdiv(n4t, 256), 4096)), dim3(256),
+                           0, st2, static_cast<const float*>(ws), static_cast<float*>(dw), n4t, mmh::wgrad_lp16t_splits(d),
+                           accumulate);
+        return mmh::check_launch("lp16_slab_reduce_kernel");
+    }
     LpWgradFKP p{};
     p.x = static_cast<const char*>(x16); p.dy = static_cast<const char*>(dy16);
     p.zeros = static_cast<const char*>(zeros);

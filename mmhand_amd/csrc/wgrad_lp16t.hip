@@ -45,21 +45,39 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 
 constexpr int TCI = 64, TCO = 128;          // tile: input channels x output channels (x 9 taps)
-constexpr int BR = 4, BC = 16;              // pixel block: rows x columns = 64 pixels = 4 k16-steps
-constexpr int HP = 20;                      // halo pitch (18 used columns; a multiple of 4: see above)
+constexpr int BC = 16;                      // pixel block columns = one k16-step
 constexpr int XROWB = TCI * 2;              // 128 B per halo pixel
 constexpr int DROWB = TCO * 2;              // 256 B per dy pixel
-constexpr int XSTAGE = 128 * XROWB;         // 120 halo rows, padded to 16 DMA instructions: 16 KiB
-constexpr int DSTAGE = BR * BC * DROWB;     // 16 KiB
-constexpr int TSTAGE = XSTAGE + DSTAGE;     // 32 KiB
+constexpr int TSTAGE = 32768;               // x halo + dy tile of a block: 32 KiB at either stride
 constexpr int RING = 4;
+// Stride 1: blocks of 4 x 16 output pixels, halo 6 x 18 at pitch 20 (16 KiB: 16 DMA instructions), dy tile 16 KiB.
+// Stride 2 (the downsampling convs and, with the roles of the tensors swapped, ConvTranspose2d: models/Generator.py:192-253;
+// zero padding): blocks of 2 x 16 output pixels, halo 5 x 33 at pitch 36 (24 KiB: 24 instructions), dy tile 8 KiB.  Tap
+// (kh, kw) of the k16-step of block row kk contracts halo row 2 kk + kh at the pixels 2 t + kw: every second pixel, so all
+// k rows of a transposed read would start 256 bytes apart - in the same banks.  The halo image is therefore stored with
+// its pixel columns PERMUTED, column c in slot c ^ ((c >> 2) & 1): for either parity of kw the eight k rows of a read then
+// spread over both 128-byte bank halves, and with the 64-byte half swap on bit 1 of the slot (as at stride 1) over all
+// four quarters.  The permutation leaves bits 2.. of the column alone, so the second read of a fragment (+ 4 k rows = + 8
+// pixels) is + 8 slots, and it is applied - like the swizzles - to the DMA's per-lane source address and the read address.
+template <int ST> struct Geo {
+    static constexpr int BR = ST == 1 ? 4 : 2;              // block rows = k16-steps per block
+    static constexpr int HP = ST == 1 ? 20 : 36;            // halo pitch, a multiple of 4
+    static constexpr int HROWS = ST * (BR - 1) + 3;         // 6 | 5 halo rows
+    static constexpr int HCOLS = ST * (BC - 1) + 3;         // 18 | 33 halo columns
+    static constexpr int XJ = ST == 1 ? 2 : 3;              // x DMA instructions per wave and stage
+    static constexpr int DJ = ST == 1 ? 2 : 1;              // dy DMA instructions per wave and stage
+    static constexpr int XSTAGE = 8 * XJ * 1024;            // 16 | 24 KiB
+    static constexpr int DSTAGE = BR * BC * DROWB;          // 16 | 8 KiB
+    static_assert(XSTAGE + DSTAGE == TSTAGE && HROWS * HP <= 8 * XJ * 8 && XJ + DJ == 4, "stage layout");
+};
+__device__ __forceinline__ int slot_of_col(int c, int st) { return st == 1 ? c : (c ^ ((c >> 2) & 1)); }
 
 struct LpWgradTP {
     const char* x;          // 16-bit activations [B][H][W][Cin], pixel stride x_cs elements
-    const char* dy;         // 16-bit output gradients [B][H][W][Cout], pixel stride dy_cs
+    const char* dy;         // 16-bit output gradients [B][Ho][Wo][Cout], pixel stride dy_cs
     const char* zeros;      // >= 256 zero bytes
     float* slab;            // [S][9][Cin][Cout]
-    int B, H, W, Cin, Cout, x_cs, dy_cs;
+    int B, H, W, Ho, Wo, Cin, Cout, x_cs, dy_cs;
     int reflect;
     int stagger;            // the two waves of a SIMD issue their DMA at different points of a block
     int TR, TC;             // blocks per image: rows, columns
@@ -85,8 +103,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* a) {
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <bool H16>
+template <bool H16, int ST>
 __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) {
+    typedef Geo<ST> G;
+    constexpr int BR = G::BR, HP = G::HP, XSTAGE = G::XSTAGE, XJ = G::XJ, DJ = G::DJ;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,25 +123,25 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
     const int blk1 = min(p.nblk, blk0 + p.bps);
     const int nsteps = blk1 - blk0;
 
-    // ---- DMA roles.  x: instruction xi (0..15) fills halo rows 8 xi + lane / 8 (wave w: xi = w, w + 8); dy: instruction
-    // dj (0..15) fills tile rows 4 dj + lane / 16 (wave w: dj = 2 w, 2 w + 1).
-    int x_hy[2], x_hx[2];
-    unsigned x_coff[2];
-    bool x_row[2];
+    // ---- DMA roles.  x: instruction xi fills halo slots 8 xi + lane / 8 (wave w: xi = w, w + 8, ..); dy: instruction
+    // dj fills tile rows 4 dj + lane / 16 (wave w: dj = DJ w ..).
+    int x_hy[XJ], x_hx[XJ];
+    unsigned x_coff[XJ];
+    bool x_row[XJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < XJ; ++j) {
         const int hr = 8 * (wave + 8 * j) + (lane >> 3);
         x_hy[j] = hr / HP;
-        x_hx[j] = hr - x_hy[j] * HP;
-        x_row[j] = hr < (BR + 2) * HP && x_hx[j] < BC + 2;
+        x_hx[j] = slot_of_col(hr - x_hy[j] * HP, ST);       // the halo column this slot holds (an involution)
+        x_row[j] = hr < G::HROWS * HP && x_hx[j] < G::HCOLS;
         const unsigned lc = (unsigned)(lane & 7) ^ ((unsigned)((hr >> 1) & 1) << 2);
         x_coff[j] = (unsigned)(ct * TCI) * 2u + lc * 16u;
     }
-    int d_py[2], d_px[2];
-    unsigned d_coff[2];
+    int d_py[DJ], d_px[DJ];
+    unsigned d_coff[DJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int dr = 4 * (2 * wave + j) + (lane >> 4);
+    for (int j = 0; j < DJ; ++j) {
+        const int dr = 4 * (DJ * wave + j) + (lane >> 4);
         d_py[j] = dr >> 4;
         d_px[j] = dr & 15;
         const unsigned lc = (unsigned)(lane & 15) ^ ((unsigned)(dr & 3) << 2);
@@ -134,17 +154,17 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
     int nb_tc = nb - (nb_img * p.TR + nb_tr) * p.TC;
     int slot_next = 0;
     const unsigned lds0 = mmh::lds_addr_of(smem);
-    const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);                   // + 8 KiB for j = 1
-    const unsigned ddst = __builtin_amdgcn_readfirstlane(lds0 + XSTAGE + (unsigned)(2 * wave) * 1024u);    // + 1 KiB for j = 1
+    const unsigned xdst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);                   // + 8 KiB per j
+    const unsigned ddst = __builtin_amdgcn_readfirstlane(lds0 + XSTAGE + (unsigned)(DJ * wave) * 1024u);   // + 1 KiB per j
     auto issue = [&]() {
         const unsigned sbase = (unsigned)slot_next * TSTAGE;
         slot_next = (slot_next + 1) & (RING - 1);
         const bool live = nb < blk1;
         const int r0 = nb_tr * BR, c0 = nb_tc * BC;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int ih = r0 + x_hy[j] - 1, iw = c0 + x_hx[j] - 1;
-            if (p.reflect) {
+        for (int j = 0; j < XJ; ++j) {
+            int ih = ST * r0 + x_hy[j] - 1, iw = ST * c0 + x_hx[j] - 1;
+            if (ST == 1 && p.reflect) {
                 ih = ih < 0 ? -ih : ih;
                 iw = iw < 0 ? -iw : iw;
                 ih = ih >= p.H ? 2 * (p.H - 1) - ih : ih;
@@ -156,10 +176,10 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
             mmh::lds_dma16(g, xdst + sbase + (unsigned)j * 8192u);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < DJ; ++j) {
             const int oh = r0 + d_py[j], ow = c0 + d_px[j];
-            const bool ok = live && oh < p.H && ow < p.W;
-            const char* g = ok ? p.dy + (size_t)((nb_img * p.H + oh) * p.W + ow) * (size_t)(p.dy_cs * 2) + d_coff[j]
+            const bool ok = live && oh < p.Ho && ow < p.Wo;
+            const char* g = ok ? p.dy + (size_t)((nb_img * p.Ho + oh) * p.Wo + ow) * (size_t)(p.dy_cs * 2) + d_coff[j]
                                : p.zeros + (lane & 15) * 16;
             mmh::lds_dma16(g, ddst + sbase + (unsigned)j * 1024u);
         }
@@ -183,7 +203,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
     unsigned a_base[3];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int row = tk + kw;                                    // + (kk + kh) * HP rows: an immediate
+        const int row = slot_of_col(ST * tk + kw, ST);              // + (ST kk + kh) * HP rows: an immediate
         const int col = wr * 32 + 16 * G1 + 4 * p2;                 // element of the 64-channel halo row
         const unsigned chunk = (unsigned)(col >> 3) ^ ((unsigned)((row >> 1) & 1) << 2);
         a_base[kw] = (unsigned)row * XROWB + (chunk << 4) + (unsigned)(col & 4) * 2u;
@@ -205,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
             const char* sX = smem;
             bfr[0] = tr_frag<DROWB>(sX + XSTAGE + b_base);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) af[0][kw] = tr_frag<XROWB>(sX + a_base[kw]);
+            for (int kw = 0; kw < 3; ++kw) af[0][kw] = tr_frag<ST * XROWB>(sX + a_base[kw]);
         }
         int slot = 0;
         for (int s = 0; s < nsteps; ++s) {
@@ -233,15 +253,15 @@ __global__ void __launch_bounds__(512, 2) wgrad_lp16t_kernel(const LpWgradTP p) 
                     if (kh < 2) {
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
-                            af[nxt][kw] = tr_frag<XROWB>(sX + a_base[kw] + (kk + kh + 1) * (HP * XROWB));
+                            af[nxt][kw] = tr_frag<ST * XROWB>(sX + a_base[kw] + (ST * kk + kh + 1) * (HP * XROWB));
                     } else if (kk < BR - 1) {
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
-                            af[nxt][kw] = tr_frag<XROWB>(sX + a_base[kw] + (kk + 1) * (HP * XROWB));
+                            af[nxt][kw] = tr_frag<ST * XROWB>(sX + a_base[kw] + ST * (kk + 1) * (HP * XROWB));
                         bfr[(kk + 1) & 1] = tr_frag<DROWB>(sX + XSTAGE + b_base + (kk + 1) * (16 * DROWB));
                     } else if (s + 1 < nsteps) {
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) af[nxt][kw] = tr_frag<XROWB>(sXn + a_base[kw]);
+                        for (int kw = 0; kw < 3; ++kw) af[nxt][kw] = tr_frag<ST * XROWB>(sXn + a_base[kw]);
                         bfr[0] = tr_frag<DROWB>(sXn + XSTAGE + b_base);
                     }
 #pragma unroll
@@ -271,17 +291,22 @@ namespace mmh {
 
 int wgrad_lp16t_splits(const mmh_conv_desc* d) {
     const int tiles = (d->Cin / TCI) * (d->Cout / TCO);
-    const long long nblk = (long long)d->B * ((d->H + BR - 1) / BR) * ((d->W + BC - 1) / BC);
+    const int br = d->stride == 2 ? Geo<2>::BR : Geo<1>::BR;
+    const long long nblk = (long long)d->B * ((d->Ho + br - 1) / br) * ((d->Wo + BC - 1) / BC);
     int S = std::max(1, 256 / tiles);                   // one round of workgroups, one per CU
     S = (int)std::min<long long>(S, std::max<long long>(1, nblk / 4));
     const long long bps = (nblk + S - 1) / S;
     return (int)((nblk + bps - 1) / bps);
 }
 
+// stride 1 ('same' output, zero or reflect padding) or stride 2 (even H, W, zero padding: Ho = H / 2)
 bool wgrad_lp16t_supported(const mmh_conv_desc* d) {
-    return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Cin % TCI == 0 && d->Cout % TCO == 0 &&
-           d->Ho == d->H && d->Wo == d->W && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16) &&
-           (d->pad_mode != MMH_PAD_REFLECT || (d->H >= 2 && d->W >= 2));
+    if (!d || d->kh != 3 || d->kw != 3 || d->pad != 1 || d->Cin % TCI || d->Cout % TCO) return false;
+    if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
+    if (d->stride == 1)
+        return d->Ho == d->H && d->Wo == d->W && (d->pad_mode != MMH_PAD_REFLECT || (d->H >= 2 && d->W >= 2));
+    return d->stride == 2 && d->pad_mode != MMH_PAD_REFLECT && d->H % 2 == 0 && d->W % 2 == 0 && d->Ho == d->H / 2 &&
+           d->Wo == d->W / 2;
 }
 
 // slab: [S][9][Cin][Cout] fp32 with S = wgrad_lp16t_splits(d)
@@ -291,10 +316,12 @@ int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16
     p.x = static_cast<const char*>(x16); p.dy = static_cast<const char*>(dy16);
     p.zeros = static_cast<const char*>(zeros);
     p.slab = slab;
-    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.Cin = d->Cin; p.Cout = d->Cout; p.x_cs = d->x_cs; p.dy_cs = d->y_cs;
     p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
     p.stagger = g_lp16_wgrad_ring != 3;
-    p.TR = (d->H + BR - 1) / BR; p.TC = (d->W + BC - 1) / BC;
+    const int br = d->stride == 2 ? Geo<2>::BR : Geo<1>::BR;
+    p.TR = (d->Ho + br - 1) / br; p.TC = (d->Wo + BC - 1) / BC;
     p.nblk = d->B * p.TR * p.TC;
     p.S = wgrad_lp16t_splits(d);
     p.bps = (p.nblk + p.S - 1) / p.S;
@@ -303,17 +330,25 @@ int launch_wgrad_lp16t(const mmh_conv_desc* d, const void* x16, const void* dy16
     constexpr int lds = RING * TSTAGE;
     static int ready = -1;
     if (ready != 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16t_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_lp16t_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipSuccess;
+        const void* fs[] = {reinterpret_cast<const void*>(wgrad_lp16t_kernel<false, 1>),
+                            reinterpret_cast<const void*>(wgrad_lp16t_kernel<true, 1>),
+                            reinterpret_cast<const void*>(wgrad_lp16t_kernel<false, 2>),
+                            reinterpret_cast<const void*>(wgrad_lp16t_kernel<true, 2>)};
+        for (const void* f : fs)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         ready = e == hipSuccess ? 0 : fail("wgrad_lp16t_kernel: %s", hipGetErrorString(e));
     }
     if (ready != 0) return ready;
     const int per_xcd = (p.items + 7) / 8;
-    if (d->dtype == MMH_FP16) hipLaunchKernelGGL(wgrad_lp16t_kernel<true>, dim3(8 * per_xcd), dim3(512), lds, st, p);
-    else hipLaunchKernelGGL(wgrad_lp16t_kernel<false>, dim3(8 * per_xcd), dim3(512), lds, st, p);
+    const bool h16 = d->dtype == MMH_FP16;
+    if (d->stride == 2) {
+        if (h16) hipLaunchKernelGGL((wgrad_lp16t_kernel<true, 2>), dim3(8 * per_xcd), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((wgrad_lp16t_kernel<false, 2>), dim3(8 * per_xcd), dim3(512), lds, st, p);
+    } else {
+        if (h16) hipLaunchKernelGGL((wgrad_lp16t_kernel<true, 1>), dim3(8 * per_xcd), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((wgrad_lp16t_kernel<false, 1>), dim3(8 * per_xcd), dim3(512), lds, st, p);
+    }
     return check_launch("wgrad_lp16t_kernel");
 }
 

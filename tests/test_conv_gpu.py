@@ -614,6 +614,43 @@ def test_conv_lp16_flat_stems(case, lp, dev):
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (1, 32, 20, 128, 256), (3, 6, 70, 64, 128), (2, 34, 8, 64, 256),
+                                  (1, 64, 64, 128, 128), (5, 2, 2, 64, 128)])
+def test_stride2_wgrad_on_the_nine_tap_halo_kernel(case, lp, dev):
+    """The weight gradient of the 3x3 / stride-2 / zero-pad convs (models/Generator.py:192-199, and ConvTranspose2d's
+    adjoint view, :246-253) on wgrad_lp16t_kernel<., 2>: blocks of 2 x 16 output pixels, the 5 x 33 input halo staged once
+    with its pixel columns permuted (so that the every-second-pixel transposed reads spread over the LDS banks), all nine
+    taps resident.  Against the fp64 oracle on rounded operands, against the flat-row kernel it replaces
+    (mmh_set_option("lp16_wgrad_s2", 0)), accumulating, reproducible; ragged blocks in both directions."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, Cout = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    mk = lambda: ops.conv_desc(B, H, W, Cin, Cout, 3, 2, 1, False)
+    d = mk()
+    dy = _mk((B, d.Ho, d.Wo, Cout), 4, dev)
+    x16, dy16 = ops.lp16_twin(x, lp), ops.lp16_twin(dy, lp)
+    dw = ops.raw_wgrad_lp16_flat(mk(), x16, Cin, dy16, lp)
+    _, _, dwr, _ = R.conv2d_grads(rb(x), torch.zeros(3, 3, Cin, Cout), None, rb(dy), 2, 1, False)
+    assert R.rel_l1(dw, dwr) < 5e-6, R.rel_l1(dw, dwr)
+    assert torch.equal(ops.raw_wgrad_lp16_flat(mk(), x16, Cin, dy16, lp), dw)
+    acc = _mk((3, 3, Cin, Cout), 9, dev)
+    acc0 = acc.clone()
+    ops.raw_wgrad_lp16_flat(mk(), x16, Cin, dy16, lp, out=acc)
+    assert torch.equal(acc, acc0 + dw)
+    lib.check(lib.load().mmh_set_option(b"lp16_wgrad_s2", 0), "mmh_set_option")
+    try:
+        flat = ops.raw_wgrad_lp16_flat(mk(), x16, Cin, dy16, lp)
+    finally:
+        lib.check(lib.load().mmh_set_option(b"lp16_wgrad_s2", 1), "mmh_set_option")
+    assert R.rel_l1(flat, dwr) < 5e-6 and R.rel_l1(dw, flat) < 5e-6
+    # ConvTranspose2d(Cout -> Cin, k3 s2 p1 op1): its weight gradient is this conv's with the tensors' roles swapped
+    dwT = ops.raw_convT_wgrad(dy16, x16, lp)
+    _, _, dwTr, _ = R.convT2d_grads(rb(dy), torch.zeros(3, 3, Cin, Cout), None, rb(x))
+    assert R.rel_l1(dwT, dwTr) < 5e-6, R.rel_l1(dwT, dwTr)
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 20, 24, 4, 64, 7, 1, True), (1, 16, 16, 44, 64, 7, 1, True), (2, 12, 13, 8, 64, 7, 1, True),
                                   (1, 18, 14, 24, 128, 7, 1, False), (2, 16, 16, 64, 128, 3, 2, False),
                                   (1, 32, 20, 128, 256, 3, 2, False), (3, 10, 14, 64, 64, 3, 1, False),
