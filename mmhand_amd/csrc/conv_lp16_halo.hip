@@ -579,7 +579,7 @@ __device__ __forceinline__ void conv_lp16h2_body(const LpConvKP& p) {
             // The keep bits of a pixel's WCH channels are 16 contiguous bytes: two more DMA instructions bring the wave's
             // 8 x 16 of them (lane (l15, g4) of instruction q: row 4 q + g4), read back as 16-bit words - in registers the
             // 16 words were what spilled.
-            static_assert(NJ == 4, "the keep-bit DMA assumes 64 channels per wave");
+            static_assert(!NBR || NJ == 4, "the keep-bit DMA assumes 64 channels per wave");
             char* const nbx = smem + wave * 18432;
             {
                 const size_t e00 = (((size_t)b * p.H + (oh0 + wr * 8)) * p.W + ow) * p.N + (size_t)(n0 + wc * WCH + cb0);
