@@ -388,9 +388,24 @@ def _side_train_run(dev, B, size, steps, warmup, stack, stack_steps, dp, seed, w
                     "inplace_param_grads": bool(getattr(model, "dp_accum", False)),
                     "syncbn_collectives_per_step": {k: round(v / steps, 1) for k, v in cc.items()} if cc else None})
     if stack:
-        with StackMeter() as m:
-            for _ in range(stack_steps):
-                model.optimize_parameters()
+        # The stack alone: the dgrad epilogue that takes the first norm's backward sums (ops.USE_NBR, on in the timed steps
+        # above) is a row kernel's work inside a conv launch - metered with it off, as in the rounds before it existed; the
+        # figure with it on goes beside it.
+        from mmhand_amd import ops as _ops
+        nbr_was = _ops.USE_NBR
+        if nbr_was:
+            with StackMeter() as m1:
+                for _ in range(stack_steps):
+                    model.optimize_parameters()
+            s1, _ = m1.summary(PEAK_BF16_MFMA_TF)
+            out["stack_frac_with_norm_sums_in_dgrad"] = s1["stack_frac"]
+        _ops.USE_NBR = False
+        try:
+            with StackMeter() as m:
+                for _ in range(stack_steps):
+                    model.optimize_parameters()
+        finally:
+            _ops.USE_NBR = nbr_was
         summ, by = m.summary(PEAK_BF16_MFMA_TF)
         out.update(summ)
         c = by.get(("fprop", (512, 512)))

@@ -38,7 +38,7 @@ out = {
                                 "conv_lp16h2_kernel<bf16, dgrad, FOLD> (mmh_conv3x3_lp16 mode 2): the complete dgrad of the ReflectionPad2d(1) "
                                 "3x3 512->512 conv, one fold accumulator per wave, halo offsets in LDS, persistent tile lists",
                                 2 * x16 + w16, "as the fprop"),
-    "wgrad": entry(r"wgrad_lp16t_kernel<false>",
+    "wgrad": entry(r"wgrad_lp16t_kernel<false,1>",
                    "wgrad_lp16t_kernel<bf16>: 3x3 512->512 wgrad @64x64, B=32 (slab reduction not included)",
                    2 * x16 + 9 * 512 * 512 * 4, "algorithmic = x16 + dy16 268 MB read + dw 9.4 MB written; WRITE_SIZE = the split-K slabs"),
     "s2d": entry(r"conv_s2d_kernel<false>",
@@ -48,6 +48,13 @@ out = {
                  32 * 128 * 128 * 128 * 2 + 32 * 256 * 256 * 64 * 2 + 9 * 64 * 128 * 2,
                  "algorithmic = dy16 134.2 MB + w16 0.15 MB read + dx16 268.4 MB written (the 9 x 17 halos of the 8 x 16 tiles overlap: "
                  "160 MB of dy are requested)", dirs=(3, 4)),
+    "wgrad_s2": entry(r"wgrad_lp16t_kernel<false,2>",
+                      "wgrad_lp16t_kernel<bf16, stride 2> (round 5: nine taps of a 64 x 128 tile resident, 2 x 16-pixel blocks, 5 x 33 halo "
+                      "with permuted pixel columns): wgrad of Conv2d(64, 128, 3, 2, 1), B=32, 256x256x64 / 128x128x128 (slab reduction not "
+                      "included)",
+                      32 * 256 * 256 * 64 * 2 + 32 * 128 * 128 * 128 * 2 + 9 * 64 * 128 * 4,
+                      "algorithmic = x16 268.4 MB + dy16 134.2 MB read + dw 0.3 MB written; WRITE_SIZE = 256 split-K slabs of 295 KB; a "
+                      "5-row halo per 4 input rows is requested", dirs=(3, 4)),
     "s2f": entry(r"conv_s2f_kernel<false,1,2,2,false,2,128>",
                  "conv_s2f_kernel<bf16, C = 64> (weights register-resident, de-interleaved 17 x 33 input halo per 8 x 16 output tile): "
                  "fprop of Conv2d(64, 128, 3, 2, 1), B=32, 256x256x64 -> 128x128x128, 16-bit y",
