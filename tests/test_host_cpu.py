@@ -284,6 +284,49 @@ def test_cpu_baseline_thread_sweep_reports_the_fastest(monkeypatch):
     assert out["value"] == 0.6 and out["thread_sweep"]["32"]["value"] is None
 
 
+def test_pack_twin_and_norm_site_registries_hand_over_once_and_notice_stale_tensors():
+    """The two hand-over registries of the 16-bit step (host logic, no GPU): ops.pack_twin_put / _get - the padded 16-bit copy a
+    pack leaves for the stem that reads the fp32 tensor - is handed out once (or every time when kept), never for a tensor that
+    changed since (its version counter) or for another tensor at the same address and shape class; it is bounded.
+    ops.nbr_site_put / _take - the norm-backward site a norm leaves under its 16-bit output - goes to the conv that consumes
+    exactly that tensor object, once."""
+    import torch
+    from mmhand_amd import ops
+    ops._pack_twins.clear(); ops._nbr_sites.clear()
+    x = torch.zeros(2, 4, 4, 12)
+    t = torch.zeros(2, 4, 4, 16, dtype=torch.bfloat16)
+    ops.pack_twin_put(x, t)
+    assert ops.pack_twin_get(x, True) is t and ops.pack_twin_get(x, True) is None          # handed out once
+    ops.pack_twin_put(x, t, keep=True)
+    assert ops.pack_twin_get(x, True) is t and ops.pack_twin_get(x, True) is t              # kept
+    assert ops.pack_twin_get(x, 2) is None                                                  # fp16 asked, bf16 parked: dropped
+    assert not ops._pack_twins
+    ops.pack_twin_put(x, t, keep=True)
+    x.add_(1.0)                                                                             # the fp32 tensor changed
+    assert ops.pack_twin_get(x, True) is None and not ops._pack_twins
+    ops.pack_twin_put(x, t, keep=True)
+    ops.pack_twin_drop(x)
+    assert ops.pack_twin_get(x, True) is None
+    ops.pack_twin_put(x, t)
+    assert ops.pack_twin_get(x[:1], True) is None                                           # same address, another shape
+    held = [torch.zeros(1, 2, 2, 4) for _ in range(40)]
+    for h in held:
+        ops.pack_twin_put(h, torch.zeros(1, 2, 2, 8, dtype=torch.bfloat16))
+    assert len(ops._pack_twins) <= 16
+    a16 = torch.zeros(2, 4, 4, 256, dtype=torch.bfloat16)
+    site = ops.NormBwdSite(a16, None, torch.zeros(2, 256), torch.ones(2, 256), 2, 0.0)
+    ops.nbr_site_put(a16, site)
+    assert ops.nbr_site_take(a16.view_as(a16)) is None                                      # a view is another object: not it
+    ops.nbr_site_put(a16, site)
+    assert ops.nbr_site_take(a16) is site and ops.nbr_site_take(a16) is None
+    for h in held[:20]:
+        ops.nbr_site_put(h, site)
+    assert len(ops._nbr_sites) <= 8
+    ops.lp_grads_reset()
+    assert not ops._nbr_sites
+    ops._pack_twins.clear()
+
+
 def test_stride2_dgrad_kernel_has_no_register_spills():
     """conv_s2d_kernel must not touch scratch: a spilled DMA address or weight fragment is reloaded inside the tile loop by
     scratch_load + s_waitcnt vmcnt(0), which drains the halo DMA of the next tile and the stores of the last one - the kernel
