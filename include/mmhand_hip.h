@@ -69,7 +69,9 @@ typedef struct mmh_conv_desc {
 const char* mmh_last_error(void);
 int mmh_version(void);
 /* Tuning knobs for A/B measurements inside one process: kernel variants ("lp16_shape" 19 = the halo
- * kernel (default) | 17 = row tiles | 20 = one wave per SIMD (make AB=1 builds only), "lp16_wgrad_ring" 2 | 3, "lp16_wgrad_s2" 0 | 1 (the stride-2 3x3 wgrads on the flat-row kernel | on the nine-tap halo kernel, default), "conv_dbuf",
+ * kernel (default) | 17 = row tiles | 20 = one wave per SIMD (make AB=1 builds only), "lp16_wgrad_ring" 2 | 3,
+ * "lp16_wgrad_s2" 0 | 1 (the stride-2 3x3 weight gradients on the flat-row kernel | on the nine-tap halo kernel,
+ * default), "conv_dbuf",
  * "wino_gemm_levels", ...) and work-list parameters ("wgrad_slots", "conv_xcd", ...): the results
  * stay within the kernels' documented tolerances.  The "*_dbg" keys are NOT such knobs: "conv_dbg",
  * "lp16_dbg" (bits 1-16), "dgrad_s2_dbg", "stem_f32_dbg" switch parts of a kernel OFF for timing
