@@ -346,6 +346,10 @@ int mmh_wgrad_lp16_flat(const mmh_conv_desc* d, const void* x16, int C8, int x_c
  * y fp32 or 16-bit (y_is16) [B,H,W,y_cs], +bias, activation.                                         */
 int mmh_conv_stem16_supported(const mmh_conv_desc* d, int C8);
 size_t mmh_conv_stem16_weights_bytes(int C8);
+/* the same kernel with a 3x3 / pad 1 filter at C8 == 8 (ks = 3; ks = 7: the functions above): VGG19's conv1_1 (3 -> 64 at
+ * full resolution, losses/L1_plus_perceptualLoss.py:22-27) - mmh_conv_stem16 takes it from the descriptor's kh           */
+size_t mmh_conv_stem16_weights_bytes_k(int C8, int ks);
+int mmh_prep_weights_stem16_k(const void* w, int Cin, int C8, int ks, int dtype, void* out, mmh_stream_t s);
 int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out, mmh_stream_t s);
 int mmh_conv_stem16(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16,
                     const void* bias, void* y, int y_is16, int act, const void* zeros,

@@ -31,7 +31,6 @@ typedef const bf16x8 __attribute__((address_space(3))) * lds_frag_p;
 __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_cast<lds_frag_p>((size_t)addr); }
 
 constexpr int TS = 16;                      // output tile 16 x 16
-constexpr int HS = TS + 6;                  // halo 22 x 22
 
 struct Stem16KP {
     const char* x;          // 16-bit [B][H][W][C8]
@@ -41,6 +40,7 @@ struct Stem16KP {
     float* y;               // fp32 [B][H][W][y_cs] ...
     char* y16;              // ... or 16-bit
     int B, H, W, C8, y_cs, reflect, act;
+    int ks, hs;             // filter size 7 (the stems) | 3 (VGG19's conv1_1, C8 = 8), halo size = 16 + ks - 1
     int Jt;                 // k-steps of 32 per filter row
     int rp;                 // bytes per halo row = 22 * C8 * 2
     int wpitch;             // bytes per weight row = (32 * Jt + 8) * 2
@@ -89,12 +89,12 @@ __global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const St
     // halo: unit u of the flat image (22 rows x upr units): row u / upr, pixel (u % upr) / c8u, chunk (u % upr) % c8u;
     // units past the image (the rounds' tail) are zero-filled: the last pixels' padded k columns read into them
     {
-        const int c8u = p.C8 / 8, upr = HS * c8u, units = HS * upr;
+        const int c8u = p.C8 / 8, upr = p.hs * c8u, units = p.hs * upr, hpad = p.ks >> 1;
         for (int r = 0; r * NT * 16 < p.halo_b; ++r) {
             const int u = r * NT + tid;
             const int row = u / upr, ur = u - row * upr;
             const int hx = ur / c8u, ck = ur - hx * c8u;
-            int ih = oh0 + row - 3, iw = ow0 + hx - 3;
+            int ih = oh0 + row - hpad, iw = ow0 + hx - hpad;
             if (p.reflect) {
                 ih = ih < 0 ? -ih : ih;
                 iw = iw < 0 ? -iw : iw;
@@ -120,10 +120,10 @@ __global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const St
     const unsigned w_lane = lds0 + (unsigned)p.halo_b + (unsigned)l15 * (unsigned)p.wpitch + (unsigned)(8 * g4) * 2u;
     const unsigned w_nt = 16u * (unsigned)p.wpitch;        // bytes between n tiles
 
-    for (int kh = 0; kh < 7; ++kh) {
+    for (int kh = 0; kh < p.ks; ++kh) {
         __builtin_amdgcn_s_waitcnt(0x0070);                 // this thread's DMA (halo, filter row kh) has landed
         __syncthreads();                                    // ... everybody's; filter row kh - 1 is no longer read
-        if (kh + 1 < 7) issue_w(kh + 1);
+        if (kh + 1 < p.ks) issue_w(kh + 1);
         const unsigned wb = w_lane + (unsigned)((kh & 1) * p.wst_b);
         const unsigned xb = x_lane + (unsigned)kh * (unsigned)p.rp;
         for (int ks = 0; ks < p.Jt; ++ks) {
@@ -204,14 +204,14 @@ __global__ void __launch_bounds__(64 * (TS / RW), 2) conv_stem16_kernel(const St
     }
 }
 
-// w fp32 [7][7][Cin][64] -> 16-bit [7][64][pitch], k = kw * C8 + c, zero padded (pitch = 32 * Jt + 8 elements)
+// w fp32 [ks][ks][Cin][64] -> 16-bit [ks][64][pitch], k = kw * C8 + c, zero padded (pitch = 32 * Jt + 8 elements)
 __global__ void prep_stem16_w_kernel(const float* __restrict__ w, int Cin, int C8, int pitch, int h16,
-                                     unsigned short* __restrict__ out) {
+                                     unsigned short* __restrict__ out, int ks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 7 * 64 * pitch) return;
+    if (i >= ks * 64 * pitch) return;
     const int j = i % pitch, n = (i / pitch) & 63, kh = i / (pitch * 64);
     const int kw = j / C8, c = j - kw * C8;
-    const float v = (kw < 7 && c < Cin) ? w[((size_t)(kh * 7 + kw) * Cin + c) * 64 + n] : 0.f;
+    const float v = (kw < ks && c < Cin) ? w[((size_t)(kh * ks + kw) * Cin + c) * 64 + n] : 0.f;
     out[i] = h16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
@@ -302,21 +302,25 @@ __global__ void head_dgrad_fold_kernel(const uint4* __restrict__ dxp, int B, int
     }
 }
 
-struct Plan { int Jt, pitch, rp, halo_b, wst_b, lds, rw; };
+struct Plan { int Jt, pitch, rp, halo_b, wst_b, lds, rw, ks, hs; };
 
+// 7x7 / pad 3 (the stems), or 3x3 / pad 1 with C8 == 8 (VGG19's conv1_1, losses/L1_plus_perceptualLoss.py:22-27: 3 -> 64 at
+// full resolution; the flat-K kernel padded its 72-deep contraction to 128 and gathered an im2col tile per k-step)
 bool plan(const mmh_conv_desc* d, int C8, Plan& q) {
-    if (!d || d->kh != 7 || d->kw != 7 || d->stride != 1 || d->pad != 3 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (!d || d->kh != d->kw || d->stride != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+    if (!((d->kh == 7 && d->pad == 3) || (d->kh == 3 && d->pad == 1 && C8 == 8))) return false;
+    q.ks = d->kh; q.hs = TS + d->kh - 1;
     if (d->dtype != MMH_BF16 && d->dtype != MMH_FP16) return false;
     if (d->Cout != 64 || d->y_cs < 64 || d->y_cs % 4 || C8 % 8 || C8 < 8 || C8 > 48 || d->Cin > C8 || d->Cin < 1) return false;
     if (d->pad_mode == MMH_PAD_REFLECT && (d->H < 4 || d->W < 4)) return false;
-    q.Jt = (7 * C8 + 31) / 32;
+    q.Jt = (q.ks * C8 + 31) / 32;
     q.pitch = 32 * q.Jt + 8;
-    q.rp = HS * C8 * 2;
+    q.rp = q.hs * C8 * 2;
     // regions in whole DMA rounds (threads x 16 bytes): 4 KiB for the four-wave kernel; where two of its work-groups do
     // not fit a CU anyway, the eight-wave kernel (8 KiB rounds)
     for (q.rw = 4; q.rw >= 2; q.rw -= 2) {
         const int rb = q.rw == 4 ? 4096 : 8192;
-        q.halo_b = (HS * q.rp + 256 + rb - 1) / rb * rb;       // + the last pixels' padded k columns
+        q.halo_b = (q.hs * q.rp + 256 + rb - 1) / rb * rb;     // + the last pixels' padded k columns
         q.wst_b = (64 * q.pitch * 2 + rb - 1) / rb * rb;
         q.lds = q.halo_b + 2 * q.wst_b;
         if (q.rw == 4 && q.lds <= 80 * 1024) return true;
@@ -332,21 +336,27 @@ int mmh_conv_stem16_supported(const mmh_conv_desc* d, int C8) {
     return plan(d, C8, q) ? 1 : 0;
 }
 
-size_t mmh_conv_stem16_weights_bytes(int C8) {
-    if (C8 % 8 || C8 < 8 || C8 > 48) return 0;
-    return (size_t)7 * 64 * (32 * ((7 * C8 + 31) / 32) + 8) * 2;
+size_t mmh_conv_stem16_weights_bytes_k(int C8, int ks) {
+    if (C8 % 8 || C8 < 8 || C8 > 48 || !(ks == 7 || (ks == 3 && C8 == 8))) return 0;
+    return (size_t)ks * 64 * (32 * ((ks * C8 + 31) / 32) + 8) * 2;
+}
+
+size_t mmh_conv_stem16_weights_bytes(int C8) { return mmh_conv_stem16_weights_bytes_k(C8, 7); }
+
+int mmh_prep_weights_stem16_k(const void* w, int Cin, int C8, int ks, int dtype, void* out, mmh_stream_t s) {
+    MMH_REQUIRE(w && out && mmh_conv_stem16_weights_bytes_k(C8, ks) > 0 && Cin >= 1 && Cin <= C8 &&
+                    (dtype == MMH_BF16 || dtype == MMH_FP16),
+                "mmh_prep_weights_stem16: bad arguments (C8 %% 8 == 0 in 8..48, Cin <= C8, 7x7 | 3x3 at C8 == 8, 16-bit dtype)");
+    const int pitch = 32 * ((ks * C8 + 31) / 32) + 8;
+    const int n = ks * 64 * pitch;
+    hipLaunchKernelGGL(prep_stem16_w_kernel, dim3((n + 255) / 256), dim3(256), 0, mmh::as_stream(s),
+                       static_cast<const float*>(w), Cin, C8, pitch, dtype == MMH_FP16 ? 1 : 0,
+                       static_cast<unsigned short*>(out), ks);
+    return mmh::check_launch("prep_stem16_w_kernel");
 }
 
 int mmh_prep_weights_stem16(const void* w, int Cin, int C8, int dtype, void* out, mmh_stream_t s) {
-    MMH_REQUIRE(w && out && mmh_conv_stem16_weights_bytes(C8) > 0 && Cin >= 1 && Cin <= C8 &&
-                    (dtype == MMH_BF16 || dtype == MMH_FP16),
-                "mmh_prep_weights_stem16: bad arguments (C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype)");
-    const int pitch = 32 * ((7 * C8 + 31) / 32) + 8;
-    const int n = 7 * 64 * pitch;
-    hipLaunchKernelGGL(prep_stem16_w_kernel, dim3((n + 255) / 256), dim3(256), 0, mmh::as_stream(s),
-                       static_cast<const float*>(w), Cin, C8, pitch, dtype == MMH_FP16 ? 1 : 0,
-                       static_cast<unsigned short*>(out));
-    return mmh::check_launch("prep_stem16_w_kernel");
+    return mmh_prep_weights_stem16_k(w, Cin, C8, 7, dtype, out, s);
 }
 
 static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, const void* w_stem16, const void* bias, void* y,
@@ -373,7 +383,8 @@ static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, co
                            int y_is16, int act, const void* zeros, void* stats, mmh_stream_t s) {
     Plan q;
     MMH_REQUIRE(plan(d, C8, q) && x16p && w_stem16 && y && zeros,
-                "mmh_conv_stem16: 7x7 / stride 1 / pad 3, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, 16-bit dtype");
+                "mmh_conv_stem16: 7x7 / pad 3 (or 3x3 / pad 1 at C8 == 8), stride 1, Cout == 64, C8 %% 8 == 0 in 8..48, Cin <= C8, "
+                "16-bit dtype");
     MMH_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (long long)d->B * d->H * d->W * std::max(C8, d->y_cs) < (1ll << 31),
                 "mmh_conv_stem16: y must be 16-byte aligned; tensor too large");
     Stem16KP p{};
@@ -383,6 +394,7 @@ static int conv_stem16_impl(const mmh_conv_desc* d, const void* x16p, int C8, co
     p.B = d->B; p.H = d->H; p.W = d->W; p.C8 = C8; p.y_cs = d->y_cs; p.reflect = d->pad_mode == MMH_PAD_REFLECT ? 1 : 0;
     p.stats = static_cast<float*>(stats);
     p.act = act; p.Jt = q.Jt; p.rp = q.rp; p.wpitch = q.pitch * 2; p.halo_b = q.halo_b; p.wst_b = q.wst_b;
+    p.ks = q.ks; p.hs = q.hs;
     p.TX = (d->W + TS - 1) / TS; p.TY = (d->H + TS - 1) / TS; p.tiles = d->B * p.TX * p.TY;
     static int ready = -1;
     if (ready != 0) {

@@ -96,6 +96,8 @@ SIGNATURES = {
     "mmh_dgrad_s2_halo_supported": (_i, [_DP, _i]),
     "mmh_conv_stem16_weights_bytes": (_sz, [_i]),
     "mmh_prep_weights_stem16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mmh_conv_stem16_weights_bytes_k": (_sz, [_i, _i]),
+    "mmh_prep_weights_stem16_k": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mmh_conv_stem16": (_i, [_DP, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "mmh_wgrad_stem_lp16_supported": (_i, [_DP, _i]),
     "mmh_wgrad_stem_lp16_ws_bytes": (_sz, [_DP, _i]),

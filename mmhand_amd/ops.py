@@ -1320,16 +1320,22 @@ _stem16_cache = {}
 
 
 def stem16_weights(w, bf16):
-    """the 7x7 stem's weight for conv_stem16.hip: 16-bit [7][64][32 ceil(7 C8 / 32) + 8] (mmh_prep_weights_stem16)"""
+    """the stem's weight [k,k,Cin,64] (k = 7, or 3 at C8 = 8) for conv_stem16.hip: 16-bit [k][64][32 ceil(k C8 / 32) + 8]
+    (mmh_prep_weights_stem16_k)"""
     key = (w.data_ptr(), tuple(w.shape), _lp(bf16))
     ent = _cache_get(_stem16_cache, key, w)
     if ent is None:
-        cin = w.shape[2]
+        ks, cin = w.shape[0], w.shape[2]
         c8 = (cin + 7) // 8 * 8
-        out = torch.empty(L.load().mmh_conv_stem16_weights_bytes(c8) // 2, dtype=_wd(bf16), device=w.device)
-        L.call("mmh_prep_weights_stem16", _ptr(w), cin, c8, _dt(bf16), _ptr(out), _stream())
+        out = torch.empty(L.load().mmh_conv_stem16_weights_bytes_k(c8, ks) // 2, dtype=_wd(bf16), device=w.device)
+        L.call("mmh_prep_weights_stem16_k", _ptr(w), cin, c8, ks, _dt(bf16), _ptr(out), _stream())
         ent = _cache_put(_stem16_cache, key, w, out)
     return ent
+
+
+# VGG19's conv1_1 (3 -> 64, 3x3, zero padding, full resolution) on the stem kernel's 3x3 form instead of the flat-K kernel
+# (72-deep contraction padded to 128, an im2col tile gathered per k-step).  MMH_STEM3=0: the flat-K kernel.
+USE_STEM3 = os.environ.get("MMH_STEM3", "1") != "0"
 
 
 def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None, want_stats=False):
@@ -1341,7 +1347,8 @@ def raw_conv_lp16_flat(d, x, w, bias, act, bf16, out16=False, x16p=None, want_st
         x16p = lp16_pad8(x, bf16)
     d.dtype = _dt(bf16)
     y = torch.empty((d.B, d.H, d.W, d.Cout), dtype=_wd(bf16) if out16 else torch.float32, device=x16p.device)
-    if USE_STEM_FPROP16 and d.kh == 7 and L.load().mmh_conv_stem16_supported(C.byref(d), c8):
+    if (USE_STEM_FPROP16 and (d.kh == 7 or (d.kh == 3 and USE_STEM3)) and w.shape[3] == 64
+            and L.load().mmh_conv_stem16_supported(C.byref(d), c8)):
         chunks = (L.load().mmh_conv_stem16_stats_chunks(C.byref(d), c8)
                   if (want_stats and FUSE_NORM_STATS and FUSE_NORM_STATS_NARROW and out16 and act == L.ACT_NONE) else 0)
         if chunks > 0:      # the InstanceNorm behind the stem merges these partials instead of reading y

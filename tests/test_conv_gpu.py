@@ -958,6 +958,37 @@ def test_conv_stem16(case, act, lp, dev):
 
 
 @pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 32, 32, 3, 1, False), (1, 16, 48, 4, 1, False), (3, 19, 21, 3, 0, False), (1, 20, 20, 8, 2, True)])
+def test_vgg_conv1_1_on_the_stem_kernels_3x3_form(case, lp, dev, monkeypatch):
+    """VGG19's conv1_1 (3 -> 64, 3x3 / pad 1, losses/L1_plus_perceptualLoss.py:22-27) on conv_stem16_kernel with a 3-row filter
+    (halo 18 x 18, one 32-deep k-step per filter row at C8 = 8): against the fp64 oracle on rounded operands and against the
+    flat-K kernel it replaces (MMH_STEM3=0), fp32 and 16-bit output, ragged tiles."""
+    from mmhand_amd import lib, ops
+    B, H, W, Cin, act, refl = case
+    x = _mk((B, H, W, Cin), 1, dev)
+    w = _mk((3, 3, Cin, 64), 2, dev) * 0.2
+    bias = _mk((64,), 3, dev)
+    ops.bump_weights_epoch()
+    rb = (lambda t: t.cpu().half().float()) if lp == 2 else (lambda t: t.cpu().bfloat16().float())
+    mk = lambda: ops.conv_desc(B, H, W, Cin, 64, 3, 1, 1, refl)
+    calls = []
+    orig = lib.call
+    lib.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        y = ops.raw_conv_lp16_flat(mk(), x, w, bias, act, lp)
+    finally:
+        lib.call = orig
+    assert "mmh_conv_stem16" in calls and "mmh_conv_lp16_flat" not in calls, calls
+    yr = R.conv2d(rb(x), rb(w), bias.cpu(), 1, 1, refl, act)
+    assert R.rel_l1(y, yr) < 5e-6, R.rel_l1(y, yr)
+    y16 = ops.raw_conv_lp16_flat(mk(), x, w, bias, act, lp, out16=True)
+    assert y16.dtype == ops._wd(lp) and R.rel_l1(y16.float(), yr) < (2e-3 if lp == 2 else 8e-3)
+    monkeypatch.setattr(ops, "USE_STEM3", False)
+    y_old = ops.raw_conv_lp16_flat(mk(), x, w, bias, act, lp)
+    assert float((y - y_old).abs().max()) < 2e-5 * max(1.0, float(y_old.abs().max()))
+
+
+@pytest.mark.parametrize("lp", [True, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 256, 256, True), (1, 20, 40, 256, 512, True), (2, 9, 11, 256, 256, False)])
 def test_conv3x3_lp16_reads_a_channel_slice(case, lp, dev):
     """The halo kernel's fprop (plain and with the statistics epilogue) and the nine-tap wgrad read their 16-bit input in

@@ -32,4 +32,4 @@ for B, H, Cin, Cout in ((32, 256, 64, 128), (64, 256, 64, 128), (32, 128, 128, 2
     fl = 2.0 * B * (H // 2) ** 2 * 9 * Cin * Cout
     mb = (x16.numel() + dy16.numel()) * 2 / 1e6
     print(f"B={B} {H}x{H} {Cin}->{Cout}: flat {res[0]:.0f} us ({fl / res[0] / 1e6:.0f} TF), halo {res[1]:.0f} us "
-          f"({fl / res[1] / 1e6:.0f} TF = {fl / res[1] / 1e6 / 2500:.2f} of 2500; {mb:.0f} MB of operands = {mb / res[1] * 1e-3:.1f} TB/s)", flush=True)
+          f"({fl / res[1] / 1e6:.0f} TF = {fl / res[1] / 1e6 / 2500:.2f} of 2500; {mb:.0f} MB of operands = {mb / res[1]:.1f} TB/s)", flush=True)
