@@ -52,6 +52,58 @@ def test_abi_rejects_bad_arguments_without_gpu(built_lib):
     assert l.mmh_loss_scale_update(None, None, 2.0, 0.5, 2000, 1.0, 2.0 ** 24, None) != 0
 
 
+def test_round5_entry_points_plan_and_validate_without_gpu(built_lib):
+    """The planning / validation half of the round-5 entry points runs on the CPU: which shapes the Generator head's 16-bit
+    weight gradient, the dgrad with the norm-backward sums, the stride-2 nine-tap weight gradient, the 3x3 form of the stem
+    kernel and the LDS-staged pack accept, their workspace sizes, and that bad arguments are refused before any launch."""
+    L = built_lib
+    l = L.load()
+    mk = lambda B, H, W, Cin, Cout, k, s, p, refl, dt=L.BF16: L.ConvDesc(B, H, W, Cin, Cout, k, k, s, p, L.PAD_REFLECT if refl else L.PAD_ZERO,
+                                                                       (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, Cin, Cout, dt)
+    by = ctypes.byref
+    # the head: 7x7 / reflect 3 / 64 -> 4 only, 16-bit only
+    head = mk(2, 32, 48, 64, 4, 7, 1, 3, True)
+    assert l.mmh_conv7_head_wgrad_lp16_supported(by(head)) == 1
+    assert l.mmh_conv7_head_wgrad_lp16_supported(by(mk(2, 32, 48, 64, 4, 7, 1, 3, True, L.F32))) == 0
+    assert l.mmh_conv7_head_wgrad_lp16_supported(by(mk(2, 32, 48, 64, 4, 7, 1, 3, False))) == 0
+    assert l.mmh_conv7_head_wgrad_lp16_supported(by(mk(2, 32, 48, 32, 4, 7, 1, 3, True))) == 0
+    need = l.mmh_conv7_head_wgrad_lp16_ws_bytes(by(head))
+    assert need >= 2 * 38 * 54 * 16 + 49 * 64 * 8 * 4            # the embedded dy + at least one slab
+    assert l.mmh_conv7_head_wgrad_lp16(by(head), None, None, None, None, 0, 0, None, None) != 0
+    # the dgrad whose epilogue takes the norm's backward sums: full 16 x 16 tiles, 256-column tiles, the halo kernel
+    assert l.mmh_conv3x3_lp16_dgrad_nbr_chunks(by(mk(2, 32, 48, 256, 256, 3, 1, 1, True)), 2) == 2 * 2 * 3
+    assert l.mmh_conv3x3_lp16_dgrad_nbr_chunks(by(mk(2, 32, 48, 256, 256, 3, 1, 1, False)), 1) == 2 * 2 * 3
+    assert l.mmh_conv3x3_lp16_dgrad_nbr_chunks(by(mk(2, 32, 40, 256, 256, 3, 1, 1, False)), 1) == 0       # ragged tiles
+    assert l.mmh_conv3x3_lp16_dgrad_nbr_chunks(by(mk(2, 16, 16, 256, 256, 3, 1, 1, True)), 2) == 0        # fold needs two tiles
+    assert l.mmh_conv3x3_lp16_dgrad_nbr_chunks(by(mk(2, 32, 48, 128, 256, 3, 1, 1, False)), 1) == 0       # 128 dx columns
+    assert l.mmh_conv3x3_lp16_dgrad_nbr(by(mk(2, 32, 40, 256, 256, 3, 1, 1, False)), 1, *([None] * 7), 2, 0.0, None, None, None, 0, None, None) != 0
+    assert b"dgrad_nbr" in l.mmh_last_error()
+    assert l.mmh_norm_bwd_sums_final(None, 2, 256, 12, None, None, None) != 0
+    # stride-2 weight gradients: the nine-tap halo kernel's slabs decide the workspace (S x 9 x Cin x Cout floats)
+    s2 = mk(4, 64, 64, 64, 128, 3, 2, 1, False)
+    assert l.mmh_wgrad_lp16_flat_supported(by(s2), 64) == 1
+    ws = l.mmh_wgrad_lp16_flat_ws_bytes(by(s2), 64)
+    assert ws == 32 * (9 * 64 * 128 * 4)        # 4 x 16 x 2 blocks of 2 x 16 output pixels, at least four per split: 32 slabs
+    assert l.mmh_set_option(b"lp16_wgrad_s2", 0) == 0
+    try:
+        assert l.mmh_wgrad_lp16_flat_ws_bytes(by(s2), 64) < ws                      # the flat-row kernel's own, smaller, slabs
+    finally:
+        assert l.mmh_set_option(b"lp16_wgrad_s2", 1) == 0
+    # the stem kernel: 7x7 at C8 in 8..48, 3x3 at C8 == 8 only
+    assert l.mmh_conv_stem16_supported(by(mk(2, 32, 32, 4, 64, 3, 1, 1, False)), 8) == 1
+    assert l.mmh_conv_stem16_supported(by(mk(2, 32, 32, 12, 64, 3, 1, 1, False)), 16) == 0
+    assert l.mmh_conv_stem16_supported(by(mk(2, 32, 32, 24, 64, 7, 1, 3, True)), 24) == 1
+    assert l.mmh_conv_stem16_weights_bytes_k(8, 3) == 3 * 64 * (32 + 8) * 2 and l.mmh_conv_stem16_weights_bytes_k(16, 3) == 0
+    assert l.mmh_conv_stem16_weights_bytes_k(24, 7) == l.mmh_conv_stem16_weights_bytes(24) > 0
+    assert l.mmh_prep_weights_stem16_k(None, 3, 8, 3, L.BF16, None, None) != 0
+    # the LDS-staged pack: Cd % 4, Cd <= 56, the 16-bit copy padded to a multiple of 8
+    src = (L.PlaneSrc * 1)(L.PlaneSrc(None, 3, 0, 0, 0, 0))
+    assert l.mmh_pack_nhwc_lp16(src, 1, None, None, 1, 4, 4, 4, 8, L.BF16, None) != 0            # neither output
+    assert l.mmh_pack_nhwc_lp16(src, 1, ctypes.c_void_p(64), None, 1, 4, 4, 60, 0, L.BF16, None) != 0  # Cd > 56
+    assert l.mmh_pack_nhwc_lp16(src, 1, None, ctypes.c_void_p(64), 1, 4, 4, 4, 12, L.BF16, None) != 0  # C8 % 8
+    assert b"mmh_pack_nhwc_lp16" in l.mmh_last_error()
+
+
 def test_mmh_options_environment(built_lib):
     """MMH_OPTIONS=key=value,... reaches mmh_set_option when the library loads; an unknown key stops the run"""
     code = "from mmhand_amd import lib; lib.load(); print('loaded')"
