@@ -100,14 +100,14 @@ def loaded_rccl_path():
 _trackers = []      # weak references to live GradBuckets objects: the conv shims report parameter uses / contributions
 
 
-def _tracker_of(p):
+def _tracker_of(p, armed_only=True):
     a = p.data_ptr()
     dead = False
     for r in _trackers:
         t = r()
         if t is None:
             dead = True
-        elif t._armed and t._lo <= a < t._hi:
+        elif (t._armed or not armed_only) and t._lo <= a < t._hi:
             return t
     if dead:
         _trackers[:] = [r for r in _trackers if r() is not None]
@@ -121,7 +121,7 @@ def tracking():
 
 def param_use(p):
     """a shim's forward will contribute to p's gradient in the coming backward pass"""
-    t = _tracker_of(p)
+    t = _tracker_of(p, armed_only=False)      # an unarmed tracker notes the use as a stray one (GradBuckets.use)
     if t is not None:
         t.use(p)
 
@@ -176,6 +176,7 @@ class GradBuckets:
         self._uses = [0] * self._n
         self._dones = [0] * self._n
         self._untracked = [False] * self._n
+        self._stray = [False] * self._n       # a shim forward used the parameter while the buckets were not armed
         self._complete = [False] * self._n
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(params)]
         # the shims find a parameter by the address of its slice of the flat PARAMETER buffer
@@ -194,13 +195,22 @@ class GradBuckets:
 
     def use(self, p):
         i = self._index.get(p.data_ptr())
-        if i is not None and self._armed:
+        if i is None:
+            return
+        if self._armed:
             self._uses[i] += 1
+        else:
+            # the backward of this forward will report a done that no counted use matches; together with counted uses of
+            # the same parameter the exact-match rule of done() would then fire one contribution early: the
+            # parameter stays untracked for the coming pass and its bucket goes out with launch_remaining()
+            self._stray[i] = True
 
     def done(self, p):
         """Complete on an EXACT match only: every counted use has reported done.  A done without a counted use (the
         forward ran before begin(), or a shim reported twice) leaves the parameter untracked - its bucket then goes
-        out with launch_remaining() at the end of the pass, never early under a later in-place add."""
+        out with launch_remaining() at the end of the pass, never early under a later in-place add.  So does
+        any use reported while unarmed since the last pass ended (`_stray`, set by use(), taken over by begin()): one
+        counted and one uncounted use would otherwise match on the first of their two dones."""
         i = self._index.get(p.data_ptr())
         if i is None or not self._armed:
             return
@@ -251,7 +261,8 @@ class GradBuckets:
         self._works = [None] * len(self.buckets)
         self._uses = [0] * self._n
         self._dones = [0] * self._n
-        self._untracked = [False] * self._n
+        self._untracked = list(self._stray)
+        self._stray = [False] * self._n
         self._complete = [False] * self._n
         self._armed = True
 

@@ -109,7 +109,9 @@ class ImagePool:
         # left it while a sibling of the same query is still inside.
         out = []                    # per output slot: a tensor, or an int k = "the k-th image stored by this query"
         stored = []                 # batch indices stored by this query, in order
-        pool = self.images          # entries: tensors (earlier queries) or ints (this query)
+        # decisions go into a COPY of the pool list, written back only once `compact` exists: an allocation failure in
+        # pass 2 (the realistic one: OOM at a step boundary) leaves self.images as it was, never holding ints
+        pool = list(self.images)    # entries: tensors (earlier queries) or ints (this query)
         for i in range(images.shape[0]):
             if len(pool) < self.pool_size:
                 pool.append(len(stored))
@@ -130,7 +132,9 @@ class ImagePool:
                 if isinstance(e, int):
                     pool[j] = compact[e:e + 1]
             out = [compact[e:e + 1] if isinstance(e, int) else e for e in out]
-        return torch.cat(out, 0)
+        result = torch.cat(out, 0)
+        self.images = pool
+        return result
 
 
 class GANLoss:

@@ -117,6 +117,26 @@ class Bag(nn.Module):
         return self._modules[str(name)]
 
 
+def logical_grads(net, device=None):
+    """{reference state_dict key: gradient in the reference's logical layout} (Conv2d OIHW, ConvTranspose2d IOHW, norm affine
+    [C]) from the physical-layout parameter gradients ([kh][kw][Cin_pad][Cout_pad] views of the flat gradient buffer):
+    what the reference's `named_parameters()` gradients are compared with (models/Generator.py, models/Discriminator.py)."""
+    out = {}
+    mv = (lambda t: t if device is None else t.to(device))
+    for name, m in net.named_modules():
+        if isinstance(m, ConvParam):
+            if m.weight.grad is not None:
+                g = m.weight.grad.permute(3, 2, 0, 1)
+                out[name + ".weight"] = mv(g[: m.cin, : m.cout] if m.transposed else g[: m.cout, : m.cin])
+            if m.bias is not None and m.bias.grad is not None:
+                out[name + ".bias"] = mv(m.bias.grad[: m.cout])
+        elif isinstance(m, NormParam):
+            if m.weight.grad is not None:
+                out[name + ".weight"] = mv(m.weight.grad)
+                out[name + ".bias"] = mv(m.bias.grad)
+    return out
+
+
 def _norm_kind(norm_layer):
     """'batch' | 'instance' from the reference's norm_layer argument (a functools.partial)."""
     f = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer

@@ -1203,7 +1203,9 @@ def pack_twin_put(x, x16p, keep=False):
     survives its use (a model input that several steps read; dropped by pack_twin_drop), else the first lp16_pad8 takes it."""
     while len(_pack_twins) >= 16:       # bounded: entries of tensors that never reached a stem
         _pack_twins.pop(next(iter(_pack_twins)))
-    _pack_twins[x.data_ptr()] = (x, x._version, x16p, keep)     # x is held so that its address stays unique
+    # a DETACHED alias is held (same storage, same version counter): the address stays unique while the entry lives, and an
+    # entry no stem consumes does not pin the autograd graph of the PackFn output it was parked under (ADVICE r5)
+    _pack_twins[x.data_ptr()] = (x.detach(), x._version, x16p, keep)
 
 
 def pack_twin_drop(x):
@@ -1427,6 +1429,8 @@ def lp_grads_reset():
     _lp_grads.clear()
     _nb_defer.clear()
     _nbr_sites.clear()
+    for k in [k for k, ent in _pack_twins.items() if not ent[3]]:      # kept entries belong to model inputs (pack_twin_drop)
+        del _pack_twins[k]
 
 
 # Norm-apply fused into the neighbouring convolutions (fp32, Winograd F(6x6,3x3) stack; models/Generator.py:66-77

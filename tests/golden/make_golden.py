@@ -350,7 +350,60 @@ def make_step():
         print(f"step_{norm}.npz", np.array(trace))
 
 
+FULLSIZE = dict(ngf=64, n_blocks=9, H=256, W=256, B=2, norm="instance", samples=1024)
+
+
+def make_fullsize():
+    """fp64 truth for the parameter gradients of the FULL-SIZE Generator (ngf 64, 9 PATBlocks, 256x256, B=2,
+    InstanceNorm, dropout off) - the reference's own models/Generator.py:269-313 in float64, on the weights the build's seeded
+    init produces (weights_init_normal, seed 49), the SURVEY 8(d) synthetic batch (seed 49) and the probe loss
+    sum(out * randn(seed 3)) bench.py's `gradient_parity` uses.  71 M gradient values do not fit a fixture, so per tensor the
+    file keeps a SKETCH: sum|g|, sqrt(sum g^2) and the values at 1024 seeded positions (`sketch_indices`; whole tensors up
+    to that size), as float32 roundings of the float64 values (6e-8: far below the 1e-3 in question).  Beside it
+    `cond/<key>`: the distance of PyTorch's own fp32 CPU run (the same reference module in float32) from the float64 run,
+    exact over the whole tensor, and `cond_sampled/<key>`: the same figure through the sketch - what the estimator is worth.
+    About 5 minutes and 20 GB on 8 cores."""
+    import time
+    from mmhand_amd.networks import Generator as BuildG
+    F = FULLSIZE
+    t0 = time.time()
+    sd = OrderedDict((k, v.detach().clone()) for k, v in
+                     BuildG([3, 42, 6], 3, F["ngf"], F["norm"], False, F["n_blocks"]).init_weights("normal", 49).state_dict().items())
+    batch = O.synthetic_batch(F["B"], F["H"], F["W"], seed=49)
+    g_in = [batch["H1"], torch.cat((batch["P1"], batch["P2"]), 1), torch.cat((batch["D1"], batch["D2"]), 1)]
+    probe = torch.randn(F["B"], 3, F["H"], F["W"], generator=torch.Generator().manual_seed(3))
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        net = RefG([3, 42, 6], 3, F["ngf"], ref_norm(F["norm"]), False, F["n_blocks"])
+        net.load_state_dict(sd)
+        net = net.to(dt).train()
+        out = net([t.to(dt) for t in g_in])
+        (out * probe.to(dt)).sum().backward()
+        res[dt] = (out.detach(), OrderedDict((k, p.grad.detach()) for k, p in net.named_parameters()))
+        print("fullsize", dt, "done at %.0f s" % (time.time() - t0), flush=True)
+        del net, out
+    o64, g64 = res[torch.float64]
+    o32, g32 = res[torch.float32]
+    rel = lambda a, c: float((a.double() - c.double()).abs().sum() / c.double().abs().sum().clamp_min(1e-300))   # noqa: E731
+    fix = {"out_l1": np.float64(o64.abs().sum()), "cond/out": np.float64(rel(o32, o64)),
+           "out_sample": o64.flatten()[RC.sketch_indices("out", o64.numel(), F["samples"])].float().numpy()}
+    conds = []
+    for k, g in g64.items():
+        idx = RC.sketch_indices(k, g.numel(), F["samples"])
+        fix["l1/" + k] = np.float64(g.abs().sum())
+        fix["l2/" + k] = np.float64(g.pow(2).sum().sqrt())
+        fix["s/" + k] = g.flatten()[idx].float().numpy()
+        if RC.is_null_grad_bias("G", k, F["norm"]) or float(g.abs().sum()) == 0.0:
+            continue
+        fix["cond/" + k] = np.float64(rel(g32[k], g))
+        fix["cond_sampled/" + k] = np.float64(rel(g32[k].flatten()[idx], g.flatten()[idx]))
+        conds.append(fix["cond/" + k])
+    np.savez_compressed(os.path.join(HERE, "fullsize_grad_sketch.npz"), **fix)
+    print("fullsize_grad_sketch.npz: %d tensors; PyTorch fp32 vs fp64: output %.2e, gradients median %.2e max %.2e (%d of %d above 1e-3)"
+          % (len(g64), fix["cond/out"], np.median(conds), max(conds), sum(c > 1e-3 for c in conds), len(conds)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "losses_mse", "adam", "pose", "visuals", "step"]
+    which = sys.argv[1:] or ["keys", "generator", "discriminator", "losses", "losses_mse", "adam", "pose", "visuals", "step", "fullsize"]
     for w in which:
         globals()["make_" + w]()

@@ -51,6 +51,15 @@ def keep_mask(key, shape):
     return (torch.rand(shape, generator=_gen(key, 13)) >= 0.5).to(torch.uint8)
 
 
+def sketch_indices(key, numel, n):
+    """the flat positions of a (logical-layout) gradient tensor that fullsize_grad_sketch.npz keeps - all of them up to n
+    elements, else n seeded draws with replacement: a function of the key only"""
+    if numel <= n:
+        return torch.arange(numel)
+    g = torch.Generator().manual_seed(zlib.crc32(("sketch." + key).encode()) % (2 ** 31))
+    return torch.randint(0, numel, (n,), generator=g)
+
+
 # reduced configuration used by the module / step fixtures
 SMALL = dict(ngf=8, ndf=8, n_blocks=2, n_layers_D=2, H=32, W=32, B=2)
 

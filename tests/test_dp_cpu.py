@@ -236,6 +236,31 @@ def _w_grad_buckets_inplace(rank, world, port):
     bk.wait()
     assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7), (gflat - ref).abs().max()
     assert [e for e in log if e[0] == "bucket"] == [("bucket", i) for i in range(n_layers)], log
+    # the MIXED case - one forward before begin() (uncounted) and one after it (counted).  With an exact-match
+    # rule alone the first of the two dones would match the single counted use and the bucket would leave before the second
+    # in-place add; a use reported while unarmed therefore keeps the parameter untracked for the coming pass.
+    gflat.zero_()
+    log.clear()
+    ya = net(xa)                            # before begin(): not counted, remembered as a stray use
+    assert all(bk._stray[2 * i] for i in range(n_layers))
+    bk.begin()
+    yb = net(xb)                            # counted
+    assert all(bk._uses[2 * i] == 1 and bk._untracked[2 * i] for i in range(n_layers))
+    (ya.square().mean() + yb.square().mean()).backward()
+    assert all(bk._dones[2 * i] == 0 for i in range(n_layers))          # no early completion through the shim path
+    bk.launch_remaining()
+    bk.wait()
+    assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7), (gflat - ref).abs().max()
+    # ... and the pass after it is tracked again (the stray mark does not outlive one pass)
+    gflat.zero_()
+    log.clear()
+    bk.begin()
+    assert not any(bk._untracked)
+    (net(xa).square().mean() + net(xb).square().mean()).backward()
+    bk.launch_remaining()
+    bk.wait()
+    assert torch.allclose(gflat, ref, rtol=1e-5, atol=1e-7)
+    assert log.index(("bucket", 0)) < log.index(("param", 0))
     bk.remove()
     assert not dp.tracking()
     dist.destroy_process_group()

@@ -99,3 +99,59 @@ def test_adam_properties_full_size(dev):
     # m = 0.5*0.37, v = 0.001*0.37^2; bias corrections 1-0.25, 1-0.999^2
     step = 2e-4 / (1 - 0.5 ** 2) * (0.5 * 0.37) / ((0.001 * 0.37 ** 2 / (1 - 0.999 ** 2)) ** 0.5 + 1e-8)
     assert ((p0 - p) - step).abs().max().item() < 1e-7
+
+
+def test_sketch_inputs_equal_the_fixture_generator():
+    """bench.sketch_inputs (no oracle import in bench.py) IS the batch tests/golden/make_golden.py make_fullsize ran on"""
+    import bench
+    from oracle import mmhand_ref as O
+    a, b = bench.sketch_inputs(2, 256, 256, 49), O.synthetic_batch(2, 256, 256, 49)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+
+
+@pytest.mark.parametrize("mode", ["off", "bwd", "all"])
+def test_fullsize_generator_gradients_vs_fp64_sketch(mode, dev):
+    """the full-size Generator (ngf 64, 9 PATBlocks, 256x256, B=2, InstanceNorm, dropout off) against FLOAT64
+    TRUTH from the reference's own module (tests/golden/fullsize_grad_sketch.npz: per parameter tensor the float64 gradient
+    at 1024 seeded positions; models/Generator.py:269-313 in double precision on identical weights and inputs).
+
+    What the fixture says about fp32 on this network: PyTorch's own fp32 CPU run is 7.7e-4 (median) / 1.63e-3 (max) from
+    float64 - 9 of 85 tensors above 1e-3.  No fp32 implementation holds 1e-3 on every tensor here.  Bars per tensor:
+      off  (direct kernels, `direct_path`)            <= max(1e-3, 1.5 x PyTorch fp32's own distance)
+      bwd  (`--fp32_exact_grads`, `hybrid_path`)      the same bar
+      all  (Winograd F(6x6,3x3), the headline)        <= 5e-3, median <= 3e-3 (the forward's 6th-digit differences flip ReLU
+                                                      masks: DESIGN 2.1), output <= 2e-5
+    """
+    import os
+    import statistics
+    import numpy as np
+    import bench
+    from mmhand_amd import ops
+    from mmhand_amd.networks import Generator, logical_grads
+    fix = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_grad_sketch.npz"))
+    b = {k: v.to(dev) for k, v in bench.sketch_inputs(2, 256, 256, 49).items()}
+    g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]), 1)]
+    probe = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(dev)
+    old = "off" if not ops.USE_WINOGRAD else "all" if ops.WINOGRAD_FPROP else "bwd"
+    try:
+        ops.set_winograd_mode(mode)
+        net = Generator([3, 42, 6], 3, 64, "instance", False, 9).init_weights("normal", 49).to(dev).train()
+        net.flatten_parameters()
+        out = net(g_in)
+        (out * probe).sum().backward()
+        errs, oerr = bench.fp64_sketch_distance(fix, logical_grads(net), out.detach().contiguous())
+    finally:
+        ops.set_winograd_mode(old)
+    cond = {k: float(fix["cond_sampled/" + k]) for k in errs}
+    v = sorted(errs.values())
+    worst = max(errs, key=errs.get)
+    print(f"\n[{mode}] output {oerr:.2e}; gradients vs fp64: median {statistics.median(v):.2e} max {v[-1]:.2e} ({worst}); "
+          f"PyTorch fp32: median {statistics.median(cond.values()):.2e} max {max(cond.values()):.2e}; "
+          f"{sum(e > 1e-3 for e in v)} of {len(v)} above 1e-3")
+    assert len(v) == 85
+    if mode == "all":
+        assert oerr < 2e-5 and v[-1] < 5e-3 and statistics.median(v) < 3e-3, (oerr, v[-1], statistics.median(v))
+    else:
+        assert oerr < 5e-6, oerr
+        bad = {k: (e, cond[k]) for k, e in errs.items() if e > max(1e-3, 1.5 * cond[k])}
+        assert not bad, bad
