@@ -440,26 +440,26 @@ def _side_train_run(dev, B, size, steps, warmup, stack, stack_steps, dp, seed, w
                     "inplace_param_grads": bool(getattr(model, "dp_accum", False)),
                     "syncbn_collectives_per_step": {k: round(v / steps, 1) for k, v in cc.items()} if cc else None})
     if stack:
-        # The stack alone: the dgrad epilogue that takes the first norm's backward sums (ops.USE_NBR, on in the timed steps
-        # above) is a row kernel's work inside a conv launch - metered with it off, as in the rounds before it existed; the
-        # figure with it on goes beside it.
+        # stack_frac describes the SHIPPED configuration: with ops.USE_NBR on - as the timed steps above ran - the
+        # dgrad launches of the stack also take the first norm's backward sums in their epilogue (a row kernel's work inside
+        # a conv launch).  The stack metered alone, with that epilogue off, goes beside it as
+        # stack_frac_without_norm_sums_in_dgrad (the figure the rounds before the epilogue existed reported).
         from mmhand_amd import ops as _ops
-        nbr_was = _ops.USE_NBR
-        if nbr_was:
-            with StackMeter() as m1:
-                for _ in range(stack_steps):
-                    model.optimize_parameters()
-            s1, _ = m1.summary(PEAK_BF16_MFMA_TF)
-            out["stack_frac_with_norm_sums_in_dgrad"] = s1["stack_frac"]
-        _ops.USE_NBR = False
-        try:
-            with StackMeter() as m:
-                for _ in range(stack_steps):
-                    model.optimize_parameters()
-        finally:
-            _ops.USE_NBR = nbr_was
+        with StackMeter() as m:
+            for _ in range(stack_steps):
+                model.optimize_parameters()
         summ, by = m.summary(PEAK_BF16_MFMA_TF)
         out.update(summ)
+        if _ops.USE_NBR:
+            nbr_was = _ops.USE_NBR
+            try:
+                _ops.USE_NBR = False
+                with StackMeter() as m0:
+                    for _ in range(stack_steps):
+                        model.optimize_parameters()
+                out["stack_frac_without_norm_sums_in_dgrad"] = m0.summary(PEAK_BF16_MFMA_TF)[0]["stack_frac"]
+            finally:
+                _ops.USE_NBR = nbr_was
         c = by.get(("fprop", (512, 512)))
         if c and c[2] > 0:
             ach = c[1] / (c[2] * 1e-3) / 1e12
@@ -588,6 +588,34 @@ def gradient_parity_run(dev, size, norm):
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def line_summary(line):
+    """The figures of the side regions in one compact object, emitted as the LAST key of the JSON line (the
+    driver keeps the tail of a long line; round 5's bf16_path.images_per_s and stack_frac fell off it)."""
+    def g(key, field="images_per_s"):
+        v = line.get(key)
+        return v.get(field) if isinstance(v, dict) else None
+    gp = line.get("gradient_parity") if isinstance(line.get("gradient_parity"), dict) else {}
+    v64 = gp.get("vs_fp64", {}) if isinstance(gp.get("vs_fp64"), dict) else {}
+    s = {"value": line.get("value"), "ms_per_step": line.get("ms_per_step"), "dtype": line.get("dtype"),
+         "roofline_frac": (line.get("roofline") or {}).get("frac"),
+         "bf16_path": g("bf16_path"), "bf16_ms_per_step": g("bf16_path", "ms_per_step"),
+         "stack_frac": g("bf16_path", "stack_frac"),
+         "stack_frac_without_norm_sums_in_dgrad": g("bf16_path", "stack_frac_without_norm_sums_in_dgrad"),
+         "bf16_roofline_frac": (g("bf16_path", "roofline") or {}).get("frac"),
+         "bf16_graph_step": g("bf16_path_graph"), "bf16_graph_host_enqueue_ms": g("bf16_path_graph", "host_enqueue_ms"),
+         "size512_bf16_b4": g("size512_bf16_b4"), "size512_graph_step": g("size512_bf16_b4_graph"),
+         "norm_batch": g("norm_batch"), "norm_batch_o1": g("norm_batch_o1"),
+         "hybrid_path": g("hybrid_path"), "direct_path": g("direct_path"), "set_input_in_loop": g("set_input_in_loop"),
+         "dp_rccl_world1": g("dp_rccl_world1"), "dp_bf16_path": g("dp_bf16_path"), "dp_norm_batch": g("dp_norm_batch"),
+         "dp_norm_batch_o1": g("dp_norm_batch_o1"), "dp_size512_bf16_b4": g("dp_size512_bf16_b4"),
+         "infer_b64_f32": g("infer_b64_f32"), "infer_b64_bf16": g("infer_b64_bf16"),
+         "grad_median_winograd_vs_direct": (gp.get("winograd_vs_direct") or {}).get("grad_rel_l1_median"),
+         "grad_vs_fp64_median": {k: (v64.get(k) or {}).get("grad_rel_l1_median")
+                                 for k in ("direct", "hybrid_winograd_bwd_only", "winograd", "pytorch_fp32_cpu")} if v64 else None,
+         "cpu_baseline": (line.get("cpu_baseline") or {}).get("value"), "rccl_ranks": line.get("rccl_ranks")}
+    return {k: v for k, v in s.items() if v is not None}
 
 
 def side_infer_run(dev, B, size, steps, bf16):
@@ -1096,6 +1124,7 @@ def main():
                 allc = cpu_baseline(H, W, a.norm, budget_s=a.cpu_all_cores, hard_timeout_s=int(a.cpu_all_cores * 2 + 60),
                                     threads=os.cpu_count(), max_steps=2)
                 line["cpu_baseline"]["all_cores"] = {k: allc.get(k) for k in ("value", "cores", "sample")}
+        line["summary"] = line_summary(line)       # LAST key: what a truncated tail of this line must still show
         print(json.dumps(line), file=_OUT, flush=True)
     if dist.is_initialized():
         dist.barrier()          # the other ranks wait here while rank 0 collects the CPU baseline and prints

@@ -1,4 +1,4 @@
-"""Data-parallel logic on CPU: world_size-2 gloo process groups (no GPU).
+"""Data-parallel logic on CPU: world_size-2 and world_size-4 gloo process groups (no GPU).
 
 What can run without the HIP kernels: the SyncBN statistics merge used by NormActFn
 (mmhand_amd.ops._sync_stats), the all-reduce(SUM) x 1/world gradient rule of MMHandModel, and the
@@ -28,7 +28,8 @@ def _w_sync_stats(rank, world, port):
     from mmhand_amd import ops
     g = torch.Generator().manual_seed(7)
     full = torch.randn((4, 6, 5, 8), generator=g) * 3 + 2          # global batch, NHWC
-    x = full[rank * 2:(rank + 1) * 2]
+    per = 4 // world
+    x = full[rank * per:(rank + 1) * per]
     rows = x.shape[0] * x.shape[1] * x.shape[2]
     flat = x.reshape(-1, 8)
     mean = flat.mean(0, keepdim=True)
@@ -50,7 +51,7 @@ def _w_sync_stats_packed(rank, world, port):
     items, fulls = [], []
     for Cc in (8, 16, 4):
         full = torch.randn((4, 3, 5, Cc), generator=g) * 2 + 1
-        x = full[rank * 2:(rank + 1) * 2].reshape(-1, Cc)
+        x = full[rank * (4 // world):(rank + 1) * (4 // world)].reshape(-1, Cc)
         mean = x.mean(0, keepdim=True)
         items.append((mean.contiguous(), ((x - mean) ** 2).sum(0, keepdim=True).contiguous(), x.shape[0]))
         fulls.append(full.reshape(-1, Cc))
@@ -68,7 +69,8 @@ def _w_sync_stats_packed(rank, world, port):
     red = ops._sync_bwd_sums_multi(pairs, dist.group.WORLD)
     assert ops.collective_counter["all_reduce"] == 1
     for (s1, s2), c in zip(red, (8, 4)):
-        assert torch.equal(s1, torch.full((1, c), 3.0)) and torch.equal(s2, torch.arange(c, dtype=torch.float32).view(1, c) * 3)
+        tot = float(world * (world + 1) // 2)        # sum over ranks of (rank + 1)
+        assert torch.equal(s1, torch.full((1, c), tot)) and torch.equal(s2, torch.arange(c, dtype=torch.float32).view(1, c) * tot)
     dist.destroy_process_group()
 
 
@@ -88,7 +90,8 @@ def _w_grad_average(rank, world, port):
         O.gan_loss(O.discriminator_forward(n, x, 1), True).backward()
         return torch.cat([p.grad.reshape(-1) for p in n.parameters()])
 
-    flat = grads(x_full[rank * 2:(rank + 1) * 2])       # this rank's flat gradient buffer
+    per = 4 // world
+    flat = grads(x_full[rank * per:(rank + 1) * per])   # this rank's flat gradient buffer
     dist.all_reduce(flat)                                # what MMHandModel._allreduce_async does
     flat *= 1.0 / world                                  # folded into mmh_adam_step(grad_scale)
     ref = grads(x_full)
@@ -281,3 +284,11 @@ def _w_options(rank, world, port):
                                           (_w_grad_buckets_inplace, 29616)])
 def test_world2_gloo(worker, port):
     mp.spawn(worker, args=(2, port), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("worker,port", [(_w_sync_stats, 29661), (_w_grad_average, 29662), (_w_grad_buckets, 29664),
+                                          (_w_sync_stats_packed, 29665), (_w_grad_buckets_inplace, 29666)])
+def test_world4_gloo(worker, port):
+    """the same workers at world size 4 (no world size above 2 had run, even functionally): statistics merged
+    over four ranks' (count, mean, M2), gradients averaged over four shards, buckets cut and issued alike on four ranks"""
+    mp.spawn(worker, args=(4, port), nprocs=4, join=True)

@@ -299,3 +299,107 @@ def test_bench_two_ranks_on_one_gpu_carry_every_multi_gpu_key(dev):
     assert j["dp_norm_batch"]["syncbn_collectives_per_step"]["all_gather"] == 50, j["dp_norm_batch"]
     assert j["dp_norm_batch"]["syncbn_collectives_per_step"]["all_reduce"] == 50
     assert j["dp_bf16_path"]["syncbn_collectives_per_step"] is None
+
+
+# ------------------------------------------------------------------ world 4 and 8
+def _worker_n(rank, world, port, norm, tmp, poison_rank=-1):
+    """rank `rank` of `world` gloo ranks that all share cuda:0, one sample per rank; poison_rank >= 0: that rank's generator
+    loss overflows in the second iteration"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MMH_DP_LOG="1", MMH_BUCKET_MB="0.02", MMH_PACK_SYNCBN="1")
+    sys.path.insert(0, ROOT)
+    from oracle import mmhand_ref as O
+    from mmhand_amd import mmhand_model, ops
+    from mmhand_amd.mmhand_model import MMHandModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = O.synthetic_batch(world, 32, 32, seed=7)
+    shard = {k: v[rank:rank + 1] for k, v in full.items()}
+    random.seed(0)
+    model = MMHandModel(_opt(norm, 1, True))
+    losses = []
+    for it in range(2):
+        if it == 1 and rank == poison_rank:
+            orig = model.loss_backward
+
+            def poisoned(loss, loss_id=0):
+                orig(loss * float("inf") if loss_id == 0 else loss, loss_id)
+            model.loss_backward = poisoned
+        if it == 1 and poison_rank >= 0:
+            snap = model.netG.flat_param.clone()
+        model.set_input(shard)
+        model.optimize_parameters()
+        losses.append([float(v) for v in model.get_current_errors().values()])
+    model._settle_overflow(drain=True)
+    torch.cuda.synchronize()
+    out = {"losses": losses, "sd": OrderedDict((k, v.detach().cpu()) for k, v in model.netG.state_dict().items()),
+           "log": list(mmhand_model._LAST_BUCKET_LOG or []), "syncbn": dict(ops.collective_counter),
+           "skipped": model.skipped_steps, "steps": [o.step_count for o in model.optimizers]}
+    if poison_rank >= 0:
+        out["unchanged"] = bool(torch.equal(model.netG.flat_param, snap))
+    torch.save(out, os.path.join(tmp, f"w{world}_rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,norm,port", [(4, "instance", 29651), (4, "batch", 29652), (8, "instance", 29653),
+                                             (8, "batch", 29654)])
+def test_world_4_and_8_equal_one_rank_on_concatenated_batch(world, norm, port, dev, tmp_path):
+    """World sizes 4 and 8 run FUNCTIONALLY before multi-GPU hardware does (options/base_options.py:171-178: the global batch
+    is cut by the world size): `world` gloo ranks share the one GPU, one sample each.  Two iterations must equal the
+    single-process step on the concatenated batch - gradient = mean over ranks through the bucketed all-reduce, SyncBN
+    statistics over the global batch (mmh_syncbn_merge_finalize over `world` rows of (count, mean, M2)) - replicas stay
+    bit-identical, and every rank issues its bucket collectives in the same order, cut at the same places."""
+    from oracle import mmhand_ref as O
+    from tests.golden.recipe import is_null_grad_bias
+    mp.spawn(_worker_n, args=(world, port, norm, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), f"w{world}_rank{r}.pt")) for r in range(world)]
+    for r in rs[1:]:
+        for k in rs[0]["sd"]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), k
+        assert [e for e in r["log"] if e[1] == "bucket"] == [e for e in rs[0]["log"] if e[1] == "bucket"]
+        assert r["syncbn"] == rs[0]["syncbn"]
+    sb = dict(rs[0]["syncbn"])
+    sb.pop("packed_sites", None)
+    assert sb == ({"all_gather": 2 * (9 + 3 * 7), "all_reduce": 2 * (9 + 3 * 7)} if norm == "batch" else {}), rs[0]["syncbn"]
+    g_buckets = [e[2] for e in rs[0]["log"] if e[0] == "G" and e[1] == "bucket"]
+    assert g_buckets[0] == 0 and max(g_buckets) >= 2, g_buckets
+    ref_losses, ref_sd = _run(norm, O.synthetic_batch(world, 32, 32, seed=7), False)
+    if norm == "instance":
+        mean_losses = np.mean([r["losses"] for r in rs], axis=0)
+        assert np.allclose(mean_losses, np.array(ref_losses), rtol=2e-4), (mean_losses, ref_losses)
+    for k, v in ref_sd.items():
+        if v.is_floating_point() and not is_null_grad_bias("G", k, norm):
+            assert torch.allclose(rs[0]["sd"][k], v, atol=2e-4 + 1e-3 * v.abs().max().item()), k
+
+
+def test_overflow_on_rank_5_of_8_skips_the_step_everywhere(dev, tmp_path):
+    """eight ranks, rank 5 alone overflows in iteration 2: all eight skip that iteration's three optimizer steps (the flag is
+    computed on the all-reduced gradients: one rank's inf is everybody's) and stay identical replicas"""
+    mp.spawn(_worker_n, args=(8, 29655, "instance", str(tmp_path), 5), nprocs=8, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), f"w8_rank{r}.pt")) for r in range(8)]
+    for r in rs:
+        assert r["unchanged"] and r["skipped"] == 3 and r["steps"] == [1, 1, 1], (r["unchanged"], r["skipped"], r["steps"])
+        for k in rs[0]["sd"]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), k
+
+
+def test_bench_eight_ranks_on_one_gpu_carry_every_multi_gpu_key(dev):
+    """`python bench.py --gpus 8 --share-gpu-gloo`: the line the driver's 8-GPU command prints, produced by eight ranks on the
+    one GPU - every multi-GPU key present and sane (global batch 16, eight ranks counted, 50 + 50 packed SyncBN collectives)"""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu-gloo", "--batch", "2",
+                          "--size", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=2400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["config"]["global_batch"] == 16 and j["value"] > 0
+    assert j["inplace_param_grads"] is True and "value" in j["comm_exposed_ms"]
+    for key in ("dp_bf16_path", "dp_norm_batch", "dp_norm_batch_o1", "dp_bf16_path_nopersist"):
+        r = j[key]
+        assert "error" not in r, (key, r)
+        assert r["n_gpus"] == 8 and r["global_batch"] == 16 and r["images_per_s"] > 0 and r["losses_finite"], (key, r)
+    assert j["dp_norm_batch"]["syncbn_collectives_per_step"] == {"all_gather": 50.0, "all_reduce": 50.0, "packed_sites": j["dp_norm_batch"]["syncbn_collectives_per_step"]["packed_sites"]}
+    assert list(j)[-1] == "summary" and j["summary"]["dp_bf16_path"] == j["dp_bf16_path"]["images_per_s"]

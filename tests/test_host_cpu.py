@@ -407,3 +407,45 @@ def test_stride2_dgrad_kernel_has_no_register_spills():
     # the default instantiations of the fprop kernel (64 -> 128 stride 2; the 64 -> 64 stride-1 form) are spill-free as well
     dflt = {k: v for k, v in seen.items() if "conv_s2f_kernel" in k and ("ELi1ELi2ELi2ELb0ELi2ELi128" in k or "ELi1ELi4ELi2ELb0ELi1ELi64" in k)}
     assert len(dflt) == 4 and all(v == 0 for v in dflt.values()), dflt
+
+
+def test_winograd_forward_gemm_keeps_scratch_out_of_its_k_loop():
+    """wino_gemm_kernel<128,2> - the dominant kernel of the fp32 headline (bench.py roofline) - carries 48 bytes of scratch
+    per lane: tile-constant addresses reloaded once per TILE of the persistent loop.  That is harmless; the same reload inside
+    the k-loop would put a scratch_load + s_waitcnt vmcnt(0) - a drain of every prefetched operand - into each of its 16
+    k-steps (what cost conv_s2d_kernel a third of its time, DESIGN.md 4.3e).  Build-time property, read from the ISA: no
+    scratch access in any basic block of loop depth >= 2, and no more scratch than round 5 measured (VERDICT r5 #3 / weak #10)."""
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "mmhand_amd", "csrc")
+    asm = "/tmp/_mmh_conv_igemm_gate.s"
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-Wno-unused-function",
+                          "-Wno-inline-asm", "-S", "--cuda-device-only", "-o", asm, "conv_igemm.hip"],
+                         cwd=src, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = open(asm).read().splitlines()
+    os.remove(asm)
+    start = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*wino_gemm_kernelILi128ELi2E\w*:", l)]
+    assert len(start) == 1, start
+    name = re.match(r"^(_Z\w+):", lines[start[0]]).group(1)
+    end = next(i for i in range(start[0], len(lines)) if lines[i].strip() == f".amdhsa_kernel {name}")
+    scratch_bytes = next(int(l.split()[-1]) for l in lines[end:end + 60] if ".amdhsa_private_segment_fixed_size" in l)
+    depth, by_depth, mfma_by_depth = 0, {}, {}
+    for l in lines[start[0] + 1:end]:
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            m = re.search(r"Depth=(\d+)", l)
+            depth = int(m.group(1)) if m else 0
+        elif re.match(r"^\s*;\s+(Parent Loop|=>|Child Loop)", l):      # continuation comments of a block label
+            m = re.search(r"=>\s*This (?:Inner )?Loop Header: Depth=(\d+)", l)
+            if m:
+                depth = int(m.group(1))
+        elif "scratch_" in l:
+            by_depth[depth] = by_depth.get(depth, 0) + 1
+        elif "v_mfma" in l:
+            mfma_by_depth[depth] = mfma_by_depth.get(depth, 0) + 1
+    assert mfma_by_depth.get(2, 0) >= 32, mfma_by_depth              # the k-loop IS the depth-2 loop (the parse found it)
+    assert not any(d >= 2 for d in by_depth), by_depth                # ... and it touches no scratch
+    assert scratch_bytes <= 48, scratch_bytes
