@@ -715,6 +715,29 @@ int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n,
                   float grad_scale, const void* skip_flag, const void* loss_scale,
                   mmh_stream_t s);
 
+/* The same update with the step count and the learning rate resident on the device - nothing in the launch depends on the
+ * iteration, so a whole training step can sit in a captured hipGraph (MMHandModel.py:310-330 replayed).  step (device
+ * int32): incremented first, unless *skip_flag != 0 (apex does not count a skipped step: no host correction afterwards);
+ * lr (device float): what update_learning_rate (models/base_model.py:82-87) last wrote; coef (device float[2]): scratch
+ * for lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t), computed in double as mmh_adam_step does on the host.             */
+int mmh_adam_step_dev(void* p, const void* g, void* m, void* v, int64_t n, const void* lr, float beta1, float beta2,
+                      float eps, void* step, float grad_scale, const void* skip_flag, const void* loss_scale, void* coef,
+                      mmh_stream_t s);
+
+/* Dropout in a captured step: every kernel that draws dropout decisions from a by-value seed (mmh_scale_shift_act[_twin],
+ * mmh_dropout_bits[_both]) adds *salt (a device uint64; NULL = none, the default) to that seed when it RUNS.  The salt is
+ * read from the pointer registered here at launch time; mmh_u64_add advances it on the stream (inside the graph), so each
+ * replay of the same launches draws fresh masks (models/Generator.py:66-77 nn.Dropout(0.5) per forward).              */
+int mmh_set_dropout_salt(const void* salt_u64);
+int mmh_u64_add(void* value_u64, uint64_t inc, mmh_stream_t s);
+
+/* ImagePool.query (util/image_pool.py:14-34) on a device-resident pool [slots][elems_per_image] fp32 with the host's
+ * decisions as device int32 indices [B]: out[i] = src_idx[i] >= 0 ? pool[src_idx[i]] (content before this query)
+ * : images[-1 - src_idx[i]]; then pool[dst_idx[i]] = images[i] where dst_idx[i] >= 0 (the host emits one writer per slot).
+ * The launches are the same every iteration - only the index arrays change - so the query can sit in a captured step.  */
+int mmh_pool_exchange(void* pool, const void* images, void* out, const void* src_idx, const void* dst_idx, int B,
+                      int64_t elems_per_image, mmh_stream_t s);
+
 /* ---- overflow detection (MMHandModel.loss_backward, MMHandModel.py:294-308) --
  * *flag_out = (flag_in ? *flag_in : 0) | any(!isfinite(g[0..n))).  flag_in carries
  * the sticky `self.overflow` of the steps already taken this iteration.  Run on

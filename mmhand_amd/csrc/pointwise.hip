@@ -8,7 +8,11 @@
 #include <cmath>
 #include "common.h"
 
-namespace mmh { int g_pw_v2 = 1; int g_col_chunks = 2048; int g_row_chunks = 4096; }   // mmh_set_option("pw_v2"): 0 = first-generation pointwise kernels (A/B)
+namespace mmh { int g_pw_v2 = 1; int g_col_chunks = 2048; int g_row_chunks = 4096; }
+// mmh_set_dropout_salt: a device uint64 that every dropout-drawing kernel adds to its by-value seed when it runs (NULL = none).
+// A captured training step (hipGraph) replays the seeds its launches were captured with; the salt, advanced by a kernel
+// inside the graph (mmh_u64_add), is what makes each replay draw fresh masks.
+static const uint64_t* g_dropout_salt = nullptr;   // mmh_set_option("pw_v2"): 0 = first-generation pointwise kernels (A/B)
 
 namespace {
 
@@ -290,7 +294,8 @@ __device__ __forceinline__ unsigned drop_byte(int64_t i, uint32_t thr16, uint64_
 }
 
 __global__ void dropout_bits_kernel(int64_t n8, uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
-                                    uint8_t* __restrict__ bits) {
+                                    uint8_t* __restrict__ bits, const uint64_t* __restrict__ salt) {
+    if (salt) seed += *salt;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     bits[i] = (uint8_t)drop_byte(i, thr16, seed, mask);
@@ -300,8 +305,9 @@ __global__ void dropout_bits_kernel(int64_t n8, uint32_t thr16, uint64_t seed, c
 // transposes them into the row words (see dropout_rows_kernel below).
 __global__ void __launch_bounds__(TPB) dropout_both_kernel(int W, int C, int nW32, uint32_t thr16, uint64_t seed,
                                                            const uint8_t* __restrict__ mask, uint8_t* __restrict__ bits,
-                                                           uint32_t* __restrict__ rows) {
+                                                           uint32_t* __restrict__ rows, const uint64_t* __restrict__ salt) {
     extern __shared__ uint8_t sm_bits[];
+    if (salt) seed += *salt;
     const int c8 = C / 8;
     const int64_t row = blockIdx.x;
     const int nb = W * c8;
@@ -347,7 +353,8 @@ __global__ void scale_shift_act_kernel(const void* __restrict__ x, int in_lp, co
                                        int64_t n4, int64_t rows_per_group, int C4, int relu,
                                        float drop_p, uint64_t seed,
                                        const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits,
-                                       int out_lp) {
+                                       int out_lp, const uint64_t* __restrict__ salt) {
+    if (salt) seed += *salt;
     const uint32_t thr = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     const float dsc = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -509,7 +516,8 @@ __global__ void __launch_bounds__(TPB) scale_shift_act_v2(
         const void* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
         const float* __restrict__ residual, void* __restrict__ out, int64_t rows, RowGeom rg, int relu,
         float drop_p, uint64_t seed, const uint8_t* __restrict__ mask, uint8_t* __restrict__ keep_bits,
-        bool xh16, bool oh16, void* __restrict__ twin = nullptr, bool th16 = false) {
+        bool xh16, bool oh16, void* __restrict__ twin, bool th16, const uint64_t* __restrict__ salt) {
+    if (salt) seed += *salt;
     const int q = threadIdx.x & (rg.c8 - 1), rsub = threadIdx.x / rg.c8;
     const int grp = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rg.rows_per_chunk;
@@ -1614,6 +1622,71 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// Adam with the step count and the learning rate RESIDENT ON THE DEVICE (mmh_adam_step_dev): one thread advances the count -
+// unless this step is skipped (overflow), as apex does not count a skipped step - and leaves lr / (1 - b1^t) and
+// 1 / sqrt(1 - b2^t), in the double arithmetic the host form uses, where the update kernel reads them.  Nothing about the
+// launch depends on the iteration any more: it can sit in a captured graph.
+__global__ void adam_tick_kernel(int* __restrict__ step, const float* __restrict__ lr, const int* __restrict__ skip,
+                                 float b1, float b2, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int t = *step;
+    if (!(skip && *skip)) *step = ++t;
+    if (t < 1) t = 1;
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    coef[0] = (float)((double)*lr / bc1);
+    coef[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
+                                float b2, float eps, const float* __restrict__ coef,
+                                float gscale, const int* __restrict__ skip,
+                                const float* __restrict__ loss_scale) {
+    if (skip && *skip) return;
+    if (loss_scale) gscale /= *loss_scale;
+    const float step_size = coef[0], inv_sqrt_bc2 = coef[1];
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gr = g[i] * gscale;
+        float mm = b1 * m[i] + (1.f - b1) * gr;
+        float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mm / denom);
+    }
+}
+
+__global__ void u64_add_kernel(uint64_t* __restrict__ p, uint64_t inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += inc;
+}
+
+// ImagePool.query (util/image_pool.py:14-34) with the host's decisions handed over as device indices: per output image
+// src[i] >= 0 -> the pool's slot src[i] (its content BEFORE this query), src[i] < 0 -> image -1 - src[i] of the batch;
+// then dst[i] >= 0 -> the pool's slot dst[i] takes image i.  Two launches (every read of the pool before any write).
+__global__ void pool_gather_kernel(const float* __restrict__ pool, const float* __restrict__ images, float* __restrict__ out,
+                                   const int* __restrict__ src, int64_t n4) {
+    const int img = blockIdx.y;
+    const int sidx = src[img];
+    const float* from = sidx >= 0 ? pool + (int64_t)sidx * n4 * 4 : images + (int64_t)(-1 - sidx) * n4 * 4;
+    float* to = out + (int64_t)img * n4 * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st4(to, i, ld4(from, i));
+}
+
+__global__ void pool_scatter_kernel(float* __restrict__ pool, const float* __restrict__ images, const int* __restrict__ dst,
+                                    int64_t n4) {
+    const int img = blockIdx.y;
+    const int d = dst[img];
+    if (d < 0) return;
+    const float* from = images + (int64_t)img * n4 * 4;
+    float* to = pool + (int64_t)d * n4 * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) st4(to, i, ld4(from, i));
+}
+
 // flag |= any(!isfinite(g)): the exponent field of inf/nan is all ones
 __global__ void grad_nonfinite_kernel(const float* __restrict__ g, int64_t n4, int64_t n,
                                       int* __restrict__ flag, int* __restrict__ own) {
@@ -2183,7 +2256,8 @@ static int scale_shift_act_impl(const void* x, const void* scale, const void* sh
                        static_cast<const float*>(scale), static_cast<const float*>(shift),                    \
                        static_cast<const float*>(residual), out, rows, rg, relu, drop_p, seed,                \
                        static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits),                   \
-                       x_dtype == MMH_FP16, out_dtype == MMH_FP16, twin, twin_dtype == MMH_FP16)
+                       x_dtype == MMH_FP16, out_dtype == MMH_FP16, twin, twin_dtype == MMH_FP16,                \
+                       drop_p > 0.f ? g_dropout_salt : nullptr)
         if (xw && ow) { MMH_SSA(true, true); }
         else if (xw) { MMH_SSA(true, false); }
         else if (ow) { MMH_SSA(false, true); }
@@ -2197,7 +2271,8 @@ static int scale_shift_act_impl(const void* x, const void* scale, const void* sh
                        x, x_dtype, static_cast<const float*>(scale),
                        static_cast<const float*>(shift), static_cast<const float*>(residual),
                        out, n4, rows, C / 4, relu, drop_p, seed,
-                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits), out_dtype);
+                       static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(keep_bits), out_dtype,
+                       drop_p > 0.f ? g_dropout_salt : nullptr);
     return mmh::check_launch("scale_shift_act");
 }
 
@@ -2366,7 +2441,7 @@ int mmh_dropout_bits(int64_t n, float drop_p, uint64_t seed, const void* mask, v
     const int64_t n8 = n / 8;
     hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)mmh::cdiv(n8, TPB)), dim3(TPB), 0, mmh::as_stream(s), n8,
                        (uint32_t)((double)drop_p * 65536.0), seed, static_cast<const uint8_t*>(mask),
-                       static_cast<uint8_t*>(bits));
+                       static_cast<uint8_t*>(bits), g_dropout_salt);
     return mmh::check_launch("dropout_bits");
 }
 
@@ -2384,7 +2459,7 @@ int mmh_dropout_bits_both(int64_t image_rows, int W, int C, float drop_p, uint64
     }
     hipLaunchKernelGGL(dropout_both_kernel, dim3((unsigned)image_rows), dim3(TPB), lds, mmh::as_stream(s), W, C, nW32,
                        thr16, seed, static_cast<const uint8_t*>(mask), static_cast<uint8_t*>(bits),
-                       static_cast<uint32_t*>(rows));
+                       static_cast<uint32_t*>(rows), g_dropout_salt);
     return mmh::check_launch("dropout_both");
 }
 
@@ -2746,6 +2821,43 @@ int mmh_adam_step(void* p, const void* g, void* m, void* v, int64_t n, float lr,
                        (float)(1.0 / std::sqrt(bc2)), grad_scale, static_cast<const int*>(skip_flag),
                        static_cast<const float*>(loss_scale));
     return mmh::check_launch("adam");
+}
+
+int mmh_adam_step_dev(void* p, const void* g, void* m, void* v, int64_t n, const void* lr, float beta1, float beta2,
+                      float eps, void* step, float grad_scale, const void* skip_flag, const void* loss_scale, void* coef,
+                      mmh_stream_t s) {
+    MMH_REQUIRE(p && g && m && v && n > 0 && lr && step && coef, "mmh_adam_step_dev: bad arguments");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, mmh::as_stream(s), static_cast<int*>(step),
+                       static_cast<const float*>(lr), static_cast<const int*>(skip_flag), beta1, beta2, static_cast<float*>(coef));
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 8192)), dim3(TPB), 0, mmh::as_stream(s),
+                       static_cast<float*>(p), static_cast<const float*>(g), static_cast<float*>(m),
+                       static_cast<float*>(v), n, beta1, beta2, eps, static_cast<const float*>(coef), grad_scale,
+                       static_cast<const int*>(skip_flag), static_cast<const float*>(loss_scale));
+    return mmh::check_launch("adam_dev");
+}
+
+int mmh_set_dropout_salt(const void* salt_u64) {
+    g_dropout_salt = static_cast<const uint64_t*>(salt_u64);
+    return 0;
+}
+
+int mmh_u64_add(void* value_u64, uint64_t inc, mmh_stream_t s) {
+    MMH_REQUIRE(value_u64, "mmh_u64_add: NULL");
+    hipLaunchKernelGGL(u64_add_kernel, dim3(1), dim3(64), 0, mmh::as_stream(s), static_cast<uint64_t*>(value_u64), inc);
+    return mmh::check_launch("u64_add");
+}
+
+int mmh_pool_exchange(void* pool, const void* images, void* out, const void* src_idx, const void* dst_idx, int B,
+                      int64_t elems_per_image, mmh_stream_t s) {
+    MMH_REQUIRE(pool && images && out && src_idx && dst_idx && B > 0 && elems_per_image > 0 && elems_per_image % 4 == 0,
+                "mmh_pool_exchange: bad arguments (elements per image must be a multiple of 4)");
+    const int64_t n4 = elems_per_image / 4;
+    const dim3 grid((unsigned)std::min<int64_t>(mmh::cdiv(n4, TPB), 256), (unsigned)B);
+    hipLaunchKernelGGL(pool_gather_kernel, grid, dim3(TPB), 0, mmh::as_stream(s), static_cast<const float*>(pool),
+                       static_cast<const float*>(images), static_cast<float*>(out), static_cast<const int*>(src_idx), n4);
+    hipLaunchKernelGGL(pool_scatter_kernel, grid, dim3(TPB), 0, mmh::as_stream(s), static_cast<float*>(pool),
+                       static_cast<const float*>(images), static_cast<const int*>(dst_idx), n4);
+    return mmh::check_launch("pool_exchange");
 }
 
 int mmh_pack_nhwc(const mmh_plane_src* srcs, int nsrc, void* nhwc, int B, int H, int W, int Cd,

@@ -37,6 +37,10 @@ _DP = C.POINTER(ConvDesc)
 # name -> (restype, argtypes); every symbol declared in include/mmhand_hip.h
 SIGNATURES = {
     "mmh_last_error": (C.c_char_p, []),
+    "mmh_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp]),
+    "mmh_set_dropout_salt": (_i, [_vp]),
+    "mmh_u64_add": (_i, [_vp, _u64, _vp]),
+    "mmh_pool_exchange": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "mmh_version": (_i, []),
     "mmh_set_option": (_i, [C.c_char_p, _i]),
     "mmh_conv2d_fprop": (_i, [_DP, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -65,6 +65,25 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(net.flat_param)
         self.step_count = 0
         self.grad_scale = 1.0
+        # --graph_step: the step count and the learning rate live on the device (mmh_adam_step_dev), so that the launch holds
+        # nothing that changes from one iteration to the next and can be replayed from a captured graph
+        self.dev_state = None       # (step int32[1], lr fp32[1], coef fp32[2]) once device_state() was called
+        self.external_count = False  # the step's owner counts step_count itself (a replayed graph never runs step())
+
+    def device_state(self):
+        if self.dev_state is None:
+            dev = self.net.flat_param.device
+            self.dev_state = (torch.full((1,), int(self.step_count), dtype=torch.int32, device=dev),
+                              torch.full((1,), float(self.param_groups[0]["lr"]), dtype=torch.float32, device=dev),
+                              torch.zeros(2, dtype=torch.float32, device=dev))
+            self._lr_on_device = float(self.param_groups[0]["lr"])
+        return self.dev_state
+
+    def sync_lr(self):
+        """after a scheduler step: the device copy of lr follows param_groups (a fill kernel, no host copy)"""
+        if self.dev_state is not None and float(self.param_groups[0]["lr"]) != self._lr_on_device:
+            self._lr_on_device = float(self.param_groups[0]["lr"])
+            self.dev_state[1].fill_(self._lr_on_device)
 
     def zero_grad(self, set_to_none=False):
         self.net.flat_grad.zero_()
@@ -76,10 +95,18 @@ class FlatAdam(torch.optim.Optimizer):
         (MMHandModel._settle_overflow), as apex does not count a skipped step.
         loss_scale: fp32 device scalar the gradient is divided by (dynamic loss scaling)."""
         g = self.param_groups[0]
-        self.step_count += 1
-        ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
-                      g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
-                      self.grad_scale, skip_flag, loss_scale)
+        if not self.external_count:
+            self.step_count += 1
+        if self.dev_state is not None:
+            step_dev, lr_dev, coef = self.dev_state
+            L.call("mmh_adam_step_dev", ops._ptr(self.net.flat_param), ops._ptr(self.net.flat_grad), ops._ptr(self.exp_avg),
+                   ops._ptr(self.exp_avg_sq), self.net.flat_param.numel(), ops._ptr(lr_dev), float(g["betas"][0]),
+                   float(g["betas"][1]), float(g["eps"]), ops._ptr(step_dev), float(self.grad_scale), ops._ptr(skip_flag),
+                   ops._ptr(loss_scale), ops._ptr(coef), ops._stream())
+        else:
+            ops.adam_step(self.net.flat_param, self.net.flat_grad, self.exp_avg, self.exp_avg_sq,
+                          g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.step_count,
+                          self.grad_scale, skip_flag, loss_scale)
         ops.bump_weights_epoch(within=self.net.flat_param)     # this network's derived weight copies only
 
     def state_dict(self):
@@ -90,6 +117,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.dev_state is not None:
+            self.dev_state[0].fill_(self.step_count)
 
 
 class ImagePool:
@@ -135,6 +164,80 @@ class ImagePool:
         result = torch.cat(out, 0)
         self.images = pool
         return result
+
+
+class DevicePool:
+    """ImagePool (util/image_pool.py:14-34) with the pool resident in ONE device buffer and every query the same two
+    launches (mmh_pool_exchange) driven by device index arrays - what a captured training step needs: the host draws the
+    reference's decisions (same `random.uniform` / `random.randint` sequence) BEFORE the step is launched (`plan`), uploads
+    them as indices, and the launches inside the step never change.  Same values as ImagePool query by query
+    (tests/test_graph_step_gpu.py)."""
+
+    def __init__(self, pool_size, queries_per_iteration=1):
+        self.pool_size = pool_size
+        self.count = 0                  # filled slots
+        self.buf = None                 # [pool_size, ...] fp32, allocated at the first query
+        self.nq = queries_per_iteration
+        self.idx = None                 # device int32 [nq, 2, B]: (src, dst) of each query of the iteration
+        self._pinned, self._events, self._slot = [], [], 0
+        self._plans = []                # decisions drawn by plan() and not yet consumed by query()
+        self._q = 0                     # query index within the iteration
+
+    def decide(self, B):
+        """one query's decisions, drawn exactly as ImagePool.query walks the batch: src[i] (>= 0: slot as it was before the
+        query; < 0: image -1 - src of the batch), dst[i] (slot image i is stored in, -1: none; one writer per slot)"""
+        src, dst = [0] * B, [-1] * B
+        holder = {}                     # slot -> batch image that holds it by now (stored earlier in this query)
+        for i in range(B):
+            if self.count < self.pool_size:
+                holder[self.count] = i
+                self.count += 1
+                src[i] = -1 - i
+            elif random.uniform(0, 1) > 0.5:
+                j = random.randint(0, self.pool_size - 1)
+                src[i] = (-1 - holder[j]) if j in holder else j
+                holder[j] = i
+            else:
+                src[i] = -1 - i
+        for j, i in holder.items():
+            dst[i] = j
+        return src, dst
+
+    def begin_iteration(self, B, device, decide=True):
+        """draw (decide) and upload the index arrays of all nq queries of the coming iteration; the upload is queued on the
+        current stream from a ring of pinned buffers, in front of the step's launches"""
+        if self.pool_size == 0:
+            return
+        if self.idx is None or self.idx.shape[2] != B:
+            self.idx = torch.zeros((self.nq, 2, B), dtype=torch.int32, device=device)
+            self._pinned = [torch.zeros((self.nq, 2, B), dtype=torch.int32).pin_memory() for _ in range(4)]
+            self._events = [None] * 4
+        if decide:
+            self._plans = [self.decide(B) for _ in range(self.nq)]
+        k = self._slot
+        self._slot = (k + 1) % len(self._pinned)
+        if self._events[k] is not None:
+            self._events[k].synchronize()       # four iterations old: long complete
+        self._pinned[k].copy_(torch.tensor(self._plans, dtype=torch.int32))
+        self.idx.copy_(self._pinned[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._events[k] = ev
+        self._q = 0
+
+    def query(self, images):
+        if self.pool_size == 0:
+            return images
+        assert images.dtype == torch.float32 and images.is_contiguous() and self.idx is not None and self._q < self.nq, \
+            "DevicePool.query without begin_iteration()"
+        if self.buf is None:
+            self.buf = torch.zeros((self.pool_size,) + tuple(images.shape[1:]), dtype=torch.float32, device=images.device)
+        out = torch.empty_like(images)
+        q = self._q
+        self._q += 1
+        L.call("mmh_pool_exchange", ops._ptr(self.buf), ops._ptr(images), ops._ptr(out), ops._ptr(self.idx[q, 0]),
+               ops._ptr(self.idx[q, 1]), images.shape[0], images[0].numel(), ops._stream())
+        return out
 
 
 class GANLoss:
@@ -270,8 +373,17 @@ class MMHandModel(torch.nn.Module):
 
         if self.isTrain:
             self.old_lr = opt.lr
-            self.fake_PP_pool = ImagePool(opt.pool_size)
-            self.fake_PB_pool = ImagePool(opt.pool_size)
+            # --graph_step (MMH_GRAPH_STEP=1): the whole iteration replayed from a captured hipGraph (single process).
+            # Everything that changes between iterations moves behind device pointers first - Adam's step count and lr,
+            # the dropout salt, the image pools' decisions - and that form also runs eagerly (warm-up, fallback), so the
+            # replayed step is the eager one bit for bit.
+            self.graph_step = bool(getattr(opt, "graph_step", False) or os.environ.get("MMH_GRAPH_STEP") == "1")
+            if self.graph_step and getattr(opt, "distributed", False) and dist.is_initialized():
+                self.pprint("--graph_step: single-process only (the data-parallel step interleaves collectives); off")
+                self.graph_step = False
+            Pool = (lambda n: DevicePool(n, opt.DG_ratio)) if self.graph_step else ImagePool
+            self.fake_PP_pool = Pool(opt.pool_size)
+            self.fake_PB_pool = Pool(opt.pool_size)
             self.criterionGAN = GANLoss()
             if opt.L1_type == "l1_plus_perL1":
                 # the reference slices vgg19.features up to (and including) this index (L1_plus_perceptualLoss.py:24-27)
@@ -334,6 +446,19 @@ class MMHandModel(torch.nn.Module):
             self._flags_pending = []        # [(event, pinned host copy)] of iterations not settled yet
             self.skipped_steps = getattr(self, "skipped_steps", 0)   # optimizer steps skipped so far
             self.last_overflow = False      # did the last settled iteration skip anything
+            self._graph = None              # the captured iteration (torch.cuda.CUDAGraph) once --graph_step has one
+            self._graph_state = "off"
+            if self.graph_step:
+                self._graph_state = "warmup"
+                self._graph_warm = max(2, int(os.environ.get("MMH_GRAPH_WARMUP", "3")))
+                self._graph_iters = 0
+                self.graph_replays = 0
+                self.graph_error = None
+                self._salt = torch.zeros(1, dtype=torch.int64, device=self.device)
+                self._seed_base = ops._seed_counter[0]
+                for o in self.optimizers:
+                    o.device_state()
+                    o.external_count = True
 
     # ------------------------------------------------------------------ data parallel
     def _init_data_parallel(self):
@@ -386,6 +511,21 @@ class MMHandModel(torch.nn.Module):
         the copies' event.  (Pinned source tensors make the copies asynchronous; the caller must not
         overwrite them before the next set_input, as with any non_blocking copy.)"""
         dev = self.device
+        if "img1" in input:
+            # a RAW batch of data.HandFolderLoader (uint8 images / depth PNGs, float64 joints): decoded on the device
+            raw = ("img1", "img2", "dep1", "dep2", "uv1", "uv2")
+            if any(not input[k].is_cuda for k in raw):
+                if getattr(self, "_copy_stream", None) is None:
+                    self._copy_stream = torch.cuda.Stream(dev)
+                cur = torch.cuda.current_stream(dev)
+                with torch.cuda.stream(self._copy_stream):
+                    t = {k: input[k].to(dev, non_blocking=True).contiguous() for k in raw}
+                cur.wait_stream(self._copy_stream)
+                for v in t.values():
+                    v.record_stream(cur)
+            else:
+                t = {k: input[k].contiguous() for k in raw}
+            return self.set_input_raw(*[t[k] for k in raw], paths=(input["H1_path"], input["H2_path"]) if "H1_path" in input else None)
         keys = ("H1", "P1", "D1", "H2", "P2", "D2")
         if dev.type == "cuda" and any(not input[k].is_cuda for k in keys):
             if getattr(self, "_copy_stream", None) is None:
@@ -398,11 +538,31 @@ class MMHandModel(torch.nn.Module):
                 v.record_stream(cur)
         else:
             t = {k: input[k].to(dev, non_blocking=True).float() for k in keys}
-        self.input_H1, self.input_P1, self.input_D1 = t["H1"], t["P1"], t["D1"]
-        self.input_H2, self.input_P2, self.input_D2 = t["H2"], t["P2"], t["D2"]
         o = self.opt
         B, _, H, W = t["H1"].shape
         hc, pc, dc = o.H_input_nc, o.P_input_nc, o.D_input_nc
+        if getattr(self, "_graph_state", "off") == "replay":
+            # the captured iteration reads these buffers by address: new batches are written INTO them
+            st = self._static_inputs
+            if tuple(st["input_H1"].shape) != tuple(t["H1"].shape):
+                raise RuntimeError(f"--graph_step: the captured iteration takes batches of shape {tuple(st['input_H1'].shape)}, "
+                                   f"got {tuple(t['H1'].shape)}")
+            for k in keys:
+                st["input_" + k].copy_(t[k])
+            tw = self.bf16 if ops.USE_LP16_EDGES else 0
+            tws = self._static_twins
+            ops.raw_pack([(st["input_H1"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H1"], twin=tw if tws["x_H1"] is not None else 0,
+                         twin_out=tws["x_H1"])
+            ops.raw_pack([(st["input_P1"], True, pc), (st["input_P2"], True, pc)], B, H, W, pad4(2 * pc), dev, out=st["x_P"],
+                         twin=tw if tws["x_P"] is not None else 0, twin_out=tws["x_P"])
+            ops.raw_pack([(st["input_D1"], True, dc), (st["input_D2"], True, dc)], B, H, W, pad4(2 * dc), dev, out=st["x_D"],
+                         twin=tw if tws["x_D"] is not None else 0, twin_out=tws["x_D"])
+            ops.raw_pack([(st["input_H2"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H2"])
+            if "H1_path" in input:
+                self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
+            return
+        self.input_H1, self.input_P1, self.input_D1 = t["H1"], t["P1"], t["D1"]
+        self.input_H2, self.input_P2, self.input_D2 = t["H2"], t["P2"], t["D2"]
         # NHWC packs: concat + zero-pad to multiples of 4 in one kernel each.  16-bit training: the same pass leaves the
         # generator stems' padded 16-bit inputs (ops.raw_pack twin; they stay valid for every step on this batch)
         tw = self.bf16 if (self.isTrain and ops.USE_LP16_EDGES) else 0
@@ -420,6 +580,17 @@ class MMHandModel(torch.nn.Module):
         joints [B,21,2] on the device.  One kernel (mmh_decode_inputs) does what the reference's
         loader workers do per sample on the CPU (data/generic_dataset.py:133-180) and writes the
         stems' NHWC buffers directly; the NCHW tensors the rest of the API exposes are views."""
+        if getattr(self, "_graph_state", "off") == "replay":
+            xh1, xh2, xp, xd = ops.decode_inputs(img1, img2, dep1, dep2, uv1, uv2)
+            v, o = ops.nhwc_to_nchw_view, self.opt
+            d = {"H1": v(xh1, o.H_input_nc), "H2": v(xh2, o.H_input_nc), "P1": v(xp)[:, : o.P_input_nc],
+                 "P2": v(xp)[:, o.P_input_nc: 2 * o.P_input_nc], "D1": v(xd)[:, : o.D_input_nc],
+                 "D2": v(xd)[:, o.D_input_nc: 2 * o.D_input_nc]}
+            if paths is not None:
+                d["H1_path"], d["H2_path"] = paths
+            return self.set_input(d)
+        for old in (getattr(self, "x_H1", None), getattr(self, "x_P", None), getattr(self, "x_D", None)):
+            ops.pack_twin_drop(old)         # 16-bit copies a set_input() parked for the previous batch
         self.x_H1, self.x_H2, self.x_P, self.x_D = ops.decode_inputs(img1, img2, dep1, dep2, uv1, uv2)
         v = ops.nhwc_to_nchw_view
         o = self.opt
@@ -634,32 +805,103 @@ class MMHandModel(torch.nn.Module):
         ops.lp_grads_reset()
         if self.dp:
             self._optimize_parameters_dp()
+        elif self.graph_step:
+            self._optimize_parameters_graph()
         else:
-            r = self.opt.DG_ratio
-            # single process: the wgrad kernels add straight into the parameters' .grad views of the flat
-            # gradient buffer (no AccumulateGrad add kernels; ops.ACCUM_PARAM_GRADS)
-            prev, ops.ACCUM_PARAM_GRADS = ops.ACCUM_PARAM_GRADS, True
-            try:
-                self.forward()
-                self.optimizer_G.zero_grad()
-                self.backward_G()
-                self._guarded_step(self.optimizer_G, 0, 0)
-                for i in range(r):
-                    self.optimizer_D_PP.zero_grad()
-                    self.backward_D_PP()
-                    self._guarded_step(self.optimizer_D_PP, 1 + i, 2)
-                for i in range(r):
-                    self.optimizer_D_PB.zero_grad()
-                    self.backward_D_PB()
-                    self._guarded_step(self.optimizer_D_PB, 1 + r + i, 1)
-            finally:
-                ops.ACCUM_PARAM_GRADS = prev
+            self._step_body()
         host = self._flags_free.pop()
         host.copy_(self._flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._flags_pending.append((ev, host))
         self.overflow = False
+
+    def _step_body(self):
+        """the single-process iteration: every launch of it, nothing else (what --graph_step captures)"""
+        r = self.opt.DG_ratio
+        # single process: the wgrad kernels add straight into the parameters' .grad views of the flat
+        # gradient buffer (no AccumulateGrad add kernels; ops.ACCUM_PARAM_GRADS)
+        prev, ops.ACCUM_PARAM_GRADS = ops.ACCUM_PARAM_GRADS, True
+        try:
+            self.forward()
+            self.optimizer_G.zero_grad()
+            self.backward_G()
+            self._guarded_step(self.optimizer_G, 0, 0)
+            for i in range(r):
+                self.optimizer_D_PP.zero_grad()
+                self.backward_D_PP()
+                self._guarded_step(self.optimizer_D_PP, 1 + i, 2)
+            for i in range(r):
+                self.optimizer_D_PB.zero_grad()
+                self.backward_D_PB()
+                self._guarded_step(self.optimizer_D_PB, 1 + r + i, 1)
+        finally:
+            ops.ACCUM_PARAM_GRADS = prev
+
+    # ------------------------------------------------------------------ the step as a captured graph
+    def _graph_body(self):
+        """the iteration in its replayable form: host dropout seeds restart from the model's base (every site draws the same
+        by-value seed each iteration), the device salt - advanced here, on the stream - makes the masks fresh"""
+        ops.set_dropout_seed(self._seed_base)
+        L.call("mmh_set_dropout_salt", ops._ptr(self._salt))
+        try:
+            L.call("mmh_u64_add", ops._ptr(self._salt), 0x9E3779B97F4A7C15, ops._stream())
+            self._step_body()
+        finally:
+            L.call("mmh_set_dropout_salt", None)
+
+    def _optimize_parameters_graph(self):
+        """models/MMHandModel.py:310-330 replayed: the first iterations run the replayable form eagerly (derived-weight
+        batches and workspaces settle), then ONE iteration is captured into a hipGraph (torch.cuda.CUDAGraph: own stream,
+        own memory pool) and every later call is: upload the image pools' decisions, replay.  A capture that fails leaves
+        the model in the eager replayable form for good (`graph_error` says why) - never a process re-exec."""
+        r = self.opt.DG_ratio
+        B = self.input_H1.shape[0]
+        for pool in (self.fake_PP_pool, self.fake_PB_pool):       # the reference's order of draws: D_PP's queries, then D_PB's
+            pool.begin_iteration(B, self.device)
+        self.optimizer_G.step_count += 1
+        self.optimizer_D_PP.step_count += r
+        self.optimizer_D_PB.step_count += r
+        self._graph_iters += 1
+        if self._graph_state == "replay":
+            if self._graph_batch != B:
+                raise RuntimeError(f"--graph_step: the captured iteration has batch {self._graph_batch}, this batch has {B} "
+                                   "(a short last batch: drop it, or run without --graph_step)")
+            self._graph.replay()
+            self.graph_replays += 1
+            return
+        if self._graph_state == "warmup" and self._graph_iters > self._graph_warm and os.environ.get("MMH_GRAPH_CAPTURE", "1") != "0":
+            try:
+                self._capture_step(B)
+                self._graph.replay()        # capture executes nothing: this replay IS the iteration
+                self.graph_replays += 1
+                return
+            except Exception as e:          # noqa: BLE001 - any capture failure: stay eager, say why
+                self._graph, self._graph_state = None, "eager"
+                self.graph_error = f"{type(e).__name__}: {e}"[:500]
+                self.pprint("--graph_step: capture failed, staying eager (%s)" % self.graph_error)
+                torch.cuda.synchronize()
+                for pool in (self.fake_PP_pool, self.fake_PB_pool):
+                    pool.begin_iteration(B, self.device, decide=False)     # the decisions already drawn for this iteration
+                ops.lp_grads_reset()
+        self._graph_body()
+
+    def _capture_step(self, B):
+        torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        self._static_inputs = {k: getattr(self, k) for k in ("input_H1", "input_P1", "input_D1", "input_H2", "input_P2",
+                                                             "input_D2", "x_H1", "x_P", "x_D", "x_H2")}
+        self._static_twins = {k: ops.pack_twin_get(self._static_inputs[k], self.bf16, pop=False) if self.bf16 else None
+                              for k in ("x_H1", "x_P", "x_D")}
+        g = torch.cuda.CUDAGraph()
+        for pool in (self.fake_PP_pool, self.fake_PB_pool):
+            pool._q = 0
+        with torch.cuda.graph(g):
+            self._graph_body()
+        # derived-weight caches filled before the capture are written by the replays: the graph keeps them alive
+        self._graph_keep = (ops.derived_weights_snapshot(), ops.derived_batches_snapshot())
+        self._graph, self._graph_state, self._graph_batch = g, "replay", B
 
     def _optimize_parameters_dp(self):
         """The same iteration under data parallelism.  Effects land in the reference's order (the
@@ -790,6 +1032,8 @@ class MMHandModel(torch.nn.Module):
     def update_learning_rate(self):
         for scheduler in self.schedulers:
             scheduler.step()
+        for o in self.optimizers:
+            o.sync_lr()         # --graph_step: the device copy the replayed Adam launches read
         lr = self.optimizers[0].param_groups[0]["lr"]
         self.pprint("learning rate = %.7f" % lr)
 

@@ -136,6 +136,18 @@ def _DERIVED_CACHES():
     return (_bf16_cache, _flat8_cache, _wino_cache, _stem16_cache)
 
 
+def derived_batches_snapshot():
+    """the tensors the per-network batches keep (the 16-bit copies of _Lp16Batch, the Winograd-domain filters of _WinoBatch,
+    their device tables): a captured TRAINING step rewrites them in every replay, so its owner holds them like
+    derived_weights_snapshot()'s"""
+    keep = []
+    for batches in (_lp16_batches, _wino_batches):
+        for b in batches.values():
+            keep.append(b.table)
+            keep.extend(e[1] for e in b.entries.values())
+    return keep
+
+
 def _cache_get(cache, key, w):
     ent = cache.get(key)
     if ent is not None and ent[0] == _weights_epoch[0] and ent[1]() is w:

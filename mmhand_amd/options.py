@@ -14,6 +14,8 @@ Differences, all deliberate:
   * conv biases that feed an InstanceNorm get their exact (zero) gradient by default instead of the reference's
     rounding noise (ops.EXACT_NULL_BIAS_GRAD; MMH_NULL_BIAS_GRAD=compute restores it; INTEGRATION.md §2b);
   * --fp32_exact_grads (addition): the gradient-exact fp32 hybrid, see ops.set_winograd_mode;
+  * --graph_step (addition): single-process training replays the whole iteration from a captured hipGraph
+    (MMHandModel._optimize_parameters_graph);
   * three additions: --G_n_blocks (the reference hard-codes 9), --vgg_weights (file with
     torchvision vgg19.features[0:4] weights; there is no download path offline) and
     --vgg_random_init (explicit opt-in to seeded random VGG weights; without either of the two
@@ -73,6 +75,10 @@ _BASE = [
                                 help="fp32 only: forward 3x3 convs on the direct implicit-GEMM kernels, dgrad / wgrad on "
                                      "Winograd F(6x6,3x3) - every gradient within 1e-3 of fp64 (the all-Winograd default "
                                      "reaches 3e-3 on this network's ill-conditioned gradients); = MMH_WINOGRAD=bwd")),
+    ("--graph_step", dict(action="store_true",
+                          help="single process: capture one optimize_parameters() - forward, three backward passes, three Adam "
+                               "steps - into a hipGraph after a few eager iterations and replay it (Adam step count / lr, dropout "
+                               "salt and image-pool decisions live behind device pointers); = MMH_GRAPH_STEP=1")),
 ]
 _TRAIN = [
     ("--display_freq", dict(type=int, default=100)),

@@ -5,15 +5,16 @@
 
 Same loop shape (epochs x batches, set_input + optimize_parameters, print/save cadence in
 *samples*, update_learning_rate per epoch) and the same loss_log.txt line format
-(util/visualizer.py:116-123).  Data are synthetic RHD/STB-shaped batches (mmhand_amd/data.py);
-`--synthetic_samples N` sets the epoch length."""
+(util/visualizer.py:116-123).  Data: with `--dataroot DIR --dataset rhd|stb` the reference's prepared directory
+(annotation.pickle + colour / depth PNGs; data.HandFolderLoader, decoded on the device), else synthetic RHD/STB-shaped
+batches (`--synthetic_samples N` sets the epoch length)."""
 import os
 import sys
 import time
 
 import torch
 
-from .data import SyntheticHandLoader
+from .data import make_loader
 from .mmhand_model import MMHandModel
 from .options import TrainOptions
 
@@ -25,8 +26,8 @@ def main(argv=None):
     opt = o.parse(argv)
     if opt.batchSize is None:
         opt.batchSize = 1
-    loader = SyntheticHandLoader(opt, opt.synthetic_samples)
     torch.cuda.set_device(opt.local_rank)
+    loader = make_loader(opt, opt.synthetic_samples)
     model = MMHandModel(opt)
     model.pprint("#training images = %d" % len(loader))
     model.pprint("model [%s] was created" % model.name())

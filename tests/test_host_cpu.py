@@ -449,3 +449,77 @@ def test_winograd_forward_gemm_keeps_scratch_out_of_its_k_loop():
     assert mfma_by_depth.get(2, 0) >= 32, mfma_by_depth              # the k-loop IS the depth-2 loop (the parse found it)
     assert not any(d >= 2 for d in by_depth), by_depth                # ... and it touches no scratch
     assert scratch_bytes <= 48, scratch_bytes
+
+
+@pytest.fixture
+def data_dir():
+    """a scratch directory whose PATH does not contain "test" (pytest's tmp_path does; generic_dataset.py:116 keys on it)"""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mmh_ds_")
+    assert "test" not in d
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def test_hand_folder_loader_host_logic(data_dir):
+    """data.HandFolderLoader without a GPU: image lists, sort keys, the augmentation_ratio split, the shuffled sources, labels,
+    the depth path rule, DistributedSampler's default order and the pinned-host raw batches, against the rules of
+    data/generic_dataset.py:100-131,204-210, data/rhd_dataset.py:25-45, data/stb_dataset.py:24-45 and
+    data/mmhand_dataset_data_loader.py:22-48 restated here on a directory the test writes."""
+    import random
+    from PIL import Image
+    from tests._dataset_fixture import write_rhd, write_stb
+    from mmhand_amd.data import HandFolderLoader
+    from mmhand_amd.options import default_train_opt
+    tmp_path = data_dir
+    root = os.path.join(tmp_path, "rhd_train")
+    names = write_rhd(root, n=10, size=16)
+    ordered = sorted(names, key=lambda x: int(x[:-4]))
+    opt = default_train_opt(batchSize=3, dataroot=root, dataset="rhd", augmentation_ratio=0.3, nThreads=2)
+    random.seed(11)
+    ld = HandFolderLoader(opt, device=torch.device("cpu"))
+    sep = int((1 - 0.3) * 10)
+    want_tgt = [os.path.join(root, "color", n) for n in ordered[sep:]]            # training: the LAST ratio share
+    assert ld.image_target == want_tgt
+    random.seed(11)
+    src = want_tgt.copy(); random.shuffle(src)
+    assert ld.image_source == src
+    opt_g = default_train_opt(batchSize=1, dataroot=root, dataset="rhd", augmentation_ratio=0.3, isTrain=False)
+    lg = HandFolderLoader(opt_g, device=torch.device("cpu"))
+    assert lg.image_target == [os.path.join(root, "color", n) for n in ordered[:sep]]   # generation: the first share
+    # one raw host batch: what cv2.imread would hand over (BGR), labels by file name, depth file by path replacement
+    hb = next(iter(ld.host_batches()))
+    assert hb["img1"].dtype == torch.uint8 and tuple(hb["img1"].shape) == (3, 16, 16, 3) and hb["uv1"].dtype == torch.float64
+    p1, p2 = hb["H1_path"][0], hb["H2_path"][0]
+    assert p1 == ld.image_source[0] and p2 == ld.image_target[0]
+    rgb = np.asarray(Image.open(p1).convert("RGB"))
+    assert np.array_equal(hb["img1"][0].numpy(), rgb[:, :, ::-1])
+    dep = np.asarray(Image.open(p2.replace("color", "depth")).convert("RGB"))
+    assert np.array_equal(hb["dep2"][0].numpy(), dep[:, :, ::-1])
+    lab = ld.annotations["color"][os.path.basename(p1)]
+    assert np.array_equal(hb["uv1"][0].numpy(), np.asarray(lab["uv_coord"]))
+    assert np.allclose(hb["C1"][0, :, 2].numpy(), np.asarray(lab["depth"]) / 700.0 * 255)
+    assert ld.n_batches() == 1 and len(ld) == 3 and len(list(ld.host_batches())) == 1
+    # max_dataset_size caps BATCHES (the reference compares the batch index with it) and __len__
+    opt.batchSize, opt.max_dataset_size = 1, 2
+    assert len(list(ld.host_batches())) == 2 and len(ld) == 2
+    # DistributedSampler defaults: permutation of seed 0, padded by wrap-around, rank r takes r, r + world, ...
+    ld.world, ld.rank = 2, 1
+    perm = torch.randperm(3, generator=torch.Generator().manual_seed(0)).tolist()
+    assert ld.indices() == (perm + perm[:1])[1:4:2]
+    # a 'test' directory: everything, generation only
+    troot = os.path.join(tmp_path, "rhd_test")
+    tn = write_rhd(troot, n=4, size=16)
+    lt = HandFolderLoader(default_train_opt(batchSize=1, dataroot=troot, dataset="rhd", augmentation_ratio=0.5, isTrain=False),
+                          device=torch.device("cpu"))
+    assert len(lt.image_target) == 4
+    with pytest.raises(AssertionError):
+        HandFolderLoader(default_train_opt(batchSize=1, dataroot=troot, dataset="rhd", augmentation_ratio=0.5), device=torch.device("cpu"))
+    # STB: BB cameras and depth files are not sources; order = (folder digit, folder letter, frame)
+    sroot = os.path.join(tmp_path, "stb")
+    write_stb(sroot, n=3, size=16)
+    ls = HandFolderLoader(default_train_opt(batchSize=1, dataroot=sroot, dataset="stb", augmentation_ratio=1.0), device=torch.device("cpu"))
+    assert [p.split("/")[-2:] for p in ls.image_target] == [[f, f"SK_color_{i}.png"] for f in ("B1Counting", "B2Random") for i in range(3)]
+    with pytest.raises(FileNotFoundError):
+        HandFolderLoader(default_train_opt(batchSize=1, dataroot=os.path.join(tmp_path, "nope"), dataset="rhd"), device=torch.device("cpu"))

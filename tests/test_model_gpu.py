@@ -522,3 +522,90 @@ def test_l1_type_origin(dev):
     assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
     with pytest.raises(Exception, match="Unsurportted"):
         MMHandModel(_small_opt("instance", L1_type="nope"))
+
+
+@pytest.fixture
+def data_dir():
+    """a scratch directory whose PATH does not contain "test" (pytest's tmp_path does; generic_dataset.py:116 keys on it)"""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mmh_ds_")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def test_hand_folder_loader_feeds_the_device_pipeline(dev, data_dir):
+    """files -> data.HandFolderLoader -> MMHandModel.set_input -> mmh_decode_inputs.  On a directory in the
+    reference's prepared layout (written by the test) the six input tensors on the device are what the reference's loader
+    makes of the same files (data/generic_dataset.py:133-180, restated by oracle.decode_sample + oracle.pose_heatmaps):
+    images and depth within 1 ulp of the float64 arithmetic, pose maps with a bit-exact support mask; joints off the image
+    and on its border included.  Then one training step on that batch runs through and equals the same step fed the
+    decoded tensors."""
+    from PIL import Image
+    from tests._dataset_fixture import write_rhd
+    from mmhand_amd.data import HandFolderLoader
+    from mmhand_amd.mmhand_model import MMHandModel
+    root = os.path.join(data_dir, "rhd")
+    write_rhd(root, n=6, size=32)
+    opt = _small_opt("instance", dataroot=root, dataset="rhd", augmentation_ratio=1.0, batchSize=2, nThreads=2)
+    random.seed(5)
+    ld = HandFolderLoader(opt, device=dev)
+    batches = list(ld)
+    assert len(batches) == 3 and all(tuple(b["img1"].shape) == (2, 32, 32, 3) and b["img1"].is_cuda for b in batches)
+    model = MMHandModel(opt)
+    b = batches[1]
+    model.set_input(b)
+    assert model.get_image_paths() == b["H1_path"][0] + "___" + b["H2_path"][0]
+    for j in range(2):
+        for s, img_k, dep_k, uv_k in (("1", "img1", "dep1", "uv1"), ("2", "img2", "dep2", "uv2")):
+            path = b["H" + s + "_path"][j]
+            bgr = np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1]
+            dbgr = np.asarray(Image.open(path.replace("color", "depth")).convert("RGB"))[:, :, ::-1]
+            h, d = O.decode_sample(bgr, dbgr)
+            lab = ld.get_labels(path)
+            p = torch.from_numpy(O.pose_heatmaps(np.asarray(lab["uv_coord"]), 32, 32))
+            got_h = getattr(model, "input_H" + s)[j].float().cpu()
+            got_d = getattr(model, "input_D" + s)[j].float().cpu()
+            got_p = getattr(model, "input_P" + s)[j].float().cpu()
+            assert torch.allclose(got_h, h, rtol=0, atol=1.2e-7) and torch.allclose(got_d, d, rtol=2e-7, atol=2e-7)
+            assert torch.equal(got_p > 0, p > 0) and torch.allclose(got_p, p, rtol=2e-7, atol=0)
+    # a step on the raw batch == a step on the same batch handed over as decoded tensors
+    random.seed(9)
+    model.optimize_parameters()
+    l_raw = [float(v) for v in model.get_current_errors().values()]
+    dec = HandFolderLoader(opt, device=dev, decoded=True)
+    dec.image_source, dec.image_target = ld.image_source, ld.image_target
+    db = list(dec)[1]
+    assert set(("H1", "P1", "D1", "H2", "P2", "D2", "C1", "C2", "H1_path", "H2_path")) <= set(db)
+    model2 = MMHandModel(opt)
+    model2.set_input(db)
+    random.seed(9)
+    model2.optimize_parameters()
+    l_dec = [float(v) for v in model2.get_current_errors().values()]
+    assert np.allclose(l_raw, l_dec, rtol=1e-6), (l_raw, l_dec)
+    assert all(np.isfinite(l_raw))
+
+
+def test_train_and_aug_run_on_files(dev, data_dir, monkeypatch):
+    """`python -m mmhand_amd.train --dataroot DIR --dataset rhd` trains on files, and `mmhand_amd.aug` with the reference's
+    own argv (aug.py:16: ckp dataroot DST dataset ratio device) writes one generated PNG per TARGET image of the generation
+    split to <DST>/<folder>/<name> - for real pairs, through HandFolderLoader -> mmh_decode_inputs -> the BN-folded graph."""
+    from PIL import Image
+    from tests._dataset_fixture import write_rhd
+    from mmhand_amd import aug, train
+    root = os.path.join(data_dir, "rhd")
+    names = write_rhd(root, n=8, size=32)
+    monkeypatch.chdir(data_dir)
+    train.main(["--name", "files", "--dataroot", root, "--dataset", "rhd", "--augmentation_ratio", "0.5", "--batchSize", "2",
+                "--ngf", "8", "--ndf", "8", "--G_n_blocks", "2", "--n_layers_D", "2", "--norm", "batch", "--fineSize", "32",
+                "--niter", "1", "--niter_decay", "0", "--print_freq", "2", "--vgg_random_init", "--checkpoints_dir", "checkpoints",
+                "--pool_size", "2"])
+    assert os.path.isfile(os.path.join("checkpoints", "files", "latest_net_netG.pth"))
+    log = open(os.path.join("checkpoints", "files", "loss_log.txt")).read()
+    assert "pair_L1loss" in log and "perceptual" in log
+    written = aug.main(["files", root, "gen", "rhd", "0.5", "0"], ngf=8, n_blocks=2)
+    ordered = sorted(names, key=lambda x: int(x[:-4]))
+    assert [os.path.relpath(p, "gen") for p in written] == [os.path.join("color", n) for n in ordered[:4]]   # the generation share
+    for p in written:
+        png = np.asarray(Image.open(p))
+        assert png.shape == (32, 32, 3) and png.dtype == np.uint8 and png.std() > 0
