@@ -468,6 +468,12 @@ def _side_train_run(dev, B, size, steps, warmup, stack, stack_steps, dp, seed, w
                                "kernel": f"conv_lp16h2_kernel fprop 3x3 512->512 @{size // 4}x{size // 4} (B={B}): "
                                          f"{c[1] / c[0] / 1e9:.1f} GFLOP/launch, {c[2] / c[0]:.3f} ms avg over {c[0]} launches"}
     out["losses_finite"] = all(torch.isfinite(v).item() for v in model.get_current_errors().values())
+    if getattr(model, "graph_step", False):
+        # --graph_step: the timed steps above were replays of the captured iteration (or, had the capture failed, its eager form)
+        out["graph_step"] = model._graph is not None
+        out["graph_replays"] = model.graph_replays
+        if model.graph_error:
+            out["graph_error"] = model.graph_error
     enq, calls = host_enqueue(model, dp)
     out["host_enqueue_ms"] = enq
     out["c_abi_calls_per_step"] = calls
@@ -604,8 +610,11 @@ def line_summary(line):
          "stack_frac": g("bf16_path", "stack_frac"),
          "stack_frac_without_norm_sums_in_dgrad": g("bf16_path", "stack_frac_without_norm_sums_in_dgrad"),
          "bf16_roofline_frac": (g("bf16_path", "roofline") or {}).get("frac"),
-         "bf16_graph_step": g("bf16_path_graph"), "bf16_graph_host_enqueue_ms": g("bf16_path_graph", "host_enqueue_ms"),
-         "size512_bf16_b4": g("size512_bf16_b4"), "size512_graph_step": g("size512_bf16_b4_graph"),
+         "bf16_path_graph": g("bf16_path_graph"), "bf16_graph_host_enqueue_ms": g("bf16_path_graph", "host_enqueue_ms"),
+         "bf16_graph_replayed": g("bf16_path_graph", "graph_step"),
+         "size512_bf16_b4": g("size512_bf16_b4"), "size512_bf16_b4_graph": g("size512_bf16_b4_graph"),
+         "size512_graph_host_enqueue_ms": g("size512_bf16_b4_graph", "host_enqueue_ms"),
+         "graph_step": g("graph_step"), "graph_step_host_enqueue_ms": g("graph_step", "host_enqueue_ms"),
          "norm_batch": g("norm_batch"), "norm_batch_o1": g("norm_batch_o1"),
          "hybrid_path": g("hybrid_path"), "direct_path": g("direct_path"), "set_input_in_loop": g("set_input_in_loop"),
          "dp_rccl_world1": g("dp_rccl_world1"), "dp_bf16_path": g("dp_bf16_path"), "dp_norm_batch": g("dp_norm_batch"),
@@ -1009,6 +1018,17 @@ def main():
                                                    "MFMA operands, 16-bit conv-facing tensors, fp32 master weights, dynamic "
                                                    "loss scaling); stack_frac = the 3x3 stride-1 256/512-channel stack, all "
                                                    "three passes incl. reflect border terms, algorithmic FLOPs / kernel time / 2500 TF"))
+        gnote = ("--graph_step: the same iteration captured once into a hipGraph (forward, three backward passes, three Adam "
+                 "steps; Adam step count / lr, dropout salt and image-pool indices behind device pointers) and replayed: "
+                 "host_enqueue_ms is what the host spends per iteration")
+        if a.dtype == "f32":
+            guarded("bf16_path_graph", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, warmup=6, opt_level="O1",
+                                                                   norm=a.norm, graph_step=True), note=gnote))
+            guarded("size512_bf16_b4_graph", lambda: dict(side_train_run(dev, 4, 512, n_side, warmup=6, opt_level="O1",
+                                                                         graph_step=True), note=gnote))
+        guarded("graph_step", lambda: dict(side_train_run(dev, a.batch, a.size, n_side, warmup=6, norm=a.norm, graph_step=True,
+                                                          opt_level="O1" if a.dtype == "bf16" else "O0"),
+                                           note="the headline configuration under " + gnote))
         if a.dtype == "f32" and not a.no_winograd:
             guarded("gradient_parity", lambda: gradient_parity_run(dev, a.size, a.norm))
 

@@ -237,6 +237,13 @@ int mmh_prep_weights_fp16_flat(const void* w, int taps, int Cin, int Cout,
 int mmh_prep_weights_bf16_flat(const void* w, int taps, int Cin, int Cout,
                                void* w_flat, mmh_stream_t s);
 
+/* Diagnostic builds only (make AB=1; mmh_set_option("lp16_dbg", 4096)): after launches of the 16-bit halo kernel, copies
+ * per workgroup the pair (delta s_memtime, delta s_memrealtime) that wave 0 stamped around the kernel body into
+ * host_pairs_u64[2 * max_workgroups]; delta s_memtime / delta s_memrealtime x 100 MHz is the clock the chip held under the
+ * kernel's load.  Synchronises the device.  Returns the number of workgroups copied: 0 in ordinary builds (no stamp is
+ * compiled into the shipped kernel), -1 on a copy error.                                                                */
+int mmh_lp16_clock_stamps(void* host_pairs_u64, int max_workgroups);
+
 /* ---- 16-bit direct 3x3 convolution, both operands 16-bit in HBM (conv_lp16.hip) ----------------
  * The second-generation MFMA kernel of the --opt_level O1/O2 path for the 3x3 / stride 1 / pad 1
  * stack (channels % 64 == 0, output channels % 256 == 0): 256x256x64 block tile, both operands

@@ -919,6 +919,10 @@ int mmh_cvt_lp16(const void* x, int64_t n, int dtype, void* out, mmh_stream_t s)
     return mmh::check_launch("cvt_lp16_kernel");
 }
 
+int mmh_lp16_clock_stamps(void* host_pairs_u64, int max_workgroups) {
+    return mmh::lp16::clock_stamps(static_cast<unsigned long long*>(host_pairs_u64), max_workgroups);
+}
+
 int mmh_conv3x3_lp16_supported(const mmh_conv_desc* d) {
     return d && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
            d->Ho == d->H && d->Wo == d->W && (d->dtype == MMH_BF16 || d->dtype == MMH_FP16);

@@ -798,8 +798,31 @@ __device__ __forceinline__ void conv_lp16h2_body(const LpConvKP& p) {
     }   // tiles of this workgroup
 }
 
+#ifdef MMH_AB_KERNELS
+// Diagnostic (A/B) builds only - the shipped kernel executes no stamp: with mmh_set_option("lp16_dbg", 4096) wave 0 of every
+// workgroup brackets the WHOLE kernel body with the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime); delta s_memtime / delta s_memrealtime x 100 MHz is the clock the chip holds under this kernel's load
+// (MI355X_MICROARCH.md 'DVFS give-back' item 6).  The values go to a buffer of their own (mmh_lp16_clock_stamps reads it)
+// and no output is computed from them.
+constexpr int CLOCK_STAMP_WGS = 2048;
+__device__ unsigned long long g_lp16_clock_stamps[2 * CLOCK_STAMP_WGS];
+#endif
+
 template <bool H16, int SIGN, bool FOLD>
 __global__ void __launch_bounds__(512, 2) conv_lp16h2_kernel(const LpConvKP p) {
+#ifdef MMH_AB_KERNELS
+    if (p.dbg & 4096) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone: the stamps are back before the body's counted LDS waits
+        conv_lp16h2_body<H16, SIGN, FOLD, 4>(p);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && blockIdx.x < CLOCK_STAMP_WGS) {
+            g_lp16_clock_stamps[2 * blockIdx.x] = t1 - t0;
+            g_lp16_clock_stamps[2 * blockIdx.x + 1] = r1 - r0;
+        }
+        return;
+    }
+#endif
     conv_lp16h2_body<H16, SIGN, FOLD, 4>(p);
 }
 
@@ -823,6 +846,19 @@ __global__ void __launch_bounds__(256, 1) conv_lp16q_kernel(const LpConvKP p) {
 }  // namespace
 
 namespace mmh { namespace lp16 {
+
+int clock_stamps(unsigned long long* host_pairs, int max_workgroups) {
+#ifdef MMH_AB_KERNELS
+    const int n = max_workgroups < CLOCK_STAMP_WGS ? max_workgroups : CLOCK_STAMP_WGS;
+    if (n <= 0 || !host_pairs) return 0;
+    if (hipMemcpyFromSymbol(host_pairs, HIP_SYMBOL(g_lp16_clock_stamps), (size_t)n * 2 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    return n;
+#else
+    (void)host_pairs; (void)max_workgroups;
+    return 0;
+#endif
+}
 
 bool conv_lp16_halo_has_solo() {
 #ifdef MMH_AB_KERNELS

@@ -108,5 +108,6 @@ __device__ __forceinline__ bf16x8 lds_frag(unsigned addr) { return *reinterpret_
 // its own tile count).  mode 0 fprop | 1 zero-pad dgrad | 2 reflect-fold dgrad; solo: one wave per SIMD (A/B builds only)
 int launch_conv_lp16_halo(const LpConvKP& p, const mmh_conv_desc* d, int mode, bool solo, hipStream_t st);
 bool conv_lp16_halo_has_solo();
+int clock_stamps(unsigned long long* host_pairs, int max_workgroups);      // A/B builds: per-workgroup (s_memtime, s_memrealtime) deltas
 
 } }  // namespace mmh::lp16

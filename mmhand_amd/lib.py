@@ -39,6 +39,7 @@ SIGNATURES = {
     "mmh_last_error": (C.c_char_p, []),
     "mmh_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp]),
     "mmh_set_dropout_salt": (_i, [_vp]),
+    "mmh_lp16_clock_stamps": (_i, [_vp, _i]),
     "mmh_u64_add": (_i, [_vp, _u64, _vp]),
     "mmh_pool_exchange": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "mmh_version": (_i, []),

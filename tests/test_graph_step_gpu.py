@@ -42,8 +42,8 @@ def _run(opt, n_iter, capture, monkeypatch, size=32, lr_drop_at=None):
     return model, losses, state
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(opt_level="O1"), dict(norm="batch"), dict(DG_ratio=2, opt_level="O1_FP16")],
-                         ids=["fp32", "bf16", "batchnorm", "fp16_dg2"])
+@pytest.mark.parametrize("kw", [dict(), dict(opt_level="O1"), dict(DG_ratio=2, opt_level="O1_FP16")],
+                         ids=["fp32", "bf16", "fp16_dg2"])
 def test_graph_step_replays_the_eager_iteration_bit_for_bit(kw, dev, monkeypatch):
     """eight iterations on changing batches, dropout ON, a pool of three images (so that swaps happen), an lr change on
     the way: captured-and-replayed == the same form run eagerly - all six losses of every iteration, every weight of the
@@ -62,6 +62,14 @@ def test_graph_step_replays_the_eager_iteration_bit_for_bit(kw, dev, monkeypatch
     assert [int(o.dev_state[0]) for o in graph.optimizers] == [o.step_count for o in graph.optimizers]
     # dropout masks differ from iteration to iteration (the salt moves) although the by-value seeds repeat
     assert l1[-1] != l1[-2]
+
+
+def test_graph_step_with_batchnorm_stays_eager(dev, monkeypatch):
+    """--norm batch: the capture is not attempted (it crashes inside hipStreamEndCapture on this ROCm, bisected in
+    tools/probes/graph_bisect.py); the model says so and keeps running the replayable form eagerly"""
+    m, l, _ = _run(_opt(norm="batch"), 6, True, monkeypatch)
+    assert m._graph is None and m.graph_replays == 0 and "norm batch" in m.graph_error
+    assert all(np.isfinite(l[-1]))
 
 
 def test_graph_step_matches_the_default_path_without_dropout(dev, monkeypatch):
@@ -93,10 +101,12 @@ def test_graph_step_overflow_skips_on_the_device(dev, monkeypatch):
     before = {n: getattr(g, n).flat_param.clone() for n in ("netG", "netD_PB", "netD_PP")}
     steps = [int(o.dev_state[0]) for o in g.optimizers]
     scale = g.loss_scale(0)
-    st = g._static_inputs["input_H2"]
     g.set_input(O.synthetic_batch(2, 32, 32, seed=7))
-    st[0, 0, 0, 0] = float("inf")           # poisons the L1 term of the captured iteration's input -> non-finite G gradient
-    g._static_inputs["x_H2"][0, 0, 0, 0] = float("inf")
+    # poison the generator's image input in the buffers the captured stems read (the L1 target would not do: the gradient
+    # of |fake - inf| is a finite sign): a non-finite image -> non-finite G gradient -> the sticky flag skips all three steps
+    g._static_inputs["x_H1"][0, 0, 0, 0] = float("inf")
+    if g._static_twins["x_H1"] is not None:
+        g._static_twins["x_H1"][0, 0, 0, 0] = float("inf")
     g.optimize_parameters()
     g._settle_overflow(drain=True)
     torch.cuda.synchronize()
