@@ -8,7 +8,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/r6prof; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-EXPECT="conv_lp16h2_kernel conv_lp16h2_nbr_kernel wgrad_lp16t_kernel conv_lp16g_kernel conv_s2f_kernel wino_gemm_kernel"
+EXPECT="conv_lp16h2_kernel conv_lp16h2_nbr_kernel wgrad_lp16t_kernel conv_lp16g conv_s2f_kernel wino_gemm_kernel"
 : > $OUT/pmc_lp16.txt
 fail=0
 for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS" \
@@ -19,11 +19,9 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA
     echo "pmc_r06.sh: the pass [$c] FAILED:" >&2; tail -20 /tmp/pmc_pass.log >&2; fail=1; continue
   fi
   echo "== --pmc $c" >> $OUT/pmc_lp16.txt
-  python3 $R/tools/pmc_summary.py /tmp/fs > /tmp/pmc_sum.txt
-  for k in $EXPECT; do
-    if ! grep -q "$k" /tmp/pmc_sum.txt; then echo "pmc_r06.sh: no counter rows for $k in the pass [$c]" >&2; fail=1; fi
-  done
-  grep -A6 "conv_lp16h2\|wgrad_lp16t\|conv_lp16g_kernel\|conv_s2f_kernel\|wino_gemm_kernel" /tmp/pmc_sum.txt | grep -v "^--" >> $OUT/pmc_lp16.txt
+  if ! python3 $R/tools/pmc_select.py /tmp/fs $EXPECT >> $OUT/pmc_lp16.txt; then
+    echo "pmc_r06.sh: the pass [$c] is incomplete" >&2; fail=1
+  fi
 done
 lines=$(wc -l < $OUT/pmc_lp16.txt)
 if [ "$lines" -lt 60 ]; then echo "pmc_r06.sh: only $lines lines of counters collected" >&2; fail=1; fi
