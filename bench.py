@@ -1081,10 +1081,10 @@ def main():
                        "conv_igemm_bf16_kernel<128,2,2>" if a.dtype == "bf16" else
                        "conv_igemm_kernel<256,2,2,false>") + " fprop 3x3 512->512 @64x64")
         traffic = None      # HBM bytes per launch of the roofline kernel, from the committed PMC run
-        tname = "r05_traffic_bf16.json" if a.dtype == "bf16" else ("r05_traffic.json" if wino else "r01_traffic.json")
+        tname = "r06_traffic_bf16.json" if a.dtype == "bf16" else ("r06_traffic.json" if wino else "r01_traffic.json")
         tj = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tj):      # the previous round's counters until this round's are collected
-            tj = os.path.join(ROOT, "profiles", tname.replace("r05_", "r04_"))
+            tj = os.path.join(ROOT, "profiles", tname.replace("r06_", "r05_"))
         if os.path.exists(tj) and a.batch == 32 and a.size == 256:
             tjd = json.load(open(tj))
             traffic = tjd.get("winograd_gemm" if wino else "direct", {}).get("hbm_bytes_per_launch")

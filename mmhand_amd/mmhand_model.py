@@ -897,6 +897,15 @@ class MMHandModel(torch.nn.Module):
     def _capture_step(self, B):
         torch.cuda.synchronize()
         import gc
+        # The previous iteration's autograd graph must be GONE before the capture builds its own: a leaf's AccumulateGrad
+        # node is bound to the stream it was created on and is re-used while anything keeps the old graph alive - the
+        # captured backward would then run the norm scales' / shifts' accumulation (the only gradients that still travel
+        # through AccumulateGrad: the conv shims add theirs in place) on the eager iterations' stream, a fork out of the
+        # capture that hipStreamEndCapture answers with a segfault (--norm batch; tools/probes/graph_bisect.py).
+        self.fake_nhwc = self.fake_p2 = None
+        self.loss_G_L1 = self.loss_G_GAN_PB = self.loss_G_GAN_PP = None
+        self._fake_cats = None
+        ops.lp_grads_reset()
         gc.collect()
         self._static_inputs = {k: getattr(self, k) for k in ("input_H1", "input_P1", "input_D1", "input_H2", "input_P2",
                                                              "input_D2", "x_H1", "x_P", "x_D", "x_H2")}

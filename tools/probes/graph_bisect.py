@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-STAGES = ["G_fwd", "G_fwd_nograd", "G_bwd", "G_step", "D_PP", "D_PB", "all"]
+STAGES = ["G_bwd", "all"]
 
 
 def child(stage, norm):
@@ -48,6 +48,12 @@ def child(stage, norm):
             m.optimizer_D_PP.zero_grad(); m.backward_D_PP(); m._guarded_step(m.optimizer_D_PP, 1, 2)
         if stage in ("D_PB", "all"):
             m.optimizer_D_PB.zero_grad(); m.backward_D_PB(); m._guarded_step(m.optimizer_D_PB, 2, 1)
+    if os.environ.get("BISECT_CLEAR", "1") == "1":      # drop the previous iteration's autograd graph (stale AccumulateGrad nodes)
+        import gc
+        m.fake_nhwc = m.fake_p2 = None
+        m.loss_G_L1 = m.loss_G_GAN_PB = m.loss_G_GAN_PP = None
+        m._fake_cats = None
+        gc.collect()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         body()

@@ -20,8 +20,9 @@ def ev():
 
 
 def run(Cin, Cout, chunk, reps=12):
-    x = torch.randn(B, H, H, Cin, device=dev)
-    w = torch.randn(3, 3, Cin, Cout, device=dev) * 0.05
+    g = torch.Generator(device=dev).manual_seed(Cin * 7 + Cout)        # the same operands for every chunk size
+    x = torch.randn(B, H, H, Cin, device=dev, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, device=dev, generator=g) * 0.05
     ops.bump_weights_epoch()
     U = ops.wino_weights(w, 6, False, False)
     y = torch.empty(B, H, H, Cout, device=dev)
