@@ -870,14 +870,6 @@ class MMHandModel(torch.nn.Module):
             self._graph.replay()
             self.graph_replays += 1
             return
-        if (self._graph_state == "warmup" and self._graph_iters > self._graph_warm and self.opt.norm != "instance"
-                and os.environ.get("MMH_GRAPH_CAPTURE_ANY_NORM") != "1"):
-            # --norm batch: with the BatchNorm backward inside the capture, hipStreamEndCapture of this ROCm segfaults (the
-            # forward alone captures: tools/probes/graph_bisect.py) - a crash no except clause sees, so it is not attempted;
-            # the iteration stays in its eager replayable form
-            self._graph_state = "eager"
-            self.graph_error = "--norm batch is not captured (hipStreamEndCapture crashes on its backward pass); eager"
-            self.pprint("--graph_step: " + self.graph_error)
         if self._graph_state == "warmup" and self._graph_iters > self._graph_warm and os.environ.get("MMH_GRAPH_CAPTURE", "1") != "0":
             try:
                 self._capture_step(B)

@@ -42,13 +42,17 @@ def _run(opt, n_iter, capture, monkeypatch, size=32, lr_drop_at=None):
     return model, losses, state
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(opt_level="O1"), dict(DG_ratio=2, opt_level="O1_FP16")],
-                         ids=["fp32", "bf16", "fp16_dg2"])
+@pytest.mark.parametrize("kw", [dict(), dict(opt_level="O1"), dict(norm="batch"), dict(norm="batch", opt_level="O1"),
+                                dict(DG_ratio=2, opt_level="O1_FP16")],
+                         ids=["fp32", "bf16", "batchnorm", "batchnorm_bf16", "fp16_dg2"])
 def test_graph_step_replays_the_eager_iteration_bit_for_bit(kw, dev, monkeypatch):
     """eight iterations on changing batches, dropout ON, a pool of three images (so that swaps happen), an lr change on
     the way: captured-and-replayed == the same form run eagerly - all six losses of every iteration, every weight of the
     three networks and the generated image identical to the bit; the graph really replayed, and a replay enqueues in a
-    fraction of the eager call's host time."""
+    fraction of the eager call's host time.  (--norm batch: the norm scales' and shifts' gradients are the only ones that
+    still travel through autograd's AccumulateGrad nodes; a node left over from the eager iterations is bound to THEIR stream
+    and forks the capture - hipStreamEndCapture then segfaults - so the capture drops the previous iteration's graph first:
+    MMHandModel._capture_step, tools/probes/graph_bisect.py.)"""
     eager, l0, s0 = _run(_opt(**kw), 8, False, monkeypatch, lr_drop_at=5)
     assert eager._graph is None and eager.graph_replays == 0
     graph, l1, s1 = _run(_opt(**kw), 8, True, monkeypatch, lr_drop_at=5)
@@ -62,14 +66,6 @@ def test_graph_step_replays_the_eager_iteration_bit_for_bit(kw, dev, monkeypatch
     assert [int(o.dev_state[0]) for o in graph.optimizers] == [o.step_count for o in graph.optimizers]
     # dropout masks differ from iteration to iteration (the salt moves) although the by-value seeds repeat
     assert l1[-1] != l1[-2]
-
-
-def test_graph_step_with_batchnorm_stays_eager(dev, monkeypatch):
-    """--norm batch: the capture is not attempted (it crashes inside hipStreamEndCapture on this ROCm, bisected in
-    tools/probes/graph_bisect.py); the model says so and keeps running the replayable form eagerly"""
-    m, l, _ = _run(_opt(norm="batch"), 6, True, monkeypatch)
-    assert m._graph is None and m.graph_replays == 0 and "norm batch" in m.graph_error
-    assert all(np.isfinite(l[-1]))
 
 
 def test_graph_step_matches_the_default_path_without_dropout(dev, monkeypatch):

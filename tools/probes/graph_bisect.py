@@ -1,5 +1,12 @@
 """Which part of a --norm batch iteration breaks hipGraph capture (segfault in hipStreamEndCapture)?  Each stage is captured in
-a child process of its own: python tools/probes/graph_bisect.py [stage]"""
+a child process of its own: python tools/probes/graph_bisect.py [stage]
+
+Found (round 6): the forward alone captures, anything with the BatchNorm BACKWARD in it crashes - unless the previous eager
+iteration's autograd graph is dropped before the capture (BISECT_CLEAR=1, the default here; BISECT_CLEAR=0 reproduces the
+crash).  The norm scales' / shifts' gradients are the only ones that still reach autograd's AccumulateGrad nodes (the conv shims
+add theirs in place); a leaf's AccumulateGrad node is bound to the stream it was created on and is re-used while the old graph
+is alive (MMHandModel keeps fake_nhwc and the generator's loss terms), so the captured backward ran it on the eager iterations'
+stream: a fork out of the capturing stream.  MMHandModel._capture_step now clears those references first."""
 import os
 import random
 import subprocess
