@@ -195,3 +195,44 @@ def test_dropout_salt(dev):
     ones = lambda b: float(torch.tensor([bin(int(v)).count("1") for v in b.cpu()[:4096]]).sum()) / (4096 * 8)   # noqa: E731
     assert abs(ones(s1) - 0.5) < 0.02 and abs(ones(s2) - 0.5) < 0.02
     assert int(salt) == (2 * 0x9E3779B97F4A7C15) % (1 << 64)
+
+
+def test_train_main_with_graph_step_on_files(dev, monkeypatch):
+    """the training driver end to end with --graph_step on a prepared directory (data.HandFolderLoader): raw uint8 batches are
+    decoded on the device and copied INTO the captured buffers, the lr schedule reaches the device copy at the epoch boundary,
+    checkpoints and the loss log are written as without the graph"""
+    import shutil
+    import tempfile
+    from tests._dataset_fixture import write_rhd
+    from mmhand_amd import train
+    d = tempfile.mkdtemp(prefix="mmh_ds_")
+    try:
+        root = os.path.join(d, "rhd")
+        write_rhd(root, n=8, size=32)
+        monkeypatch.chdir(d)
+        monkeypatch.setenv("MMH_GRAPH_CAPTURE", "1")
+        seen = {}
+        from mmhand_amd import mmhand_model as MM
+        real_init = MM.MMHandModel.__init__
+
+        def spy_init(self, opt):
+            real_init(self, opt)
+            seen["model"] = self
+        monkeypatch.setattr(MM.MMHandModel, "__init__", spy_init)
+        train.main(["--name", "g", "--dataroot", root, "--dataset", "rhd", "--augmentation_ratio", "1.0", "--batchSize", "2",
+                    "--ngf", "8", "--ndf", "8", "--G_n_blocks", "2", "--n_layers_D", "2", "--norm", "instance", "--fineSize", "32",
+                    "--niter", "1", "--niter_decay", "1", "--print_freq", "2", "--vgg_random_init", "--checkpoints_dir", "ck",
+                    "--pool_size", "3", "--graph_step", "--opt_level", "O1"])
+        m = seen["model"]
+        assert m.graph_error is None and m._graph is not None and m.graph_replays == 8 - m._graph_warm
+        assert os.path.isfile(os.path.join("ck", "g", "latest_net_netG.pth"))
+        log = open(os.path.join("ck", "g", "loss_log.txt")).read().strip().splitlines()
+        assert len(log) == 8 and all("pair_L1loss" in l for l in log)
+        # the schedule moved twice (network_utils.py:92-95 with niter 1, niter_decay 1: epoch 2 runs at lr 0, and the rule goes
+        # negative behind it, as the reference's does): the replayed Adam launches read whatever it says from the device
+        lr = m.optimizer_G.param_groups[0]["lr"]
+        assert abs(float(m.optimizer_G.dev_state[1]) - lr) <= 1e-6 * max(abs(lr), 1e-12) and lr < m.opt.lr
+        m._settle_overflow(drain=True)
+        assert m.optimizer_G.step_count == 8 and int(m.optimizer_G.dev_state[0]) == 8 and m.skipped_steps == 0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
