@@ -180,6 +180,7 @@ class DevicePool:
         self.nq = queries_per_iteration
         self.idx = None                 # device int32 [nq, 2, B]: (src, dst) of each query of the iteration
         self._pinned, self._events, self._slot = [], [], 0
+        self._by_batch = {}
         self._plans = []                # decisions drawn by plan() and not yet consumed by query()
         self._q = 0                     # query index within the iteration
 
@@ -209,9 +210,11 @@ class DevicePool:
         if self.pool_size == 0:
             return
         if self.idx is None or self.idx.shape[2] != B:
-            self.idx = torch.zeros((self.nq, 2, B), dtype=torch.int32, device=device)
-            self._pinned = [torch.zeros((self.nq, 2, B), dtype=torch.int32).pin_memory() for _ in range(4)]
-            self._events = [None] * 4
+            # one index array (and pinned ring) per batch size, never re-allocated: a captured iteration holds its address
+            if B not in self._by_batch:
+                self._by_batch[B] = (torch.zeros((self.nq, 2, B), dtype=torch.int32, device=device),
+                                     [torch.zeros((self.nq, 2, B), dtype=torch.int32).pin_memory() for _ in range(4)], [None] * 4)
+            self.idx, self._pinned, self._events = self._by_batch[B]
         if decide:
             self._plans = [self.decide(B) for _ in range(self.nq)]
         k = self._slot
@@ -542,25 +545,28 @@ class MMHandModel(torch.nn.Module):
         B, _, H, W = t["H1"].shape
         hc, pc, dc = o.H_input_nc, o.P_input_nc, o.D_input_nc
         if getattr(self, "_graph_state", "off") == "replay":
-            # the captured iteration reads these buffers by address: new batches are written INTO them
             st = self._static_inputs
-            if tuple(st["input_H1"].shape) != tuple(t["H1"].shape):
-                raise RuntimeError(f"--graph_step: the captured iteration takes batches of shape {tuple(st['input_H1'].shape)}, "
-                                   f"got {tuple(t['H1'].shape)}")
-            for k in keys:
-                st["input_" + k].copy_(t[k])
-            tw = self.bf16 if ops.USE_LP16_EDGES else 0
-            tws = self._static_twins
-            ops.raw_pack([(st["input_H1"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H1"], twin=tw if tws["x_H1"] is not None else 0,
-                         twin_out=tws["x_H1"])
-            ops.raw_pack([(st["input_P1"], True, pc), (st["input_P2"], True, pc)], B, H, W, pad4(2 * pc), dev, out=st["x_P"],
-                         twin=tw if tws["x_P"] is not None else 0, twin_out=tws["x_P"])
-            ops.raw_pack([(st["input_D1"], True, dc), (st["input_D2"], True, dc)], B, H, W, pad4(2 * dc), dev, out=st["x_D"],
-                         twin=tw if tws["x_D"] is not None else 0, twin_out=tws["x_D"])
-            ops.raw_pack([(st["input_H2"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H2"])
-            if "H1_path" in input:
-                self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
-            return
+            self._graph_odd = tuple(st["input_H1"].shape) != tuple(t["H1"].shape)
+            if not self._graph_odd:
+                # the captured iteration reads these buffers by address: new batches are written INTO them
+                for k, v in st.items():
+                    setattr(self, k, v)         # (an odd-shaped batch before this one had re-pointed the attributes)
+                for k in keys:
+                    st["input_" + k].copy_(t[k])
+                tw = self.bf16 if ops.USE_LP16_EDGES else 0
+                tws = self._static_twins
+                ops.raw_pack([(st["input_H1"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H1"],
+                             twin=tw if tws["x_H1"] is not None else 0, twin_out=tws["x_H1"])
+                ops.raw_pack([(st["input_P1"], True, pc), (st["input_P2"], True, pc)], B, H, W, pad4(2 * pc), dev, out=st["x_P"],
+                             twin=tw if tws["x_P"] is not None else 0, twin_out=tws["x_P"])
+                ops.raw_pack([(st["input_D1"], True, dc), (st["input_D2"], True, dc)], B, H, W, pad4(2 * dc), dev, out=st["x_D"],
+                             twin=tw if tws["x_D"] is not None else 0, twin_out=tws["x_D"])
+                ops.raw_pack([(st["input_H2"], True, hc)], B, H, W, pad4(hc), dev, out=st["x_H2"])
+                if "H1_path" in input:
+                    self.image_paths = input["H1_path"][0] + "___" + input["H2_path"][0]
+                return
+            # a batch of another shape (the short last batch of an epoch): this iteration runs in the eager form on buffers of
+            # its own; the captured buffers stay untouched for the next full batch
         self.input_H1, self.input_P1, self.input_D1 = t["H1"], t["P1"], t["D1"]
         self.input_H2, self.input_P2, self.input_D2 = t["H2"], t["P2"], t["D2"]
         # NHWC packs: concat + zero-pad to multiples of 4 in one kernel each.  16-bit training: the same pass leaves the
@@ -863,12 +869,10 @@ class MMHandModel(torch.nn.Module):
         self.optimizer_D_PP.step_count += r
         self.optimizer_D_PB.step_count += r
         self._graph_iters += 1
-        if self._graph_state == "replay":
-            if self._graph_batch != B:
-                raise RuntimeError(f"--graph_step: the captured iteration has batch {self._graph_batch}, this batch has {B} "
-                                   "(a short last batch: drop it, or run without --graph_step)")
+        if self._graph_state == "replay" and not getattr(self, "_graph_odd", False):
             self._graph.replay()
             self.graph_replays += 1
+            self.__dict__.update(self._graph_outputs)      # (an odd-shaped batch in between had re-pointed them)
             return
         if self._graph_state == "warmup" and self._graph_iters > self._graph_warm and os.environ.get("MMH_GRAPH_CAPTURE", "1") != "0":
             try:
@@ -910,6 +914,10 @@ class MMHandModel(torch.nn.Module):
             self._graph_body()
         # derived-weight caches filled before the capture are written by the replays: the graph keeps them alive
         self._graph_keep = (ops.derived_weights_snapshot(), ops.derived_batches_snapshot())
+        # what the captured iteration leaves behind (static tensors the replays refill): losses, the generated image
+        self._graph_outputs = {k: self.__dict__[k] for k in (
+            "fake_nhwc", "fake_p2", "pair_L1loss", "pair_GANloss", "loss_D_PP", "loss_D_PB", "loss_originL1", "loss_perceptual",
+            "loss_G_L1", "loss_G_GAN_PB", "loss_G_GAN_PP", "_fake_cats") if k in self.__dict__}
         self._graph, self._graph_state, self._graph_batch = g, "replay", B
 
     def _optimize_parameters_dp(self):

@@ -236,3 +236,28 @@ def test_train_main_with_graph_step_on_files(dev, monkeypatch):
         assert m.optimizer_G.step_count == 8 and int(m.optimizer_G.dev_state[0]) == 8 and m.skipped_steps == 0
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_graph_step_survives_a_short_batch(dev, monkeypatch):
+    """the last batch of an epoch may be short (the reference's DataLoader does not drop it): in replay mode such an iteration
+    runs in the eager form on buffers of its own, and the next full batch is a replay again - the whole sequence equal, bit
+    for bit, to the same sequence without any capture"""
+    from mmhand_amd.mmhand_model import MMHandModel
+
+    def seq(capture):
+        monkeypatch.setenv("MMH_GRAPH_CAPTURE", "1" if capture else "0")
+        random.seed(3)
+        m = MMHandModel(_opt(opt_level="O1"))
+        out = []
+        for it, B in enumerate((2, 2, 2, 2, 2, 1, 2, 1, 2)):
+            m.set_input(O.synthetic_batch(B, 32, 32, seed=200 + it))
+            m.optimize_parameters()
+            out.append([float(v) for v in m.get_current_errors().values()])
+        m._settle_overflow(drain=True)
+        torch.cuda.synchronize()
+        return m, out, m.netG.flat_param.detach().clone(), m.fake_p2.detach().clone()
+    e, le, we, fe = seq(False)
+    g, lg, wg, fg = seq(True)
+    assert g.graph_error is None and g.graph_replays == 4          # iterations 4, 5, 7, 9; 6 and 8 are the short ones
+    assert np.array_equal(np.array(le), np.array(lg)), (le, lg)
+    assert torch.equal(we, wg) and torch.equal(fe, fg) and tuple(fg.shape) == (2, 3, 32, 32)
