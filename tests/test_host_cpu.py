@@ -523,3 +523,33 @@ def test_hand_folder_loader_host_logic(data_dir):
     assert [p.split("/")[-2:] for p in ls.image_target] == [[f, f"SK_color_{i}.png"] for f in ("B1Counting", "B2Random") for i in range(3)]
     with pytest.raises(FileNotFoundError):
         HandFolderLoader(default_train_opt(batchSize=1, dataroot=os.path.join(tmp_path, "nope"), dataset="rhd"), device=torch.device("cpu"))
+
+
+def test_device_pool_decisions_equal_image_pool_on_the_host():
+    """DevicePool.decide (the host half of --graph_step's image pool: indices for mmh_pool_exchange) against ImagePool.query
+    (util/image_pool.py:14-34 restated) on the same `random` sequence, the exchange itself emulated with index arithmetic:
+    the same images come back, the same images stay in the same slots - through the fill phase, repeated swaps with one slot
+    inside a query and images that enter and leave within one query.  (The kernel is held to this in tests/test_graph_step_gpu.py.)"""
+    import random
+    from mmhand_amd.mmhand_model import DevicePool, ImagePool
+    for pool_size, B in ((3, 4), (1, 5), (2, 6), (5, 2), (50, 3)):
+        a, b = ImagePool(pool_size), DevicePool(pool_size, 1)
+        slots = [None] * pool_size                      # the emulated device buffer: image ids
+        next_id = 0
+        for it in range(40):
+            ids = list(range(next_id, next_id + B))
+            next_id += B
+            x = torch.tensor(ids, dtype=torch.float32).view(B, 1, 1, 1)
+            random.seed(500 + it)
+            want = a.query(x).view(-1).tolist()
+            random.seed(500 + it)
+            src, dst = b.decide(B)
+            got = [slots[s] if s >= 0 else ids[-1 - s] for s in src]       # every read of the pool before any write
+            assert all(s < 0 or slots[s] is not None for s in src)
+            writers = [d for d in dst if d >= 0]
+            assert len(writers) == len(set(writers))                       # one writer per slot
+            for i, d in enumerate(dst):
+                if d >= 0:
+                    slots[d] = ids[i]
+            assert got == [int(v) for v in want], (pool_size, B, it)
+            assert [s for s in slots[: b.count]] == [int(t.view(-1)[0]) for t in a.images]

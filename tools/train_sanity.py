@@ -23,7 +23,7 @@ def child(a):
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
     opt = default_train_opt(batchSize=a.batch, norm=a.norm, name="sanity", checkpoints_dir="/tmp/mmh_sanity",
-                            opt_level={"f32": "O0", "bf16": "O1", "fp16": "O1_FP16"}[a.dtype])
+                            opt_level={"f32": "O0", "bf16": "O1", "fp16": "O1_FP16"}[a.dtype], graph_step=bool(a.graph))
     model = MMHandModel(opt)
     model.set_input(synthetic_batch_gpu(a.batch, 256, 256, 49, dev))
     hist = []
@@ -38,6 +38,9 @@ def child(a):
     first, last = hist[0][1], hist[-1][1]
     key = next(k for k in first if "L1" in k)
     ok = all(v == v and abs(v) < 1e4 for v in last.values()) and last[key] < first[key]
+    if a.graph:
+        print(f"  --graph_step: {model.graph_replays} replays of the captured iteration, graph_error = {model.graph_error}")
+        ok = ok and model.graph_error is None and model.graph_replays == a.iters - model._graph_warm
     print(f"  {key}: {first[key]} -> {last[key]}  {'OK' if ok else 'NOT DECREASING'}")
     sys.exit(0 if ok else 1)
 
@@ -48,14 +51,20 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--norm", default="instance")
     ap.add_argument("--dtype", default=None)
+    ap.add_argument("--graph", type=int, default=0, help="1: --graph_step (the iteration replayed from a captured hipGraph)")
+    ap.add_argument("--graph-soak", action="store_true",
+                    help="the three precisions with --graph_step beside their eager runs (round 6: a soak of the replayed step)")
     a = ap.parse_args()
     if a.dtype is not None:
         return child(a)
     rc = 0
-    for dtype, env in (("f32", {}), ("f32", {"MMH_FUSE_NORMACT": "0"}), ("bf16", {}), ("fp16", {})):
-        print(f"== {dtype} {env or ''}", flush=True)
+    runs = [("f32", {}, 0), ("f32", {"MMH_FUSE_NORMACT": "0"}, 0), ("bf16", {}, 0), ("fp16", {}, 0)]
+    if a.graph_soak:
+        runs = [("f32", {}, 0), ("f32", {}, 1), ("bf16", {}, 0), ("bf16", {}, 1), ("fp16", {}, 0), ("fp16", {}, 1)]
+    for dtype, env, graph in runs:
+        print(f"== {dtype} {env or ''}{' --graph_step' if graph else ''}", flush=True)
         r = subprocess.run([sys.executable, __file__, "--dtype", dtype, "--iters", str(a.iters), "--batch", str(a.batch),
-                            "--norm", a.norm], env={**os.environ, **env})
+                            "--norm", a.norm, "--graph", str(graph)], env={**os.environ, **env})
         rc |= r.returncode
     sys.exit(rc)
 
