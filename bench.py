@@ -533,12 +533,12 @@ def gradient_parity_run(dev, size, norm):
     fix = np.load(sketch_path) if (size == 256 and norm == "instance" and os.path.exists(sketch_path)) else None
     vs64 = {}
     res, old_mode = {}, ("off" if not ops.USE_WINOGRAD else "all" if ops.WINOGRAD_FPROP else "bwd")
-    # key -> (ops.set_winograd_mode, factor on the network input)
-    runs = {"direct": ("off", 1.0), "winograd": ("all", 1.0), "winograd_bwd_only": ("bwd", 1.0),
-            "direct_input_2ulp": ("off", 1.0 + 2.0 ** -22)}
+    # key -> (ops.set_winograd_mode, factor on the network input, summation levels of the direct fp32 fprop)
+    runs = {"direct": ("off", 1.0, 1), "direct_two_level": ("off", 1.0, 2), "winograd": ("all", 1.0, 1),
+            "winograd_bwd_only": ("bwd", 1.0, 2), "direct_input_2ulp": ("off", 1.0 + 2.0 ** -22, 1)}
     try:
-        for key, (mode, scale) in runs.items():
-            ops.set_winograd_mode(mode)
+        for key, (mode, scale, levels) in runs.items():
+            ops.set_winograd_mode(mode, direct_levels=levels)
             net = Generator([3, 42, 6], 3, 64, norm, False, 9).init_weights("normal", 49).to(dev).train()
             net.flatten_parameters()
             out = net([t * scale for t in g_in])
@@ -551,9 +551,9 @@ def gradient_parity_run(dev, size, norm):
         ops.set_winograd_mode(old_mode)
     rel = lambda a, c: float((a.double() - c.double()).abs().sum() / c.double().abs().sum().clamp_min(1e-30))   # noqa: E731
 
-    def against_direct(key):
-        errs = sorted(rel(res[key][1][n], g) for n, g in res["direct"][1].items() if float(g.abs().sum()) > 0)
-        return {"output_rel_l1": float(f"{rel(res[key][0], res['direct'][0]):.3e}"),
+    def against_direct(key, base="direct"):
+        errs = sorted(rel(res[key][1][n], g) for n, g in res[base][1].items() if float(g.abs().sum()) > 0)
+        return {"output_rel_l1": float(f"{rel(res[key][0], res[base][0]):.3e}"),
                 "grad_rel_l1_median": float(f"{statistics.median(errs):.3e}"),
                 "grad_rel_l1_p90": float(f"{errs[(len(errs) * 9) // 10]:.3e}"),
                 "grad_rel_l1_max": float(f"{errs[-1]:.3e}"), "tensors": len(errs)}
@@ -568,19 +568,20 @@ def gradient_parity_run(dev, size, norm):
                 "tensors_above_1e-3_and_1p5x_pytorch_fp32": sum(e > max(1e-3, 1.5 * cond[k]) for k, e in errs.items())}
 
     out = {"winograd_vs_direct": against_direct("winograd"),
-           "winograd_dgrad_wgrad_only_vs_direct": against_direct("winograd_bwd_only"),
+           "winograd_dgrad_wgrad_only_vs_direct": against_direct("winograd_bwd_only", "direct_two_level"),
            "direct_input_times_1p2e-22_vs_direct": against_direct("direct_input_2ulp"),
            "note": f"full-size Generator (ngf 64, 9 PATBlocks, {size}x{size}, B={B}, --norm {norm}, dropout off), gradients of "
-                   "sum(out * probe) per parameter tensor against direct_path's kernels (whose own distance from the fp64 "
-                   "oracle is 1e-6: tests/test_winograd_step_gpu.py).  Second key: --fp32_exact_grads (ops.set_winograd_mode('bwd'), "
-                   "timed as hybrid_path): direct fprop, Winograd dgrad and wgrad, i.e. what the backward kernels themselves add.  Third key: the direct kernels against "
+                   "sum(out * probe) per parameter tensor against direct_path's kernels (their own distance from float64 truth: "
+                   "vs_fp64).  Second key: --fp32_exact_grads (ops.set_winograd_mode('bwd'), timed as hybrid_path): direct fprop "
+                   "with two-level summation, Winograd dgrad and wgrad, against the all-direct run with the SAME forward "
+                   "(direct_two_level), i.e. what the backward kernels themselves add.  Third key: the direct kernels against "
                    "themselves with the network input scaled by (1 + 2^-22) - the gradients' conditioning, which the "
                    "Winograd fprop's 7e-6 output difference excites (ReLU masks within rounding of zero flip)"}
     if fix is not None:
         cond = sorted(float(fix[k]) for k in fix.files if k.startswith("cond_sampled/"))
         out["vs_fp64"] = {
-            "direct": against_fp64("direct"), "hybrid_winograd_bwd_only": against_fp64("winograd_bwd_only"),
-            "winograd": against_fp64("winograd"),
+            "direct": against_fp64("direct"), "direct_two_level": against_fp64("direct_two_level"),
+            "hybrid_winograd_bwd_only": against_fp64("winograd_bwd_only"), "winograd": against_fp64("winograd"),
             "pytorch_fp32_cpu": {"output_rel_l1": float(f"{float(fix['cond/out']):.3e}"),
                                  "grad_rel_l1_median": float(f"{statistics.median(cond):.3e}"),
                                  "grad_rel_l1_max": float(f"{cond[-1]:.3e}"), "tensors": len(cond),
@@ -589,7 +590,10 @@ def gradient_parity_run(dev, size, norm):
                     "(models/Generator.py in double precision, run in the build container: tests/golden/make_golden.py "
                     "make_fullsize) at 1024 seeded positions per tensor, identical inputs and weights bit for bit; "
                     "pytorch_fp32_cpu = the same reference module in float32 on the CPU through the same positions: no fp32 "
-                    "implementation, PyTorch's included, holds 1e-3 on every tensor of this network at 256x256"}
+                    "implementation, PyTorch's included, holds 1e-3 on every tensor of this network at 256x256.  direct = the "
+                    "direct kernels with one k-ordered MFMA chain per output (direct_path); direct_two_level / hybrid = the "
+                    "same forward with two-level summation (ops.set_winograd_mode's default for 'off' / 'bwd': what "
+                    "--fp32_exact_grads and hybrid_path run)"}
     del res
     gc.collect()
     torch.cuda.empty_cache()
@@ -622,7 +626,7 @@ def line_summary(line):
          "infer_b64_f32": g("infer_b64_f32"), "infer_b64_bf16": g("infer_b64_bf16"),
          "grad_median_winograd_vs_direct": (gp.get("winograd_vs_direct") or {}).get("grad_rel_l1_median"),
          "grad_vs_fp64_median": {k: (v64.get(k) or {}).get("grad_rel_l1_median")
-                                 for k in ("direct", "hybrid_winograd_bwd_only", "winograd", "pytorch_fp32_cpu")} if v64 else None,
+                                 for k in ("direct", "direct_two_level", "hybrid_winograd_bwd_only", "winograd", "pytorch_fp32_cpu")} if v64 else None,
          "cpu_baseline": (line.get("cpu_baseline") or {}).get("value"), "rccl_ranks": line.get("rccl_ranks")}
     return {k: v for k, v in s.items() if v is not None}
 
@@ -794,6 +798,9 @@ def main():
                     help="seconds after which a self-started multi-rank run (a hung collective) is ended with exit code 124")
     ap.add_argument("--dp-side-runs", action="store_true",
                     help="with MMH_FORCE_DP=1 and one rank: also run the data-parallel side regions of an N-GPU launch")
+    ap.add_argument("--dp-regions", default="all",
+                    help="N-GPU launch: comma-separated side regions to run (dp_bf16_path, dp_norm_batch, dp_norm_batch_o1, "
+                         "dp_bf16_path_nopersist, dp_size512_bf16_b4, dp_size512_bf16_b4_norm_batch); default all")
     ap.add_argument("--dp-512", action="store_true",
                     help="N-GPU launch: also time configs[4]'s shape (512x512, per-GPU batch 4, bf16); default only at N = 4")
     ap.add_argument("--share-gpu-gloo", action="store_true",
@@ -925,7 +932,11 @@ def main():
         n_side = max(2, min(5, a.steps))
         dp_info["comm_exposed_ms"] = comm_exposed_ms(model, dev, dt / a.steps * 1e3, max(2, min(3, a.steps)))
 
+        dp_regions = None if a.dp_regions == "all" else set(a.dp_regions.split(","))
+
         def guarded_dp(key, fn):
+            if dp_regions is not None and key not in dp_regions:
+                return
             try:
                 side[key] = fn()
             except Exception as e:      # noqa: BLE001 - every rank raises alike (same code, same shapes): no rank is left behind

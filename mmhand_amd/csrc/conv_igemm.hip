@@ -233,7 +233,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // barrier per k-step (2 workgroups/CU) instead of one buffer and two barriers
 // (3 workgroups/CU; measured 5-6 % faster on the 512-channel shapes).
 // ---------------------------------------------------------------------------
-template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF, int BMT = 128>   // BMT: rows per workgroup
+// LEVELS = 2 (fprop form only; mmh_set_option("conv_levels", 2)): two-level summation over the contraction, as in
+// wino_gemm_kernel below - every k-step (32 of the (tap, channel) index) starts a fresh MFMA chain (C operand = 0) that is
+// folded into the totals by vector adds, one tile row at a time.  A k-ordered fp32 chain over K = 9 * 512 carries a relative
+// rounding error of ~u sqrt(K) / 2.4 = 1.1e-6 (oneDNN's blocked accumulation on the CPU: 2.4e-7), and at 256x256 the
+// Generator's parameter gradients follow the FORWARD's error: the gradient-exact hybrid runs its forward 3x3
+// convolutions on this form.
+template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF, int BMT = 128, int LEVELS = 1>   // BMT: rows per workgroup
 __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, const int by,
                                                 const int gx, const int gy) {
     constexpr int WTM = BMT / WAVES_M, WTN = BN / WAVES_N;
@@ -462,6 +468,34 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             if (!(p.dbg & 4)) kstate_next(ks_t, g);        // dbg 4: loads still issue, from stale addresses
             if (!(p.dbg & 1) && !IL) load_tiles(ks + 1);   // global -> registers, one burst
         }
+        if constexpr (LEVELS == 2 && !B_NMAJOR) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x16 part[TN];
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4 av = *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 32 + l31) * LDA + kg * 8 + h * 4]);
+                    float bsc[TN][4];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bsc[j][e] = Bs[(kg * 8 + h * 4 + e) * BN + wn * WTN + j * 32 + l31];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = e == 0 ? av.x : e == 1 ? av.y : e == 2 ? av.z : av.w;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            part[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], (kg == 0 && e == 0) ? f32x16{} : part[j],
+                                                                           0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += part[j][r];
+                __builtin_amdgcn_sched_barrier(0);      // row i + 1's chains must not start before this fold
+            }
+        } else {
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             if (IL && more) load_part(ks + 1, kg);         // ... or spread over the MFMA groups
@@ -495,6 +529,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bsc[j][e], acc[i][j], 0, 0, 0);
                 }
             }
+        }
         }
         if (!(p.dbg & 2)) {
             if (!DBUF) __syncthreads();      // everyone is done reading the single buffer
@@ -576,6 +611,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
 template <int BN, int WAVES_M, int WAVES_N, bool B_NMAJOR, bool DBUF>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvKP p) {
     conv_igemm_body<BN, WAVES_M, WAVES_N, B_NMAJOR, DBUF>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// the fprop form with two-level summation (LEVELS = 2 above): 128 x 128 block tile, wave tile 64 x 64
+__global__ void __launch_bounds__(256, 2) conv_igemm_levels2_kernel(const ConvKP p) {
+    conv_igemm_body<128, 2, 2, false, false, 128, 2>(p, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // 256-row tiles for the narrow GEMMs (N <= 64: 7x7 stems, stride-2 dgrad): per MFMA half the weight
@@ -2308,10 +2348,26 @@ int launch_conv_bf16(ConvKP& p, hipStream_t st) {
 int g_conv_tall = 1;    // 256x64 block tile for the stride-2 dgrad with N <= 64 (+6 %); 2: also plain fprop/dgrad
 int g_conv_xcd1 = 1;    // XCD-banded row tiles also when there is a single column tile (halo rows meet in one L2)
 int g_conv_bn256 = 1;   // 128x256 block tile (wave tile 64x128) when N % 256 == 0: +2.4 % on fprop
+int g_conv_levels = 1;  // 2: fprop (N > 64, chunk-major k order) on conv_igemm_levels2_kernel - two-level summation
+
+int launch_conv_levels2(const ConvKP& p, hipStream_t st) {
+    constexpr size_t lds = (BM * LDA + BK * 128) * sizeof(float) + tab_bytes(BM);
+    static int ready = -1;
+    if (ready != 0) ready = allow_lds(conv_igemm_levels2_kernel, lds);
+    if (ready != 0) return ready;
+    dim3 grid((p.N + 127) / 128, (p.M + BM - 1) / BM);
+    hipLaunchKernelGGL(conv_igemm_levels2_kernel, grid, dim3(256), lds, st, p);
+    return mmh::check_launch("conv_igemm_levels2_kernel");
+}
 
 template <bool NMAJOR>
 int launch_conv(const ConvKP& p, hipStream_t st) {
     const_cast<ConvKP&>(p).dbg = g_conv_dbg;
+    if (g_conv_levels == 2 && !NMAJOR && p.N > 64 && p.g.chunk_major) {
+        const int gx = (p.N + 127) / 128, gy = (p.M + BM - 1) / BM;
+        const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
+        return launch_conv_levels2(p, st);
+    }
     if (g_conv_bn256 && !NMAJOR && p.N % 256 == 0) {
         const int gx = p.N / 256, gy = (p.M + BM - 1) / BM;
         const_cast<ConvKP&>(p).xcd_remap = (g_conv_xcd && gx > 1 && gy >= 8) ? 1 : 0;
@@ -3145,6 +3201,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
     if (!strcmp(key, "conv_cw")) { g_conv_cw = value; return 0; }
     if (!strcmp(key, "conv_bn256")) { g_conv_bn256 = value; return 0; }
+    if (!strcmp(key, "conv_levels")) { g_conv_levels = value == 2 ? 2 : 1; return 0; }
     if (!strcmp(key, "wino_bn256")) { g_wino_bn256 = value; return 0; }
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "conv_xcd1")) { g_conv_xcd1 = value; return 0; }

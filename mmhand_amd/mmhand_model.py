@@ -326,6 +326,9 @@ class MMHandModel(torch.nn.Module):
                                                and dist.is_initialized()) else 1
         if getattr(opt, "fp32_exact_grads", False):
             ops.set_winograd_mode("bwd")     # process-wide, like MMH_WINOGRAD=bwd (one model family per process)
+        elif os.environ.get("MMH_WINOGRAD") in ("bwd", "0"):
+            # the environment form of the same choice: the direct fprop's two-level summation comes with it
+            ops.set_winograd_mode("bwd" if os.environ["MMH_WINOGRAD"] == "bwd" else "off")
         seed = getattr(opt, "seed", 49)
         # dropout masks: an independent stream per rank, as each reference rank has its own RNG
         # (the weights are seeded identically on every rank and broadcast from rank 0).  ImagePool

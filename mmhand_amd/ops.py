@@ -288,13 +288,23 @@ USE_WINOGRAD = os.environ.get("MMH_WINOGRAD", "1") != "0"
 WINOGRAD_FPROP = os.environ.get("MMH_WINOGRAD", "1") != "bwd"
 
 
-def set_winograd_mode(mode):
+def set_winograd_mode(mode, direct_levels=None):
     """"all" (default: every pass of the eligible fp32 3x3 convs on Winograd), "bwd" (direct fprop, Winograd dgrad + wgrad:
-    gradients within 1e-3 of fp64 on every tensor), "off" (direct kernels everywhere)"""
+    the gradient-exact hybrid), "off" (direct kernels everywhere).
+    direct_levels (1 | 2; default 2 for "bwd" and "off", 1 for "all"; MMH_DIRECT_LEVELS overrides the default): summation
+    levels of the direct fp32 fprop with more than 64 output channels (mmh_set_option("conv_levels")).  Two levels - a fresh
+    MFMA chain per 32-deep k-step, folded by vector adds - take the full-size Generator's output from 2.9e-6 to 1.3e-6 of
+    float64 (PyTorch's fp32 on the CPU: 1.2e-6) and with it the parameter gradients from a median 2.2e-3 to 1.0e-3 (PyTorch:
+    7.6e-4): at 256x256 the gradients' distance follows the FORWARD's (DESIGN 2.1).  The modes whose point is accuracy get it;
+    the all-Winograd headline keeps the one-level direct kernels for its stride-2 convs (its forward error is the
+    Winograd transforms')."""
     global USE_WINOGRAD, WINOGRAD_FPROP
     if mode not in ("all", "bwd", "off"):
         raise ValueError(f"winograd mode {mode!r}: expected all | bwd | off")
     USE_WINOGRAD, WINOGRAD_FPROP = mode != "off", mode != "bwd"
+    if direct_levels is None:
+        direct_levels = int(os.environ.get("MMH_DIRECT_LEVELS", "2" if mode != "all" else "1"))
+    L.call("mmh_set_option", b"conv_levels", 2 if int(direct_levels) == 2 else 1)
     bump_weights_epoch()
 WINOGRAD_TILE = int(os.environ.get("MMH_WINOGRAD_TILE", "6"))
 WINO6_MIN = 128 * 128      # F(6x6,3x3) from this Cin*Cout up (64 planes of filter transform per conv)

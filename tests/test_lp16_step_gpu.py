@@ -269,8 +269,9 @@ def test_batched_weight_copies_change_nothing(level, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["all", "bwd"])
-def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypatch):
-    """mode "bwd" = --fp32_exact_grads (ops.set_winograd_mode("bwd")): direct fprop, F(6x6,3x3) dgrad and
+def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypatch, request):
+    """mode "bwd" = --fp32_exact_grads (ops.set_winograd_mode("bwd")): direct fprop (round 6: with two-level
+    summation, mmh_set_option("conv_levels", 2) - the all-direct comparison below runs the same forward), F(6x6,3x3) dgrad and
     wgrad with the transformed input made in the backward; the forward Winograd GEMM entry point is never called.  Bounds,
     per Generator gradient tensor: (1) within 1e-4 of the gradients of the all-direct kernels (Winograd off; measured 1e-6:
     identical activations and ReLU masks, the backward GEMMs add rounding only), and (2) against fp64 no further than
@@ -299,6 +300,7 @@ def test_optimize_parameters_fp32_full_width_vs_fp64_oracle(mode, dev, monkeypat
         return real(name, *a)
     monkeypatch.setattr(lib, "call", spy)
     monkeypatch.setattr(ops, "WINOGRAD_FPROP", ops.WINOGRAD_FPROP)     # restored after the test (the option sets it)
+    request.addfinalizer(lambda: lib.call("mmh_set_option", b"conv_levels", 1))     # ... and the direct fprop's summation levels
     model = MMHandModel(_opt("O0", fp32_exact_grads=mode == "bwd"))
     assert not model.bf16 and ops.WINOGRAD_FPROP == (mode != "bwd") and ops.USE_WINOGRAD
     for net, sd in zip((model.netG, model.netD_PB, model.netD_PP, model.vgg), nets()):
