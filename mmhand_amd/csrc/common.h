@@ -189,7 +189,7 @@ bool stem_f32_ok(const mmh_conv_desc* d);
 int stem_f32_stats_chunks(const mmh_conv_desc* d);
 int launch_stem_f32(const mmh_conv_desc* d, const void* x, const void* w, const void* bias, void* y, int act, float* stats,
                     hipStream_t st);
-extern int g_stem_f32, g_stem_f32_dbg;
+extern int g_stem_f32, g_stem_f32_dbg, g_stem_f32_levels;
 // fp32 Winograd-domain wgrad GEMMs as a three-stage LDS-DMA ring (wino_wgrad_dma.hip)
 bool wino_wgrad_dma_ok(int64_t tiles, int Cin, int Cout, int nbatch);
 size_t wino_wgrad_dma_ws_bytes(int64_t tiles, int Cin, int Cout, int nbatch);

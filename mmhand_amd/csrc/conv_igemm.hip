@@ -3201,7 +3201,7 @@ int mmh_set_option(const char* key, int value) {
     if (!strcmp(key, "conv_dbg")) { g_conv_dbg = value; return 0; }
     if (!strcmp(key, "conv_cw")) { g_conv_cw = value; return 0; }
     if (!strcmp(key, "conv_bn256")) { g_conv_bn256 = value; return 0; }
-    if (!strcmp(key, "conv_levels")) { g_conv_levels = value == 2 ? 2 : 1; return 0; }
+    if (!strcmp(key, "conv_levels")) { g_conv_levels = value == 2 ? 2 : 1; mmh::g_stem_f32_levels = g_conv_levels; return 0; }
     if (!strcmp(key, "wino_bn256")) { g_wino_bn256 = value; return 0; }
     if (!strcmp(key, "conv_xcd")) { g_conv_xcd = value; return 0; }
     if (!strcmp(key, "conv_xcd1")) { g_conv_xcd1 = value; return 0; }

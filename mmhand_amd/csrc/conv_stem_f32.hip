@@ -22,7 +22,7 @@
 #include <algorithm>
 #include "common.h"
 
-namespace mmh { int g_stem_f32 = 1; int g_stem_f32_dbg = 0; }
+namespace mmh { int g_stem_f32 = 1; int g_stem_f32_dbg = 0; int g_stem_f32_levels = 1; }   // levels 2: with mmh_set_option("conv_levels", 2)
 
 namespace {
 
@@ -64,7 +64,10 @@ __device__ __forceinline__ float act_of(float v, int act) {
 }
 
 // MT: 32-pixel accumulator tiles per wave: output tile 8 MT rows x 16 pixels (wave: rows 2 pg, 2 pg + 1 of each half of 8)
-template <int MT>
+// LEVELS = 2 (mmh_set_option("conv_levels", 2), the accuracy modes of ops.set_winograd_mode): two-level summation - every
+// filter phase (<= 160 of the 7 x 7 Cin contraction values) runs its own MFMA chain in `part`, folded into the totals by
+// vector adds - instead of one k-ordered chain up to 2156 deep (conv_igemm.hip: conv_igemm_levels2_kernel)
+template <int MT, int LEVELS = 1>
 __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p) {
     constexpr int TR = 8 * MT, HR = TR + 6;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -144,6 +147,17 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
             if (q == 0 && p.nhalo == 2 && !(p.dbg & 2)) issue_halo(tile + p.slots, buf ^ 1);
             const int kh = q / p.parts, part = q - kh * p.parts;
             const int kcs = (min(p.pj, p.J - part * p.pj) + 7) >> 3;
+            f32x16 chain[MT];       // LEVELS == 2: this phase's own MFMA chains
+            if (LEVELS == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) chain[mt][i] = 0.f;
+            }
+            auto mf = [&](int mt, float a, float b) {
+                if (LEVELS == 2) chain[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, chain[mt], 0, 0, 0);
+                else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+            };
             unsigned ab = a_lane + (unsigned)(buf * p.halo_b + kh * p.rp + part * p.pj * 4);
             unsigned bb = b_lane + (unsigned)(st * p.wst_b);
             st ^= 1;
@@ -161,7 +175,7 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][t], b0[t], acc[mt], 0, 0, 0);
+                            mf(mt, a0[mt][t], b0[t]);
                 }
             }
             for (; kc + 2 <= kcs; kc += 2) {
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][t], b0[t], acc[mt], 0, 0, 0);
+                        mf(mt, a0[mt][t], b0[t]);
                 ab += 64;
                 bb += 4096;
                 // past the last k-step: inside the stage / halo buffer, never multiplied
@@ -185,14 +199,20 @@ __global__ void __launch_bounds__(NT, 1) conv_stem_f32_kernel(const StemF32KP p)
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[mt][t], b1[t], acc[mt], 0, 0, 0);
+                        mf(mt, a1[mt][t], b1[t]);
             }
             if (kc < kcs) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[mt][t], b0[t], acc[mt], 0, 0, 0);
+                        mf(mt, a0[mt][t], b0[t]);
+            }
+            if (LEVELS == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mt][i] += chain[mt][i];
             }
         }
         const int b = tile / tpi;
@@ -336,13 +356,17 @@ int launch_stem_f32(const mmh_conv_desc* d, const void* x, const void* w, const 
     p.dbg = g_stem_f32_dbg;
     static int ready = -1;
     if (ready != 0) {
-        for (const void* k : {reinterpret_cast<const void*>(conv_stem_f32_kernel<1>), reinterpret_cast<const void*>(conv_stem_f32_kernel<2>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(conv_stem_f32_kernel<1>), reinterpret_cast<const void*>(conv_stem_f32_kernel<2>),
+                              reinterpret_cast<const void*>(conv_stem_f32_kernel<1, 2>), reinterpret_cast<const void*>(conv_stem_f32_kernel<2, 2>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return fail("conv_stem_f32: %s", hipGetErrorString(e));
         }
         ready = 0;
     }
-    if (q.mt == 2) hipLaunchKernelGGL(conv_stem_f32_kernel<2>, dim3(8 * p.slots), dim3(NT), q.lds, st, p);
+    if (g_stem_f32_levels == 2) {
+        if (q.mt == 2) hipLaunchKernelGGL((conv_stem_f32_kernel<2, 2>), dim3(8 * p.slots), dim3(NT), q.lds, st, p);
+        else hipLaunchKernelGGL((conv_stem_f32_kernel<1, 2>), dim3(8 * p.slots), dim3(NT), q.lds, st, p);
+    } else if (q.mt == 2) hipLaunchKernelGGL(conv_stem_f32_kernel<2>, dim3(8 * p.slots), dim3(NT), q.lds, st, p);
     else hipLaunchKernelGGL(conv_stem_f32_kernel<1>, dim3(8 * p.slots), dim3(NT), q.lds, st, p);
     return check_launch("conv_stem_f32_kernel");
 }

@@ -293,8 +293,8 @@ def set_winograd_mode(mode, direct_levels=None):
     the gradient-exact hybrid), "off" (direct kernels everywhere).
     direct_levels (1 | 2; default 2 for "bwd" and "off", 1 for "all"; MMH_DIRECT_LEVELS overrides the default): summation
     levels of the direct fp32 fprop with more than 64 output channels (mmh_set_option("conv_levels")).  Two levels - a fresh
-    MFMA chain per 32-deep k-step, folded by vector adds - take the full-size Generator's output from 2.9e-6 to 1.3e-6 of
-    float64 (PyTorch's fp32 on the CPU: 1.2e-6) and with it the parameter gradients from a median 2.2e-3 to 1.0e-3 (PyTorch:
+    MFMA chain per 32-deep k-step, folded by vector adds - take the full-size Generator's output from 2.9e-6 to 1.1e-6 of
+    float64 (PyTorch's fp32 on the CPU: 1.2e-6) and with it the parameter gradients from a median 2.2e-3 to 9.5e-4 (PyTorch:
     7.6e-4): at 256x256 the gradients' distance follows the FORWARD's (DESIGN 2.1).  The modes whose point is accuracy get it;
     the all-Winograd headline keeps the one-level direct kernels for its stride-2 convs (its forward error is the
     Winograd transforms')."""

@@ -73,7 +73,7 @@ _BASE = [
                                     "not the reference's objective)")),
     ("--fp32_exact_grads", dict(action="store_true",
                                 help="fp32 only: forward 3x3 convs on the direct implicit-GEMM kernels with two-level summation, "
-                                     "dgrad / wgrad on Winograd F(6x6,3x3) - at 256x256 the parameter gradients a median 1.0e-3 "
+                                     "dgrad / wgrad on Winograd F(6x6,3x3) - at 256x256 the parameter gradients a median 9.5e-4 "
                                      "from float64 (PyTorch's own fp32: 7.6e-4; the all-Winograd default: 3e-3 on this network's "
                                      "ill-conditioned gradients); = MMH_WINOGRAD=bwd")),
     ("--graph_step", dict(action="store_true",

@@ -1446,3 +1446,39 @@ def test_conv3x3_lp16_one_wave_per_simd_ab_build(case, dev):
             assert torch.equal(r, o)
     finally:
         lib.check(L_.mmh_set_option(b"lp16_shape", 19), "set")
+
+
+@pytest.mark.parametrize("case", [("3x3", 2, 32, 32, 512, 512), ("3x3", 1, 24, 40, 256, 128), ("s2", 2, 32, 32, 128, 256),
+                                  ("stem", 2, 64, 64, 44, 64), ("stem", 1, 48, 32, 24, 64)])
+def test_two_level_direct_fprop_is_closer_to_fp64(case, dev, monkeypatch):
+    """mmh_set_option("conv_levels", 2) - ops.set_winograd_mode's default for the accuracy modes "bwd" / "off" (DESIGN 2.1):
+    the direct fp32 fprop (conv_igemm_levels2_kernel for more than 64 output channels; conv_stem_f32_kernel<., 2> for the 7x7
+    stems) starts a fresh MFMA chain per k-step / filter phase and folds it by vector adds.  Against the fp64 oracle the
+    two-level result is at least 1.7x closer than the k-ordered chain at a contraction of 4608 (1.3x at the shorter ones),
+    it carries bias / ReLU and the statistics partials like the one-level kernel, and the option switches back."""
+    import ctypes
+    from mmhand_amd import lib, ops
+    kind, B, H, W, Cin, Cout = case
+    k, s, p, refl = (7, 1, 3, True) if kind == "stem" else ((3, 2, 1, False) if kind == "s2" else (3, 1, 1, True))
+    monkeypatch.setattr(ops, "USE_WINOGRAD", False)         # the DIRECT kernels (the 3x3 stride-1 cases would run F(6x6,3x3))
+    x = _mk((B, H, W, Cin), 11, dev)
+    w = _mk((k, k, Cin, Cout), 12, dev) * 0.05
+    bias = _mk((Cout,), 13, dev)
+    yr = R.conv2d(x.cpu(), w.cpu(), bias.cpu(), s, p, refl, 1)
+    ops.bump_weights_epoch()
+    y1 = ops.raw_conv_fprop(x, w, bias, s, p, refl, 1)
+    lib.call("mmh_set_option", b"conv_levels", 2)
+    try:
+        y2 = ops.raw_conv_fprop(x, w, bias, s, p, refl, 1)
+        if lib.load().mmh_conv2d_fprop_stats_chunks(ctypes.byref(ops.conv_desc(B, H, W, Cin, Cout, k, s, p, refl))) > 0:
+            ops._pending_stats.clear()
+            y3 = ops.raw_conv_fprop(x, w, None, s, p, refl, want_stats=True)
+            assert torch.equal(torch.relu(y3 + bias), y2) or R.rel_l1(torch.relu(y3 + bias), y2) < 1e-7
+            ops._pending_stats.clear()
+    finally:
+        lib.call("mmh_set_option", b"conv_levels", 1)
+    assert torch.equal(ops.raw_conv_fprop(x, w, bias, s, p, refl, 1), y1)           # switched back
+    e1, e2 = R.rel_l1(y1, yr), R.rel_l1(y2, yr)
+    deep = k * k * Cin >= 4000
+    print(f"\\n{case}: one level {e1:.2e}, two levels {e2:.2e}")
+    assert not torch.equal(y1, y2) and e2 < e1 / (1.7 if deep else 1.3) and e2 < 6e-7, (e1, e2)

@@ -122,10 +122,11 @@ def test_fullsize_generator_gradients_vs_fp64_sketch(mode, dev):
     scales with the forward's own distance: the direct kernels' output is 2.9e-6 from float64 (k-ordered fp32 MFMA chains
     4608 deep, fp32 statistics; PyTorch on the CPU accumulates its norm statistics in double) and their gradients a median
     2.2e-3.  With TWO-LEVEL summation in the direct fprop (a fresh chain per 32-deep k-step; ops.set_winograd_mode's default for
-    "off" and "bwd") the output is 1.3e-6 from float64 and the gradients a median 1.0e-3 - PyTorch's neighbourhood.
+    "off" and "bwd"; the 3x3 / stride-2 convs and the 7x7 stems) the output is 1.1e-6 from float64 and the gradients a
+    median 9.5e-4, max 1.4e-3 - PyTorch's neighbourhood (its max is 1.6e-3).
     Bars per tensor = what round 6 measured + a third:
       off1 (direct kernels, one level: `direct_path`)  median <= 2.9e-3, max <= 4.1e-3, output <= 5e-6  (measured 2.17e-3 / 3.06e-3 / 2.9e-6)
-      off  (direct kernels, two-level fprop)           median <= 1.35e-3, max <= 2.6e-3, output <= 2e-6  (measured 1.00e-3 / 1.91e-3 / 1.32e-6)
+      off  (direct kernels, two-level fprop)           median <= 1.3e-3, max <= 1.9e-3, output <= 1.6e-6  (measured 9.5e-4 / 1.43e-3 / 1.13e-6)
       bwd  (`--fp32_exact_grads`, `hybrid_path`)       the same bars (the same two-level forward)
       all  (Winograd F(6x6,3x3), the headline)        median <= 4e-3, max <= 5.6e-3, output <= 1e-5  (measured 3.05e-3 / 4.30e-3 / 6.5e-6)
     """
@@ -164,4 +165,4 @@ def test_fullsize_generator_gradients_vs_fp64_sketch(mode, dev):
     elif mode == "off1":
         assert oerr < 5e-6 and v[-1] < 4.1e-3 and statistics.median(v) < 2.9e-3, (oerr, v[-1], statistics.median(v))
     else:
-        assert oerr < 2e-6 and v[-1] < 2.6e-3 and statistics.median(v) < 1.35e-3, (oerr, v[-1], statistics.median(v))
+        assert oerr < 1.6e-6 and v[-1] < 1.9e-3 and statistics.median(v) < 1.3e-3, (oerr, v[-1], statistics.median(v))

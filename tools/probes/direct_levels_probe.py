@@ -22,8 +22,7 @@ g_in = [b["H1"], torch.cat((b["P1"], b["P2"]), 1), torch.cat((b["D1"], b["D2"]),
 probe = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(dev)
 for mode in ("bwd", "off"):
     for levels in (1, 2):
-        lib.check(L.mmh_set_option(b"conv_levels", levels), "opt")
-        ops.set_winograd_mode(mode)
+        ops.set_winograd_mode(mode, direct_levels=levels)
         net = Generator([3, 42, 6], 3, 64, "instance", False, 9).init_weights("normal", 49).to(dev).train()
         net.flatten_parameters()
         for rep in range(2):
